@@ -1,0 +1,236 @@
+/*
+ * isf_hip.h -- C ABI of libisf_hip.so: the MI355X (gfx950) implementation of IS-Fusion's
+ * LiDAR voxelization -> sparse-conv -> BEV hot path (BASELINE.json north_star).
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch/ATen types.  All data pointers are DEVICE pointers
+ *     unless the parameter name ends in `_host`.  All tensors are dense, row-major, contiguous.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous on
+ *     that stream, except where an output count is returned through a `*_host` pointer: those calls
+ *     synchronise the stream once before returning (the reference ops do the same, see each entry).
+ *   - Return value: ISF_OK (0) or a negative ISF_ERR_* code; never throws.  isf_last_error() returns a
+ *     thread-local message for the last failure.
+ *   - Buffers are caller-owned.  Scratch memory comes from a per-device arena owned by the library
+ *     (grown on demand with hipMalloc, released by isf_release_workspace()).  One call at a time per
+ *     device (the reference ops are likewise called from the single Python thread of the rank).
+ *   - Voxel coordinates are int32 (z, y, x) or (b, z, y, x) exactly like the reference.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef ISF_HIP_H
+#define ISF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISF_OK 0
+#define ISF_ERR_ARG (-1)         /* bad argument (null pointer, negative size, unsupported shape) */
+#define ISF_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define ISF_ERR_NOMEM (-3)       /* workspace allocation failed */
+#define ISF_ERR_UNSUPPORTED (-4) /* valid request outside what this build implements */
+#define ISF_ERR_CAPACITY (-5)    /* caller-provided output capacity too small */
+
+#define ISF_REDUCE_SUM 0
+#define ISF_REDUCE_MEAN 1
+#define ISF_REDUCE_MAX 2
+
+#define ISF_CONV_SUBM 0   /* SubMConv3d  */
+#define ISF_CONV_SPARSE 1 /* SparseConv3d */
+
+typedef void* isf_stream_t; /* hipStream_t */
+
+/* library / runtime ----------------------------------------------------------------------------- */
+int isf_version(void);                 /* (major<<16)|(minor<<8)|patch */
+const char* isf_last_error(void);      /* message of the last failure on this thread ("" if none) */
+int isf_device_count(int* count_host); /* number of visible HIP devices (0 on a CPU-only host) */
+int isf_release_workspace(void);       /* free the per-device arenas */
+int isf_workspace_bytes(size_t* bytes_host); /* current arena size on the current device */
+
+/* A1  dynamic voxelization ------------------------------------------------------------------------
+ * replaces voxel_layer.dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3)
+ *   mmdet3d/ops/voxel/src/voxelization.h:83-95, voxelization_cuda.cu:24-61,485-528; caller
+ *   mmdet3d/ops/voxel/voxelize.py:52-55.
+ * points [P, C>=3] fp32 -> coors [P,3] int32 (z,y,x); rows with any axis outside the grid become
+ * (-1,-1,-1) (CPU-path semantics, voxelization_cpu.cpp:8-43).  fp32 arithmetic: floor((p-min)/vs).
+ * Asynchronous; no device-wide sync (the reference calls cudaDeviceSynchronize, :524). */
+int isf_dynamic_voxelize(const float* points, int num_points, int num_features,
+                         const float voxel_size_host[3], const float coors_range_host[6],
+                         int32_t* coors, isf_stream_t stream);
+
+/* Batched form used by ISFusionDetector.dynamic_voxelize (detectors/isfusion.py:123-146): samples
+ * are concatenated, point_offsets_host[b]..[b+1] delimits sample b; writes coors4 [P,4] (b,z,y,x). */
+int isf_dynamic_voxelize_batched(const float* points, const int64_t* point_offsets_host,
+                                 int batch_size, int num_features, const float voxel_size_host[3],
+                                 const float coors_range_host[6], int32_t* coors4,
+                                 isf_stream_t stream);
+
+/* A2  hard (deterministic) voxelization -----------------------------------------------------------
+ * replaces voxel_layer.hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size,
+ *   coors_range, max_points, max_voxels, NDim=3, deterministic=True) -> int voxel_num
+ *   voxelization.h:58-81, voxelization_cpu.cpp:45-144, voxelization_cuda.cu:231-373;
+ *   caller voxelize.py:56-70 (outputs pre-allocated at max size and ZERO-FILLED by the caller).
+ * Voxels in first-appearance order of the points, first max_points points of each in point order,
+ * voxels beyond max_voxels dropped.  Writes the prefix [0, voxel_num) of voxels [max_voxels,
+ * max_points, C], coors [max_voxels,3], num_points_per_voxel [max_voxels].  Synchronises once to
+ * return *voxel_num_host (the reference returns the count to Python as well). */
+int isf_hard_voxelize(const float* points, int num_points, int num_features,
+                      const float voxel_size_host[3], const float coors_range_host[6],
+                      int max_points, int max_voxels, float* voxels, int32_t* coors,
+                      int32_t* num_points_per_voxel, int* voxel_num_host, isf_stream_t stream);
+
+/* A3  DynamicScatter ------------------------------------------------------------------------------
+ * replaces voxel_layer.dynamic_point_to_voxel_forward(feats, coors, reduce_type) ->
+ *   [reduced_feats, out_coors, coors_map int32, reduce_count int32]
+ *   voxelization.h:108-121, scatter_points_cuda.cu:183-239.
+ * feats [P,C], coors [P,3] int32 (any row with a negative entry is dropped).  Outputs have capacity
+ * P rows; the first *num_voxels_host rows are valid: out_coors sorted lexicographically (the order of
+ * at::unique_dim(sorted=true)), coors_map[i] = voxel of point i (-1 if dropped), reduce_count.
+ * Synchronises once to return the count. */
+int isf_dynamic_point_to_voxel_forward(const float* feats, const int32_t* coors, int num_points,
+                                       int num_feats, int reduce_type, float* reduced_feats,
+                                       int32_t* out_coors, int32_t* coors_map,
+                                       int32_t* reduce_count, int* num_voxels_host,
+                                       isf_stream_t stream);
+
+/* replaces voxel_layer.dynamic_point_to_voxel_backward(grad_feats, grad_reduced_feats, feats,
+ *   reduced_feats, coors_idx, reduce_count, reduce_type)   voxelization.h:123-140,
+ *   scatter_points_cuda.cu:241-308.  grad_feats [P,C] is fully overwritten.  Asynchronous. */
+int isf_dynamic_point_to_voxel_backward(float* grad_feats, const float* grad_reduced_feats,
+                                        const float* feats, const float* reduced_feats,
+                                        const int32_t* coors_map, const int32_t* reduce_count,
+                                        int num_points, int num_voxels, int num_feats,
+                                        int reduce_type, isf_stream_t stream);
+
+/* A4  DynamicVFE.forward (fused) -------------------------------------------------------------------
+ * replaces DynamicVFE.forward(features, coors) for the IS-Fusion configuration
+ *   (with_cluster_center, with_voxel_center, mode='max', two DynamicVFELayers, eval-mode BN)
+ *   mmdet3d/models/voxel_encoders/voxel_encoder.py:453-547, utils.py:129-144.
+ * points [P,Cin], coors4 [P,4] (b,z,y,x).  w1 [c1, Cin+6], w2 [c2, 2*c1] in torch Linear layout;
+ * scaleN/shiftN = eval BatchNorm1d folded to y = x*scale + shift.  Outputs (capacity P rows):
+ * voxel_feats [N,c2], voxel_coors [N,4] sorted by (b,z,y,x) (= per-sample unique_dim order,
+ * scatter_points.py:75-96), optional pt2vox [P] (may be NULL).  Synchronises once for the count. */
+int isf_dynamic_vfe_forward(const float* points, const int32_t* coors4, int num_points,
+                            int in_channels, int batch_size, const float voxel_size_host[3],
+                            const float coors_range_host[6], const float* w1, const float* scale1,
+                            const float* shift1, int c1, const float* w2, const float* scale2,
+                            const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
+                            int32_t* pt2vox, int* num_voxels_host, isf_stream_t stream);
+
+/* cfg-1 VFE: HardSimpleVFE.forward(features[M,T,C], num_points[M]) -> [M, num_features]
+ *   voxel_encoder.py:28-45.  Asynchronous. */
+int isf_hard_simple_vfe(const float* voxels, const int32_t* num_points, int num_voxels,
+                        int max_points, int num_point_features, int num_features, float* out,
+                        isf_stream_t stream);
+
+/* A5  sparse-conv rulebook --------------------------------------------------------------------------
+ * replaces sparse_conv_ext.get_indice_pairs_3d(indices, batch_size, out_shape, spatial_shape, ksize,
+ *   stride, padding, dilation, out_padding, subm, transpose) -> [outids, indice_pairs, indice_num]
+ *   mmdet3d/ops/bevfusion-ops/spconv/src/all.cc:21-51, include/spconv/spconv_ops.h:27-141,
+ *   geometry.h:24-297 (same role: spconv.pytorch / mmcv.ops get_indice_pairs).
+ * Native format = output-stationary neighbour table: nbr [K, nbr_stride] int32 with
+ * nbr[k*nbr_stride + o] = input row feeding output row o through tap k (-1 if none), tap index
+ * k = (kz*Ky + ky)*Kx + kx, in = out*stride - padding + k (cross-correlation, dilation 1).
+ * SubM: outputs = inputs in the SAME row order (out_indices may be NULL).  Sparse (strided):
+ * out_indices [cap,4] are written sorted by (b,z,y,x) (spconv's GPU path sorts too,
+ * spconv_ops.h:130; the CPU path numbers them first-come -- irrelevant after dense()).
+ * nbr_stride >= round_up(num_out, 128); the caller provides nbr with K*nbr_stride entries where
+ * nbr_stride = isf_nbr_stride(capacity).  Synchronises once for *num_out_host (sparse only). */
+int isf_nbr_stride(int num_rows);
+int isf_conv_out_shape(const int in_shape_host[3], const int ksize_host[3],
+                       const int stride_host[3], const int padding_host[3], int out_shape_host[3]);
+int isf_build_rulebook(const int32_t* indices, int num_in, int batch_size,
+                       const int spatial_shape_host[3], const int ksize_host[3],
+                       const int stride_host[3], const int padding_host[3], int conv_type,
+                       int32_t* out_indices, int out_capacity, int32_t* nbr, int nbr_stride,
+                       int* num_out_host, isf_stream_t stream);
+
+/* spconv-1 interchange format: indice_pairs [K,2,num_in] (-1 padded) + indice_num [K]
+ * (what indice_conv_fp32 consumes, spconv_ops.h:260-271).  Pairs of one tap are ordered by output row. */
+int isf_rulebook_to_indice_pairs(const int32_t* nbr, int nbr_stride, int num_out, int num_taps,
+                                 int num_in, int32_t* indice_pairs, int32_t* indice_num,
+                                 isf_stream_t stream);
+int isf_indice_pairs_to_rulebook(const int32_t* indice_pairs, const int32_t* indice_num,
+                                 int num_taps, int num_in, int num_out, int32_t* nbr,
+                                 int nbr_stride, isf_stream_t stream);
+
+/* A6/A7  sparse convolution forward, fused epilogue ---------------------------------------------------
+ * replaces sparse_conv_ext.indice_conv_fp32(features, filters, indice_pairs, indice_num,
+ *   num_act_out, inverse, subm)  (spconv_ops.h:260-361; functional.py:22-97) PLUS the
+ *   BatchNorm1d(eval) / residual add / ReLU that follow it in SparseSequential / SparseBasicBlock
+ *   (ops/sparse_block.py:117-134, sparse_encoder.py:75-104):
+ *     y[o,:] = act( (sum_k x[nbr[k][o],:] @ W[k]) * scale + shift + residual[o,:] )
+ * features [num_in,Cin]; filters [K,Cin,Cout] = the reference layout [kD,kH,kW,Cin,Cout] (conv.py:100);
+ * scale/shift [Cout] (NULL = identity); residual [num_out,Cout] or NULL; relu 0/1; out [num_out,Cout].
+ * Each output row is written exactly once (no scatter-add, no atomics).  Asynchronous. */
+int isf_sparse_conv_forward(const float* features, int num_in, int c_in, const float* filters,
+                            int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                            const float* scale, const float* shift, const float* residual, int relu,
+                            float* out, isf_stream_t stream);
+
+/* Same with filters pre-packed by isf_pack_filters (MFMA fragment order); packed size in floats =
+ * isf_packed_filter_elems(K, Cin, Cout).  Use this on the hot path: weights are static. */
+size_t isf_packed_filter_elems(int num_taps, int c_in, int c_out);
+int isf_pack_filters(const float* filters, int num_taps, int c_in, int c_out, float* packed,
+                     isf_stream_t stream);
+int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, const float* packed,
+                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride,
+                                   int num_out, const float* scale, const float* shift,
+                                   const float* residual, int relu, float* out, isf_stream_t stream);
+
+/* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
+ * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros
+ * elsewhere; out [B, C*D, H, W] is written completely (no separate memset).  Asynchronous. */
+int isf_sparse_to_dense_bev(const float* features, const int32_t* indices, int num_rows, int channels,
+                            int batch_size, int D, int H, int W, float* out, isf_stream_t stream);
+
+/* A7  whole SparseEncoder.forward in one call -----------------------------------------------------------
+ * replaces SparseEncoder.forward(voxel_features, coors, batch_size)
+ *   mmdet3d/models/middle_encoders/sparse_encoder.py:107-138 (eval-mode BN folded).
+ * A plan is an ordered list of conv layers; SubM layers at one resolution share one rulebook. */
+typedef struct isf_conv_layer {
+  int conv_type;       /* ISF_CONV_SUBM | ISF_CONV_SPARSE */
+  int ksize[3], stride[3], padding[3];
+  int c_in, c_out;
+  const float* packed; /* device: isf_pack_filters output */
+  const float* scale;  /* device [c_out] */
+  const float* shift;  /* device [c_out] */
+  int relu;            /* apply ReLU at the end */
+  int residual_from;   /* -2 none; -1 the encoder input; i>=0 output of layer i (added before ReLU) */
+} isf_conv_layer;
+
+typedef struct isf_encoder_stats { /* filled on the host after the call (for roofline accounting) */
+  int num_layers;
+  int num_in[32], num_out[32];
+  long long pairs[32]; /* sum over taps of valid (in,out) pairs of layer i */
+  float ms[32];        /* hipEvent time of layer i's conv kernel when timing was requested, else 0 */
+} isf_encoder_stats;
+
+int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors, int num_voxels,
+                               int batch_size, const int sparse_shape_host[3],
+                               const isf_conv_layer* layers_host, int num_layers,
+                               float* spatial_features, /* [B, C_last*D_last, H_last, W_last] */
+                               int out_shape_host[4],   /* C*D, H, W and N_last (may be NULL) */
+                               isf_encoder_stats* stats_host /* may be NULL */, int time_layers,
+                               isf_stream_t stream);
+
+/* LiDAR branch in one call: dynamic voxelize + DynamicVFE + SparseEncoder (isfusion.py:103-111) */
+typedef struct isf_vfe_params {
+  int in_channels, c1, c2;
+  const float *w1, *scale1, *shift1, *w2, *scale2, *shift2; /* device */
+  float voxel_size[3], coors_range[6];
+} isf_vfe_params;
+
+int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_host, int batch_size,
+                             const isf_vfe_params* vfe_host, const int sparse_shape_host[3],
+                             const isf_conv_layer* layers_host, int num_layers,
+                             float* spatial_features, int out_shape_host[4],
+                             isf_encoder_stats* stats_host, int time_layers, isf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISF_HIP_H */

@@ -1,0 +1,159 @@
+"""ctypes binding of libisf_hip.so (C ABI declared in include/isf_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C is-fusion_amd/csrc``.  There is NO
+CPU or PyTorch fallback: if the shared library is missing or a call fails, the ops raise.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libisf_hip.so")
+
+c_int = ctypes.c_int
+c_void_p = ctypes.c_void_p
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+ISF_OK = 0
+REDUCE = {"sum": 0, "mean": 1, "max": 2}
+CONV_SUBM, CONV_SPARSE = 0, 1
+
+
+class ConvLayer(ctypes.Structure):
+    """struct isf_conv_layer (include/isf_hip.h)."""
+    _fields_ = [
+        ("conv_type", c_int),
+        ("ksize", c_int * 3), ("stride", c_int * 3), ("padding", c_int * 3),
+        ("c_in", c_int), ("c_out", c_int),
+        ("packed", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+        ("relu", c_int), ("residual_from", c_int),
+    ]
+
+
+class EncoderStats(ctypes.Structure):
+    """struct isf_encoder_stats."""
+    _fields_ = [
+        ("num_layers", c_int),
+        ("num_in", c_int * 32), ("num_out", c_int * 32),
+        ("pairs", ctypes.c_longlong * 32),
+        ("ms", ctypes.c_float * 32),
+    ]
+
+
+class VfeParams(ctypes.Structure):
+    """struct isf_vfe_params."""
+    _fields_ = [
+        ("in_channels", c_int), ("c1", c_int), ("c2", c_int),
+        ("w1", c_void_p), ("scale1", c_void_p), ("shift1", c_void_p),
+        ("w2", c_void_p), ("scale2", c_void_p), ("shift2", c_void_p),
+        ("voxel_size", ctypes.c_float * 3), ("coors_range", ctypes.c_float * 6),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/isf_hip.h declares
+_F3 = ctypes.c_float * 3
+_F6 = ctypes.c_float * 6
+_I3 = c_int * 3
+_I4 = c_int * 4
+SIGNATURES = {
+    "isf_version": (c_int, []),
+    "isf_last_error": (ctypes.c_char_p, []),
+    "isf_device_count": (c_int, [c_int_p]),
+    "isf_release_workspace": (c_int, []),
+    "isf_workspace_bytes": (c_int, [ctypes.POINTER(ctypes.c_size_t)]),
+    "isf_dynamic_voxelize": (c_int, [c_void_p, c_int, c_int, _F3, _F6, c_void_p, c_void_p]),
+    "isf_dynamic_voxelize_batched": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), c_int, c_int, _F3,
+                                             _F6, c_void_p, c_void_p]),
+    "isf_hard_voxelize": (c_int, [c_void_p, c_int, c_int, _F3, _F6, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_int_p, c_void_p]),
+    "isf_dynamic_point_to_voxel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                                   c_void_p, c_void_p, c_void_p, c_int_p, c_void_p]),
+    "isf_dynamic_point_to_voxel_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "isf_dynamic_vfe_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _F3, _F6, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_int_p, c_void_p]),
+    "isf_hard_simple_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_nbr_stride": (c_int, [c_int]),
+    "isf_conv_out_shape": (c_int, [_I3, _I3, _I3, _I3, _I3]),
+    "isf_build_rulebook": (c_int, [c_void_p, c_int, c_int, _I3, _I3, _I3, _I3, c_int, c_void_p, c_int,
+                                   c_void_p, c_int, c_int_p, c_void_p]),
+    "isf_rulebook_to_indice_pairs": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                             c_void_p]),
+    "isf_indice_pairs_to_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                             c_void_p]),
+    "isf_sparse_conv_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                        c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "isf_packed_filter_elems": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "isf_pack_filters": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_sparse_conv_forward_packed": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                               c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                               c_void_p]),
+    "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p]),
+    "isf_sparse_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, _I3,
+                                           ctypes.POINTER(ConvLayer), c_int, c_void_p, _I4,
+                                           ctypes.POINTER(EncoderStats), c_int, c_void_p]),
+    "isf_lidar_branch_forward": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), c_int,
+                                         ctypes.POINTER(VfeParams), _I3, ctypes.POINTER(ConvLayer), c_int,
+                                         c_void_p, _I4, ctypes.POINTER(EncoderStats), c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class IsfError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libisf_hip.so; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IsfError(
+            f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C is-fusion_amd/csrc).  isfusion_amd has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != ISF_OK:
+        msg = load().isf_last_error().decode("utf-8", "replace")
+        raise IsfError(f"{what or 'libisf_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise IsfError("isfusion_amd ops run on the GPU only (HIP kernels); got a CPU tensor. "
+                           "There is deliberately no CPU fallback.")
+
+
+def f3(v):
+    return _F3(*[float(x) for x in v])
+
+
+def f6(v):
+    return _F6(*[float(x) for x in v])
+
+
+def i3(v):
+    return _I3(*[int(x) for x in v])

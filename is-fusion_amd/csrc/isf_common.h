@@ -1,0 +1,131 @@
+// isf_common.h -- internal helpers shared by the HIP translation units of libisf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+#include "isf_hip.h"
+
+namespace isf {
+
+// ----------------------------------------------------------------------------- error handling
+void set_error(const char* fmt, ...);
+
+#define ISF_HIP_TRY(expr)                                                                   \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      ::isf::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return ISF_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+#define ISF_REQUIRE(cond, code, ...)  \
+  do {                                \
+    if (!(cond)) {                    \
+      ::isf::set_error(__VA_ARGS__);  \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define ISF_TRY(expr)          \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != ISF_OK) return _r; \
+  } while (0)
+
+#define ISF_LAUNCH_CHECK() ISF_HIP_TRY(hipGetLastError())
+
+// ----------------------------------------------------------------------------- workspace arena
+// Bump allocator over a few large hipMalloc'd blocks.  reset() at the start of every top-level API
+// call; if more than one block had to be created the arena is coalesced into one block at the next
+// reset (after a device sync), so the steady state is exactly one block and zero hipMalloc calls.
+class Arena {
+ public:
+  int reset();                              // start of a top-level call
+  int alloc(void** out, size_t bytes);      // 256-byte aligned
+  template <typename T>
+  int alloc_n(T** out, size_t n) { return alloc(reinterpret_cast<void**>(out), n * sizeof(T)); }
+  int release();
+  size_t capacity() const;
+ private:
+  struct Block { char* base; size_t cap; size_t off; };
+  std::vector<Block> blocks_;
+};
+
+Arena& arena_for_current_device();
+
+static inline hipStream_t as_stream(isf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ----------------------------------------------------------------------------- occupancy index
+// Minimal perfect hash of the active voxel set: one bit per grid cell + an exclusive popcount prefix
+// per 64-bit word.  rank(cell) = prefix[word] + popc(bits[word] & below(bit)) is the row of that voxel
+// in (b,z,y,x)-sorted order -- i.e. the order at::unique_dim(sorted=true) produces -- with no sort.
+struct OccIndex {
+  int B, D, H, W;
+  unsigned long long ncells;
+  size_t nwords;
+  unsigned long long* bits;  // [nwords]
+  uint32_t* prefix;          // [nwords] exclusive popcount prefix
+  int* total;                // device scalar: number of set bits
+};
+
+int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st);  // zeroed bits
+int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st);                           // prefix + total
+int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
+// coords of all set bits in rank order -> out [total,4]
+int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st);
+int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream sync
+
+__device__ __forceinline__ int occ_lookup(const unsigned long long* __restrict__ bits,
+                                          const uint32_t* __restrict__ prefix,
+                                          unsigned long long cell) {
+  const size_t w = (size_t)(cell >> 6);
+  const unsigned long long word = bits[w];
+  const unsigned long long bit = 1ull << (cell & 63);
+  if (!(word & bit)) return -1;
+  return (int)(prefix[w] + (uint32_t)__popcll(word & (bit - 1)));
+}
+
+// ----------------------------------------------------------------------------- internal ops (arena-aware)
+// isf_voxelize.hip
+int dynamic_voxelize_impl(const float* points, int P, int C, const float vs[3], const float range[6],
+                          int32_t* coors, int coors_stride, int coors_col0, int batch_idx,
+                          hipStream_t st);
+// isf_vfe.hip
+int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P, int Cin, int B,
+                     const float vs[3], const float range[6], const float* w1, const float* scale1,
+                     const float* shift1, int c1, const float* w2, const float* scale2,
+                     const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
+                     int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
+                     hipStream_t st);
+// isf_rulebook.hip
+int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int32_t** perm_out,
+               hipStream_t st);
+int launch_nbr(const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
+               const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
+               int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_);
+int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], const int ks[3],
+                    const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_);
+// isf_spconv.hip
+bool sparse_conv_mfma_supported(int c_in, int c_out);
+int pack_filters_impl(const float* w, int K, int cin, int cout, float* packed, hipStream_t st);
+int sparse_conv_forward_packed_impl(const float* x, int n_in, int c_in, const float* packed, int K,
+                                    int c_out, const int32_t* nbr, int nbr_stride, int n_out,
+                                    const float* scale, const float* shift, const float* residual,
+                                    int relu, float* y, hipStream_t st);
+int sparse_conv_forward_generic_impl(const float* x, int c_in, const float* w, int K, int c_out,
+                                     const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
+                                     const float* shift, const float* residual, int relu, float* y,
+                                     hipStream_t st);
+// isf_encoder.hip
+int sparse_to_dense_bev_impl(Arena& a, const float* feats, const int32_t* indices, int n, int C,
+                             int B, int D, int H, int W, float* out, const OccIndex* occ,
+                             hipStream_t st);
+
+}  // namespace isf

@@ -1,0 +1,355 @@
+// isf_encoder.hip -- A7: dense BEV write-out, SparseEncoder.forward and the fused LiDAR branch.
+#include "isf_common.h"
+
+#include <algorithm>
+
+namespace isf {
+
+// ----------------------------------------------------------------------------------------- dense BEV
+// out[b, c*D + z, y, x] = feats[row(b,z,y,x), c] or 0.  Dense-stationary: a workgroup owns 64 consecutive
+// x cells of one (b, y) line, looks the <= 64*D rows up in the occupancy index, transposes 64x64 blocks
+// through LDS and writes 256-B runs; every output element is written exactly once (no memset pass).
+static constexpr int kDenseX = 64;
+
+__global__ __launch_bounds__(256) void dense_bev_kernel(const float* __restrict__ feats, int C, int D,
+                                                        int H, int W,
+                                                        const unsigned long long* __restrict__ bits,
+                                                        const uint32_t* __restrict__ prefix,
+                                                        const int32_t* __restrict__ perm,
+                                                        float* __restrict__ out) {
+  __shared__ float tile[64][kDenseX + 1];
+  __shared__ int rows[kDenseX];
+  const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+  const int x0 = xt * kDenseX;
+  const int t = threadIdx.x;
+  for (int z = 0; z < D; ++z) {
+    __syncthreads();
+    if (t < kDenseX) {
+      int r = -1;
+      const int x = x0 + t;
+      if (x < W) {
+        r = occ_lookup(bits, prefix, (((unsigned long long)b * D + z) * H + y) * W + x);
+        if (r >= 0 && perm) r = perm[r];
+      }
+      rows[t] = r;
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      // load: thread -> (row xx = t/16 + 16*j, 4 channels c0 + 4*(t%16))
+      const int c4 = (t & 15) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xx = (t >> 4) + 16 * j;
+        const int r = rows[xx];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0 && c0 + c4 < C) v = *reinterpret_cast<const float4*>(feats + (size_t)r * C + c0 + c4);
+        tile[c4 + 0][xx] = v.x;
+        tile[c4 + 1][xx] = v.y;
+        tile[c4 + 2][xx] = v.z;
+        tile[c4 + 3][xx] = v.w;
+      }
+      __syncthreads();
+      // store: lane -> x, wave -> channel stripe
+      const int lane = t & 63, wv = t >> 6;
+      if (x0 + lane < W) {
+        for (int cc = wv; cc < 64 && c0 + cc < C; cc += 4) {
+          const size_t ch = (size_t)(c0 + cc) * D + z;
+          out[(((size_t)b * C * D + ch) * H + y) * W + x0 + lane] = tile[cc][lane];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int sparse_to_dense_bev_impl(Arena& a, const float* feats, const int32_t* indices, int n, int C, int B,
+                             int D, int H, int W, float* out, const OccIndex* occ_in, hipStream_t st) {
+  ISF_REQUIRE(C % 4 == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of 4", C);
+  OccIndex occ;
+  const int32_t* perm = nullptr;
+  if (occ_in) {
+    occ = *occ_in;  // rows already in rank order
+  } else {
+    ISF_TRY(occ_create(a, &occ, B, D, H, W, st));
+    ISF_TRY(occ_mark_coords4(occ, indices, n, st));
+    ISF_TRY(occ_scan(a, occ, st));
+    int32_t* p = nullptr;
+    ISF_TRY(build_perm(a, occ, indices, n, &p, st));
+    perm = p;
+  }
+  dim3 grid(ceil_div(W, kDenseX), H, B);
+  hipLaunchKernelGGL(dense_bev_kernel, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix, perm, out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+__global__ void check_rank_order_kernel(const int32_t* __restrict__ coors4, int n, int D, int H, int W,
+                                        const unsigned long long* __restrict__ bits,
+                                        const uint32_t* __restrict__ prefix, int* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coors4)[i];
+  int r = -1;
+  if (c.x >= 0 && c.y >= 0 && c.z >= 0 && c.w >= 0 && c.y < D && c.z < H && c.w < W)
+    r = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
+  if (r != i) *flag = 1;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ perm, int n, int C,
+                                   float* __restrict__ xs) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * C) return;
+  xs[t] = x[(size_t)perm[t / C] * C + (t % C)];
+}
+
+// ----------------------------------------------------------------------------------------- encoder
+struct LevelState {
+  int shape[3];
+  int n;                  // active rows (host)
+  const int32_t* coors;   // [n,4] sorted
+  OccIndex occ;
+  bool has_occ;
+  // SubM rulebook cache for this level (all SubM convs of one level share the active set)
+  int cache_ks[3];
+  int32_t* cache_nbr;
+  int cache_stride;
+  long long cache_pairs;
+};
+
+static int ensure_occ(Arena& a, LevelState& L, int B, hipStream_t st) {
+  if (L.has_occ) return ISF_OK;
+  ISF_TRY(occ_create(a, &L.occ, B, L.shape[0], L.shape[1], L.shape[2], st));
+  ISF_TRY(occ_mark_coords4(L.occ, L.coors, L.n, st));
+  ISF_TRY(occ_scan(a, L.occ, st));
+  L.has_occ = true;
+  return ISF_OK;
+}
+
+int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0, int n0, int B,
+                                const int shape0[3], const OccIndex* occ0, const isf_conv_layer* layers,
+                                int num_layers, float* spatial_features, int out_shape[4],
+                                isf_encoder_stats* stats, int time_layers, hipStream_t st) {
+  ISF_REQUIRE(num_layers > 0 && num_layers <= 32, ISF_ERR_ARG, "sparse_encoder: %d layers (1..32)", num_layers);
+  LevelState L;
+  for (int j = 0; j < 3; ++j) L.shape[j] = shape0[j];
+  L.n = n0;
+  L.coors = coors0;
+  L.has_occ = false;
+  if (occ0) { L.occ = *occ0; L.has_occ = true; }
+  L.cache_nbr = nullptr;
+  const float* outputs[32];
+  int out_rows[32];
+  const float* x = x0;
+  unsigned long long* pair_counts = nullptr;
+  ISF_TRY(a.alloc_n(&pair_counts, 32));
+  ISF_HIP_TRY(hipMemsetAsync(pair_counts, 0, 32 * sizeof(unsigned long long), st));
+  std::vector<hipEvent_t> ev;
+  if (time_layers && stats) {
+    ev.resize((size_t)num_layers * 2);
+    for (auto& e : ev) ISF_HIP_TRY(hipEventCreate(&e));
+  }
+  int c_last = layers[0].c_in;
+  for (int i = 0; i < num_layers; ++i) {
+    const isf_conv_layer& ly = layers[i];
+    const int K = ly.ksize[0] * ly.ksize[1] * ly.ksize[2];
+    ISF_REQUIRE(K >= 1 && K <= 27, ISF_ERR_UNSUPPORTED, "sparse_encoder: layer %d has %d taps", i, K);
+    ISF_REQUIRE(ly.c_in == c_last, ISF_ERR_ARG, "sparse_encoder: layer %d expects %d channels, got %d", i, ly.c_in, c_last);
+    int32_t* nbr = nullptr;
+    int stride = 0;
+    int n_out = L.n;
+    int n_in = L.n;
+    if (ly.conv_type == ISF_CONV_SUBM) {
+      const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
+                       L.cache_ks[2] == ly.ksize[2];
+      if (!hit) {
+        ISF_TRY(ensure_occ(a, L, B, st));
+        stride = isf_nbr_stride(L.n);
+        ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
+        ISF_TRY(launch_nbr(L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
+                           stride, pair_counts + i, st));
+        L.cache_nbr = nbr;
+        L.cache_stride = stride;
+        for (int j = 0; j < 3; ++j) L.cache_ks[j] = ly.ksize[j];
+        L.cache_pairs = -(long long)i - 1;  // pairs live in pair_counts[i]; resolved after the final sync
+      } else {
+        nbr = L.cache_nbr;
+        stride = L.cache_stride;
+      }
+      if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
+    } else {
+      ISF_TRY(ensure_occ(a, L, B, st));
+      LevelState Nx;
+      ISF_TRY(isf_conv_out_shape(L.shape, ly.ksize, ly.stride, ly.padding, Nx.shape));
+      ISF_REQUIRE(Nx.shape[0] > 0 && Nx.shape[1] > 0 && Nx.shape[2] > 0, ISF_ERR_ARG,
+                  "sparse_encoder: layer %d output shape empty", i);
+      ISF_TRY(occ_create(a, &Nx.occ, B, Nx.shape[0], Nx.shape[1], Nx.shape[2], st));
+      ISF_TRY(launch_mark_out(L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, Nx.occ, st));
+      ISF_TRY(occ_scan(a, Nx.occ, st));
+      ISF_TRY(read_int(Nx.occ.total, &Nx.n, st));  // host sync: sizes the next level's buffers / grids
+      Nx.has_occ = true;
+      int32_t* nc = nullptr;
+      ISF_TRY(a.alloc_n(&nc, (size_t)std::max(Nx.n, 1) * 4));
+      if (Nx.n > 0) ISF_TRY(occ_compact_coords4(Nx.occ, nc, st));
+      Nx.coors = nc;
+      stride = isf_nbr_stride(Nx.n);
+      ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
+      ISF_TRY(launch_nbr(Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
+                         stride, pair_counts + i, st));
+      if (stats) stats->pairs[i] = -(long long)i - 1;
+      Nx.cache_nbr = nullptr;
+      n_out = Nx.n;
+      L = Nx;
+    }
+    float* y = nullptr;
+    ISF_TRY(a.alloc_n(&y, (size_t)std::max(n_out, 1) * ly.c_out));
+    const float* res = nullptr;
+    if (ly.residual_from == -1) res = x0;
+    else if (ly.residual_from >= 0) {
+      ISF_REQUIRE(ly.residual_from < i && out_rows[ly.residual_from] == n_out, ISF_ERR_ARG,
+                  "sparse_encoder: layer %d residual source %d incompatible", i, ly.residual_from);
+      res = outputs[ly.residual_from];
+    }
+    if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i], st));
+    if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
+      ISF_TRY(sparse_conv_forward_packed_impl(x, n_in, ly.c_in, ly.packed, K, ly.c_out, nbr, stride, n_out,
+                                              ly.scale, ly.shift, res, ly.relu, y, st));
+    else
+      ISF_TRY(sparse_conv_forward_generic_impl(x, ly.c_in, ly.packed, K, ly.c_out, nbr, stride, n_out, ly.scale,
+                                               ly.shift, res, ly.relu, y, st));
+    if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
+    outputs[i] = y;
+    out_rows[i] = n_out;
+    if (stats) { stats->num_in[i] = n_in; stats->num_out[i] = n_out; stats->ms[i] = 0.f; }
+    x = y;
+    c_last = ly.c_out;
+  }
+  // dense BEV of the last level
+  ISF_TRY(ensure_occ(a, L, B, st));
+  ISF_TRY(sparse_to_dense_bev_impl(a, x, L.coors, L.n, c_last, B, L.shape[0], L.shape[1], L.shape[2],
+                                   spatial_features, &L.occ, st));
+  if (out_shape) { out_shape[0] = c_last * L.shape[0]; out_shape[1] = L.shape[1]; out_shape[2] = L.shape[2]; out_shape[3] = L.n; }
+  if (stats) {
+    unsigned long long h_pairs[32];
+    ISF_HIP_TRY(hipMemcpyAsync(h_pairs, pair_counts, sizeof(h_pairs), hipMemcpyDeviceToHost, st));
+    ISF_HIP_TRY(hipStreamSynchronize(st));
+    stats->num_layers = num_layers;
+    for (int i = 0; i < num_layers; ++i)
+      if (stats->pairs[i] < 0) stats->pairs[i] = (long long)h_pairs[-(stats->pairs[i] + 1)];
+    for (int i = 0; i < num_layers && !ev.empty(); ++i)
+      ISF_HIP_TRY(hipEventElapsedTime(&stats->ms[i], ev[2 * i], ev[2 * i + 1]));
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return ISF_OK;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_sparse_to_dense_bev(const float* features, const int32_t* indices, int num_rows, int channels,
+                            int batch_size, int D, int H, int W, float* out, isf_stream_t stream) {
+  ISF_REQUIRE(num_rows >= 0 && channels > 0 && batch_size > 0 && D > 0 && H > 0 && W > 0 && out, ISF_ERR_ARG,
+              "sparse_to_dense_bev: bad arguments");
+  ISF_REQUIRE(num_rows == 0 || (features && indices), ISF_ERR_ARG, "sparse_to_dense_bev: null pointer");
+  isf::Arena& a = isf::arena_for_current_device();
+  ISF_TRY(a.reset());
+  return isf::sparse_to_dense_bev_impl(a, features, indices, num_rows, channels, batch_size, D, H, W, out,
+                                       nullptr, isf::as_stream(stream));
+}
+
+int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors, int num_voxels,
+                               int batch_size, const int sparse_shape_host[3],
+                               const isf_conv_layer* layers_host, int num_layers, float* spatial_features,
+                               int out_shape_host[4], isf_encoder_stats* stats_host, int time_layers,
+                               isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(num_voxels > 0 && batch_size > 0 && sparse_shape_host && layers_host && spatial_features &&
+                  voxel_features && coors && num_layers > 0,
+              ISF_ERR_ARG, "sparse_encoder_forward: bad arguments");
+  hipStream_t st = as_stream(stream);
+  Arena& a = arena_for_current_device();
+  ISF_TRY(a.reset());
+  // The kernels want rows in rank ((b,z,y,x)-sorted) order, which is what DynamicVFE emits.  Verify it on
+  // the device; arbitrary / duplicated input rows (e.g. the reference's shape test feeds random coords)
+  // are re-ranked once: x_sorted[rank(coord_i)] = x[i] (a duplicate coordinate keeps one of its rows).
+  OccIndex occ0;
+  ISF_TRY(occ_create(a, &occ0, batch_size, sparse_shape_host[0], sparse_shape_host[1], sparse_shape_host[2], st));
+  ISF_TRY(occ_mark_coords4(occ0, coors, num_voxels, st));
+  ISF_TRY(occ_scan(a, occ0, st));
+  int* flag = nullptr;
+  ISF_TRY(a.alloc_n(&flag, 64));
+  ISF_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
+  hipLaunchKernelGGL(check_rank_order_kernel, dim3(ceil_div(num_voxels, 256)), dim3(256), 0, st, coors,
+                     num_voxels, occ0.D, occ0.H, occ0.W, occ0.bits, occ0.prefix, flag);
+  ISF_LAUNCH_CHECK();
+  int h[2] = {0, 0};
+  ISF_HIP_TRY(hipMemcpyAsync(&h[0], flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  ISF_HIP_TRY(hipMemcpyAsync(&h[1], occ0.total, sizeof(int), hipMemcpyDeviceToHost, st));
+  ISF_HIP_TRY(hipStreamSynchronize(st));
+  const float* x = voxel_features;
+  const int32_t* c = coors;
+  int n = num_voxels;
+  if (h[0] != 0 || h[1] != num_voxels) {
+    n = h[1];
+    ISF_REQUIRE(n > 0, ISF_ERR_ARG, "sparse_encoder_forward: no coordinate inside sparse_shape");
+    int32_t* perm = nullptr;
+    ISF_TRY(build_perm(a, occ0, coors, num_voxels, &perm, st));
+    int32_t* cs = nullptr;
+    float* xs = nullptr;
+    const int C = layers_host[0].c_in;
+    ISF_TRY(a.alloc_n(&cs, (size_t)n * 4));
+    ISF_TRY(a.alloc_n(&xs, (size_t)n * C));
+    ISF_TRY(occ_compact_coords4(occ0, cs, st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long long)n * C, 256)), dim3(256), 0, st,
+                       voxel_features, perm, n, C, xs);
+    ISF_LAUNCH_CHECK();
+    x = xs;
+    c = cs;
+  }
+  return sparse_encoder_forward_impl(a, x, c, n, batch_size, sparse_shape_host, &occ0, layers_host, num_layers,
+                                     spatial_features, out_shape_host, stats_host, time_layers, st);
+}
+
+int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_host, int batch_size,
+                             const isf_vfe_params* vfe_host, const int sparse_shape_host[3],
+                             const isf_conv_layer* layers_host, int num_layers, float* spatial_features,
+                             int out_shape_host[4], isf_encoder_stats* stats_host, int time_layers,
+                             isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(points && point_offsets_host && batch_size > 0 && vfe_host && sparse_shape_host && layers_host &&
+                  spatial_features,
+              ISF_ERR_ARG, "lidar_branch_forward: bad arguments");
+  hipStream_t st = as_stream(stream);
+  Arena& a = arena_for_current_device();
+  ISF_TRY(a.reset());
+  const int64_t P64 = point_offsets_host[batch_size];
+  ISF_REQUIRE(P64 > 0 && P64 < (1ll << 31), ISF_ERR_ARG, "lidar_branch_forward: bad point count");
+  const int P = (int)P64;
+  const int Cin = vfe_host->in_channels;
+  int32_t* coors4 = nullptr;
+  ISF_TRY(a.alloc_n(&coors4, (size_t)P * 4));
+  for (int b = 0; b < batch_size; ++b) {
+    const int64_t lo = point_offsets_host[b], hi = point_offsets_host[b + 1];
+    ISF_REQUIRE(hi >= lo, ISF_ERR_ARG, "lidar_branch_forward: bad offsets");
+    ISF_TRY(dynamic_voxelize_impl(points + lo * Cin, (int)(hi - lo), Cin, vfe_host->voxel_size,
+                                  vfe_host->coors_range, coors4 + lo * 4, 4, 1, b, st));
+  }
+  float* vf = nullptr;
+  int32_t* vc = nullptr;
+  ISF_TRY(a.alloc_n(&vf, (size_t)P * vfe_host->c2));
+  ISF_TRY(a.alloc_n(&vc, (size_t)P * 4));
+  int n0 = 0;
+  OccIndex occ0;
+  ISF_TRY(dynamic_vfe_impl(a, points, coors4, P, Cin, batch_size, vfe_host->voxel_size, vfe_host->coors_range,
+                           vfe_host->w1, vfe_host->scale1, vfe_host->shift1, vfe_host->c1, vfe_host->w2,
+                           vfe_host->scale2, vfe_host->shift2, vfe_host->c2, vf, vc, nullptr, &n0, &occ0,
+                           sparse_shape_host[0], st));
+  ISF_REQUIRE(n0 > 0, ISF_ERR_ARG, "lidar_branch_forward: no point falls inside the voxel grid");
+  const bool occ_ok = occ0.D == sparse_shape_host[0] && occ0.H == sparse_shape_host[1] &&
+                      occ0.W == sparse_shape_host[2];
+  return sparse_encoder_forward_impl(a, vf, vc, n0, batch_size, sparse_shape_host, occ_ok ? &occ0 : nullptr,
+                                     layers_host, num_layers, spatial_features, out_shape_host, stats_host,
+                                     time_layers, st);
+}
+
+}  // extern "C"

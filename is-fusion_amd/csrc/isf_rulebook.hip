@@ -1,0 +1,302 @@
+// isf_rulebook.hip -- A5 sparse-conv rulebook as an OUTPUT-stationary neighbour table.
+//
+// Reference (spconv 1.x, indice.cu.h:22-203 / geometry.h): a dense int32 grid of B*D*H*W entries per
+// call (340 MB/sample at level 0) + per-tap (in,out) pair lists built with atomics, and a sort-unique
+// for strided convs.  Here the active set of a level lives in a 1-bit-per-cell occupancy index whose
+// popcount rank IS the row number (sorted (b,z,y,x) order), so
+//   - SubM:    nbr[k][o] = rank(coord(o) + offset(k))                   (27 bit tests per voxel)
+//   - strided: mark out = (in + pad - k)/stride in a fresh bitmap -> scan -> rows; nbr by lookup.
+// Rows are sorted by (b,z,y,x), so consecutive threads probe neighbouring words: the probes are
+// L2-local.  The table layout nbr[K][stride] makes the conv kernel's per-tap tile loads contiguous.
+#include "isf_common.h"
+
+namespace isf {
+
+struct RbGeom {
+  int ks[3], st[3], pd[3];
+  int in_shape[3], out_shape[3];
+};
+
+__global__ void rb_perm_kernel(const int32_t* __restrict__ coors4, int n, int D, int H, int W,
+                               const unsigned long long* __restrict__ bits,
+                               const uint32_t* __restrict__ prefix, int32_t* __restrict__ perm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coors4)[i];
+  const int r = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
+  if (r >= 0) perm[r] = i;
+}
+
+// thread per output row (rows >= n_out up to nbr_stride are filled with -1)
+__global__ __launch_bounds__(256) void rb_nbr_kernel(const int32_t* __restrict__ out_coors4, int n_out,
+                                                     RbGeom g,
+                                                     const unsigned long long* __restrict__ in_bits,
+                                                     const uint32_t* __restrict__ in_prefix,
+                                                     const int32_t* __restrict__ perm,
+                                                     int32_t* __restrict__ nbr, int nbr_stride,
+                                                     unsigned long long* __restrict__ pair_count) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  int found = 0;
+  if (o < nbr_stride) {
+    const int K = g.ks[0] * g.ks[1] * g.ks[2];
+    if (o >= n_out) {
+      for (int k = 0; k < K; ++k) nbr[(size_t)k * nbr_stride + o] = -1;
+    } else {
+      const int4 c = reinterpret_cast<const int4*>(out_coors4)[o];
+      const unsigned long long bbase = (unsigned long long)c.x * g.in_shape[0];
+      int k = 0;
+      for (int kz = 0; kz < g.ks[0]; ++kz) {
+        const int iz = c.y * g.st[0] - g.pd[0] + kz;
+        for (int ky = 0; ky < g.ks[1]; ++ky) {
+          const int iy = c.z * g.st[1] - g.pd[1] + ky;
+          for (int kx = 0; kx < g.ks[2]; ++kx, ++k) {
+            const int ix = c.w * g.st[2] - g.pd[2] + kx;
+            int r = -1;
+            if (iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && ix >= 0 &&
+                ix < g.in_shape[2]) {
+              r = occ_lookup(in_bits, in_prefix, ((bbase + iz) * g.in_shape[1] + iy) * g.in_shape[2] + ix);
+              if (r >= 0 && perm) r = perm[r];
+            }
+            found += (r >= 0);
+            nbr[(size_t)k * nbr_stride + o] = r;
+          }
+        }
+      }
+    }
+  }
+  if (pair_count) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d, 64);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(pair_count, (unsigned long long)found);
+  }
+}
+
+// strided conv: every input voxel marks the outputs it feeds
+__global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restrict__ in_coors4, int n_in,
+                                                          RbGeom g,
+                                                          unsigned long long* __restrict__ out_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  const int4 c = reinterpret_cast<const int4*>(in_coors4)[i];
+  const unsigned long long bbase = (unsigned long long)c.x * g.out_shape[0];
+  for (int kz = 0; kz < g.ks[0]; ++kz) {
+    const int tz = c.y + g.pd[0] - kz;
+    if (tz < 0 || tz % g.st[0]) continue;
+    const int oz = tz / g.st[0];
+    if (oz >= g.out_shape[0]) continue;
+    for (int ky = 0; ky < g.ks[1]; ++ky) {
+      const int ty = c.z + g.pd[1] - ky;
+      if (ty < 0 || ty % g.st[1]) continue;
+      const int oy = ty / g.st[1];
+      if (oy >= g.out_shape[1]) continue;
+      for (int kx = 0; kx < g.ks[2]; ++kx) {
+        const int tx = c.w + g.pd[2] - kx;
+        if (tx < 0 || tx % g.st[2]) continue;
+        const int ox = tx / g.st[2];
+        if (ox >= g.out_shape[2]) continue;
+        const unsigned long long cell = ((bbase + oz) * g.out_shape[1] + oy) * g.out_shape[2] + ox;
+        const unsigned long long bit = 1ull << (cell & 63);
+        unsigned long long* p = out_bits + (cell >> 6);
+        if (!(*p & bit)) atomicOr(p, bit);
+      }
+    }
+  }
+}
+
+static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[3], const int pd[3],
+                           bool subm) {
+  RbGeom g;
+  for (int j = 0; j < 3; ++j) {
+    g.ks[j] = ks[j];
+    g.st[j] = subm ? 1 : st[j];
+    g.pd[j] = subm ? ks[j] / 2 : pd[j];  // spconv_ops.h:76-79
+    g.in_shape[j] = in_shape[j];
+    g.out_shape[j] = subm ? in_shape[j] : (in_shape[j] + 2 * g.pd[j] - (ks[j] - 1) - 1) / g.st[j] + 1;
+  }
+  return g;
+}
+
+int launch_nbr(const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
+               const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
+               int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_) {
+  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, subm);
+  hipLaunchKernelGGL(rb_nbr_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st_, out_coors4,
+                     n_out, g, in_occ.bits, in_occ.prefix, perm, nbr, nbr_stride, pair_count);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], const int ks[3],
+                    const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_) {
+  if (n_in <= 0) return ISF_OK;
+  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, false);
+  hipLaunchKernelGGL(rb_mark_out_kernel, dim3(ceil_div(n_in, 256)), dim3(256), 0, st_, in_coors4, n_in, g,
+                     out_occ.bits);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int32_t** perm_out,
+               hipStream_t st) {
+  int32_t* perm = nullptr;
+  ISF_TRY(a.alloc_n(&perm, (size_t)(n > 0 ? n : 1)));
+  if (n > 0) {
+    hipLaunchKernelGGL(rb_perm_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, coors4, n, occ.D, occ.H,
+                       occ.W, occ.bits, occ.prefix, perm);
+    ISF_LAUNCH_CHECK();
+  }
+  *perm_out = perm;
+  return ISF_OK;
+}
+
+// ------------------------------------------------------------------------------- spconv-1 interchange
+// one workgroup per tap: ordered compaction of the valid rows of nbr[k][:]
+__global__ __launch_bounds__(1024) void rb_to_pairs_kernel(const int32_t* __restrict__ nbr, int nbr_stride,
+                                                           int n_out, int n_in,
+                                                           int32_t* __restrict__ pairs,
+                                                           int32_t* __restrict__ num) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base_s;
+  const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t* pin = pairs + ((size_t)k * 2 + 0) * n_in;
+  int32_t* pout = pairs + ((size_t)k * 2 + 1) * n_in;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int o0 = 0; o0 < n_out; o0 += 1024) {
+    const int o = o0 + threadIdx.x;
+    const int v = o < n_out ? nbr[(size_t)k * nbr_stride + o] : -1;
+    const unsigned long long m = __ballot(v >= 0);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (v >= 0) {
+      const int pos = off + __popcll(m & ((1ull << lane) - 1));
+      pin[pos] = v;
+      pout[pos] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_cnt[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  const int total = base_s;
+  for (int s = total + threadIdx.x; s < n_in; s += 1024) { pin[s] = -1; pout[s] = -1; }
+  if (threadIdx.x == 0) num[k] = total;
+}
+
+__global__ void rb_from_pairs_kernel(const int32_t* __restrict__ pairs, const int32_t* __restrict__ num,
+                                     int K, int n_in, int n_out, int32_t* __restrict__ nbr,
+                                     int nbr_stride) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)K * n_in) return;
+  const int k = (int)(t / n_in), s = (int)(t % n_in);
+  if (s >= num[k]) return;
+  const int i = pairs[((size_t)k * 2 + 0) * n_in + s];
+  const int o = pairs[((size_t)k * 2 + 1) * n_in + s];
+  if (i >= 0 && o >= 0 && o < n_out) nbr[(size_t)k * nbr_stride + o] = i;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_nbr_stride(int num_rows) { return (int)isf::round_up((size_t)(num_rows > 0 ? num_rows : 1), 128); }
+
+int isf_conv_out_shape(const int in_shape_host[3], const int ksize_host[3], const int stride_host[3],
+                       const int padding_host[3], int out_shape_host[3]) {
+  if (!in_shape_host || !ksize_host || !stride_host || !padding_host || !out_shape_host) return ISF_ERR_ARG;
+  for (int j = 0; j < 3; ++j) {
+    if (stride_host[j] <= 0 || ksize_host[j] <= 0) return ISF_ERR_ARG;
+    out_shape_host[j] = (in_shape_host[j] + 2 * padding_host[j] - (ksize_host[j] - 1) - 1) / stride_host[j] + 1;
+  }
+  return ISF_OK;
+}
+
+int isf_build_rulebook(const int32_t* indices, int num_in, int batch_size, const int spatial_shape_host[3],
+                       const int ksize_host[3], const int stride_host[3], const int padding_host[3],
+                       int conv_type, int32_t* out_indices, int out_capacity, int32_t* nbr, int nbr_stride,
+                       int* num_out_host, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(num_in >= 0 && batch_size > 0 && spatial_shape_host && ksize_host && stride_host &&
+                  padding_host && nbr && num_out_host,
+              ISF_ERR_ARG, "build_rulebook: bad arguments");
+  const int K = ksize_host[0] * ksize_host[1] * ksize_host[2];
+  ISF_REQUIRE(K >= 1 && K <= 27, ISF_ERR_UNSUPPORTED, "build_rulebook: kernel volume %d (max 27)", K);
+  hipStream_t st = as_stream(stream);
+  Arena& a = arena_for_current_device();
+  ISF_TRY(a.reset());
+  const bool subm = conv_type == ISF_CONV_SUBM;
+  *num_out_host = 0;
+  if (num_in == 0) {
+    ISF_HIP_TRY(hipMemsetAsync(nbr, 0xff, (size_t)K * nbr_stride * sizeof(int32_t), st));
+    return ISF_OK;
+  }
+  ISF_REQUIRE(indices, ISF_ERR_ARG, "build_rulebook: null indices");
+  OccIndex in_occ;
+  ISF_TRY(occ_create(a, &in_occ, batch_size, spatial_shape_host[0], spatial_shape_host[1],
+                     spatial_shape_host[2], st));
+  ISF_TRY(occ_mark_coords4(in_occ, indices, num_in, st));
+  ISF_TRY(occ_scan(a, in_occ, st));
+  int32_t* perm = nullptr;
+  ISF_TRY(build_perm(a, in_occ, indices, num_in, &perm, st));
+  if (subm) {
+    ISF_REQUIRE(nbr_stride >= isf_nbr_stride(num_in), ISF_ERR_CAPACITY, "build_rulebook: nbr_stride too small");
+    ISF_TRY(launch_nbr(indices, num_in, spatial_shape_host, ksize_host, stride_host, padding_host, true,
+                       in_occ, perm, nbr, nbr_stride, nullptr, st));
+    if (out_indices && out_indices != indices)
+      ISF_HIP_TRY(hipMemcpyAsync(out_indices, indices, (size_t)num_in * 4 * sizeof(int32_t),
+                                 hipMemcpyDeviceToDevice, st));
+    *num_out_host = num_in;
+    return ISF_OK;
+  }
+  int out_shape[3];
+  ISF_TRY(isf_conv_out_shape(spatial_shape_host, ksize_host, stride_host, padding_host, out_shape));
+  ISF_REQUIRE(out_shape[0] > 0 && out_shape[1] > 0 && out_shape[2] > 0, ISF_ERR_ARG,
+              "build_rulebook: empty output shape");
+  OccIndex out_occ;
+  ISF_TRY(occ_create(a, &out_occ, batch_size, out_shape[0], out_shape[1], out_shape[2], st));
+  ISF_TRY(launch_mark_out(indices, num_in, spatial_shape_host, ksize_host, stride_host, padding_host,
+                          out_occ, st));
+  ISF_TRY(occ_scan(a, out_occ, st));
+  int n_out = 0;
+  ISF_TRY(read_int(out_occ.total, &n_out, st));
+  ISF_REQUIRE(out_indices && n_out <= out_capacity, ISF_ERR_CAPACITY,
+              "build_rulebook: %d outputs exceed out_capacity %d", n_out, out_capacity);
+  ISF_REQUIRE(nbr_stride >= isf_nbr_stride(n_out), ISF_ERR_CAPACITY, "build_rulebook: nbr_stride too small");
+  ISF_TRY(occ_compact_coords4(out_occ, out_indices, st));
+  ISF_TRY(launch_nbr(out_indices, n_out, spatial_shape_host, ksize_host, stride_host, padding_host, false,
+                     in_occ, perm, nbr, nbr_stride, nullptr, st));
+  *num_out_host = n_out;
+  return ISF_OK;
+}
+
+int isf_rulebook_to_indice_pairs(const int32_t* nbr, int nbr_stride, int num_out, int num_taps, int num_in,
+                                 int32_t* indice_pairs, int32_t* indice_num, isf_stream_t stream) {
+  ISF_REQUIRE(nbr && indice_pairs && indice_num && num_taps > 0 && num_in >= 0 && num_out >= 0, ISF_ERR_ARG,
+              "rulebook_to_indice_pairs: bad arguments");
+  if (num_in == 0) return ISF_OK;
+  hipLaunchKernelGGL(isf::rb_to_pairs_kernel, dim3(num_taps), dim3(1024), 0, isf::as_stream(stream), nbr,
+                     nbr_stride, num_out, num_in, indice_pairs, indice_num);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_indice_pairs_to_rulebook(const int32_t* indice_pairs, const int32_t* indice_num, int num_taps,
+                                 int num_in, int num_out, int32_t* nbr, int nbr_stride, isf_stream_t stream) {
+  ISF_REQUIRE(indice_pairs && indice_num && nbr && num_taps > 0 && num_in >= 0 && num_out >= 0 &&
+                  nbr_stride >= isf_nbr_stride(num_out),
+              ISF_ERR_ARG, "indice_pairs_to_rulebook: bad arguments");
+  hipStream_t st = isf::as_stream(stream);
+  ISF_HIP_TRY(hipMemsetAsync(nbr, 0xff, (size_t)num_taps * nbr_stride * sizeof(int32_t), st));
+  if (num_in == 0) return ISF_OK;
+  hipLaunchKernelGGL(isf::rb_from_pairs_kernel, dim3(isf::ceil_div((long long)num_taps * num_in, 256)),
+                     dim3(256), 0, st, indice_pairs, indice_num, num_taps, num_in, num_out, nbr, nbr_stride);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// isf_runtime.hip -- error state, per-device workspace arena, occupancy-index (rank bitmap) kernels.
+#include "isf_common.h"
+
+#include <mutex>
+
+namespace isf {
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------ arena
+static const size_t kMinBlock = (size_t)64 << 20;
+
+int Arena::reset() {
+  if (blocks_.size() > 1) {  // coalesce into one block so the steady state never calls hipMalloc
+    size_t total = 0;
+    for (auto& b : blocks_) total += b.cap;
+    ISF_HIP_TRY(hipDeviceSynchronize());
+    for (auto& b : blocks_) ISF_HIP_TRY(hipFree(b.base));
+    blocks_.clear();
+    char* p = nullptr;
+    size_t want = total + total / 4;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("arena: hipMalloc(%zu) failed", want);
+      return ISF_ERR_NOMEM;
+    }
+    blocks_.push_back({p, want, 0});
+  }
+  for (auto& b : blocks_) b.off = 0;
+  return ISF_OK;
+}
+
+int Arena::alloc(void** out, size_t bytes) {
+  bytes = round_up(bytes ? bytes : 1, 256);
+  for (auto& b : blocks_) {
+    if (b.off + bytes <= b.cap) {
+      *out = b.base + b.off;
+      b.off += bytes;
+      return ISF_OK;
+    }
+  }
+  size_t cap = bytes > kMinBlock ? bytes : kMinBlock;
+  char* p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("arena: hipMalloc(%zu) failed", cap);
+    return ISF_ERR_NOMEM;
+  }
+  blocks_.push_back({p, cap, bytes});
+  *out = p;
+  return ISF_OK;
+}
+
+int Arena::release() {
+  if (!blocks_.empty()) ISF_HIP_TRY(hipDeviceSynchronize());
+  for (auto& b : blocks_) ISF_HIP_TRY(hipFree(b.base));
+  blocks_.clear();
+  return ISF_OK;
+}
+
+size_t Arena::capacity() const {
+  size_t t = 0;
+  for (auto& b : blocks_) t += b.cap;
+  return t;
+}
+
+static Arena g_arenas[16];
+
+Arena& arena_for_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  return g_arenas[dev];
+}
+
+int read_int(const int* dev, int* host, hipStream_t st) {
+  ISF_HIP_TRY(hipMemcpyAsync(host, dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  ISF_HIP_TRY(hipStreamSynchronize(st));
+  return ISF_OK;
+}
+
+// ------------------------------------------------------------------------------------ occupancy index
+// Three streaming kernels over the bitmap words: per-block popcount totals -> scan of the block totals
+// -> per-word exclusive prefix.  HBM-bound integer work: reads the bitmap twice, writes nwords*4 B.
+static constexpr int kScanThreads = 256;
+static constexpr int kWordsPerThread = 4;
+static constexpr int kWordsPerBlock = kScanThreads * kWordsPerThread;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+  // wave-level inclusive scan with DPP-free shuffles (64-wide), then scan of the 4 wave totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    uint32_t s = lds[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void occ_block_count_kernel(
+    const unsigned long long* __restrict__ bits, size_t nwords, uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t lds[kScanThreads / 64];
+  const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+  uint32_t c = 0;
+  if (w0 + kWordsPerThread <= nwords) {
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(bits + w0);
+    ulonglong2 a = p[0], b = p[1];
+    c = __popcll(a.x) + __popcll(a.y) + __popcll(b.x) + __popcll(b.y);
+  } else {
+    for (int i = 0; i < kWordsPerThread; ++i)
+      if (w0 + i < nwords) c += __popcll(bits[w0 + i]);
+  }
+  uint32_t tot;
+  (void)block_exclusive_scan(c, lds, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void occ_scan_sums_kernel(uint32_t* __restrict__ block_sums,
+                                                             int nblocks, int* __restrict__ total) {
+  // single workgroup; nblocks is at most a few hundred thousand -> chunked scan with a running carry
+  __shared__ uint32_t lds[1024];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    uint32_t v = i < nblocks ? block_sums[i] : 0;
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      uint32_t t = threadIdx.x >= d ? lds[threadIdx.x - d] : 0;
+      __syncthreads();
+      lds[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const uint32_t carry = carry_s;
+    const uint32_t inc = lds[threadIdx.x];
+    if (i < nblocks) block_sums[i] = carry + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = (int)carry_s;
+}
+
+__global__ __launch_bounds__(kScanThreads) void occ_write_prefix_kernel(
+    const unsigned long long* __restrict__ bits, size_t nwords,
+    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ prefix) {
+  __shared__ uint32_t lds[kScanThreads / 64];
+  const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+  uint32_t pc[kWordsPerThread];
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) pc[i] = (w0 + i < nwords) ? __popcll(bits[w0 + i]) : 0;
+  uint32_t c = pc[0] + pc[1] + pc[2] + pc[3];
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(c, lds, &tot) + block_offsets[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) {
+    if (w0 + i < nwords) prefix[w0 + i] = ex;
+    ex += pc[i];
+  }
+}
+
+int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st) {
+  occ->B = B; occ->D = D; occ->H = H; occ->W = W;
+  occ->ncells = (unsigned long long)B * D * H * W;
+  occ->nwords = (size_t)((occ->ncells + 63) / 64);
+  // pad the word count to a multiple of kWordsPerThread so vector loads stay in bounds
+  const size_t alloc_words = round_up(occ->nwords, kWordsPerBlock);
+  ISF_TRY(a.alloc_n(&occ->bits, alloc_words));
+  ISF_TRY(a.alloc_n(&occ->prefix, alloc_words));
+  ISF_TRY(a.alloc_n(&occ->total, 64));
+  ISF_HIP_TRY(hipMemsetAsync(occ->bits, 0, alloc_words * sizeof(unsigned long long), st));
+  return ISF_OK;
+}
+
+int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st) {
+  const int nblocks = ceil_div((long long)occ.nwords, kWordsPerBlock);
+  uint32_t* sums = nullptr;
+  ISF_TRY(a.alloc_n(&sums, (size_t)nblocks + 1));
+  hipLaunchKernelGGL(occ_block_count_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, occ.bits,
+                     occ.nwords, sums);
+  hipLaunchKernelGGL(occ_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks, occ.total);
+  hipLaunchKernelGGL(occ_write_prefix_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, occ.bits,
+                     occ.nwords, sums, occ.prefix);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+__global__ void occ_mark_coords4_kernel(unsigned long long* __restrict__ bits,
+                                        const int32_t* __restrict__ coors4, int n, int B, int D, int H,
+                                        int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(coors4)[i];
+  if (c.x < 0 || c.y < 0 || c.z < 0 || c.w < 0 || c.x >= B || c.y >= D || c.z >= H || c.w >= W) return;
+  const unsigned long long cell = (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w;
+  const unsigned long long bit = 1ull << (cell & 63);
+  unsigned long long* p = bits + (cell >> 6);
+  if (!(__builtin_nontemporal_load(p) & bit)) atomicOr(p, bit);
+}
+
+int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st) {
+  if (n <= 0) return ISF_OK;
+  hipLaunchKernelGGL(occ_mark_coords4_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, occ.bits,
+                     coors4, n, occ.B, occ.D, occ.H, occ.W);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+__global__ void occ_compact_coords4_kernel(const unsigned long long* __restrict__ bits,
+                                           const uint32_t* __restrict__ prefix, size_t nwords, int D,
+                                           int H, int W, int32_t* __restrict__ out) {
+  const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned long long word = bits[w];
+  if (!word) return;
+  uint32_t r = prefix[w];
+  while (word) {
+    const int b = __ffsll((long long)word) - 1;
+    word &= word - 1;
+    unsigned long long cell = (w << 6) + b;
+    const int x = (int)(cell % W); cell /= W;
+    const int y = (int)(cell % H); cell /= H;
+    const int z = (int)(cell % D); cell /= D;
+    reinterpret_cast<int4*>(out)[r] = make_int4((int)cell, z, y, x);
+    ++r;
+  }
+}
+
+int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(occ_compact_coords4_kernel, dim3(ceil_div((long long)occ.nwords, 256)), dim3(256),
+                     0, st, occ.bits, occ.prefix, occ.nwords, occ.D, occ.H, occ.W, out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // namespace isf
+
+// ------------------------------------------------------------------------------------ C ABI: runtime
+extern "C" {
+
+int isf_version(void) { return (0 << 16) | (1 << 8) | 0; }
+
+const char* isf_last_error(void) { return isf::g_err; }
+
+int isf_device_count(int* count_host) {
+  if (!count_host) return ISF_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count_host = n;
+  return ISF_OK;
+}
+
+int isf_release_workspace(void) {
+  for (int d = 0; d < 16; ++d) {
+    if (isf::g_arenas[d].capacity() == 0) continue;
+    int cur = 0;
+    ISF_HIP_TRY(hipGetDevice(&cur));
+    ISF_HIP_TRY(hipSetDevice(d));
+    int r = isf::g_arenas[d].release();
+    ISF_HIP_TRY(hipSetDevice(cur));
+    if (r != ISF_OK) return r;
+  }
+  return ISF_OK;
+}
+
+int isf_workspace_bytes(size_t* bytes_host) {
+  if (!bytes_host) return ISF_ERR_ARG;
+  *bytes_host = isf::arena_for_current_device().capacity();
+  return ISF_OK;
+}
+
+}  // extern "C"

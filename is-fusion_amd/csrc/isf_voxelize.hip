@@ -1,0 +1,233 @@
+// isf_voxelize.hip -- A1 dynamic voxelization, A2 deterministic hard (pillar) voxelization.
+//
+// A2 design (replaces the reference's O(P^2) point_to_voxelidx_kernel + single-thread
+// determin_voxel_num, voxelization_cuda.cu:105-180):
+//   1. every point bubbles its index into a per-cell sorted list of the max_points smallest point
+//      indices (one atomicMin per slot; order-independent, deterministic result);
+//   2. a cell's voxel id in "first appearance" order is the rank of its smallest point index among
+//      all cells' smallest indices -> one bitmap over point indices + the popcount-prefix scan;
+//   3. one gather pass writes voxels / coors / num_points for ids < max_voxels.
+// All of it is HBM/L2-bound integer work: O(P * max_points) atomics worst case, O(P) typical.
+#include "isf_common.h"
+
+namespace isf {
+
+__device__ __forceinline__ bool voxel_of_point(const float* __restrict__ p, float vx, float vy, float vz,
+                                               float x0, float y0, float z0, int gx, int gy, int gz,
+                                               int& cx, int& cy, int& cz) {
+  // fp32 subtract, fp32 IEEE divide, floor -- exactly voxelization_cpu.cpp:24 / voxelization_cuda.cu:37
+  const float fx = floorf(__fdiv_rn(__fsub_rn(p[0], x0), vx));
+  const float fy = floorf(__fdiv_rn(__fsub_rn(p[1], y0), vy));
+  const float fz = floorf(__fdiv_rn(__fsub_rn(p[2], z0), vz));
+  // float -> int: everything outside [0, grid) (incl. NaN / huge) is invalid
+  if (!(fx >= 0.f && fx < (float)gx && fy >= 0.f && fy < (float)gy && fz >= 0.f && fz < (float)gz))
+    return false;
+  cx = (int)fx; cy = (int)fy; cz = (int)fz;
+  return true;
+}
+
+struct VoxGeom {
+  float vx, vy, vz, x0, y0, z0;
+  int gx, gy, gz;
+};
+
+static VoxGeom make_geom(const float vs[3], const float range[6]) {
+  VoxGeom g;
+  g.vx = vs[0]; g.vy = vs[1]; g.vz = vs[2];
+  g.x0 = range[0]; g.y0 = range[1]; g.z0 = range[2];
+  // grid = round((max-min)/vs) in fp32 (voxelization_cpu.cpp:120-123)
+  g.gx = (int)roundf((range[3] - range[0]) / vs[0]);
+  g.gy = (int)roundf((range[4] - range[1]) / vs[1]);
+  g.gz = (int)roundf((range[5] - range[2]) / vs[2]);
+  return g;
+}
+
+__global__ void dynamic_voxelize_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+                                        int32_t* __restrict__ coors, int stride, int col0,
+                                        int batch_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  int cx, cy, cz;
+  const bool ok = voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy,
+                                 g.gz, cx, cy, cz);
+  int32_t* o = coors + (size_t)i * stride;
+  if (col0) o[0] = batch_idx;
+  o[col0 + 0] = ok ? cz : -1;
+  o[col0 + 1] = ok ? cy : -1;
+  o[col0 + 2] = ok ? cx : -1;
+}
+
+int dynamic_voxelize_impl(const float* points, int P, int C, const float vs[3], const float range[6],
+                          int32_t* coors, int coors_stride, int coors_col0, int batch_idx,
+                          hipStream_t st) {
+  if (P <= 0) return ISF_OK;
+  hipLaunchKernelGGL(dynamic_voxelize_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C,
+                     make_geom(vs, range), coors, coors_stride, coors_col0, batch_idx);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- A2
+static constexpr int kEmpty = 0x7f7f7f7f;  // hipMemset byte pattern 0x7f; larger than any point index
+
+__global__ void hv_mark_cells_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+                                     unsigned long long* __restrict__ cbits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  int cx, cy, cz;
+  if (!voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx,
+                      cy, cz))
+    return;
+  const unsigned long long cell = ((unsigned long long)cz * g.gy + cy) * g.gx + cx;
+  const unsigned long long bit = 1ull << (cell & 63);
+  unsigned long long* p = cbits + (cell >> 6);
+  if (!(*p & bit)) atomicOr(p, bit);
+}
+
+__global__ void hv_insert_kernel(const float* __restrict__ points, int P, int C, VoxGeom g, int T,
+                                 const unsigned long long* __restrict__ cbits,
+                                 const uint32_t* __restrict__ cprefix,
+                                 int* __restrict__ slots /*[occupied cells][T]*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  int cx, cy, cz;
+  if (!voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx,
+                      cy, cz))
+    return;
+  const int row = occ_lookup(cbits, cprefix, ((unsigned long long)cz * g.gy + cy) * g.gx + cx);
+  int* s = slots + (size_t)row * T;
+  // prune: the last slot only ever decreases, so a (possibly stale) read that is already smaller
+  // than i proves this point cannot be among the T smallest
+  if (s[T - 1] < i) return;
+  int v = i;
+  for (int t = 0; t < T; ++t) {
+    const int old = atomicMin(&s[t], v);
+    if (old == kEmpty) break;     // took a free slot; nothing to carry
+    if (old > v) v = old;         // displaced a larger index: carry it down
+                                  // else: slot keeps its smaller index, carry v unchanged
+  }
+}
+
+__global__ void hv_mark_first_kernel(const int* __restrict__ slots, const int* __restrict__ nrows,
+                                     int T, unsigned long long* __restrict__ pbits) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *nrows) return;
+  const int first = slots[(size_t)r * T];
+  atomicOr(pbits + (first >> 6), 1ull << (first & 63));
+}
+
+__global__ void hv_gather_kernel(const float* __restrict__ points, int C, const int* __restrict__ slots,
+                                 const int* __restrict__ nrows, const int32_t* __restrict__ cell_coors4,
+                                 int T, const unsigned long long* __restrict__ pbits,
+                                 const uint32_t* __restrict__ pprefix, int max_voxels,
+                                 float* __restrict__ voxels, int32_t* __restrict__ coors,
+                                 int32_t* __restrict__ num_points) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long long)(*nrows) * T) return;
+  const int r = (int)(tid / T), t = (int)(tid % T);
+  const int* s = slots + (size_t)r * T;
+  const int vid = occ_lookup(pbits, pprefix, (unsigned long long)s[0]);
+  if (vid < 0 || vid >= max_voxels) return;
+  const int pi = s[t];
+  if (pi != kEmpty) {
+    const float* p = points + (size_t)pi * C;
+    float* o = voxels + ((size_t)vid * T + t) * C;
+    for (int k = 0; k < C; ++k) o[k] = p[k];
+  }
+  if (t == 0) {
+    int n = 0;
+    for (int k = 0; k < T; ++k) n += (s[k] != kEmpty);
+    num_points[vid] = n;
+    const int4 c = reinterpret_cast<const int4*>(cell_coors4)[r];  // (0, z, y, x)
+    coors[(size_t)vid * 3 + 0] = c.y;
+    coors[(size_t)vid * 3 + 1] = c.z;
+    coors[(size_t)vid * 3 + 2] = c.w;
+  }
+}
+
+int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float vs[3],
+                       const float range[6], int max_points, int max_voxels, float* voxels,
+                       int32_t* coors, int32_t* num_points, int* voxel_num_host, hipStream_t st) {
+  const VoxGeom g = make_geom(vs, range);
+  ISF_REQUIRE(g.gx > 0 && g.gy > 0 && g.gz > 0, ISF_ERR_ARG, "hard_voxelize: empty grid");
+  *voxel_num_host = 0;
+  if (P <= 0) return ISF_OK;
+  const long long cells = (long long)g.gx * g.gy * g.gz;
+  const int row_cap = (int)(cells < P ? cells : P);
+  OccIndex cocc;  // occupied cells of this sample
+  ISF_TRY(occ_create(a, &cocc, 1, g.gz, g.gy, g.gx, st));
+  hipLaunchKernelGGL(hv_mark_cells_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g,
+                     cocc.bits);
+  ISF_LAUNCH_CHECK();
+  ISF_TRY(occ_scan(a, cocc, st));
+  int* slots = nullptr;
+  int32_t* cell_coors = nullptr;
+  ISF_TRY(a.alloc_n(&slots, (size_t)row_cap * max_points));
+  ISF_TRY(a.alloc_n(&cell_coors, (size_t)row_cap * 4));
+  ISF_HIP_TRY(hipMemsetAsync(slots, 0x7f, (size_t)row_cap * max_points * sizeof(int), st));
+  ISF_TRY(occ_compact_coords4(cocc, cell_coors, st));
+  OccIndex pocc;  // bitmap over POINT indices: rank of a cell's first point = its voxel id
+  ISF_TRY(occ_create(a, &pocc, 1, 1, 1, P, st));
+  hipLaunchKernelGGL(hv_insert_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g,
+                     max_points, cocc.bits, cocc.prefix, slots);
+  hipLaunchKernelGGL(hv_mark_first_kernel, dim3(ceil_div(row_cap, 256)), dim3(256), 0, st, slots,
+                     cocc.total, max_points, pocc.bits);
+  ISF_LAUNCH_CHECK();
+  ISF_TRY(occ_scan(a, pocc, st));
+  hipLaunchKernelGGL(hv_gather_kernel, dim3(ceil_div((long long)row_cap * max_points, 256)), dim3(256),
+                     0, st, points, C, slots, cocc.total, cell_coors, max_points, pocc.bits,
+                     pocc.prefix, max_voxels, voxels, coors, num_points);
+  ISF_LAUNCH_CHECK();
+  int total = 0;
+  ISF_TRY(read_int(pocc.total, &total, st));
+  *voxel_num_host = total < max_voxels ? total : max_voxels;
+  return ISF_OK;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_dynamic_voxelize(const float* points, int num_points, int num_features,
+                         const float voxel_size_host[3], const float coors_range_host[6],
+                         int32_t* coors, isf_stream_t stream) {
+  ISF_REQUIRE(num_points >= 0 && num_features >= 3 && voxel_size_host && coors_range_host,
+              ISF_ERR_ARG, "dynamic_voxelize: bad arguments");
+  ISF_REQUIRE(num_points == 0 || (points && coors), ISF_ERR_ARG, "dynamic_voxelize: null pointer");
+  return isf::dynamic_voxelize_impl(points, num_points, num_features, voxel_size_host,
+                                    coors_range_host, coors, 3, 0, 0, isf::as_stream(stream));
+}
+
+int isf_dynamic_voxelize_batched(const float* points, const int64_t* point_offsets_host,
+                                 int batch_size, int num_features, const float voxel_size_host[3],
+                                 const float coors_range_host[6], int32_t* coors4,
+                                 isf_stream_t stream) {
+  ISF_REQUIRE(point_offsets_host && batch_size >= 0 && num_features >= 3, ISF_ERR_ARG,
+              "dynamic_voxelize_batched: bad arguments");
+  for (int b = 0; b < batch_size; ++b) {
+    const int64_t lo = point_offsets_host[b], hi = point_offsets_host[b + 1];
+    ISF_REQUIRE(hi >= lo && hi - lo < (1ll << 31), ISF_ERR_ARG, "dynamic_voxelize_batched: bad offsets");
+    ISF_TRY(isf::dynamic_voxelize_impl(points + lo * num_features, (int)(hi - lo), num_features,
+                                       voxel_size_host, coors_range_host, coors4 + lo * 4, 4, 1, b,
+                                       isf::as_stream(stream)));
+  }
+  return ISF_OK;
+}
+
+int isf_hard_voxelize(const float* points, int num_points, int num_features,
+                      const float voxel_size_host[3], const float coors_range_host[6],
+                      int max_points, int max_voxels, float* voxels, int32_t* coors,
+                      int32_t* num_points_per_voxel, int* voxel_num_host, isf_stream_t stream) {
+  ISF_REQUIRE(num_points >= 0 && num_features >= 3 && max_points > 0 && max_voxels > 0 &&
+                  voxel_num_host && voxel_size_host && coors_range_host,
+              ISF_ERR_ARG, "hard_voxelize: bad arguments");
+  ISF_REQUIRE(num_points == 0 || (points && voxels && coors && num_points_per_voxel), ISF_ERR_ARG,
+              "hard_voxelize: null pointer");
+  isf::Arena& a = isf::arena_for_current_device();
+  ISF_TRY(a.reset());
+  return isf::hard_voxelize_impl(a, points, num_points, num_features, voxel_size_host,
+                                 coors_range_host, max_points, max_voxels, voxels, coors,
+                                 num_points_per_voxel, voxel_num_host, isf::as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""LiDAR branch of ISFusionDetector.extract_pts_feat (detectors/isfusion.py:103-111) as one engine:
+
+    dynamic_voxelize(pts) -> DynamicVFE -> SparseEncoder -> spatial_features [B, 512, 180, 180]
+
+``LidarBranch.forward`` is ONE C call (isf_lidar_branch_forward): no per-sample Python loop, no
+``coors[-1,0].item()`` sync; the only host syncs left are the data-dependent voxel counts (one per
+resolution level).  The sub-modules are the drop-in ``DynamicVFE`` / ``SparseEncoder`` classes, so a
+reference state dict (keys ``pts_voxel_encoder.*`` / ``pts_middle_encoder.*``) loads directly.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from .norm import fold_bn
+from .sparse_encoder import SparseEncoder
+from .voxel_encoder import DynamicVFE
+
+# configs/isfusion/isfusion_0075voxel.py:5-7,60-84 (values restated, not imported)
+ISFUSION_0075 = dict(
+    voxel_size=[0.075, 0.075, 0.2],
+    point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0],
+    pts_voxel_encoder=dict(in_channels=5, feat_channels=[64, 64], with_distance=False, with_cluster_center=True,
+                           with_voxel_center=True, norm_cfg=dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01)),
+    pts_middle_encoder=dict(in_channels=64, sparse_shape=[41, 1440, 1440], base_channels=32, output_channels=256,
+                            order=("conv", "norm", "act"),
+                            encoder_channels=((32, 32, 64), (64, 64, 128), (128, 128, 256), (256, 256)),
+                            encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)),
+                            block_type="basicblock"),
+)
+
+
+class LidarBranch(nn.Module):
+
+    def __init__(self, voxel_size=None, point_cloud_range=None, pts_voxel_encoder=None, pts_middle_encoder=None):
+        super().__init__()
+        cfg = ISFUSION_0075
+        self.voxel_size = list(voxel_size or cfg["voxel_size"])
+        self.point_cloud_range = list(point_cloud_range or cfg["point_cloud_range"])
+        ve = dict(pts_voxel_encoder or cfg["pts_voxel_encoder"])
+        ve.pop("type", None)
+        ve.setdefault("voxel_size", self.voxel_size)
+        ve.setdefault("point_cloud_range", self.point_cloud_range)
+        me = dict(pts_middle_encoder or cfg["pts_middle_encoder"])
+        me.pop("type", None)
+        self.pts_voxel_encoder = DynamicVFE(**ve)
+        self.pts_middle_encoder = SparseEncoder(**me)
+        self.last_stats = None
+        self._vfe_cache = None
+        self._vfe_key = None
+
+    def randomize_bn_(self, seed=0):
+        """Random but well-conditioned BN running statistics / affine parameters (bench + parity tests:
+        a freshly constructed BN is the identity, which would hide scale/shift mistakes)."""
+        g = torch.Generator().manual_seed(seed)
+        for m in self.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                with torch.no_grad():
+                    m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                    m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+                    m.weight.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+                    m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+        return self
+
+    def freeze(self, flag=True):
+        """Skip the per-call parameter-change scans (weights are static at inference)."""
+        self.pts_middle_encoder.freeze(flag)
+        self._frozen = bool(flag)
+        return self
+
+    def _vfe_params(self):
+        vfe = self.pts_voxel_encoder
+        if getattr(self, "_frozen", False) and self._vfe_cache is not None:
+            return self._vfe_cache
+        key = tuple((p._version, p.data_ptr()) for p in list(vfe.parameters()) + list(vfe.buffers()))
+        if self._vfe_cache is not None and self._vfe_key == key:
+            return self._vfe_cache
+        l1, l2 = vfe.vfe_layers
+        s1, b1 = fold_bn(l1.norm)
+        s2, b2 = fold_bn(l2.norm)
+        w1 = l1.linear.weight.detach().float().contiguous()
+        w2 = l2.linear.weight.detach().float().contiguous()
+        p = _lib.VfeParams()
+        p.in_channels, p.c1, p.c2 = vfe.raw_in_channels, w1.size(0), w2.size(0)
+        p.w1, p.scale1, p.shift1 = w1.data_ptr(), s1.data_ptr(), b1.data_ptr()
+        p.w2, p.scale2, p.shift2 = w2.data_ptr(), s2.data_ptr(), b2.data_ptr()
+        for j in range(3):
+            p.voxel_size[j] = float(self.voxel_size[j])
+        for j in range(6):
+            p.coors_range[j] = float(self.point_cloud_range[j])
+        self._vfe_cache = (p, (w1, w2, s1, b1, s2, b2))
+        self._vfe_key = key
+        return self._vfe_cache
+
+    @torch.no_grad()
+    def forward(self, points, time_layers=False, want_stats=False):
+        """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W]."""
+        assert not self.training, "LidarBranch is the inference engine; training composes the sub-modules"
+        pts = torch.cat(points, dim=0).contiguous().float()
+        _lib.require_cuda(pts)
+        offs = [0]
+        for p in points:
+            offs.append(offs[-1] + p.size(0))
+        B = len(points)
+        me = self.pts_middle_encoder
+        arr, n, _keep, _plan = me._c_plan()
+        vp, _keep2 = self._vfe_params()
+        cd, H, W = me.out_channels_and_shape()
+        out = torch.empty((B, cd, H, W), dtype=torch.float32, device=pts.device)
+        oshape = (ctypes.c_int * 4)()
+        stats = _lib.EncoderStats() if (want_stats or time_layers) else None
+        lib = _lib.load()
+        _lib.check(lib.isf_lidar_branch_forward(
+            _lib.ptr(pts), (ctypes.c_int64 * len(offs))(*offs), B, ctypes.byref(vp), _lib.i3(me.sparse_shape),
+            arr, n, _lib.ptr(out), oshape, ctypes.byref(stats) if stats is not None else None,
+            int(bool(time_layers)), _lib.stream()), "isf_lidar_branch_forward")
+        self.last_stats = stats
+        return out
+
+    def conv_layer_table(self):
+        """[(kind, c_in, c_out, K)] of the encoder plan, for roofline accounting."""
+        plan = self.pts_middle_encoder.export_plan()
+        return [(L["kind"], L["c_in"], L["c_out"], L["ksize"][0] * L["ksize"][1] * L["ksize"][2])
+                for L in plan["layers"]]

@@ -1,0 +1,289 @@
+"""Sparse-convolution module surface (drop-in for what the IS-Fusion path imports from ``spconv.pytorch`` /
+``mmcv.ops`` / the vendored mmdet3d/ops/bevfusion-ops/spconv: SparseConvTensor, SparseModule,
+SparseSequential, SubMConv3d, SparseConv3d).
+
+Differences that matter to a maintainer:
+  * the rulebook is an output-stationary neighbour table (``isf_build_rulebook``), cached on the tensor per
+    (type, kernel, stride, padding, spatial shape) -- so SubM convs WITHOUT an indice_key (SparseBasicBlock,
+    ops/sparse_block.py:100-115) share the level's rulebook too (same active set => identical rulebook);
+  * weights live in the spconv-1 / mmcv layout [kD,kH,kW,Cin,Cout] (bevfusion-ops/spconv/conv.py:100);
+    checkpoints in the spconv-2 layout [Cout,kD,kH,kW,Cin] are permuted on load
+    (ops/spconv/overwrite_spconv/write_spconv2.py:62-124 does the opposite conversion);
+  * forward only this round: calling a conv with autograd enabled on tensors that require grad raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class SparseConvTensor:
+    """structure.py:21-63 (same attributes / methods)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self.grid = grid
+        self._rulebooks = {}
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def find_indice_pair(self, key):
+        return self.indice_dict.get(key) if key is not None else None
+
+    def replace_feature(self, new_features):
+        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.grid)
+        out.indice_dict = self.indice_dict
+        out._rulebooks = self._rulebooks
+        return out
+
+    def dense(self, channels_first=True):
+        """[B, C, D, H, W] (structure.py:49-59) through isf_sparse_to_dense_bev."""
+        _lib.require_cuda(self.features)
+        D, H, W = self.spatial_shape
+        C = self.features.size(1)
+        out = torch.empty((self.batch_size, C * D, H, W), dtype=torch.float32, device=self.features.device)
+        lib = _lib.load()
+        _lib.check(lib.isf_sparse_to_dense_bev(_lib.ptr(self.features.contiguous().float()),
+                                               _lib.ptr(self.indices.contiguous()), self.features.size(0), C,
+                                               self.batch_size, D, H, W, _lib.ptr(out), _lib.stream()),
+                   "isf_sparse_to_dense_bev")
+        out = out.view(self.batch_size, C, D, H, W)
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+
+class Rulebook:
+    """Output-stationary neighbour table of one conv geometry on one active set."""
+
+    def __init__(self, nbr, stride, num_in, num_out, out_indices, out_shape):
+        self.nbr, self.stride = nbr, stride
+        self.num_in, self.num_out = num_in, num_out
+        self.out_indices, self.out_shape = out_indices, out_shape
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, subm):
+    """isf_build_rulebook wrapper -> Rulebook."""
+    _lib.require_cuda(indices)
+    lib = _lib.load()
+    n_in = indices.size(0)
+    K = int(np.prod(ksize))
+    dev = indices.device
+    if subm:
+        out_shape = list(spatial_shape)
+        cap = n_in
+    else:
+        o = _lib.i3([0, 0, 0])
+        _lib.check(lib.isf_conv_out_shape(_lib.i3(spatial_shape), _lib.i3(ksize), _lib.i3(stride),
+                                          _lib.i3(padding), o))
+        out_shape = list(o)
+        # every input feeds at most prod(ceil(k/s)) outputs; the grid bounds it too
+        per_in = int(np.prod([math.ceil(k / s) for k, s in zip(ksize, stride)]))
+        cap = max(1, min(n_in * per_in, int(np.prod(out_shape)) * batch_size))
+    nstride = lib.isf_nbr_stride(cap)
+    nbr = torch.empty((K, nstride), dtype=torch.int32, device=dev)
+    out_idx = indices if subm else torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    n_out = ctypes.c_int(0)
+    _lib.check(lib.isf_build_rulebook(_lib.ptr(indices), n_in, batch_size, _lib.i3(spatial_shape),
+                                      _lib.i3(ksize), _lib.i3(stride), _lib.i3(padding),
+                                      _lib.CONV_SUBM if subm else _lib.CONV_SPARSE,
+                                      None if subm else _lib.ptr(out_idx), cap, _lib.ptr(nbr), nstride,
+                                      ctypes.byref(n_out), _lib.stream()), "isf_build_rulebook")
+    m = n_out.value
+    return Rulebook(nbr, nstride, n_in, m, out_idx if subm else out_idx[:m], out_shape)
+
+
+def pack_filters(weight):
+    """[kD,kH,kW,Cin,Cout] -> MFMA fragment order (isf_pack_filters)."""
+    w = weight.detach().float().contiguous()
+    K = int(np.prod(w.shape[:-2]))
+    packed = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+    lib = _lib.load()
+    _lib.check(lib.isf_pack_filters(_lib.ptr(w), K, w.shape[-2], w.shape[-1], _lib.ptr(packed), _lib.stream()),
+               "isf_pack_filters")
+    return packed
+
+
+def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False):
+    """isf_sparse_conv_forward_packed wrapper (conv + optional folded BN / residual / ReLU)."""
+    _lib.require_cuda(features)
+    out = torch.empty((rb.num_out, c_out), dtype=torch.float32, device=features.device)
+    lib = _lib.load()
+    _lib.check(lib.isf_sparse_conv_forward_packed(
+        _lib.ptr(features), rb.num_in, c_in, _lib.ptr(packed), K, c_out, _lib.ptr(rb.nbr), rb.stride,
+        rb.num_out, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), int(bool(relu)), _lib.ptr(out),
+        _lib.stream()), "isf_sparse_conv_forward_packed")
+    return out
+
+
+class SparseModule(nn.Module):
+    """marker base class (modules.py:38-41)."""
+
+
+def _triple(v):
+    return [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
+
+
+class SparseConvolution(SparseModule):
+    """conv.py:41-223 surface: weight [k,k,k,Cin,Cout], optional bias, ``indice_key`` rulebook sharing."""
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, subm=False, output_padding=0, transposed=False, inverse=False,
+                 indice_key=None, fused_bn=False):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse, \
+            "only the 3-D forward convs of the IS-Fusion path are built"
+        assert _triple(dilation) == [1, 1, 1], "dilation 1 only"
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
+        self.padding, self.dilation = _triple(padding), _triple(dilation)
+        self.conv1x1 = int(np.prod(self.kernel_size)) == 1
+        self.transposed, self.inverse = transposed, inverse
+        self.output_padding = _triple(output_padding)
+        self.groups, self.subm, self.indice_key, self.fused_bn = groups, subm, indice_key, fused_bn
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._packed = None
+        self._packed_key = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # conv.py:105-112: kaiming uniform with fan_in computed the torch way on this layout
+        n = self.in_channels
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = n * int(np.prod(self.kernel_size))
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + "weight"
+        if key in state_dict:
+            w = state_dict[key]
+            native = tuple(self.weight.shape)
+            spconv2 = (self.out_channels, *self.kernel_size, self.in_channels)
+            if tuple(w.shape) != native and tuple(w.shape) == spconv2:
+                state_dict[key] = w.permute(1, 2, 3, 4, 0).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def packed_weight(self):
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        if self._packed is None or self._packed_key != key:
+            self._packed = pack_filters(self.weight)
+            self._packed_key = key
+        return self._packed
+
+    def rulebook_for(self, x):
+        key = ("subm" if self.subm else "conv", tuple(self.kernel_size), tuple(self.stride),
+               tuple(self.padding), tuple(x.spatial_shape))
+        if self.subm:
+            key = ("subm", tuple(self.kernel_size), tuple(x.spatial_shape))
+        rb = x._rulebooks.get(key)
+        if rb is None:
+            rb = build_rulebook(x.indices.contiguous(), x.batch_size, x.spatial_shape, self.kernel_size,
+                                self.stride, self.padding, self.subm)
+            x._rulebooks[key] = rb
+            if self.indice_key is not None:
+                x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        feats = input.features
+        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError(
+                "isfusion_amd sparse conv: backward kernels are not built yet (SURVEY.md section 8f #2); "
+                "call under torch.no_grad() / module.eval() with requires_grad_(False)")
+        rb = self.rulebook_for(input)
+        K = int(np.prod(self.kernel_size))
+        shift = self.bias.detach().float() if self.bias is not None else None
+        scale = torch.ones_like(shift) if shift is not None else None
+        out_f = sparse_conv_forward(feats.contiguous().float(), self.packed_weight(), K, self.in_channels,
+                                    self.out_channels, rb, scale, shift)
+        out = SparseConvTensor(out_f, rb.out_indices, rb.out_shape, input.batch_size)
+        out.indice_dict = input.indice_dict
+        if self.subm:
+            out._rulebooks = input._rulebooks  # same active set
+        out.grid = input.grid
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         True, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """modules.py:44-139: applies sparse modules to the tensor and dense modules to ``.features``
+    (skipped when there is no active voxel, :133-135)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f"index {idx} is out of range")
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input = input.replace_feature(module(input.features))
+            else:
+                input = module(input)
+        return input

@@ -1,0 +1,95 @@
+"""Voxelization (drop-in for ``mmdet3d.ops.Voxelization`` / ``voxelization``).
+
+Mirrors mmdet3d/ops/voxel/voxelize.py:10-148: same constructor arguments, same ``forward`` return
+conventions (dynamic: coors [P,3] int32 (z,y,x); hard: (voxels, coors, num_points_per_voxel)).
+The arithmetic runs in libisf_hip.so (isf_dynamic_voxelize / isf_hard_voxelize).
+"""
+import ctypes
+
+import torch
+from torch import nn
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+
+def dynamic_voxelize(points, voxel_size, coors_range):
+    """voxel_layer.dynamic_voxelize: points [P,C] -> coors [P,3] int32 (z,y,x), invalid rows -1."""
+    _lib.require_cuda(points)
+    points = points.contiguous().float()
+    coors = torch.empty((points.size(0), 3), dtype=torch.int32, device=points.device)
+    lib = _lib.load()
+    _lib.check(lib.isf_dynamic_voxelize(_lib.ptr(points), points.size(0), points.size(1),
+                                        _lib.f3(voxel_size), _lib.f6(coors_range), _lib.ptr(coors),
+                                        _lib.stream()), "isf_dynamic_voxelize")
+    return coors
+
+
+def dynamic_voxelize_batched(points_list, voxel_size, coors_range):
+    """ISFusionDetector.dynamic_voxelize (detectors/isfusion.py:123-146):
+    list of [P_i,C] -> (points [sum P,C], coors [sum P,4] (b,z,y,x))."""
+    points = torch.cat(points_list, dim=0).contiguous().float()
+    _lib.require_cuda(points)
+    offs = [0]
+    for p in points_list:
+        offs.append(offs[-1] + p.size(0))
+    coors = torch.empty((points.size(0), 4), dtype=torch.int32, device=points.device)
+    lib = _lib.load()
+    arr = (ctypes.c_int64 * len(offs))(*offs)
+    _lib.check(lib.isf_dynamic_voxelize_batched(_lib.ptr(points), arr, len(points_list), points.size(1),
+                                                _lib.f3(voxel_size), _lib.f6(coors_range), _lib.ptr(coors),
+                                                _lib.stream()), "isf_dynamic_voxelize_batched")
+    return points, coors
+
+
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """voxel_layer.hard_voxelize (deterministic) -> (voxels[M,T,C], coors[M,3], num_points[M])."""
+    _lib.require_cuda(points)
+    points = points.contiguous().float()
+    # outputs pre-allocated at max size and zero-filled, exactly like voxelize.py:57-61
+    voxels = points.new_zeros((max_voxels, max_points, points.size(1)))
+    coors = points.new_zeros((max_voxels, 3), dtype=torch.int32)
+    num = points.new_zeros((max_voxels,), dtype=torch.int32)
+    n = ctypes.c_int(0)
+    lib = _lib.load()
+    _lib.check(lib.isf_hard_voxelize(_lib.ptr(points), points.size(0), points.size(1),
+                                     _lib.f3(voxel_size), _lib.f6(coors_range), int(max_points),
+                                     int(max_voxels), _lib.ptr(voxels), _lib.ptr(coors), _lib.ptr(num),
+                                     ctypes.byref(n), _lib.stream()), "isf_hard_voxelize")
+    m = n.value
+    return voxels[:m], coors[:m], num[:m]
+
+
+def voxelization(points, voxel_size, coors_range, max_points=35, max_voxels=20000, deterministic=True):
+    """Functional form (voxelize.py:10-76).  ``deterministic=False`` selects the same deterministic kernel:
+    the non-deterministic CUDA variant exists only to dodge the O(P^2) kernel this build does not have."""
+    if max_points == -1 or max_voxels == -1:
+        return dynamic_voxelize(points, voxel_size, coors_range)
+    return hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels)
+
+
+class Voxelization(nn.Module):
+    """Same constructor / forward as mmdet3d.ops.Voxelization (voxelize.py:79-148)."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, deterministic=True):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.point_cloud_range = point_cloud_range
+        self.max_num_points = max_num_points
+        self.max_voxels = max_voxels if isinstance(max_voxels, tuple) else _pair(max_voxels)
+        self.deterministic = deterministic
+        pcr = torch.tensor(point_cloud_range, dtype=torch.float32)
+        vs = torch.tensor(voxel_size, dtype=torch.float32)
+        grid_size = torch.round((pcr[3:] - pcr[:3]) / vs).long()
+        self.grid_size = grid_size
+        self.pcd_shape = [*grid_size[:2], 1][::-1]
+
+    def forward(self, input):
+        max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
+        return voxelization(input, self.voxel_size, self.point_cloud_range, self.max_num_points, max_voxels,
+                            self.deterministic)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range="
+                f"{self.point_cloud_range}, max_num_points={self.max_num_points}, max_voxels="
+                f"{self.max_voxels}, deterministic={self.deterministic})")
