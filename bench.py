@@ -1,0 +1,204 @@
+"""bench.py -- IS-Fusion LiDAR-branch forward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1] -- "isfusion_0075voxel LiDAR-only branch
+(voxelize + spconv backbone -> BEV), synthetic 300k-pt sweeps, batch=4" per GPU.  One "step" = one forward
+of the whole LiDAR branch (dynamic voxelization -> DynamicVFE -> 21-layer SparseEncoder -> dense BEV
+[4,512,180,180]) over one batch whose points are already resident in HBM.  Weights: random init of the
+isfusion_0075voxel architecture (no checkpoint / dataset access), eval-mode BN, fp32.
+
+Multi-GPU: frames are independent units => every rank runs its own batch of 4 frames, no data-path
+collective (scaling "weak"); timing = barrier + synchronize on both sides, max over ranks.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  "roofline":     dominant kernel (sparse-conv template instantiation with the largest share of GPU time),
+                  achieved = algorithmic flops (2*pairs*Cin*Cout) / mean hipEvent kernel time, vs the fp32 MFMA
+                  peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- plus the per-kernel table;
+  "cpu_baseline": the CPU oracle (scalar C port of the reference algorithm) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)
+POINTS_PER_FRAME = 300000
+BATCH_PER_GPU = 4
+CFG_ID = 2
+
+
+def frames_for_rank(rank, world, batch):
+    """Global frame ids processed by `rank`: disjoint across ranks, `batch` per rank (weak scaling)."""
+    return [rank * batch + i for i in range(batch)]
+
+
+def make_frames(rank, world, batch, num_points):
+    from isfusion_amd import synthetic
+    return [synthetic.lidar_sweeps(1234 + 1000 * CFG_ID + f, num_points) for f in frames_for_rank(rank, world, batch)]
+
+
+def conv_layer_bytes_flops(kind, cin, cout, K, n_in, n_out, pairs):
+    """SURVEY.md section 8d algorithmic (compulsory) traffic of one sparse-conv layer, fp32."""
+    s = 4
+    by = n_in * cin * s + n_out * cout * s + pairs * 8 + K * cin * cout * s
+    fl = 2.0 * pairs * cin * cout
+    return by, fl
+
+
+def cpu_baseline(num_points, seed_frame):
+    """Oracle ("port") timed on this host: 1 frame of `num_points` points through voxelize + VFE + encoder."""
+    import numpy as np
+    import torch
+    import isfusion_amd as m
+    import oracle
+    from isfusion_amd import synthetic
+    from isfusion_amd.norm import fold_bn
+    oracle.build()
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval()
+    pts = synthetic.lidar_sweeps(seed_frame, num_points)
+    vs, rg = lb.voxel_size, lb.point_cloud_range
+    vfe = lb.pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    plan = lb.pts_middle_encoder.plan_to_numpy()
+    t0 = time.perf_counter()
+    coors = np.concatenate([np.zeros((num_points, 1), np.int32), oracle.dynamic_voxelize(pts, vs, rg)], 1)
+    vf, vc, _ = oracle.dynamic_vfe(pts, coors, vs, rg, vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                   vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    bev, outs = oracle.sparse_encoder_forward(plan, vf, vc, 1)
+    dt = time.perf_counter() - t0
+    return dt, int(vf.shape[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--cpu-points", type=int, default=20000, help="points of the CPU-baseline sample frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import isfusion_amd as m
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
+    frames = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = lb(frames)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    # timed region: exactly K steps; per-layer hipEvents are recorded inside the library on the launch stream
+    import numpy as np
+    nl = len(lb.conv_layer_table())
+    ms_acc = np.zeros(nl)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = lb(frames, time_layers=True)
+        st = lb.last_stats
+        ms_acc += np.array([st.ms[i] for i in range(nl)])
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        st = lb.last_stats
+        tab = lb.conv_layer_table()
+        ms_layer = ms_acc / args.steps
+        groups = {}
+        tot_bytes = tot_flops = 0.0
+        for i, (kind, cin, cout, K) in enumerate(tab):
+            by, fl = conv_layer_bytes_flops(kind, cin, cout, K, st.num_in[i], st.num_out[i], st.pairs[i])
+            tot_bytes += by
+            tot_flops += fl
+            g = groups.setdefault(f"spconv_mfma<cin={cin},cout={cout}>", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            g["ms"] += float(ms_layer[i]); g["flops"] += fl; g["bytes"] += by; g["launches"] += 1
+        name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        t_s = dom["ms"] * 1e-3
+        tflops = dom["flops"] / t_s / 1e12 if t_s > 0 else 0.0
+        gbs = dom["bytes"] / t_s / 1e9 if t_s > 0 else 0.0
+        t_roof_mfma = dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        t_roof_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
+        if t_roof_mfma >= t_roof_hbm:
+            roof = dict(bound="mfma", achieved=round(tflops, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(tflops / MFMA_F32_PEAK_TFLOPS, 4))
+        else:
+            roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(gbs / HBM_PEAK_GBS, 4))
+        roof.update(traffic=None, kernel=name, launches_per_step=dom["launches"],
+                    avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                    algorithmic_gbs=round(gbs, 1), algorithmic_tflops=round(tflops, 3),
+                    conv_ms_per_step=round(float(ms_layer.sum()), 3),
+                    all_conv_tflops=round(tot_flops / (ms_layer.sum() * 1e-3) / 1e12, 3) if ms_layer.sum() > 0 else 0,
+                    all_conv_algorithmic_gbs=round(tot_bytes / (ms_layer.sum() * 1e-3) / 1e9, 1) if ms_layer.sum() > 0 else 0,
+                    per_kernel={k: dict(ms=round(v["ms"], 4), tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3)
+                                        if v["ms"] > 0 else 0, gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+                                        if v["ms"] > 0 else 0, launches=v["launches"]) for k, v in groups.items()},
+                    voxels_per_level=[int(st.num_in[0])] + [int(st.num_out[i]) for i, t in enumerate(tab) if t[0] == "spconv"])
+        frames_total = args.batch * world * args.steps
+        line = {
+            "metric": "nuScenes frames/sec forward (0.075 voxel), LiDAR branch voxelize+spconv->BEV",
+            "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: isfusion_0075voxel LiDAR-only branch (dynamic voxelize + "
+                                   "DynamicVFE + 21-layer SparseEncoder -> BEV [B,512,180,180]), synthetic "
+                                   f"nuScenes-shaped {args.points}-pt sweeps, batch={args.batch}/GPU, random-init "
+                                   "weights, eval BN, fp32",
+                       "points_per_frame": args.points, "batch_per_gpu": args.batch, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cdt, n0 = cpu_baseline(args.cpu_points, 1234 + 1000 * CFG_ID)
+            n0_full = st.num_in[0] / args.batch
+            line["cpu_baseline"] = {
+                "value": round(1.0 / cdt * (n0 / n0_full), 4), "unit": "frames/s (300k-pt-frame equivalent)",
+                "cores": 1, "kind": "port",
+                "sample": f"oracle (scalar C port, oracle/isf_oracle.c) on 1 frame of {args.cpu_points} points "
+                          f"({n0} voxels) took {cdt:.2f} s; scaled linearly by level-0 voxels to a "
+                          f"{args.points}-pt frame ({int(n0_full)} voxels)",
+                "sample_seconds": round(cdt, 2)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

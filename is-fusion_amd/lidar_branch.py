@@ -63,6 +63,26 @@ class LidarBranch(nn.Module):
                     m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
         return self
 
+    def randomize_weights_(self, seed=0, fan_taps=9.0):
+        """Random weights sized for the SPARSE fan-in (roughly ``fan_taps`` of the 27 taps are active for
+        LiDAR voxels) and for metre-scale inputs, so activations stay O(1) through the VFE and the 21 conv
+        layers and a 1e-3 absolute parity bound is a meaningful relative bound too.  (The default init
+        follows the reference's kaiming_uniform on the [k,k,k,Cin,Cout] layout, conv.py:105-112, which
+        shrinks activations by ~100x over the encoder.)"""
+        g = torch.Generator().manual_seed(seed)
+        from .spconv import SparseConvolution
+        for m in self.modules():
+            if isinstance(m, SparseConvolution):
+                std = (1.0 / (fan_taps * m.in_channels)) ** 0.5
+                with torch.no_grad():
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * std)
+            elif isinstance(m, nn.Linear):
+                # layer 1 sees raw coordinates (tens of metres); layer 2 sees post-ReLU features
+                std = 0.02 if m.in_features < 32 else (1.0 / m.in_features) ** 0.5
+                with torch.no_grad():
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * std)
+        return self
+
     def freeze(self, flag=True):
         """Skip the per-call parameter-change scans (weights are static at inference)."""
         self.pts_middle_encoder.freeze(flag)

@@ -1,0 +1,380 @@
+"""GPU parity tests (-m gpu): every HIP entry point, called through the C ABI (ctypes), against the CPU
+oracle on the same seeded inputs, against the committed golden vectors, and -- at BASELINE config sizes --
+through size-independent properties.  Integer / index outputs must be bit-exact; floating point within the
+tolerance written next to each check (north_star: 1e-3 fp32 on BEV features)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VS = [0.075, 0.075, 0.2]
+RG = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def lexsort4(a):
+    return np.lexsort(tuple(a[:, j] for j in range(a.shape[1] - 1, -1, -1)))
+
+
+# ------------------------------------------------------------------------------------------- A1 / A2
+@pytest.mark.parametrize("case", ["pillar", "pillar_capped", "fine", "kitti"])
+def test_voxelize_golden_reference_vectors(dev, golden, case):
+    import isfusion_amd as m
+    g = golden("voxelize_ref.npz")
+    cfg = g[case + "_cfg"]
+    vs, rg, Tm, MV = list(cfg[:3]), list(cfg[3:9]), int(cfg[9]), int(cfg[10])
+    pts = T(g[case + "_points"], dev)
+    coors = m.voxelization(pts, vs, rg, -1, -1)
+    assert coors.dtype == torch.int32 and np.array_equal(coors.cpu().numpy(), g[case + "_dyn_coors"])
+    v, c, n = m.voxelization(pts, vs, rg, Tm, MV)
+    assert np.array_equal(c.cpu().numpy(), g[case + "_coors"])
+    assert np.array_equal(n.cpu().numpy(), g[case + "_num"])
+    assert np.array_equal(v.cpu().numpy(), g[case + "_voxels"])
+
+
+def test_voxelize_vs_oracle_synthetic(dev, oracle_mod):
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    pts = synthetic.lidar_sweeps(5, 120000)
+    pts[:500, 0] += 60.0  # some out-of-range rows
+    d = m.voxelization(T(pts, dev), VS, RG, -1, -1).cpu().numpy()
+    assert np.array_equal(d, oracle_mod.dynamic_voxelize(pts, VS, RG))
+    for vs, Tm, MV in (([0.6, 0.6, 8.0], 12, 30000), ([0.6, 0.6, 8.0], 12, 1000), (VS, 10, 60000)):
+        v, c, n = m.voxelization(T(pts, dev), vs, RG, Tm, MV)
+        ov, oc, on = oracle_mod.hard_voxelize(pts, vs, RG, Tm, MV)
+        assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(n.cpu().numpy(), on)
+        assert np.array_equal(v.cpu().numpy(), ov)
+    # module surface + empty input
+    layer = m.Voxelization(voxel_size=[0.6, 0.6, 8], point_cloud_range=RG, max_num_points=12,
+                           max_voxels=(30000, 60000)).eval()
+    v, c, n = layer(T(pts[:1000], dev))
+    assert v.shape[1:] == (12, 5) and c.shape[1] == 3 and n.max() <= 12
+    v, c, n = m.voxelization(torch.zeros((0, 5), device=dev), [0.6, 0.6, 8.0], RG, 12, 100)
+    assert v.shape == (0, 12, 5) and c.shape == (0, 3)
+
+
+def test_dynamic_voxelize_batched(dev, oracle_mod):
+    from isfusion_amd.voxelize import dynamic_voxelize_batched
+    from isfusion_amd import synthetic
+    pl = [synthetic.lidar_sweeps(i, 5000 + 100 * i) for i in range(3)]
+    pts, coors = dynamic_voxelize_batched([T(p, dev) for p in pl], VS, RG)
+    exp = np.concatenate([np.concatenate([np.full((p.shape[0], 1), b, np.int32),
+                                          oracle_mod.dynamic_voxelize(p, VS, RG)], 1) for b, p in enumerate(pl)])
+    assert np.array_equal(coors.cpu().numpy(), exp) and pts.shape[0] == exp.shape[0]
+
+
+# ------------------------------------------------------------------------------------------- A3
+def test_dynamic_scatter_golden_and_oracle(dev, golden, oracle_mod):
+    from isfusion_amd.scatter_points import dynamic_point_to_voxel_forward
+    g = golden("scatter_ref.npz")
+    for red, key in (("mean", "ref_mean"), ("max", "ref_max")):
+        f, c, cmap, cnt = dynamic_point_to_voxel_forward(T(g["feats"], dev), T(g["coors"], dev), red)
+        assert np.array_equal(c.cpu().numpy(), g["ref_coors"])
+        assert np.allclose(f.cpu().numpy(), g[key], atol=1e-2, rtol=1e-5)  # reference test tolerance
+        of, oc, om, on = oracle_mod.dynamic_scatter(g["feats"], g["coors"], red)
+        assert np.array_equal(cmap.cpu().numpy(), om) and np.array_equal(cnt.cpu().numpy(), on)
+        assert np.allclose(f.cpu().numpy(), of, atol=1e-4, rtol=1e-5)
+    f, c, cmap, cnt = dynamic_point_to_voxel_forward(T(g["feats"], dev), T(g["coors"], dev), "sum")
+    of = oracle_mod.dynamic_scatter(g["feats"], g["coors"], "sum")[0]
+    assert np.allclose(f.cpu().numpy(), of, atol=1e-3, rtol=1e-5)
+
+
+def test_dynamic_scatter_module_edge_cases_and_grad(dev, oracle_mod):
+    """mirrors reference tests/test_models/test_voxel_encoder/test_dynamic_scatter.py:9-94"""
+    import isfusion_amd as m
+    dsmean = m.DynamicScatter([0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4], True)
+    dsmax = m.DynamicScatter([0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4], False)
+    ef = torch.empty((0, 3), device=dev).requires_grad_()
+    ec = torch.empty((0, 3), dtype=torch.int32, device=dev)
+    fo, co = dsmean(ef, ec)
+    fo.sum().backward()
+    assert fo.shape == ef.shape and co.shape == ec.shape
+    fo, co = dsmax(ef, ec)
+    assert fo.shape == ef.shape
+    of = (torch.rand((20000, 3), device=dev) * 100 - 50).requires_grad_()
+    oc = torch.full((20000, 3), -1, dtype=torch.int32, device=dev)
+    for ds in (dsmean, dsmax):
+        fo, co = ds(of, oc)
+        assert fo.shape[0] == 0
+        fo.sum().backward()
+        assert (of.grad == 0).all()
+    # backward vs oracle, all three reductions
+    rng = np.random.default_rng(3)
+    feats = (rng.random((5000, 4), dtype=np.float32) * 100 - 50)
+    coors = rng.integers(-1, 6, (5000, 3)).astype(np.int32)
+    for red in ("mean", "max", "sum"):
+        x = T(feats, dev).requires_grad_()
+        f, c = m.dynamic_scatter(x, T(coors, dev), red)
+        gout = rng.normal(size=tuple(f.shape)).astype(np.float32)
+        f.backward(T(gout, dev))
+        ofw, oc_, om, on = oracle_mod.dynamic_scatter(feats, coors, red)
+        og = oracle_mod.dynamic_scatter_backward(gout, feats, ofw, om, on, red)
+        assert np.allclose(x.grad.cpu().numpy(), og, atol=1e-5), red
+    # batched (b,z,y,x) form == per-sample loop of the reference
+    c4 = np.concatenate([np.sort(rng.integers(0, 3, (5000, 1)), 0), coors], 1).astype(np.int32)
+    f, c = dsmax(T(feats, dev), T(c4, dev))
+    of_, oc4 = oracle_mod.dynamic_scatter_batched(feats, c4, "max")
+    assert np.array_equal(c.cpu().numpy(), oc4) and np.allclose(f.cpu().numpy(), of_, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- A4
+def _vfe_case(oracle_mod, dev, P=30000, B=2, seed=0):
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    from isfusion_amd.norm import fold_bn
+    lb = m.LidarBranch().randomize_weights_(seed).randomize_bn_(seed + 1).eval()
+    pl = [synthetic.lidar_sweeps(100 + seed + i, P) for i in range(B)]
+    pl[0][:50, 2] = 100.0  # out of range points must be ignored
+    pts = np.concatenate(pl)
+    coors = np.concatenate([np.concatenate([np.full((p.shape[0], 1), b, np.int32),
+                                            oracle_mod.dynamic_voxelize(p, VS, RG)], 1) for b, p in enumerate(pl)])
+    vfe = lb.pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    ovf, ovc, op2v = oracle_mod.dynamic_vfe(pts, coors, VS, RG, vfe.vfe_layers[0].linear.weight.detach().numpy(),
+                                            bn1, vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    return lb.to(dev), pl, pts, coors, ovf, ovc, op2v
+
+
+def test_dynamic_vfe_fused_vs_oracle(dev, oracle_mod):
+    lb, pl, pts, coors, ovf, ovc, _ = _vfe_case(oracle_mod, dev)
+    vf, vc = lb.pts_voxel_encoder(T(pts, dev), T(coors, dev))
+    assert vc.dtype == torch.int32 and np.array_equal(vc.cpu().numpy(), ovc)  # sorted (b,z,y,x), bit exact
+    err = np.abs(vf.cpu().numpy() - ovf).max()
+    assert err < 1e-4, err  # fp32, different summation order only
+    assert np.abs(ovf).max() > 0.5
+
+
+def test_dynamic_vfe_composed_path_matches_fused(dev, oracle_mod):
+    lb, pl, pts, coors, ovf, ovc, _ = _vfe_case(oracle_mod, dev, P=8000, B=2, seed=3)
+    vfe = lb.pts_voxel_encoder
+    with torch.no_grad():
+        vf2, vc2 = vfe._forward_composed(T(pts, dev), T(coors, dev))
+    keep = np.ones(len(ovc), bool)
+    assert np.array_equal(vc2.cpu().numpy(), ovc)
+    assert np.abs(vf2.cpu().numpy() - ovf).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- A5 / A6
+def _pairs_set(nbr, n_out):
+    K = nbr.shape[0]
+    s = set()
+    for k in range(K):
+        o = np.nonzero(nbr[k, :n_out] >= 0)[0]
+        s.update(zip([k] * len(o), nbr[k, o].tolist(), o.tolist()))
+    return s
+
+
+@pytest.mark.parametrize("case", ["subm_k3", "conv_s2p1", "conv_s2p011", "conv_311", "subm_5to16"])
+def test_rulebook_and_conv_golden_dense_identity(dev, golden, oracle_mod, case):
+    from isfusion_amd import spconv as sp
+    g = golden("spconv_dense_ref.npz")
+    cfg = g[case + "_cfg"]
+    B, shape, ks, st, pd, subm = int(cfg[0]), list(cfg[1:4]), list(cfg[4:7]), list(cfg[7:10]), list(cfg[10:13]), bool(cfg[13])
+    idx, feats, w = g[case + "_idx"], g[case + "_feats"], g[case + "_w"]
+    for perm_seed in (None, 1):  # rows in sorted order, then shuffled (exercises the perm path)
+        order = np.arange(len(idx)) if perm_seed is None else np.random.default_rng(perm_seed).permutation(len(idx))
+        rb = sp.build_rulebook(T(idx[order], dev), B, shape, ks, st, pd, subm)
+        oidx, pairs, num = oracle_mod.get_indice_pairs(idx[order], B, shape, ks, st, pd, subm=subm)
+        assert rb.num_out == len(oidx)
+        out_idx = rb.out_indices.cpu().numpy()
+        # same set of output sites; same set of (tap, in, out) pairs after mapping oracle out ids to ours
+        assert np.array_equal(out_idx[lexsort4(out_idx)], oidx[lexsort4(oidx)])
+        lut = {tuple(r): i for i, r in enumerate(out_idx.tolist())}
+        remap = np.array([lut[tuple(r)] for r in oidx.tolist()])
+        exp = set()
+        for k in range(pairs.shape[0]):
+            for s in range(num[k]):
+                exp.add((k, int(pairs[k, 0, s]), int(remap[pairs[k, 1, s]])))
+        assert _pairs_set(rb.nbr.cpu().numpy(), rb.num_out) == exp
+        K = int(np.prod(ks))
+        y = sp.sparse_conv_forward(T(feats[order], dev), sp.pack_filters(T(w, dev)), K, w.shape[-2], w.shape[-1], rb)
+        y = y.cpu().numpy()
+        gi = g[case + "_out_idx"]
+        ref = g[case + "_out"][lexsort4(gi)]
+        assert np.allclose(y[lexsort4(out_idx)], ref, atol=2e-4, rtol=1e-4), np.abs(y[lexsort4(out_idx)] - ref).max()
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 256),
+                                      (256, 256), (16, 16), (16, 32)])
+def test_sparse_conv_shapes_epilogue_vs_oracle(dev, oracle_mod, cin, cout):
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin * 1000 + cout)
+    B, shape = 2, [9, 24, 20]
+    cells = B * int(np.prod(shape))
+    n = 700
+    lin = np.sort(rng.choice(cells, n, replace=False))
+    D, H, W = shape
+    idx = np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+    feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+        w = rng.normal(0, (1.0 / (6 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32)
+        scale = (rng.random(cout, dtype=np.float32) + 0.5)
+        shift = rng.normal(0, 0.2, cout).astype(np.float32)
+        rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+        oidx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, ks, st, pd, subm=subm)
+        res = rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32)
+        y = sp.sparse_conv_forward(T(feats, dev), sp.pack_filters(T(w, dev)), 27, cin, cout, rb, T(scale, dev),
+                                   T(shift, dev), T(res, dev), relu=True).cpu().numpy()
+        oy = oracle_mod.indice_conv(feats, w, pairs, num, len(oidx))
+        out_idx = rb.out_indices.cpu().numpy()
+        o1, o2 = lexsort4(out_idx), lexsort4(oidx)
+        oy = oracle_mod.bn_act(oy[o2], scale, shift, res[o1], relu=True)
+        assert np.abs(y[o1] - oy).max() < 2e-4, (cin, cout, subm, np.abs(y[o1] - oy).max())
+        assert (y >= 0).all() and y.max() > 0.5
+
+
+def test_spconv1_interchange_format_roundtrip(dev, oracle_mod):
+    from isfusion_amd import _lib, spconv as sp
+    rng = np.random.default_rng(9)
+    B, shape = 1, [8, 16, 16]
+    lin = np.sort(rng.choice(int(np.prod(shape)), 400, replace=False))
+    D, H, W = shape
+    idx = np.stack([lin * 0, (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+    rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    lib = _lib.load()
+    pairs = torch.empty((27, 2, 400), dtype=torch.int32, device=dev)
+    num = torch.empty((27,), dtype=torch.int32, device=dev)
+    _lib.check(lib.isf_rulebook_to_indice_pairs(_lib.ptr(rb.nbr), rb.stride, rb.num_out, 27, 400, _lib.ptr(pairs),
+                                                _lib.ptr(num), _lib.stream()))
+    _, opairs, onum = oracle_mod.get_indice_pairs(idx, B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], subm=True)
+    assert np.array_equal(num.cpu().numpy(), onum)
+    p = pairs.cpu().numpy()
+    for k in range(27):
+        a = set(zip(p[k, 0, :onum[k]].tolist(), p[k, 1, :onum[k]].tolist()))
+        b = set(zip(opairs[k, 0, :onum[k]].tolist(), opairs[k, 1, :onum[k]].tolist()))
+        assert a == b and (p[k, :, onum[k]:] == -1).all()
+    nbr2 = torch.empty_like(rb.nbr)
+    _lib.check(lib.isf_indice_pairs_to_rulebook(_lib.ptr(pairs), _lib.ptr(num), 27, 400, rb.num_out, _lib.ptr(nbr2),
+                                                rb.stride, _lib.stream()))
+    assert torch.equal(nbr2[:, :rb.num_out], rb.nbr[:, :rb.num_out])
+    # drop-in op: raw (unpacked) filters through isf_sparse_conv_forward
+    w = rng.normal(0, 0.1, (3, 3, 3, 16, 32)).astype(np.float32)
+    feats = rng.normal(0, 1, (400, 16)).astype(np.float32)
+    out = torch.empty((400, 32), device=dev)
+    _lib.check(lib.isf_sparse_conv_forward(_lib.ptr(T(feats, dev)), 400, 16, _lib.ptr(T(w, dev)), 27, 32,
+                                           _lib.ptr(rb.nbr), rb.stride, 400, None, None, None, 0, _lib.ptr(out),
+                                           _lib.stream()))
+    assert np.abs(out.cpu().numpy() - oracle_mod.indice_conv(feats, w, opairs, onum, 400)).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- A7
+def test_dense_bev(dev, oracle_mod):
+    import isfusion_amd as m
+    rng = np.random.default_rng(4)
+    B, shape, C = 3, [2, 180, 180], 256
+    lin = rng.choice(B * int(np.prod(shape)), 5000, replace=False)  # unsorted rows on purpose
+    D, H, W = shape
+    idx = np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+    feats = rng.normal(0, 1, (5000, C)).astype(np.float32)
+    x = m.SparseConvTensor(T(feats, dev), T(idx, dev), shape, B)
+    d = x.dense()
+    assert d.shape == (B, C, D, H, W)
+    ref = oracle_mod.dense_bev(feats, idx, B, shape)
+    assert np.array_equal(d.reshape(B, C * D, H, W).cpu().numpy(), ref)
+
+
+def _encoder_case(oracle_mod, dev, P, B, seed):
+    lb, pl, pts, coors, ovf, ovc, _ = _vfe_case(oracle_mod, dev, P=P, B=B, seed=seed)
+    bev, outs = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), ovf, ovc, B)
+    return lb, pl, ovf, ovc, bev, outs
+
+
+def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
+    """cfg-2-shaped (dynamic voxelize + DynamicVFE + full 21-layer SparseEncoder -> [B,512,180,180]) at a size
+    the scalar oracle finishes in seconds.  Tolerance: 1e-3 absolute on BEV features (north_star)."""
+    from isfusion_amd import _lib
+    B = 2
+    lb, pl, ovf, ovc, bev, outs = _encoder_case(oracle_mod, dev, P=5000, B=B, seed=7)
+    enc = lb.pts_middle_encoder
+    # (1) SparseEncoder.forward, fused C call, oracle VFE output as input
+    stats = _lib.EncoderStats()
+    sp = enc.forward_fused(T(ovf, dev), T(ovc, dev), B, stats=stats)
+    got = sp.cpu().numpy()
+    assert got.shape == (B, 512, 180, 180)
+    err = np.abs(got - bev).max()
+    assert err < 1e-3, err
+    assert np.array_equal(got != 0, bev != 0)
+    assert np.abs(bev).max() > 1.0
+    for i, (f, ix, shp) in enumerate(outs):  # voxel counts of every layer, bit exact
+        assert stats.num_out[i] == f.shape[0], (i, stats.num_out[i], f.shape[0])
+    # (2) the 3-tuple module surface (isfusion.py:111 unpacks x, _, kwargs)
+    x, enc_feats, kw = enc(T(ovf, dev), T(ovc, dev), B, foo=1)
+    assert torch.equal(x, sp) and kw == {"foo": 1}
+    # (3) module-by-module path (SparseSequential / SparseBasicBlock / dense) agrees
+    with torch.no_grad():
+        x2, feats2 = enc.forward_modules(T(ovf, dev), T(ovc, dev), B)
+    assert np.abs(x2.cpu().numpy() - bev).max() < 1e-3
+    assert len(feats2) == 5 and feats2[-1].features.shape[0] == outs[-2][0].shape[0]
+    # (4) unsorted input rows are re-ranked by the library
+    perm = np.random.default_rng(0).permutation(len(ovc))
+    sp3 = enc.forward_fused(T(ovf[perm], dev), T(ovc[perm], dev), B)
+    assert np.abs(sp3.cpu().numpy() - bev).max() < 1e-3
+    # (5) whole LiDAR branch in one call from raw points
+    out = lb([T(p, dev) for p in pl], want_stats=True)
+    err = np.abs(out.cpu().numpy() - bev).max()
+    assert err < 1e-3, err
+    assert lb.last_stats.num_in[0] == len(ovc)
+    pairs0 = sum(int(n) for n in oracle_mod.get_indice_pairs(ovc, B, [41, 1440, 1440], [3, 3, 3], [1, 1, 1],
+                                                              [1, 1, 1], subm=True)[2])
+    assert lb.last_stats.pairs[0] == pairs0 and lb.last_stats.pairs[1] == pairs0
+
+
+def test_encoder_training_mode_is_loud(dev):
+    import isfusion_amd as m
+    conv = m.SubMConv3d(16, 16, 3, padding=1, bias=False).to(dev)
+    x = m.SparseConvTensor(torch.rand(10, 16, device=dev), torch.zeros((10, 4), dtype=torch.int32, device=dev),
+                           [4, 4, 4], 1)
+    with pytest.raises(NotImplementedError):
+        conv(x)
+
+
+# ------------------------------------------------------------------------------------------- full size
+def test_full_size_properties_cfg2(dev):
+    """BASELINE configs[1]: B=4 x 300k points.  No oracle at this size: size-independent properties."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    from isfusion_amd.voxelize import dynamic_voxelize_batched
+    B, P = 4, 300000
+    pl = [T(synthetic.lidar_sweeps(1234 + 2000 + i, P), dev) for i in range(B)]
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    out = lb(pl, want_stats=True)
+    st = lb.last_stats
+    assert out.shape == (B, 512, 180, 180) and torch.isfinite(out).all()
+    # voxel count == number of distinct in-range coordinates (torch.unique as independent counter)
+    pts, coors = dynamic_voxelize_batched(pl, VS, RG)
+    uniq = torch.unique(coors[(coors[:, 1:] >= 0).all(1)], dim=0)
+    assert st.num_in[0] == uniq.shape[0]
+    # SubM layers keep the active set; strided layers: N_out <= 8 * N_in and pairs >= N_out
+    tab = lb.conv_layer_table()
+    for i, (kind, cin, cout, K) in enumerate(tab):
+        if kind == "subm":
+            assert st.num_out[i] == st.num_in[i] and st.pairs[i] >= st.num_in[i]
+        else:
+            assert 0 < st.num_out[i] <= 8 * st.num_in[i] and st.pairs[i] >= st.num_out[i]
+    # determinism: same inputs -> bit-identical BEV (no atomics in the float path except the exact
+    # fixed-point centroid sums and max reductions)
+    out2 = lb(pl)
+    assert torch.equal(out, out2)
+    # frames are independent: running sample 2 alone reproduces its slice of the batch
+    out_single = lb([pl[2]])
+    assert torch.equal(out_single[0], out[2])
+    # active BEV cells == cells of the last level's voxels
+    nz_cells = (out != 0).any(dim=1).sum().item()
+    assert 0 < nz_cells <= st.num_out[len(tab) - 1]
+    # hard (pillar) voxelization at full size: voxels are distinct, counts within bounds, first points are
+    # increasing in first-appearance order
+    v, c, n = m.voxelization(pl[0], [0.6, 0.6, 8.0], RG, 12, 30000)
+    assert torch.unique(c, dim=0).shape[0] == c.shape[0] and n.min() >= 1 and n.max() <= 12
+    first = v[:, 0, :]
+    # every stored first point really lies in its voxel
+    cx = torch.floor((first[:, 0] - RG[0]) / 0.6).int()
+    cy = torch.floor((first[:, 1] - RG[1]) / 0.6).int()
+    assert torch.equal(cx, c[:, 2]) and torch.equal(cy, c[:, 1])

@@ -1,0 +1,166 @@
+"""CPU tests: the oracle (oracle/isf_oracle.c) against the committed golden vectors.
+
+These pin the checker itself: reference-C++-generated voxelization vectors, the known-answer vector of the
+reference's test_voxel_generator.py, the brute-force DynamicScatter reference of the reference's
+test_dynamic_scatter.py, and the dense-conv3d identity for sparse convolution.
+"""
+import numpy as np
+import pytest
+import torch
+
+
+def _cfg(a):
+    vs, rg = list(a[:3]), list(a[3:9])
+    return vs, rg, int(a[9]), int(a[10])
+
+
+@pytest.mark.parametrize("case", ["pillar", "pillar_capped", "fine", "kitti"])
+def test_voxelize_matches_reference_cpp(oracle_mod, golden, case):
+    g = golden("voxelize_ref.npz")
+    vs, rg, T, MV = _cfg(g[case + "_cfg"])
+    pts = g[case + "_points"]
+    assert np.array_equal(oracle_mod.dynamic_voxelize(pts, vs, rg), g[case + "_dyn_coors"])
+    v, c, n = oracle_mod.hard_voxelize(pts, vs, rg, T, MV)
+    assert np.array_equal(c, g[case + "_coors"])
+    assert np.array_equal(n, g[case + "_num"])
+    assert np.array_equal(v, g[case + "_voxels"])
+
+
+def test_voxel_generator_known_answer(oracle_mod):
+    # reference tests/test_models/test_voxel_encoder/test_voxel_generator.py:6-22
+    np.random.seed(0)
+    pts = np.random.rand(1000, 4).astype(np.float32)
+    _, coors, num = oracle_mod.hard_voxelize(pts, [0.5, 0.5, 0.5], [0, -40, -3, 70.4, 40, 1], 1000, 20000)
+    exp = np.array([[7, 81, 1], [6, 81, 0], [7, 80, 1], [6, 81, 1], [7, 81, 0], [6, 80, 1], [7, 80, 0], [6, 80, 0]])
+    assert np.array_equal(coors, exp)
+    assert np.array_equal(num, [120, 121, 127, 134, 115, 127, 125, 131])
+
+
+def test_dynamic_scatter_matches_bruteforce(oracle_mod, golden):
+    g = golden("scatter_ref.npz")
+    for red, key in (("mean", "ref_mean"), ("max", "ref_max")):
+        f, c, cmap, cnt = oracle_mod.dynamic_scatter(g["feats"], g["coors"], red)
+        assert np.array_equal(c, g["ref_coors"])
+        # tolerance of the reference test (test_dynamic_scatter.py:80-84)
+        assert np.allclose(f, g[key], atol=1e-2, rtol=1e-5)
+        valid = (g["coors"] >= 0).all(1)
+        assert ((cmap >= 0) == valid).all()
+        assert np.array_equal(c[cmap[valid]], g["coors"][valid])
+        assert cnt.sum() == valid.sum()
+
+
+def test_dynamic_scatter_edge_cases(oracle_mod):
+    # test_dynamic_scatter.py:23-54: empty input, every row invalid
+    f, c, m, n = oracle_mod.dynamic_scatter(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), "mean")
+    assert f.shape == (0, 3) and c.shape == (0, 3)
+    feats = np.random.default_rng(0).random((500, 3), dtype=np.float32)
+    coors = -np.ones((500, 3), np.int32)
+    f, c, m, n = oracle_mod.dynamic_scatter(feats, coors, "max")
+    assert f.shape[0] == 0 and (m == -1).all()
+    g = oracle_mod.dynamic_scatter_backward(np.zeros((0, 3), np.float32), feats, f, m, n, "max")
+    assert (g == 0).all()
+
+
+def test_dynamic_scatter_backward_matches_autograd(oracle_mod):
+    rng = np.random.default_rng(5)
+    feats = (rng.random((300, 4), dtype=np.float32) * 100 - 50)
+    coors = rng.integers(-1, 3, (300, 3)).astype(np.int32)
+    for red in ("mean", "max", "sum"):
+        f, c, cmap, cnt = oracle_mod.dynamic_scatter(feats, coors, red)
+        gout = rng.normal(size=f.shape).astype(np.float32)
+        g = oracle_mod.dynamic_scatter_backward(gout, feats, f, cmap, cnt, red)
+        # autograd reference with torch index ops
+        x = torch.from_numpy(feats).double().requires_grad_()
+        m = torch.from_numpy(cmap).long()
+        valid = m >= 0
+        M = f.shape[0]
+        if red == "max":
+            out = torch.full((M, 4), -float("inf"), dtype=torch.float64)
+            out = out.scatter_reduce(0, m[valid][:, None].expand(-1, 4), x[valid], "amax", include_self=True)
+        else:
+            out = torch.zeros((M, 4), dtype=torch.float64).index_add(0, m[valid], x[valid])
+            if red == "mean":
+                out = out / torch.from_numpy(cnt).double()[:, None]
+        out.backward(torch.from_numpy(gout).double())
+        assert np.allclose(g, x.grad.numpy(), atol=1e-5), red
+
+
+@pytest.mark.parametrize("case", ["subm_k3", "conv_s2p1", "conv_s2p011", "conv_311", "subm_5to16"])
+def test_sparse_conv_matches_dense_conv3d(oracle_mod, golden, case):
+    g = golden("spconv_dense_ref.npz")
+    cfg = g[case + "_cfg"]
+    B, shape, ks, st, pd, subm = int(cfg[0]), list(cfg[1:4]), list(cfg[4:7]), list(cfg[7:10]), list(cfg[10:13]), bool(cfg[13])
+    idx, feats, w = g[case + "_idx"], g[case + "_feats"], g[case + "_w"]
+    out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, ks, st, pd, subm=subm)
+    y = oracle_mod.indice_conv(feats, w, pairs, num, out_idx.shape[0])
+    # the CPU reference numbers strided outputs first-come; compare after sorting by (b,z,y,x)
+    key = lambda a: np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0]))
+    o = key(out_idx)
+    assert np.array_equal(out_idx[o], g[case + "_out_idx"][key(g[case + "_out_idx"])])
+    assert np.allclose(y[o], g[case + "_out"][key(g[case + "_out_idx"])], atol=2e-4, rtol=1e-4)
+
+
+def test_rulebook_conventions(oracle_mod):
+    """Hand-checkable case: one voxel, stride-2 k3 p1 conv -> the outputs and taps geometry.h defines."""
+    idx = np.array([[0, 3, 4, 5]], np.int32)
+    out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, 1, [8, 8, 8], [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    # z=3 (odd): o in {2,1} with taps k = 3 - 2o + 1 = {0,2}; y=4 (even): o=2,k=1; x=5 (odd): o in {3,2}, k={0,2}
+    got = {(tuple(out_idx[pairs[k, 1, 0]][1:]), k) for k in range(27) if num[k]}
+    exp = set()
+    for oz, kz in ((2, 0), (1, 2)):
+        for ox, kx in ((3, 0), (2, 2)):
+            exp.add(((oz, 2, ox), (kz * 3 + 1) * 3 + kx))
+    assert got == exp and num.sum() == 4
+    # first-come numbering: largest output coordinate first, x fastest (geometry.h:60-83)
+    assert out_idx[0].tolist() == [0, 2, 2, 3] and out_idx[1].tolist() == [0, 2, 2, 2]
+
+
+def test_sparse_encoder_shape_known_answer(oracle_mod):
+    """reference tests/test_models/test_common_modules/test_middle_encoders.py:8-27: [4,256,128,128]
+    (the level shapes only; run on a thin slab of voxels so the scalar oracle stays fast)."""
+    shape = [40, 1024, 1024]
+    for _ in range(3):
+        shape = oracle_mod.conv_out_shape(shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    shape = oracle_mod.conv_out_shape(shape, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+    assert [128 * shape[0], shape[1], shape[2]] == [256, 128, 128]
+    # IS-Fusion config: [41,1440,1440] -> [2,180,180], 256*2 = 512 channels (sparse_encoder.py:75-104)
+    s = [41, 1440, 1440]
+    s = oracle_mod.conv_out_shape(s, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    s = oracle_mod.conv_out_shape(s, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    s = oracle_mod.conv_out_shape(s, [3, 3, 3], [2, 2, 2], [0, 1, 1])
+    s = oracle_mod.conv_out_shape(s, [3, 1, 1], [2, 1, 1], [0, 0, 0])
+    assert s == [2, 180, 180]
+
+
+def test_dynamic_vfe_matches_torch_composition(oracle_mod):
+    """oracle DynamicVFE vs the reference's composition written with torch ops (voxel_encoder.py:453-547)."""
+    rng = np.random.default_rng(2)
+    vs, rg = [0.5, 0.5, 1.0], [0, 0, 0, 8, 8, 4]
+    P = 600
+    pts = rng.random((P, 5), dtype=np.float32) * np.array([8, 8, 4, 1, 1], np.float32)
+    coors3 = oracle_mod.dynamic_voxelize(pts, vs, rg)
+    b = (np.arange(P) >= P // 2).astype(np.int32)
+    coors4 = np.concatenate([b[:, None], coors3], 1).astype(np.int32)
+    w1 = rng.normal(0, 0.3, (64, 11)).astype(np.float32)
+    w2 = rng.normal(0, 0.2, (64, 128)).astype(np.float32)
+    bn = lambda: (rng.random(64, dtype=np.float32) + 0.5, rng.normal(0, 0.1, 64).astype(np.float32))
+    bn1, bn2 = bn(), bn()
+    vf, vc, p2v = oracle_mod.dynamic_vfe(pts, coors4, vs, rg, w1, bn1, w2, bn2)
+    # torch composition
+    x = torch.from_numpy(pts)
+    c = torch.from_numpy(coors4).long()
+    uc, inv = torch.unique(c, dim=0, sorted=True, return_inverse=True)
+    assert np.array_equal(uc.numpy(), vc) and np.array_equal(inv.numpy(), p2v)
+    N = uc.shape[0]
+    mean = torch.zeros((N, 3)).index_add(0, inv, x[:, :3]) / torch.bincount(inv, minlength=N)[:, None]
+    f_cluster = x[:, :3] - mean[inv]
+    off = [vs[0] / 2 + rg[0], vs[1] / 2 + rg[1], vs[2] / 2 + rg[2]]
+    f_center = torch.stack([x[:, 0] - (c[:, 3].float() * vs[0] + off[0]), x[:, 1] - (c[:, 2].float() * vs[1] + off[1]),
+                            x[:, 2] - (c[:, 1].float() * vs[2] + off[2])], 1)
+    f = torch.cat([x, f_cluster, f_center], 1)
+    h1 = torch.relu(f @ torch.from_numpy(w1).T * torch.from_numpy(bn1[0]) + torch.from_numpy(bn1[1]))
+    vmax1 = torch.full((N, 64), -float("inf")).scatter_reduce(0, inv[:, None].expand(-1, 64), h1, "amax")
+    g = torch.cat([h1, vmax1[inv]], 1)
+    h2 = torch.relu(g @ torch.from_numpy(w2).T * torch.from_numpy(bn2[0]) + torch.from_numpy(bn2[1]))
+    ref = torch.full((N, 64), -float("inf")).scatter_reduce(0, inv[:, None].expand(-1, 64), h2, "amax")
+    assert np.allclose(vf, ref.numpy(), atol=1e-4, rtol=1e-4)
