@@ -259,7 +259,8 @@ def test_spconv1_interchange_format_roundtrip(dev, oracle_mod):
     w = rng.normal(0, 0.1, (3, 3, 3, 16, 32)).astype(np.float32)
     feats = rng.normal(0, 1, (400, 16)).astype(np.float32)
     out = torch.empty((400, 32), device=dev)
-    _lib.check(lib.isf_sparse_conv_forward(_lib.ptr(T(feats, dev)), 400, 16, _lib.ptr(T(w, dev)), 27, 32,
+    d_feats, d_w = T(feats, dev), T(w, dev)  # keep the device tensors alive across the asynchronous call
+    _lib.check(lib.isf_sparse_conv_forward(_lib.ptr(d_feats), 400, 16, _lib.ptr(d_w), 27, 32,
                                            _lib.ptr(rb.nbr), rb.stride, 400, None, None, None, 0, _lib.ptr(out),
                                            _lib.stream()))
     assert np.abs(out.cpu().numpy() - oracle_mod.indice_conv(feats, w, opairs, onum, 400)).max() < 1e-4
