@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak (v_mfma_f32_16x16x4_f32)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (never the 2:1-sparsity figure)
 POINTS_PER_FRAME = 300000
 BATCH_PER_GPU = 4
 CFG_ID = 2
@@ -88,6 +89,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
     ap.add_argument("--cpu-points", type=int, default=20000, help="points of the CPU-baseline sample frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +107,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
 
+    from isfusion_amd import _lib
+    _lib.check(_lib.load().isf_set_conv_precision(1 if args.fp32 else 0))
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
     frames = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
     torch.cuda.synchronize()
@@ -154,11 +158,17 @@ def main():
         t_s = dom["ms"] * 1e-3
         tflops = dom["flops"] / t_s / 1e12 if t_s > 0 else 0.0
         gbs = dom["bytes"] / t_s / 1e9 if t_s > 0 else 0.0
-        t_roof_mfma = dom["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        # precision 1: the f16x3 split kernels EXECUTE 3 f16 MFMA passes per algorithmic fp32 multiply-add, so
+        # the matrix-pipe roofline is the f16 peak against 3x the algorithmic flops
+        split = st.precision == 1
+        mult, peak = (3.0, MFMA_F16_PEAK_TFLOPS) if split else (1.0, MFMA_F32_PEAK_TFLOPS)
+        t_roof_mfma = mult * dom["flops"] / (peak * 1e12)
         t_roof_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
         if t_roof_mfma >= t_roof_hbm:
-            roof = dict(bound="mfma", achieved=round(tflops, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(tflops / MFMA_F32_PEAK_TFLOPS, 4))
+            roof = dict(bound="mfma", achieved=round(mult * tflops, 3), peak=peak, unit="TFLOP/s",
+                        frac=round(mult * tflops / peak, 4),
+                        arithmetic="f16x3 split MFMA (3 f16 passes per fp32 product, fp32 accumulate)"
+                        if split else "fp32 MFMA")
         else:
             roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(gbs / HBM_PEAK_GBS, 4))
@@ -177,7 +187,9 @@ def main():
             "metric": "nuScenes frames/sec forward (0.075 voxel), LiDAR branch voxelize+spconv->BEV",
             "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f16x3 split-precision MFMA, fp32 accumulate)" if st.precision == 1 else "f32",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: isfusion_0075voxel LiDAR-only branch (dynamic voxelize + "
                                    "DynamicVFE + 21-layer SparseEncoder -> BEV [B,512,180,180]), synthetic "
                                    f"nuScenes-shaped {args.points}-pt sweeps, batch={args.batch}/GPU, random-init "

@@ -181,6 +181,25 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
                                    int num_out, const float* scale, const float* shift,
                                    const float* residual, int relu, float* out, isf_stream_t stream);
 
+/* Split-precision ("f16x3") sparse convolution -------------------------------------------------------------
+ * Same contract as isf_sparse_conv_forward_packed, evaluated on the f16 matrix cores with fp32-equivalent
+ * accuracy: operands are carried as hi + lo f16 halves (22 significant bits), products as
+ * a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with fp32 accumulation.  Activations are exchanged in the SPLIT format:
+ * row-major [N, C/8] units of 32 bytes = 8 x f16 hi followed by 8 x f16 lo (same 4 bytes/element as fp32);
+ * isf_f32_to_split / isf_split_to_f32 convert.  |activation| must be < 65504.  Cin, Cout in {32,64,128,256}.
+ * isf_set_conv_precision(0) (default): isf_sparse_encoder_forward / isf_lidar_branch_forward use this path
+ * when every layer carries packed16; isf_set_conv_precision(1) forces the fp32 MFMA kernels. */
+size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
+int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
+                           isf_stream_t stream);
+int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream);
+int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream);
+int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
+                                  int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                                  const float* scale, const float* shift, const void* residual_split, int relu,
+                                  void* out_split, isf_stream_t stream);
+int isf_set_conv_precision(int mode);
+
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
  * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros
  * elsewhere; out [B, C*D, H, W] is written completely (no separate memset).  Asynchronous. */
@@ -195,7 +214,8 @@ typedef struct isf_conv_layer {
   int conv_type;       /* ISF_CONV_SUBM | ISF_CONV_SPARSE */
   int ksize[3], stride[3], padding[3];
   int c_in, c_out;
-  const float* packed; /* device: isf_pack_filters output */
+  const float* packed; /* device: isf_pack_filters output (fp32 MFMA path) */
+  const void* packed16; /* device: isf_pack_filters_f16x3 output, or NULL (then the fp32 path runs) */
   const float* scale;  /* device [c_out] */
   const float* shift;  /* device [c_out] */
   int relu;            /* apply ReLU at the end */
@@ -207,6 +227,7 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
   int num_in[32], num_out[32];
   long long pairs[32]; /* sum over taps of valid (in,out) pairs of layer i */
   float ms[32];        /* hipEvent time of layer i's conv kernel when timing was requested, else 0 */
+  int precision;       /* 0 = fp32 MFMA kernels ran, 1 = f16x3 split-precision MFMA kernels ran */
 } isf_encoder_stats;
 
 int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors, int num_voxels,

@@ -25,7 +25,7 @@ class ConvLayer(ctypes.Structure):
         ("conv_type", c_int),
         ("ksize", c_int * 3), ("stride", c_int * 3), ("padding", c_int * 3),
         ("c_in", c_int), ("c_out", c_int),
-        ("packed", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+        ("packed", c_void_p), ("packed16", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
         ("relu", c_int), ("residual_from", c_int),
     ]
 
@@ -37,6 +37,7 @@ class EncoderStats(ctypes.Structure):
         ("num_in", c_int * 32), ("num_out", c_int * 32),
         ("pairs", ctypes.c_longlong * 32),
         ("ms", ctypes.c_float * 32),
+        ("precision", c_int),
     ]
 
 
@@ -89,6 +90,13 @@ SIGNATURES = {
     "isf_sparse_conv_forward_packed": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                                c_void_p]),
+    "isf_packed_filter16_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "isf_pack_filters_f16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_f32_to_split": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
+    "isf_split_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
+    "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "isf_set_conv_precision": (c_int, [c_int]),
     "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p]),
     "isf_sparse_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, _I3,

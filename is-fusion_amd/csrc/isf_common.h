@@ -123,8 +123,17 @@ int sparse_conv_forward_generic_impl(const float* x, int c_in, const float* w, i
                                      const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                      const float* shift, const float* residual, int relu, float* y,
                                      hipStream_t st);
+// isf_spconv16.hip
+bool sparse_conv_f16x3_supported(int c_in, int c_out);
+int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
+                                   const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
+                                   const float* shift, const void* residual, int relu, void* ys,
+                                   hipStream_t st);
+int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st);
+int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st);
+int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st);
 // isf_encoder.hip
-int sparse_to_dense_bev_impl(Arena& a, const float* feats, const int32_t* indices, int n, int C,
+int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int32_t* indices, int n, int C,
                              int B, int D, int H, int W, float* out, const OccIndex* occ,
                              hipStream_t st);
 

@@ -11,7 +11,8 @@ namespace isf {
 // through LDS and writes 256-B runs; every output element is written exactly once (no memset pass).
 static constexpr int kDenseX = 64;
 
-__global__ __launch_bounds__(256) void dense_bev_kernel(const float* __restrict__ feats, int C, int D,
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__ feats_v, int C, int D,
                                                         int H, int W,
                                                         const unsigned long long* __restrict__ bits,
                                                         const uint32_t* __restrict__ prefix,
@@ -35,18 +36,41 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const float* __restrict_
     }
     __syncthreads();
     for (int c0 = 0; c0 < C; c0 += 64) {
-      // load: thread -> (row xx = t/16 + 16*j, 4 channels c0 + 4*(t%16))
-      const int c4 = (t & 15) * 4;
+      if (SPLIT) {
+        // split format: row = C/8 units of (hi8 | lo8) f16; thread -> (row xx = t/8 + 32*j, unit t%8)
+        const uint4* fs = reinterpret_cast<const uint4*>(feats_v);
+        const int u = t & 7;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int xx = (t >> 4) + 16 * j;
-        const int r = rows[xx];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= 0 && c0 + c4 < C) v = *reinterpret_cast<const float4*>(feats + (size_t)r * C + c0 + c4);
-        tile[c4 + 0][xx] = v.x;
-        tile[c4 + 1][xx] = v.y;
-        tile[c4 + 2][xx] = v.z;
-        tile[c4 + 3][xx] = v.w;
+        for (int j = 0; j < 2; ++j) {
+          const int xx = (t >> 3) + 32 * j;
+          const int r = rows[xx];
+          float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (r >= 0 && c0 + u * 8 < C) {
+            const uint4* p = fs + ((size_t)r * (C >> 3) + (c0 >> 3) + u) * 2;
+            const uint4 hi = p[0], lo = p[1];
+            const _Float16* h = reinterpret_cast<const _Float16*>(&hi);
+            const _Float16* l = reinterpret_cast<const _Float16*>(&lo);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (float)h[q] + (float)l[q];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) tile[u * 8 + q][xx] = v[q];
+        }
+      } else {
+        // load: thread -> (row xx = t/16 + 16*j, 4 channels c0 + 4*(t%16))
+        const float* feats = reinterpret_cast<const float*>(feats_v);
+        const int c4 = (t & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int xx = (t >> 4) + 16 * j;
+          const int r = rows[xx];
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (r >= 0 && c0 + c4 < C) v = *reinterpret_cast<const float4*>(feats + (size_t)r * C + c0 + c4);
+          tile[c4 + 0][xx] = v.x;
+          tile[c4 + 1][xx] = v.y;
+          tile[c4 + 2][xx] = v.z;
+          tile[c4 + 3][xx] = v.w;
+        }
       }
       __syncthreads();
       // store: lane -> x, wave -> channel stripe
@@ -62,9 +86,10 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const float* __restrict_
   }
 }
 
-int sparse_to_dense_bev_impl(Arena& a, const float* feats, const int32_t* indices, int n, int C, int B,
-                             int D, int H, int W, float* out, const OccIndex* occ_in, hipStream_t st) {
-  ISF_REQUIRE(C % 4 == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of 4", C);
+int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int32_t* indices, int n, int C,
+                             int B, int D, int H, int W, float* out, const OccIndex* occ_in, hipStream_t st) {
+  ISF_REQUIRE(C % (split ? 8 : 4) == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of %d", C,
+              split ? 8 : 4);
   OccIndex occ;
   const int32_t* perm = nullptr;
   if (occ_in) {
@@ -78,7 +103,12 @@ int sparse_to_dense_bev_impl(Arena& a, const float* feats, const int32_t* indice
     perm = p;
   }
   dim3 grid(ceil_div(W, kDenseX), H, B);
-  hipLaunchKernelGGL(dense_bev_kernel, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix, perm, out);
+  if (split)
+    hipLaunchKernelGGL(dense_bev_kernel<true>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
+                       perm, out);
+  else
+    hipLaunchKernelGGL(dense_bev_kernel<false>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
+                       perm, out);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -103,6 +133,8 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* _
 }
 
 // ----------------------------------------------------------------------------------------- encoder
+int g_conv_precision = 0;  // 0 = auto (f16x3 split MFMA where packed), 1 = force fp32 MFMA
+
 struct LevelState {
   int shape[3];
   int n;                  // active rows (host)
@@ -137,9 +169,21 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.has_occ = false;
   if (occ0) { L.occ = *occ0; L.has_occ = true; }
   L.cache_nbr = nullptr;
-  const float* outputs[32];
+  // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
+  bool use16 = g_conv_precision != 1;
+  for (int i = 0; i < num_layers; ++i)
+    use16 = use16 && layers[i].packed16 && sparse_conv_f16x3_supported(layers[i].c_in, layers[i].c_out);
+  const void* outputs[32];
   int out_rows[32];
-  const float* x = x0;
+  const void* x = x0;
+  const void* x_in0 = x0;
+  if (use16) {  // inter-layer activations live in the split (hi8|lo8 f16) format: same bytes as fp32
+    void* xs0 = nullptr;
+    ISF_TRY(a.alloc(&xs0, (size_t)std::max(n0, 1) * layers[0].c_in * 4));
+    ISF_TRY(f32_to_split_impl(x0, (size_t)n0 * layers[0].c_in, xs0, st));
+    x = xs0;
+    x_in0 = xs0;
+  }
   unsigned long long* pair_counts = nullptr;
   ISF_TRY(a.alloc_n(&pair_counts, 32));
   ISF_HIP_TRY(hipMemsetAsync(pair_counts, 0, 32 * sizeof(unsigned long long), st));
@@ -200,22 +244,29 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       n_out = Nx.n;
       L = Nx;
     }
-    float* y = nullptr;
-    ISF_TRY(a.alloc_n(&y, (size_t)std::max(n_out, 1) * ly.c_out));
-    const float* res = nullptr;
-    if (ly.residual_from == -1) res = x0;
+    void* y = nullptr;
+    ISF_TRY(a.alloc(&y, (size_t)std::max(n_out, 1) * ly.c_out * 4));
+    const void* res = nullptr;
+    if (ly.residual_from == -1) res = x_in0;
     else if (ly.residual_from >= 0) {
       ISF_REQUIRE(ly.residual_from < i && out_rows[ly.residual_from] == n_out, ISF_ERR_ARG,
                   "sparse_encoder: layer %d residual source %d incompatible", i, ly.residual_from);
       res = outputs[ly.residual_from];
     }
     if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i], st));
-    if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
-      ISF_TRY(sparse_conv_forward_packed_impl(x, n_in, ly.c_in, ly.packed, K, ly.c_out, nbr, stride, n_out,
-                                              ly.scale, ly.shift, res, ly.relu, y, st));
+    if (use16)
+      ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
+                                             ly.shift, res, ly.relu, y, st));
+    else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
+      ISF_TRY(sparse_conv_forward_packed_impl(reinterpret_cast<const float*>(x), n_in, ly.c_in, ly.packed, K,
+                                              ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
+                                              reinterpret_cast<const float*>(res), ly.relu,
+                                              reinterpret_cast<float*>(y), st));
     else
-      ISF_TRY(sparse_conv_forward_generic_impl(x, ly.c_in, ly.packed, K, ly.c_out, nbr, stride, n_out, ly.scale,
-                                               ly.shift, res, ly.relu, y, st));
+      ISF_TRY(sparse_conv_forward_generic_impl(reinterpret_cast<const float*>(x), ly.c_in, ly.packed, K, ly.c_out,
+                                               nbr, stride, n_out, ly.scale, ly.shift,
+                                               reinterpret_cast<const float*>(res), ly.relu,
+                                               reinterpret_cast<float*>(y), st));
     if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i + 1], st));
     outputs[i] = y;
     out_rows[i] = n_out;
@@ -225,8 +276,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   }
   // dense BEV of the last level
   ISF_TRY(ensure_occ(a, L, B, st));
-  ISF_TRY(sparse_to_dense_bev_impl(a, x, L.coors, L.n, c_last, B, L.shape[0], L.shape[1], L.shape[2],
+  ISF_TRY(sparse_to_dense_bev_impl(a, x, use16, L.coors, L.n, c_last, B, L.shape[0], L.shape[1], L.shape[2],
                                    spatial_features, &L.occ, st));
+  if (stats) stats->precision = use16 ? 1 : 0;
   if (out_shape) { out_shape[0] = c_last * L.shape[0]; out_shape[1] = L.shape[1]; out_shape[2] = L.shape[2]; out_shape[3] = L.n; }
   if (stats) {
     unsigned long long h_pairs[32];
@@ -246,6 +298,12 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
 
 extern "C" {
 
+int isf_set_conv_precision(int mode) {
+  if (mode != 0 && mode != 1) return ISF_ERR_ARG;
+  isf::g_conv_precision = mode;
+  return ISF_OK;
+}
+
 int isf_sparse_to_dense_bev(const float* features, const int32_t* indices, int num_rows, int channels,
                             int batch_size, int D, int H, int W, float* out, isf_stream_t stream) {
   ISF_REQUIRE(num_rows >= 0 && channels > 0 && batch_size > 0 && D > 0 && H > 0 && W > 0 && out, ISF_ERR_ARG,
@@ -253,7 +311,7 @@ int isf_sparse_to_dense_bev(const float* features, const int32_t* indices, int n
   ISF_REQUIRE(num_rows == 0 || (features && indices), ISF_ERR_ARG, "sparse_to_dense_bev: null pointer");
   isf::Arena& a = isf::arena_for_current_device();
   ISF_TRY(a.reset());
-  return isf::sparse_to_dense_bev_impl(a, features, indices, num_rows, channels, batch_size, D, H, W, out,
+  return isf::sparse_to_dense_bev_impl(a, features, false, indices, num_rows, channels, batch_size, D, H, W, out,
                                        nullptr, isf::as_stream(stream));
 }
 

@@ -1,0 +1,428 @@
+// isf_spconv16.hip -- sparse convolution forward on the f16 matrix cores with fp32-equivalent accuracy.
+//
+// Arithmetic ("f16x3 split"): every fp32 operand is carried as two halves, v = hi + lo with hi = f16(v),
+// lo = f16(v - hi) (22 significant bits), and a product is evaluated as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi
+// with v_mfma_f32_16x16x32_f16 accumulating in fp32 (the dropped a_lo*b_lo term is 2^-22 relative).
+// Measured on the CPU (tests/test_host.py::test_f16x3_numerics): same error as an fp32 matmul.  The f16
+// MFMA pipe is 16x the fp32 MFMA rate on gfx950 (2.5 PFLOP/s vs 157 TFLOP/s dense), so three passes are
+// still 5.3x the fp32 matrix rate.  Weights are scaled by a power of two at pack time so their low halves
+// stay in the normal f16 range; activations are stored between layers already split (same 4 B/element as
+// fp32), so the inner loop has no conversions at all.  |activation| must stay below 65504 (f16 max):
+// outside that range the result is inf/NaN, never silently wrong.
+//
+// Structure (register-stationary; differs from the fp32 kernel in isf_spconv.hip):
+//   workgroup = 4 waves, 128 consecutive output rows x BN = 16*NT output channels;
+//   wave w owns rows [32w, 32w+32) = two 16-row MFMA row groups, all BN columns: 2*NT accumulators of
+//   4 VGPRs stay in registers over all taps and input channels -- no LDS accumulation, no atomics;
+//   A (gathered input rows, split format): global -> VGPR directly in the MFMA A-fragment layout, 32 B
+//   (hi8|lo8) contiguous per lane, prefetched one step ahead;
+//   B (weights, pre-split, fragment order): one contiguous NT*2 KiB block per (tap, 32-channel chunk) is
+//   DMA'd global -> LDS with global_load_lds_dwordx4 into a double buffer shared by the 4 waves;
+//   one barrier per step; taps that no row of the tile uses are skipped by the whole workgroup, taps that a
+//   16-row group does not use are skipped by that wave (wave-uniform branch);
+//   epilogue: LDS transpose, y = act(acc*scale + shift + residual), rows written once in split format.
+#include "isf_common.h"
+
+namespace isf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int kTM = 128;
+static constexpr int kMaxTaps = 27;
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const f32x8 v, uint4& hi, uint4& lo) {
+  const h8 h = __builtin_convertvector(v, h8);
+  const f32x8 r = v - __builtin_convertvector(h, f32x8);
+  const h8 l = __builtin_convertvector(r, h8);
+  hi = *reinterpret_cast<const uint4*>(&h);
+  lo = *reinterpret_cast<const uint4*>(&l);
+}
+
+__device__ __forceinline__ f32x8 join8(const uint4 hi, const uint4 lo) {
+  const h8 h = *reinterpret_cast<const h8*>(&hi);
+  const h8 l = *reinterpret_cast<const h8*>(&lo);
+  return __builtin_convertvector(h, f32x8) + __builtin_convertvector(l, f32x8);
+}
+
+template <int NT>
+struct Conv16Smem {
+  static constexpr int nbr_bytes = kMaxTaps * kTM * 4;
+  static constexpr int bbuf_bytes = 2 * NT * 2048;                       // double-buffered weight stage
+  static constexpr int epi_bytes = 4 * 16 * (16 * NT + 4) * 4;           // per-wave 16 x (BN+4) fp32
+  static constexpr int work_bytes = bbuf_bytes > epi_bytes ? bbuf_bytes : epi_bytes;
+  static constexpr int bytes = nbr_bytes + work_bytes + 256;
+};
+
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void spconv_f16x3_kernel(
+    const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
+    const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
+    const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
+    uint4* __restrict__ ys, int n_out, int relu) {
+  using S = Conv16Smem<NT>;
+  constexpr int NCH = CIN / 32;       // 32-channel chunks
+  constexpr int CH8 = CIN / 8;        // 8-channel (32-byte) units per input row
+  constexpr int BN = 16 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* nbr_l = reinterpret_cast<int*>(smem);                                  // [27][128]
+  uint4* bbuf = reinterpret_cast<uint4*>(smem + S::nbr_bytes);                // [2][NT][2][64]
+  int* misc = reinterpret_cast<int*>(smem + S::nbr_bytes + S::work_bytes);    // [4] wave masks
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kg = lane >> 4;
+  const int row0 = blockIdx.x * kTM;
+  const int cb = blockIdx.y;
+  const int ntiles_total = cout >> 4;
+
+  // ---- prologue: neighbour tile -> LDS, per-row-group tap masks
+  for (int i = tid; i < K * kTM; i += 256) {
+    const int k = i >> 7, r = i & 127;
+    nbr_l[i] = nbr[(size_t)k * nbr_stride + row0 + r];
+  }
+  __syncthreads();
+  unsigned mask0 = 0, mask1 = 0;
+  for (int k = 0; k < K; ++k) {
+    const int v = nbr_l[k * kTM + wave * 32 + (lane & 31)];
+    const unsigned long long m = __ballot(v >= 0);
+    mask0 |= ((m & 0xffffull) ? 1u : 0u) << k;
+    mask1 |= ((m & 0xffff0000ull) ? 1u : 0u) << k;
+  }
+  if (lane == 0) misc[wave] = (int)(mask0 | mask1);
+  __syncthreads();
+  unsigned wg_mask = (unsigned)(misc[0] | misc[1] | misc[2] | misc[3]);
+  wg_mask = __builtin_amdgcn_readfirstlane(wg_mask);
+  const int ntaps = __popc(wg_mask);
+  const int nsteps = ntaps * NCH;
+
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // step s -> (tap, chunk): taps are the set bits of wg_mask in increasing order
+  unsigned rem_mask = wg_mask;   // bits of taps not yet started (for the prefetch cursor)
+  int pf_tap = -1, pf_ch = NCH;  // prefetch cursor
+  auto advance = [&]() {
+    if (++pf_ch >= NCH) {
+      pf_ch = 0;
+      pf_tap = rem_mask ? (__ffs(rem_mask) - 1) : -1;
+      rem_mask &= rem_mask - 1;
+    }
+  };
+
+  uint4 a_nxt[2][2];  // [row group][hi, lo]
+  auto load_A = [&](int tap, int ch) {
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) {
+      const int idx = nbr_l[tap * kTM + wave * 32 + rg * 16 + col];
+      a_nxt[rg][0] = make_uint4(0, 0, 0, 0);
+      a_nxt[rg][1] = make_uint4(0, 0, 0, 0);
+      if (idx >= 0) {
+        const uint4* p = xs + ((size_t)idx * CH8 + ch * 4 + kg) * 2;
+        a_nxt[rg][0] = p[0];
+        a_nxt[rg][1] = p[1];
+      }
+    }
+  };
+  auto stage_B = [&](int tap, int ch, int buf) {
+    const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
+    uint4* dst = bbuf + buf * (NT * 128);
+#pragma unroll
+    for (int i = 0; i < (NT * 128) / 256; ++i) glds16(src + i * 256 + tid, dst + i * 256 + wave * 64);
+  };
+
+  if (nsteps > 0) {
+    advance();
+    load_A(pf_tap, pf_ch);
+    stage_B(pf_tap, pf_ch, 0);
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    const int tap = pf_tap;
+    uint4 a_cur[2][2];
+#pragma unroll
+    for (int rg = 0; rg < 2; ++rg) { a_cur[rg][0] = a_nxt[rg][0]; a_cur[rg][1] = a_nxt[rg][1]; }
+    __syncthreads();  // B(s) has landed for every wave (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free
+    if (s + 1 < nsteps) {
+      advance();
+      load_A(pf_tap, pf_ch);
+      stage_B(pf_tap, pf_ch, (s + 1) & 1);
+    }
+    const bool use0 = (mask0 >> tap) & 1u, use1 = (mask1 >> tap) & 1u;
+    if (use0 | use1) {
+      const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint4 bhu = b[(nt * 2 + 0) * 64];
+        const uint4 blu = b[(nt * 2 + 1) * 64];
+        const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+        const h8 bl = *reinterpret_cast<const h8*>(&blu);
+        if (use0) {
+          const h8 ah = *reinterpret_cast<const h8*>(&a_cur[0][0]);
+          const h8 al = *reinterpret_cast<const h8*>(&a_cur[0][1]);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[0][nt], 0, 0, 0);
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[0][nt], 0, 0, 0);
+        }
+        if (use1) {
+          const h8 ah = *reinterpret_cast<const h8*>(&a_cur[1][0]);
+          const h8 al = *reinterpret_cast<const h8*>(&a_cur[1][1]);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[1][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[1][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[1][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
+
+  // ---- epilogue: per row group, accumulator (col = lane&15, row = 4*(lane>>4)+t) -> LDS row-major ->
+  //      one lane per (row, 8-channel unit): BN fold (incl. the weight scale), residual, ReLU, split, store
+  constexpr int RS = BN + 4;
+  float* tile = reinterpret_cast<float*>(smem + S::nbr_bytes) + wave * 16 * RS;
+  const float winv = *w_inv_scale;
+#pragma unroll
+  for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tile[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][nt][t];
+    // wave-private tile: a wave-level fence is enough (LDS ops of one wave complete in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    constexpr int UNITS = BN / 8;  // 8-channel units per row
+    for (int i = lane; i < 16 * UNITS; i += 64) {
+      const int r = i / UNITS, u = i % UNITS;
+      const int grow = row0 + wave * 32 + rg * 16 + r;
+      if (grow < n_out) {
+        const float* tp = tile + r * RS + u * 8;
+        f32x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tp[j];
+        const int gc = cb * BN + u * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float sc = scale ? scale[gc + j] * winv : winv;
+          const float sh = shift ? shift[gc + j] : 0.f;
+          v[j] = fmaf(v[j], sc, sh);
+        }
+        const size_t o = ((size_t)grow * (cout >> 3) + (gc >> 3)) * 2;
+        if (residual) v += join8(residual[o], residual[o + 1]);
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        uint4 hi, lo;
+        split8(v, hi, lo);
+        ys[o] = hi;
+        ys[o + 1] = lo;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+}
+
+// ------------------------------------------------------------------------------------------ format kernels
+__global__ void f32_to_split_kernel(const float* __restrict__ x, size_t n8, uint4* __restrict__ xs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const f32x8 v = *reinterpret_cast<const f32x8*>(x + i * 8);
+  uint4 hi, lo;
+  split8(v, hi, lo);
+  xs[i * 2] = hi;
+  xs[i * 2 + 1] = lo;
+}
+
+__global__ void split_to_f32_kernel(const uint4* __restrict__ xs, size_t n8, float* __restrict__ x) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  *reinterpret_cast<f32x8*>(x + i * 8) = join8(xs[i * 2], xs[i * 2 + 1]);
+}
+
+__global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// packed16[tap][chunk][ntile][hi|lo][lane][8 halves], lane = (col j = lane&15, k-group = lane>>4):
+//   element jj = W[tap][32*chunk + 8*(lane>>4) + jj][16*ntile + (lane&15)] * 2^sw
+// header (after the data): float inv_scale = 2^-sw
+__global__ void pack_filters16_kernel(const float* __restrict__ w, int K, int cin, int cout,
+                                      const unsigned* __restrict__ absmax_bits, uint4* __restrict__ packed,
+                                      float* __restrict__ header) {
+  const float amax = __uint_as_float(*absmax_bits);
+  int e = 0;
+  if (amax > 0.f) (void)frexpf(amax, &e);
+  const int sw = amax > 0.f ? 13 - e : 0;  // max|w|*2^sw in [2^12, 2^13)
+  const float s = ldexpf(1.f, sw);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) header[0] = ldexpf(1.f, -sw);
+  const int nch = cin >> 5, ntiles = cout >> 4;
+  const long long total = (long long)K * nch * ntiles * 64;
+  if (t >= total) return;
+  const int lane = (int)(t & 63);
+  long long r = t >> 6;
+  const int nt = (int)(r % ntiles); r /= ntiles;
+  const int ch = (int)(r % nch);
+  const int k = (int)(r / nch);
+  f32x8 v;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+    v[jj] = w[((size_t)k * cin + 32 * ch + 8 * (lane >> 4) + jj) * cout + 16 * nt + (lane & 15)] * s;
+  uint4 hi, lo;
+  split8(v, hi, lo);
+  const size_t base = (((size_t)k * nch + ch) * ntiles + nt) * 128;
+  packed[base + lane] = hi;
+  packed[base + 64 + lane] = lo;
+}
+
+bool sparse_conv_f16x3_supported(int c_in, int c_out) {
+  return (c_in == 32 || c_in == 64 || c_in == 128 || c_in == 256) &&
+         (c_out == 32 || c_out == 64 || c_out == 128 || c_out == 256);
+}
+
+template <int CIN, int NT>
+static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
+                    int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
+                    int relu, uint4* ys, hipStream_t st) {
+  using S = Conv16Smem<NT>;
+  auto kern = spconv_f16x3_kernel<CIN, NT>;
+  static bool attr_set = false;
+  if (!attr_set && S::bytes > 48 * 1024) {
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, S::bytes));
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(n_out, kTM), cout / (16 * NT));
+  hipLaunchKernelGGL(kern, grid, dim3(256), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K, cout, scale, shift,
+                     residual, ys, n_out, relu);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+template <int CIN>
+static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
+                      int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
+                      int relu, uint4* ys, hipStream_t st) {
+  switch (cout) {
+    case 32:  return launch16<CIN, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 64:  return launch16<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 128: return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 256: return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+  }
+  return ISF_ERR_UNSUPPORTED;
+}
+
+// packed16 = K*Cin*Cout*4 bytes of fragments followed by a 64-byte header
+int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
+                                   const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
+                                   const float* shift, const void* residual, int relu, void* ys,
+                                   hipStream_t st) {
+  if (n_out <= 0) return ISF_OK;
+  ISF_REQUIRE(K >= 1 && K <= kMaxTaps, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d taps (max 27)", K);
+  ISF_REQUIRE(sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
+              "sparse_conv16: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
+  ISF_REQUIRE(nbr_stride % 128 == 0 && nbr_stride >= n_out, ISF_ERR_ARG, "sparse_conv16: bad nbr_stride");
+  const uint4* w = reinterpret_cast<const uint4*>(packed16);
+  const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) +
+                                                     (size_t)K * c_in * c_out * 4);
+  const uint4* x = reinterpret_cast<const uint4*>(xs);
+  const uint4* r = reinterpret_cast<const uint4*>(residual);
+  uint4* y = reinterpret_cast<uint4*>(ys);
+  switch (c_in) {
+    case 32:  return dispatch16<32>(x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
+    case 64:  return dispatch16<64>(x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
+    case 128: return dispatch16<128>(x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
+    case 256: return dispatch16<256>(x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
+  }
+  return ISF_ERR_UNSUPPORTED;
+}
+
+int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st) {
+  unsigned* amax = nullptr;
+  ISF_TRY(a.alloc_n(&amax, 64));
+  ISF_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
+  const size_t n = (size_t)K * cin * cout;
+  hipLaunchKernelGGL(absmax_kernel, dim3(ceil_div((long long)n, 1024) < 1024 ? ceil_div((long long)n, 1024) : 1024),
+                     dim3(256), 0, st, w, n, amax);
+  const long long total = (long long)K * (cin >> 5) * (cout >> 4) * 64;
+  hipLaunchKernelGGL(pack_filters16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, w, K, cin, cout, amax,
+                     reinterpret_cast<uint4*>(packed16),
+                     reinterpret_cast<float*>(reinterpret_cast<char*>(packed16) + n * 4));
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st) {
+  if (n_elems == 0) return ISF_OK;
+  ISF_REQUIRE(n_elems % 8 == 0, ISF_ERR_ARG, "f32_to_split: element count must be a multiple of 8");
+  hipLaunchKernelGGL(f32_to_split_kernel, dim3(ceil_div((long long)(n_elems / 8), 256)), dim3(256), 0, st, x,
+                     n_elems / 8, reinterpret_cast<uint4*>(xs));
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st) {
+  if (n_elems == 0) return ISF_OK;
+  ISF_REQUIRE(n_elems % 8 == 0, ISF_ERR_ARG, "split_to_f32: element count must be a multiple of 8");
+  hipLaunchKernelGGL(split_to_f32_kernel, dim3(ceil_div((long long)(n_elems / 8), 256)), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(xs), n_elems / 8, x);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out) {
+  return (size_t)num_taps * (size_t)c_in * (size_t)c_out * 4 + 64;
+}
+
+int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
+                           isf_stream_t stream) {
+  ISF_REQUIRE(filters && packed16 && num_taps > 0, ISF_ERR_ARG, "pack_filters_f16x3: bad arguments");
+  ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
+              "pack_filters_f16x3: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
+  isf::Arena& a = isf::arena_for_current_device();
+  ISF_TRY(a.reset());
+  return isf::pack_filters16_impl(a, filters, num_taps, c_in, c_out, packed16, isf::as_stream(stream));
+}
+
+int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream) {
+  ISF_REQUIRE(num_elems == 0 || (x && xs), ISF_ERR_ARG, "f32_to_split: null pointer");
+  return isf::f32_to_split_impl(x, num_elems, xs, isf::as_stream(stream));
+}
+
+int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream) {
+  ISF_REQUIRE(num_elems == 0 || (x && xs), ISF_ERR_ARG, "split_to_f32: null pointer");
+  return isf::split_to_f32_impl(xs, num_elems, x, isf::as_stream(stream));
+}
+
+int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
+                                  int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                                  const float* scale, const float* shift, const void* residual_split, int relu,
+                                  void* out_split, isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0, ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3: bad arguments");
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
+              ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
+  return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
+                                             num_out, scale, shift, residual_split, relu, out_split,
+                                             isf::as_stream(stream));
+}
+
+}  // extern "C"

@@ -164,6 +164,9 @@ class SparseEncoder(nn.Module):
                 c.ksize[j], c.stride[j], c.padding[j] = L["ksize"][j], L["stride"][j], L["padding"][j]
             c.c_in, c.c_out = L["c_in"], L["c_out"]
             packed = L["conv"].packed_weight()
+            packed16 = L["conv"].packed16_weight()
+            c.packed16 = packed16.data_ptr() if packed16 is not None else None
+            keep.append(packed16)
             scale = L["scale"] if L["scale"] is not None else torch.ones(L["c_out"], device=packed.device)
             shift = L["shift"] if L["shift"] is not None else torch.zeros(L["c_out"], device=packed.device)
             keep += [packed, scale, shift]

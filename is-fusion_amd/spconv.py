@@ -116,6 +116,54 @@ def pack_filters(weight):
     return packed
 
 
+F16X3_CHANNELS = (32, 64, 128, 256)
+
+
+def f16x3_supported(c_in, c_out):
+    return c_in in F16X3_CHANNELS and c_out in F16X3_CHANNELS
+
+
+def pack_filters_f16x3(weight):
+    """[kD,kH,kW,Cin,Cout] fp32 -> pre-split (hi|lo f16, power-of-two scaled) MFMA fragments + header."""
+    w = weight.detach().float().contiguous()
+    K = int(np.prod(w.shape[:-2]))
+    lib = _lib.load()
+    nbytes = lib.isf_packed_filter16_bytes(K, w.shape[-2], w.shape[-1])
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.isf_pack_filters_f16x3(_lib.ptr(w), K, w.shape[-2], w.shape[-1], _lib.ptr(packed),
+                                          _lib.stream()), "isf_pack_filters_f16x3")
+    return packed
+
+
+def to_split(x):
+    """fp32 [N,C] -> split activation buffer (same bytes; opaque uint8 tensor)."""
+    x = x.contiguous().float()
+    out = torch.empty(x.numel() * 4, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().isf_f32_to_split(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def from_split(xs, shape):
+    out = torch.empty(shape, dtype=torch.float32, device=xs.device)
+    _lib.check(_lib.load().isf_split_to_f32(_lib.ptr(xs), out.numel(), _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
+                              relu=False):
+    """fp32 in / fp32 out convenience wrapper around the split-precision kernel (converts at both ends)."""
+    _lib.require_cuda(features)
+    xs = to_split(features)
+    rs = to_split(residual) if residual is not None else None
+    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)
+    lib = _lib.load()
+    _lib.check(lib.isf_sparse_conv_forward_f16x3(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), _lib.stream()),
+        "isf_sparse_conv_forward_f16x3")
+    return from_split(ys, (rb.num_out, c_out))
+
+
 def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False):
     """isf_sparse_conv_forward_packed wrapper (conv + optional folded BN / residual / ReLU)."""
     _lib.require_cuda(features)
@@ -161,6 +209,8 @@ class SparseConvolution(SparseModule):
             self.register_parameter("bias", None)
         self._packed = None
         self._packed_key = None
+        self._packed16 = None
+        self._packed16_key = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -190,6 +240,16 @@ class SparseConvolution(SparseModule):
             self._packed = pack_filters(self.weight)
             self._packed_key = key
         return self._packed
+
+    def packed16_weight(self):
+        """Split-precision packing, or None when (Cin, Cout) is outside the f16x3 kernel's shapes."""
+        if not f16x3_supported(self.in_channels, self.out_channels):
+            return None
+        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        if self._packed16 is None or self._packed16_key != key:
+            self._packed16 = pack_filters_f16x3(self.weight)
+            self._packed16_key = key
+        return self._packed16
 
     def rulebook_for(self, x):
         key = ("subm" if self.subm else "conv", tuple(self.kernel_size), tuple(self.stride),

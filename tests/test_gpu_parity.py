@@ -231,6 +231,59 @@ def test_sparse_conv_shapes_epilogue_vs_oracle(dev, oracle_mod, cin, cout):
         assert (y >= 0).all() and y.max() > 0.5
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 256),
+                                      (256, 256)])
+def test_sparse_conv_f16x3_split_precision_vs_oracle(dev, oracle_mod, cin, cout):
+    """Split-precision (f16 hi/lo, 3 MFMA passes, fp32 accumulate) kernel: fp32-class accuracy.
+    Tolerance 2e-4 absolute on outputs of magnitude O(1) -- the same bound as the fp32 MFMA kernel."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin * 7 + cout)
+    B, shape = 2, [9, 24, 20]
+    cells = B * int(np.prod(shape))
+    n = 1500
+    lin = np.sort(rng.choice(cells, n, replace=False))
+    D, H, W = shape
+    idx = np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+    feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
+    feats[::7] *= 100.0     # wide dynamic range inside one tensor
+    feats[1::7] *= 1e-3
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                             (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+        K = int(np.prod(ks))
+        w = rng.normal(0, (1.0 / (6 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32)
+        scale = (rng.random(cout, dtype=np.float32) + 0.5)
+        shift = rng.normal(0, 0.2, cout).astype(np.float32)
+        rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+        oidx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, ks, st, pd, subm=subm)
+        res = rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32)
+        p16 = sp.pack_filters_f16x3(T(w, dev))
+        out_idx = rb.out_indices.cpu().numpy()
+        o1, o2 = lexsort4(out_idx), lexsort4(oidx)
+        raw = oracle_mod.indice_conv(feats, w, pairs, num, len(oidx))[o2]
+        # (a) plain conv, no epilogue
+        y = sp.sparse_conv_forward_f16x3(T(feats, dev), p16, K, cin, cout, rb).cpu().numpy()
+        denom = np.abs(raw).max()
+        assert np.abs(y[o1] - raw).max() < 3e-6 * max(denom, 1.0), (cin, cout, subm, np.abs(y[o1] - raw).max(), denom)
+        # (b) BN fold + residual + ReLU epilogue
+        y = sp.sparse_conv_forward_f16x3(T(feats, dev), p16, K, cin, cout, rb, T(scale, dev), T(shift, dev),
+                                         T(res, dev), relu=True).cpu().numpy()
+        oy = oracle_mod.bn_act(raw, scale, shift, res[o1], relu=True)
+        assert np.abs(y[o1] - oy).max() < 3e-6 * max(denom, 1.0) + 1e-6
+        assert (y >= 0).all()
+
+
+def test_split_format_roundtrip(dev):
+    from isfusion_amd import spconv as sp
+    x = torch.randn(1000, 64, device=dev) * torch.logspace(-6, 4, 64, device=dev)
+    y = sp.from_split(sp.to_split(x), (1000, 64))
+    # 22 significant bits while the low half is a normal f16 number; below that the error is absolute and
+    # bounded by half an f16 subnormal step (2^-25)
+    bound = torch.maximum(x.abs() * 2.0 ** -21, torch.full_like(x, 2.0 ** -24))
+    assert ((y - x).abs() <= bound).all(), ((y - x).abs() / bound).max().item()
+    big = x.abs() > 1e-2
+    assert (((y - x).abs() / x.abs())[big]).max().item() < 2.0 ** -21
+
+
 def test_spconv1_interchange_format_roundtrip(dev, oracle_mod):
     from isfusion_amd import _lib, spconv as sp
     rng = np.random.default_rng(9)
@@ -295,14 +348,19 @@ def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
     B = 2
     lb, pl, ovf, ovc, bev, outs = _encoder_case(oracle_mod, dev, P=5000, B=B, seed=7)
     enc = lb.pts_middle_encoder
-    # (1) SparseEncoder.forward, fused C call, oracle VFE output as input
-    stats = _lib.EncoderStats()
-    sp = enc.forward_fused(T(ovf, dev), T(ovc, dev), B, stats=stats)
-    got = sp.cpu().numpy()
-    assert got.shape == (B, 512, 180, 180)
-    err = np.abs(got - bev).max()
-    assert err < 1e-3, err
-    assert np.array_equal(got != 0, bev != 0)
+    # (1) SparseEncoder.forward, fused C call, oracle VFE output as input -- both arithmetic paths
+    lib = _lib.load()
+    for mode in (1, 0):  # 1 = fp32 MFMA kernels, 0 = default (f16x3 split-precision MFMA)
+        _lib.check(lib.isf_set_conv_precision(mode))
+        stats = _lib.EncoderStats()
+        sp = enc.forward_fused(T(ovf, dev), T(ovc, dev), B, stats=stats)
+        assert stats.precision == (0 if mode == 1 else 1)
+        got = sp.cpu().numpy()
+        assert got.shape == (B, 512, 180, 180)
+        err = np.abs(got - bev).max()
+        assert err < 1e-3, (mode, err)
+        assert err < 2e-4, (mode, err)  # what both paths actually achieve (fp32-class accuracy)
+        assert np.array_equal(got != 0, bev != 0)
     assert np.abs(bev).max() > 1.0
     for i, (f, ix, shp) in enumerate(outs):  # voxel counts of every layer, bit exact
         assert stats.num_out[i] == f.shape[0], (i, stats.num_out[i], f.shape[0])
