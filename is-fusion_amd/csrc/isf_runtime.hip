@@ -207,6 +207,55 @@ int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st) {
   return ISF_OK;
 }
 
+// ---- generic exclusive scan of uint32 (same three-kernel scheme); out has n + 1 entries, out[n] = total
+__global__ __launch_bounds__(kScanThreads) void scan_u32_block_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                                      uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t lds[kScanThreads / 64];
+  const size_t i0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i)
+    if (i0 + i < n) c += in[i0 + i];
+  uint32_t tot;
+  (void)block_exclusive_scan(c, lds, &tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_u32_write_kernel(const uint32_t* __restrict__ in, size_t n,
+                                                                      const uint32_t* __restrict__ block_offsets,
+                                                                      uint32_t* __restrict__ out) {
+  __shared__ uint32_t lds[kScanThreads / 64];
+  const size_t i0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
+  uint32_t v[kWordsPerThread];
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) v[i] = (i0 + i < n) ? in[i0 + i] : 0;
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], lds, &tot) + block_offsets[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) {
+    if (i0 + i < n) out[i0 + i] = ex;
+    ex += v[i];
+    if (i0 + i + 1 == n) out[n] = ex;
+  }
+}
+
+int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st) {
+  if (n == 0) {
+    ISF_HIP_TRY(hipMemsetAsync(out, 0, sizeof(uint32_t), st));
+    return ISF_OK;
+  }
+  const int nblocks = ceil_div((long long)n, kWordsPerBlock);
+  uint32_t* sums = nullptr;
+  int* total = nullptr;
+  ISF_TRY(a.alloc_n(&sums, (size_t)nblocks + 1));
+  ISF_TRY(a.alloc_n(&total, 64));
+  hipLaunchKernelGGL(scan_u32_block_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, in, n, sums);
+  hipLaunchKernelGGL(occ_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks, total);
+  hipLaunchKernelGGL(scan_u32_write_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, in, n, sums, out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 __global__ void occ_mark_coords4_kernel(unsigned long long* __restrict__ bits,
                                         const int32_t* __restrict__ coors4, int n, int B, int D, int H,
                                         int W) {

@@ -23,6 +23,8 @@
 //   epilogue: LDS transpose, y = act(acc*scale + shift + residual), rows written once in split format.
 #include "isf_common.h"
 
+#include <stdlib.h>
+
 namespace isf {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -32,9 +34,26 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 static constexpr int kTM = 128;
 static constexpr int kMaxTaps = 27;
 
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// LDS-DMA of 16 B per lane: LDS[lds_base + lane*16] = *gsrc.  Issued through inline asm on purpose: when hipcc
+// sees a global_load_lds it drains vmcnt(0) before every later ds_read (it cannot prove the buffers differ),
+// which would serialise the next step's weight/activation prefetch behind the current step's MFMAs.  Hidden
+// here, the DMA stays in flight during the compute; the loop waits for it explicitly (s_waitcnt vmcnt(0) +
+// barrier) right before the buffer is read.  M0 carries the wave-uniform LDS base and is restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_bytes /* wave-uniform */) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base_bytes)
+      : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
 __device__ __forceinline__ void split8(const f32x8 v, uint4& hi, uint4& lo) {
@@ -55,13 +74,14 @@ template <int NT>
 struct Conv16Smem {
   static constexpr int nbr_bytes = kMaxTaps * kTM * 4;
   static constexpr int bbuf_bytes = 2 * NT * 2048;                       // double-buffered weight stage
-  static constexpr int epi_bytes = 4 * 16 * (16 * NT + 4) * 4;           // per-wave 16 x (BN+4) fp32
+  static constexpr int EPN = NT > 8 ? 8 : NT;                            // column tiles per epilogue pass
+  static constexpr int epi_bytes = 4 * 16 * (16 * EPN + 4) * 4;          // per-wave 16 x (16*EPN+4) fp32
   static constexpr int work_bytes = bbuf_bytes > epi_bytes ? bbuf_bytes : epi_bytes;
   static constexpr int bytes = nbr_bytes + work_bytes + 256;
 };
 
 template <int CIN, int NT>
-__global__ __launch_bounds__(256) void spconv_f16x3_kernel(
+__global__ __launch_bounds__(256, (NT > 8 ? 2 : 3)) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
@@ -109,15 +129,18 @@ __global__ __launch_bounds__(256) void spconv_f16x3_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // step s -> (tap, chunk): taps are the set bits of wg_mask in increasing order
-  unsigned rem_mask = wg_mask;   // bits of taps not yet started (for the prefetch cursor)
-  int pf_tap = -1, pf_ch = NCH;  // prefetch cursor
+  // step s -> (chunk, tap): CHUNK-OUTER, taps (set bits of wg_mask, increasing) inner.  An input row is the
+  // tap-k neighbour of up to ~15 output rows of this tile and its neighbours, so with the taps innermost the
+  // same 128-byte row segment is re-gathered within a few steps (L1/L2 hits) instead of 8 chunks later.
+  unsigned rem_mask = 0;         // taps of the current chunk not yet started (prefetch cursor)
+  int pf_tap = -1, pf_ch = -1;   // prefetch cursor
   auto advance = [&]() {
-    if (++pf_ch >= NCH) {
-      pf_ch = 0;
-      pf_tap = rem_mask ? (__ffs(rem_mask) - 1) : -1;
-      rem_mask &= rem_mask - 1;
+    if (rem_mask == 0) {
+      rem_mask = wg_mask;
+      ++pf_ch;
     }
+    pf_tap = __ffs(rem_mask) - 1;
+    rem_mask &= rem_mask - 1;
   };
 
   uint4 a_nxt[2][2];  // [row group][hi, lo]
@@ -134,11 +157,12 @@ __global__ __launch_bounds__(256) void spconv_f16x3_kernel(
       }
     }
   };
+  const unsigned bbuf_addr = __builtin_amdgcn_readfirstlane(lds_addr(bbuf));
   auto stage_B = [&](int tap, int ch, int buf) {
     const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
-    uint4* dst = bbuf + buf * (NT * 128);
+    const unsigned dst = bbuf_addr + (unsigned)(buf * (NT * 128) + wave * 64) * 16u;
 #pragma unroll
-    for (int i = 0; i < (NT * 128) / 256; ++i) glds16(src + i * 256 + tid, dst + i * 256 + wave * 64);
+    for (int i = 0; i < (NT * 128) / 256; ++i) glds16(src + i * 256 + tid, dst + (unsigned)i * 4096u);
   };
 
   if (nsteps > 0) {
@@ -151,35 +175,36 @@ __global__ __launch_bounds__(256) void spconv_f16x3_kernel(
     uint4 a_cur[2][2];
 #pragma unroll
     for (int rg = 0; rg < 2; ++rg) { a_cur[rg][0] = a_nxt[rg][0]; a_cur[rg][1] = a_nxt[rg][1]; }
-    __syncthreads();  // B(s) has landed for every wave (vmcnt(0) precedes the barrier); buffer (s+1)&1 is free
+    // this wave's share of B(s) (and its A(s) rows) must have landed before anyone reads the buffer
+    // (the builtin, not inline asm, so that hipcc's own scoreboard knows every tracked load has landed too and
+    //  does not re-wait for the A(s) registers in the middle of the next prefetch; simm16 0x0F70 = vmcnt(0))
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();  // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
     if (s + 1 < nsteps) {
       advance();
       load_A(pf_tap, pf_ch);
       stage_B(pf_tap, pf_ch, (s + 1) & 1);
     }
-    const bool use0 = (mask0 >> tap) & 1u, use1 = (mask1 >> tap) & 1u;
-    if (use0 | use1) {
+    // A row group without a neighbour through this tap carries zero A fragments, so running it is harmless;
+    // the wave skips the tap only when neither of its row groups needs it (one code path, no divergence).
+    if (((mask0 | mask1) >> tap) & 1u) {
       const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
+      const h8 ah0 = *reinterpret_cast<const h8*>(&a_cur[0][0]);
+      const h8 al0 = *reinterpret_cast<const h8*>(&a_cur[0][1]);
+      const h8 ah1 = *reinterpret_cast<const h8*>(&a_cur[1][0]);
+      const h8 al1 = *reinterpret_cast<const h8*>(&a_cur[1][1]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const uint4 bhu = b[(nt * 2 + 0) * 64];
         const uint4 blu = b[(nt * 2 + 1) * 64];
         const h8 bh = *reinterpret_cast<const h8*>(&bhu);
         const h8 bl = *reinterpret_cast<const h8*>(&blu);
-        if (use0) {
-          const h8 ah = *reinterpret_cast<const h8*>(&a_cur[0][0]);
-          const h8 al = *reinterpret_cast<const h8*>(&a_cur[0][1]);
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[0][nt], 0, 0, 0);
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[0][nt], 0, 0, 0);
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[0][nt], 0, 0, 0);
-        }
-        if (use1) {
-          const h8 ah = *reinterpret_cast<const h8*>(&a_cur[1][0]);
-          const h8 al = *reinterpret_cast<const h8*>(&a_cur[1][1]);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[1][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[1][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[1][nt], 0, 0, 0);
-        }
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc[1][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc[1][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc[1][nt], 0, 0, 0);
       }
     }
   }
@@ -187,46 +212,50 @@ __global__ __launch_bounds__(256) void spconv_f16x3_kernel(
 
   // ---- epilogue: per row group, accumulator (col = lane&15, row = 4*(lane>>4)+t) -> LDS row-major ->
   //      one lane per (row, 8-channel unit): BN fold (incl. the weight scale), residual, ReLU, split, store
-  constexpr int RS = BN + 4;
+  constexpr int EPN = S::EPN;
+  constexpr int RS = 16 * EPN + 4;
   float* tile = reinterpret_cast<float*>(smem + S::nbr_bytes) + wave * 16 * RS;
   const float winv = *w_inv_scale;
 #pragma unroll
   for (int rg = 0; rg < 2; ++rg) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int ps = 0; ps < NT / EPN; ++ps) {  // passes of EPN column tiles (keeps the transpose tile small)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) tile[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][nt][t];
-    // wave-private tile: a wave-level fence is enough (LDS ops of one wave complete in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    constexpr int UNITS = BN / 8;  // 8-channel units per row
-    for (int i = lane; i < 16 * UNITS; i += 64) {
-      const int r = i / UNITS, u = i % UNITS;
-      const int grow = row0 + wave * 32 + rg * 16 + r;
-      if (grow < n_out) {
-        const float* tp = tile + r * RS + u * 8;
-        f32x8 v;
+      for (int nt = 0; nt < EPN; ++nt)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tp[j];
-        const int gc = cb * BN + u * 8;
+        for (int t = 0; t < 4; ++t) tile[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][ps * EPN + nt][t];
+      // wave-private tile: a wave-level fence is enough (LDS ops of one wave complete in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      constexpr int UNITS = (16 * EPN) / 8;  // 8-channel units per row in this pass
+      for (int i = lane; i < 16 * UNITS; i += 64) {
+        const int r = i / UNITS, u = i % UNITS;
+        const int grow = row0 + wave * 32 + rg * 16 + r;
+        if (grow < n_out) {
+          const float* tp = tile + r * RS + u * 8;
+          f32x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float sc = scale ? scale[gc + j] * winv : winv;
-          const float sh = shift ? shift[gc + j] : 0.f;
-          v[j] = fmaf(v[j], sc, sh);
+          for (int j = 0; j < 8; ++j) v[j] = tp[j];
+          const int gc = cb * BN + ps * (16 * EPN) + u * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float sc = scale ? scale[gc + j] * winv : winv;
+            const float sh = shift ? shift[gc + j] : 0.f;
+            v[j] = fmaf(v[j], sc, sh);
+          }
+          const size_t o = ((size_t)grow * (cout >> 3) + (gc >> 3)) * 2;
+          if (residual) v += join8(residual[o], residual[o + 1]);
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          uint4 hi, lo;
+          split8(v, hi, lo);
+          ys[o] = hi;
+          ys[o + 1] = lo;
         }
-        const size_t o = ((size_t)grow * (cout >> 3) + (gc >> 3)) * 2;
-        if (residual) v += join8(residual[o], residual[o + 1]);
-        if (relu) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        uint4 hi, lo;
-        split8(v, hi, lo);
-        ys[o] = hi;
-        ys[o + 1] = lo;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
 }
 
@@ -288,6 +317,13 @@ __global__ void pack_filters16_kernel(const float* __restrict__ w, int K, int ci
   packed[base + 64 + lane] = lo;
 }
 
+// Cout = 256: one 256-column workgroup (NT = 16, 128 accumulator registers, A gathered once) instead of two
+// 128-column workgroups.  Tuning switch (env ISF_CONV16_WIDE=0/1 read once).
+static const bool g_conv16_wide = [] {
+  const char* e = getenv("ISF_CONV16_WIDE");
+  return e ? (e[0] != '0') : false;
+}();
+
 bool sparse_conv_f16x3_supported(int c_in, int c_out) {
   return (c_in == 32 || c_in == 64 || c_in == 128 || c_in == 256) &&
          (c_out == 32 || c_out == 64 || c_out == 128 || c_out == 256);
@@ -320,7 +356,10 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 32:  return launch16<CIN, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 64:  return launch16<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 128: return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
-    case 256: return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 256:
+      if (g_conv16_wide)
+        return launch16<CIN, 16>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+      return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }
   return ISF_ERR_UNSUPPORTED;
 }

@@ -1,22 +1,30 @@
 // isf_vfe.hip -- A4 DynamicVFE.forward fused (voxel_encoder.py:453-547).
 //
-// Reference data flow: 3x (unique_dim sort + atomic scatter) + 2 dense int64 canvases of B*D*H*W
-// entries (663 MB/sample) to map voxels back to points.  Here:
-//   mark bitmap -> popcount scan (voxel id = rank, sorted (b,z,y,x) order, no sort, no canvas)
-//   pass A  per point: voxel id, exact fixed-point xyz sums + count          (cluster centre)
-//   pass B  per point: 11 features -> Linear+BN+ReLU (64) -> per-voxel max   (layer 1, h1 never stored)
-//   pass C  per voxel: u = W2[:,64:] . vmax1                                  (voxel half of layer 2)
-//   pass D  per point: recompute h1, W2[:,:64].h1 + u[voxel] -> BN+ReLU -> per-voxel max (layer 2)
-// Point features [P,64] are never written to HBM (307 MB at P=1.2M); they are recomputed (704 FMA).
-// Thread-per-point kernels keep the 64 accumulators in VGPRs and stream the weights through SGPRs
-// (wave-uniform s_load), i.e. the FMA pipe sees one VGPR + one SGPR operand per op; the per-voxel max
-// is issued channel-per-lane (one 256-B row per wave instruction) after an LDS transpose.
+// Reference data flow: 3x (unique_dim sort + atomic scatter) + 2 dense int64 canvases of B*D*H*W entries
+// (663 MB/sample) to map voxels back to points.  Here:
+//   mark bitmap -> popcount scan            voxel id = rank, sorted (b,z,y,x) order, no sort, no canvas
+//   count / scan / order                    points grouped by voxel (counting sort: 1 int atomic per point)
+//   mean        thread per voxel            exact 2^-24 fixed-point int64 sums -> order independent
+//   layer 1     128 sorted points / block   11 features -> Linear+BN+ReLU (fp32 VALU, weights through SGPRs)
+//                                           -> per-voxel max
+//   layer 2     64 sorted points / wave     h1 recomputed (never stored: 307 MB at P=1.2M), [h1 | vmax1[voxel]]
+//                                           (128) x W2^T on the f16 matrix cores with the hi/lo split
+//                                           arithmetic of isf_spconv16.hip (fp32-class accuracy), BN+ReLU,
+//                                           per-voxel max
+// Because a voxel's points are contiguous after the counting sort, the per-voxel max is a segmented
+// reduction inside the wave (channel per lane, 256-byte row stores); only segments cut by a wave boundary
+// fall back to atomics (order independent: max of non-negative floats in their integer view).  Every
+// reduction is order independent => the VFE is bit-reproducible run to run.
 #include "isf_common.h"
 
 namespace isf {
 
-static constexpr int kVfeThreads = 128;
-static constexpr int kC = 64;            // c1 == c2 == 64 (config); other widths -> ISF_ERR_UNSUPPORTED
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int kC = 64;  // c1 == c2 == 64 (config); other widths -> ISF_ERR_UNSUPPORTED
+static constexpr int kL1Threads = 128;
 static constexpr int kLdsStride = kC + 1;
 static constexpr double kFix = 16777216.0;  // 2^24 fixed point for the exact coordinate sums
 
@@ -24,24 +32,62 @@ struct VfeGeom {
   float vx, vy, vz, ox, oy, oz;  // voxel size, centre offsets (vs/2 + range_min)
 };
 
-__global__ void vfe_transpose_kernel(const float* __restrict__ w, int rows, int cols, int col0,
-                                     int ncols, float* __restrict__ wt) {
-  // wt[k][o] = w[o][col0 + k]   (w is [rows, cols] torch Linear layout; wt is [ncols, rows])
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * ncols) return;
-  const int k = t / rows, o = t % rows;
-  wt[t] = w[(size_t)o * cols + col0 + k];
+__device__ __forceinline__ void vfe_split8(const f32x8 v, uint4& hi, uint4& lo) {
+  const h8 h = __builtin_convertvector(v, h8);
+  const f32x8 r = v - __builtin_convertvector(h, f32x8);
+  const h8 l = __builtin_convertvector(r, h8);
+  hi = *reinterpret_cast<const uint4*>(&h);
+  lo = *reinterpret_cast<const uint4*>(&l);
 }
 
-template <int CIN>
-__global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__ points,
-                                                       const int32_t* __restrict__ coors4, int P, int D,
-                                                       int H, int W,
-                                                       const unsigned long long* __restrict__ bits,
-                                                       const uint32_t* __restrict__ prefix,
-                                                       int32_t* __restrict__ pt2vox,
-                                                       long long* __restrict__ sums /*[N][3]*/,
-                                                       int32_t* __restrict__ cnt) {
+// ------------------------------------------------------------------------------------------ weight prep
+// w1t[k][o] = w1[o][k]                                   (fp32, SGPR-streamed by layer 1)
+// w2p[kc][nt][hi|lo][lane][8] = split(w2[16nt + (lane&15)][32kc + 8(lane>>4) + jj] * 2^sw), kc = 0..3
+// sc2[o] = scale2[o] * 2^-sw
+__global__ void vfe_prep_kernel(const float* __restrict__ w1, int F, const float* __restrict__ w2,
+                                const float* __restrict__ scale2, float* __restrict__ w1t,
+                                uint4* __restrict__ w2p, float* __restrict__ sc2) {
+  __shared__ float amax_s;
+  const int t = threadIdx.x;  // 256 threads, one block
+  float m = 0.f;
+  for (int i = t; i < kC * 2 * kC; i += 256) m = fmaxf(m, fabsf(w2[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if (t == 0) amax_s = 0.f;
+  __syncthreads();
+  if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(&amax_s), __float_as_uint(m));
+  __syncthreads();
+  const float amax = amax_s;
+  int e = 0;
+  if (amax > 0.f) (void)frexpf(amax, &e);
+  const int sw = amax > 0.f ? 13 - e : 0;
+  const float s = ldexpf(1.f, sw), inv = ldexpf(1.f, -sw);
+  for (int i = t; i < F * kC; i += 256) {
+    const int k = i / kC, o = i % kC;
+    w1t[i] = w1[(size_t)o * F + k];
+  }
+  if (t < kC) sc2[t] = scale2[t] * inv;
+  for (int i = t; i < 4 * 4 * 64; i += 256) {  // (kc, nt, lane)
+    const int lane = i & 63, nt = (i >> 6) & 3, kc = i >> 8;
+    f32x8 v;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      v[jj] = w2[(size_t)(16 * nt + (lane & 15)) * (2 * kC) + 32 * kc + 8 * (lane >> 4) + jj] * s;
+    uint4 hi, lo;
+    vfe_split8(v, hi, lo);
+    w2p[(size_t)(kc * 4 + nt) * 128 + lane] = hi;
+    w2p[(size_t)(kc * 4 + nt) * 128 + 64 + lane] = lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ grouping
+__global__ __launch_bounds__(256) void vfe_count_kernel(const int32_t* __restrict__ coors4, int P, int D,
+                                                        int H, int W,
+                                                        const unsigned long long* __restrict__ bits,
+                                                        const uint32_t* __restrict__ prefix,
+                                                        int32_t* __restrict__ pt2vox,
+                                                        int32_t* __restrict__ slot,
+                                                        uint32_t* __restrict__ cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const int4 c = reinterpret_cast<const int4*>(coors4)[i];
@@ -49,29 +95,48 @@ __global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__
   if (c.y >= 0 && c.z >= 0 && c.w >= 0)
     v = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
   pt2vox[i] = v;
-  if (v < 0) return;
-  const float* p = points + (size_t)i * CIN;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const long long q = __double2ll_rn((double)p[k] * kFix);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&sums[(size_t)v * 3 + k]), (unsigned long long)q);
-  }
-  atomicAdd(&cnt[v], 1);
+  if (v >= 0) slot[i] = (int32_t)atomicAdd(&cnt[v], 1u);
+}
+
+__global__ __launch_bounds__(256) void vfe_order_kernel(const int32_t* __restrict__ pt2vox,
+                                                        const int32_t* __restrict__ slot, int P,
+                                                        const uint32_t* __restrict__ start,
+                                                        int32_t* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int v = pt2vox[i];
+  if (v >= 0) order[start[v] + slot[i]] = i;
 }
 
 template <int CIN>
-__device__ __forceinline__ void vfe_point_features(const float* __restrict__ p, int4 c, int v,
-                                                   const long long* __restrict__ sums,
-                                                   const int32_t* __restrict__ cnt, VfeGeom g,
+__global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__ points,
+                                                       const int32_t* __restrict__ order,
+                                                       const uint32_t* __restrict__ start, int N,
+                                                       float4* __restrict__ mean4) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= N) return;
+  const uint32_t j0 = start[v], j1 = start[v + 1];
+  long long sx = 0, sy = 0, sz = 0;
+  for (uint32_t j = j0; j < j1; ++j) {
+    const float* p = points + (size_t)order[j] * CIN;
+    sx += __double2ll_rn((double)p[0] * kFix);
+    sy += __double2ll_rn((double)p[1] * kFix);
+    sz += __double2ll_rn((double)p[2] * kFix);
+  }
+  const double d = kFix * (double)(j1 - j0);
+  mean4[v] = make_float4((float)((double)sx / d), (float)((double)sy / d), (float)((double)sz / d),
+                         (float)(j1 - j0));
+}
+
+// ------------------------------------------------------------------------------------------ per-point math
+template <int CIN>
+__device__ __forceinline__ void vfe_point_features(const float* __restrict__ p, int4 c, float4 mean, VfeGeom g,
                                                    float (&f)[CIN + 6]) {
 #pragma unroll
   for (int k = 0; k < CIN; ++k) f[k] = p[k];
-  const double n = (double)cnt[v];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float mean = (float)((double)sums[(size_t)v * 3 + k] / (kFix * n));
-    f[CIN + k] = __fsub_rn(p[k], mean);                        // xyz - cluster centre (:500-503)
-  }
+  f[CIN + 0] = __fsub_rn(p[0], mean.x);  // xyz - cluster centre (:500-503)
+  f[CIN + 1] = __fsub_rn(p[1], mean.y);
+  f[CIN + 2] = __fsub_rn(p[2], mean.z);
   // xyz - voxel centre, centre = idx*vs + (vs/2 + min)  (:505-512); no FMA contraction
   f[CIN + 3] = __fsub_rn(p[0], __fadd_rn(__fmul_rn((float)c.w, g.vx), g.ox));
   f[CIN + 4] = __fsub_rn(p[1], __fadd_rn(__fmul_rn((float)c.z, g.vy), g.oy));
@@ -93,122 +158,189 @@ __device__ __forceinline__ void vfe_layer1(const float (&f)[F], const float* __r
   for (int o = 0; o < kC; ++o) h[o] = fmaxf(fmaf(h[o], scale[o], shift[o]), 0.f);
 }
 
-// per-voxel max, channel-per-lane: values are post-ReLU (>= 0) so the int view is order preserving and
-// the zero-initialised destination equals the reference's -inf start for every non-empty voxel.
-__device__ __forceinline__ void vfe_wave_max_rows(const float* __restrict__ tile /*[64][kLdsStride]*/,
-                                                  const int* __restrict__ vox /*[64]*/, int lane,
-                                                  int* __restrict__ dst /*[N][64] as int*/) {
+// Segmented per-voxel max over the 64 sorted points of one wave; lane = channel.  `val(p)` yields this
+// lane's channel of point p (>= 0: post-ReLU).  A voxel whose whole segment [start[v], start[v+1]) lies
+// inside the wave's range is written with one 256-byte row store; a cut segment uses integer atomicMax on
+// the zero-initialised destination (identical result for non-negative floats).
+template <typename ValFn>
+__device__ __forceinline__ void vfe_segmented_max(const int* __restrict__ vox, uint32_t j0, int lane,
+                                                  const uint32_t* __restrict__ start, float* __restrict__ dst,
+                                                  ValFn val) {
+  int run = -1;
+  float m = 0.f;
+  auto flush = [&]() {
+    if (run < 0) return;
+    const bool whole = start[run] >= j0 && start[run + 1] <= j0 + 64;
+    if (whole) dst[(size_t)run * kC + lane] = m;
+    else if (m > 0.f) atomicMax(reinterpret_cast<int*>(dst) + (size_t)run * kC + lane, __float_as_int(m));
+  };
   for (int p = 0; p < 64; ++p) {
     const int v = vox[p];
     if (v < 0) continue;
-    const float val = tile[p * kLdsStride + lane];
-    if (val > 0.f) atomicMax(&dst[(size_t)v * kC + lane], __float_as_int(val));
-  }
-}
-
-template <int CIN>
-__global__ __launch_bounds__(kVfeThreads) void vfe_layer1_kernel(
-    const float* __restrict__ points, const int32_t* __restrict__ coors4, int P,
-    const int32_t* __restrict__ pt2vox, const long long* __restrict__ sums,
-    const int32_t* __restrict__ cnt, VfeGeom g, const float* __restrict__ w1t,
-    const float* __restrict__ scale1, const float* __restrict__ shift1, int* __restrict__ vmax1) {
-  __shared__ float tile[kVfeThreads * kLdsStride];
-  __shared__ int vox[kVfeThreads];
-  const int t = threadIdx.x, i = blockIdx.x * kVfeThreads + t;
-  const int v = i < P ? pt2vox[i] : -1;
-  vox[t] = v;
-  if (v >= 0) {
-    float f[CIN + 6], h[kC];
-    vfe_point_features<CIN>(points + (size_t)i * CIN, reinterpret_cast<const int4*>(coors4)[i], v, sums,
-                            cnt, g, f);
-    vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
-#pragma unroll
-    for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = h[o];
-  }
-  __syncthreads();
-  const int wave = t >> 6, lane = t & 63;
-  vfe_wave_max_rows(tile + wave * 64 * kLdsStride, vox + wave * 64, lane, vmax1);
-}
-
-// u[v][o] = sum_k vmax1[v][k] * w2bt[k][o]
-__global__ __launch_bounds__(kVfeThreads) void vfe_voxel_term_kernel(const float* __restrict__ vmax1,
-                                                                      const int* __restrict__ nvox,
-                                                                      const float* __restrict__ w2bt,
-                                                                      float* __restrict__ u) {
-  __shared__ float tile[kVfeThreads * kLdsStride];
-  const int N = *nvox;
-  const int t = threadIdx.x, v0 = blockIdx.x * kVfeThreads;
-  if (v0 >= N) return;
-  // coalesced load of this block's rows (channel-per-lane), transposed into row-per-thread via LDS
-  for (int idx = t; idx < kVfeThreads * kC; idx += kVfeThreads) {
-    const int r = idx / kC, k = idx % kC;
-    tile[r * kLdsStride + k] = (v0 + r < N) ? vmax1[(size_t)(v0 + r) * kC + k] : 0.f;
-  }
-  __syncthreads();
-  float acc[kC];
-#pragma unroll
-  for (int o = 0; o < kC; ++o) acc[o] = 0.f;
-  for (int k = 0; k < kC; ++k) {
-    const float gk = tile[t * kLdsStride + k];
-#pragma unroll
-    for (int o = 0; o < kC; ++o) acc[o] = fmaf(gk, w2bt[k * kC + o], acc[o]);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = acc[o];
-  __syncthreads();
-  for (int idx = t; idx < kVfeThreads * kC; idx += kVfeThreads) {
-    const int r = idx / kC, k = idx % kC;
-    if (v0 + r < N) u[(size_t)(v0 + r) * kC + k] = tile[r * kLdsStride + k];
-  }
-}
-
-template <int CIN>
-__global__ __launch_bounds__(kVfeThreads) void vfe_layer2_kernel(
-    const float* __restrict__ points, const int32_t* __restrict__ coors4, int P,
-    const int32_t* __restrict__ pt2vox, const long long* __restrict__ sums,
-    const int32_t* __restrict__ cnt, VfeGeom g, const float* __restrict__ w1t,
-    const float* __restrict__ scale1, const float* __restrict__ shift1,
-    const float* __restrict__ w2at, const float* __restrict__ u, const float* __restrict__ scale2,
-    const float* __restrict__ shift2, int* __restrict__ out) {
-  __shared__ float tile[kVfeThreads * kLdsStride];
-  __shared__ int vox[kVfeThreads];
-  const int t = threadIdx.x, i = blockIdx.x * kVfeThreads + t;
-  const int v = i < P ? pt2vox[i] : -1;
-  vox[t] = v;
-  if (v >= 0) {
-    float f[CIN + 6], h[kC];
-    vfe_point_features<CIN>(points + (size_t)i * CIN, reinterpret_cast<const int4*>(coors4)[i], v, sums,
-                            cnt, g, f);
-    vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
-    // stage h1 in this thread's LDS row so the k loop can index it at run time
-#pragma unroll
-    for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = h[o];
-    float acc[kC];
-#pragma unroll
-    for (int o = 0; o < kC; ++o) acc[o] = 0.f;
-    for (int k = 0; k < kC; ++k) {
-      const float gk = tile[t * kLdsStride + k];
-#pragma unroll
-      for (int o = 0; o < kC; ++o) acc[o] = fmaf(gk, w2at[k * kC + o], acc[o]);
+    if (v != run) {
+      flush();
+      run = v;
+      m = 0.f;
     }
-#pragma unroll
-    for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = acc[o];
+    m = fmaxf(m, val(p));
   }
-  __syncthreads();
-  // epilogue channel-per-lane: + voxel term, BN, ReLU, per-voxel max
-  const int wave = t >> 6, lane = t & 63;
-  const float sc = scale2[lane], sh = shift2[lane];
-  const float* wt = tile + wave * 64 * kLdsStride;
-  const int* wv = vox + wave * 64;
-  for (int p = 0; p < 64; ++p) {
-    const int vv = wv[p];
-    if (vv < 0) continue;
-    float val = wt[p * kLdsStride + lane] + u[(size_t)vv * kC + lane];
-    val = fmaf(val, sc, sh);
-    if (val > 0.f) atomicMax(&out[(size_t)vv * kC + lane], __float_as_int(val));
-  }
+  flush();
 }
+
+template <int CIN>
+__global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
+    const float* __restrict__ points, const int32_t* __restrict__ coors4, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ pt2vox, const int* __restrict__ n_valid, const uint32_t* __restrict__ start,
+    const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
+    const float* __restrict__ scale1, const float* __restrict__ shift1, float* __restrict__ vmax1) {
+  __shared__ float tile[kL1Threads * kLdsStride];
+  __shared__ int vox[kL1Threads];
+  const int t = threadIdx.x;
+  const uint32_t j = blockIdx.x * kL1Threads + t;
+  int v = -1;
+  if (j < (uint32_t)*n_valid) {
+    const int i = order[j];
+    v = pt2vox[i];
+    float f[CIN + 6], h[kC];
+    vfe_point_features<CIN>(points + (size_t)i * CIN, reinterpret_cast<const int4*>(coors4)[i], mean4[v], g, f);
+    vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
+#pragma unroll
+    for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = h[o];
+  }
+  vox[t] = v;
+  __syncthreads();
+  const int wave = t >> 6, lane = t & 63;
+  const float* wt = tile + wave * 64 * kLdsStride;
+  vfe_segmented_max(vox + wave * 64, blockIdx.x * kL1Threads + wave * 64, lane, start, vmax1,
+                    [&](int p) { return wt[p * kLdsStride + lane]; });
+}
+
+// ------------------------------------------------------------------------------------------ layer 2 (MFMA)
+// One wave = 64 sorted points = 4 MFMA row groups; K = 128 = [h1 (64) | vmax1[voxel] (64)] in two halves.
+// LDS per wave: A tile, split format [unit 8][hi|lo][point 64][8 halves] = 16 KiB (conflict free for both
+// the point-per-lane writes and the ds_read_b128 fragment reads), reused as the fp32 [64][65] output tile.
+static constexpr int kL2Waves = 2;
+static constexpr int kL2WaveBytes = 64 * kLdsStride * 4;  // 16640 >= 16384
+
+template <int CIN>
+__global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
+    const float* __restrict__ points, const int32_t* __restrict__ coors4, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ pt2vox, const int* __restrict__ n_valid, const uint32_t* __restrict__ start,
+    const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
+    const float* __restrict__ scale1, const float* __restrict__ shift1, const float* __restrict__ vmax1,
+    const uint4* __restrict__ w2p, const float* __restrict__ sc2, const float* __restrict__ shift2,
+    float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char smem[kL2Waves * kL2WaveBytes];
+  __shared__ int vox_s[kL2Waves * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t j0 = (blockIdx.x * kL2Waves + wave) * 64;
+  const uint32_t nv = (uint32_t)*n_valid;
+  if (j0 >= nv) return;  // wave-uniform; no block-level barrier below
+  uint4* atile = reinterpret_cast<uint4*>(smem + wave * kL2WaveBytes);  // [unit][hi|lo][pt] uint4
+  float* ftile = reinterpret_cast<float*>(smem + wave * kL2WaveBytes);  // [pt][65]
+  int* vox = vox_s + wave * 64;
+  const int col = lane & 15, kg = lane >> 4;
+
+  const uint32_t j = j0 + lane;
+  int v = -1;
+  float h[kC];
+  if (j < nv) {
+    const int i = order[j];
+    v = pt2vox[i];
+    float f[CIN + 6];
+    vfe_point_features<CIN>(points + (size_t)i * CIN, reinterpret_cast<const int4*>(coors4)[i], mean4[v], g, f);
+    vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
+  } else {
+#pragma unroll
+    for (int o = 0; o < kC; ++o) h[o] = 0.f;
+  }
+  vox[lane] = v;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto mfma_half = [&](int half) {  // consumes the 64 channels currently in the A tile
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      uint4 ah[4], al[4];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        ah[rg] = atile[((4 * kc + kg) * 2 + 0) * 64 + rg * 16 + col];
+        al[rg] = atile[((4 * kc + kg) * 2 + 1) * 64 + rg * 16 + col];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const uint4 bhu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + lane];
+        const uint4 blu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + 64 + lane];
+        const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+        const h8 bl = *reinterpret_cast<const h8*>(&blu);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const h8 a_h = *reinterpret_cast<const h8*>(&ah[rg]);
+          const h8 a_l = *reinterpret_cast<const h8*>(&al[rg]);
+          acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, bh, acc[rg][nt], 0, 0, 0);
+          acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bl, acc[rg][nt], 0, 0, 0);
+          acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bh, acc[rg][nt], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto store_units = [&](const float (&x)[kC]) {  // this lane's point -> A tile (split)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      f32x8 vv;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) vv[q] = x[u * 8 + q];
+      uint4 hi, lo;
+      vfe_split8(vv, hi, lo);
+      atile[(u * 2 + 0) * 64 + lane] = hi;
+      atile[(u * 2 + 1) * 64 + lane] = lo;
+    }
+  };
+
+  // half 0: h1
+  store_units(h);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  mfma_half(0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // half 1: the voxel's layer-1 max (map_voxel_center_to_point gather, voxel_encoder.py:541-544)
+  {
+    float r[kC];
+    if (v >= 0) {
+      const float4* src = reinterpret_cast<const float4*>(vmax1 + (size_t)v * kC);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 t4 = src[q];
+        r[4 * q + 0] = t4.x; r[4 * q + 1] = t4.y; r[4 * q + 2] = t4.z; r[4 * q + 3] = t4.w;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < kC; ++o) r[o] = 0.f;
+    }
+    store_units(r);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  mfma_half(1);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // accumulators (col = lane&15 -> channel, row = 4*(lane>>4)+t -> point) -> fp32 tile [pt][65]
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ftile[(rg * 16 + 4 * kg + t) * kLdsStride + nt * 16 + col] = acc[rg][nt][t];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const float sc = sc2[lane], sh = shift2[lane];
+  vfe_segmented_max(vox, j0, lane, start, out,
+                    [&](int p) { return fmaxf(fmaf(ftile[p * kLdsStride + lane], sc, sh), 0.f); });
+}
+
+// ------------------------------------------------------------------------------------------ driver
+int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
 
 template <int CIN>
 static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, int B, const int grid[3],
@@ -221,13 +353,12 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(occ_create(a, &occ, B, d_alloc > grid[2] ? d_alloc : grid[2], grid[1], grid[0], st));
   ISF_TRY(occ_mark_coords4(occ, coors4, P, st));
   ISF_TRY(occ_scan(a, occ, st));
-  float *w1t, *w2at, *w2bt;
+  float *w1t, *sc2;
+  uint4* w2p;
   ISF_TRY(a.alloc_n(&w1t, (size_t)F * kC));
-  ISF_TRY(a.alloc_n(&w2at, (size_t)kC * kC));
-  ISF_TRY(a.alloc_n(&w2bt, (size_t)kC * kC));
-  hipLaunchKernelGGL(vfe_transpose_kernel, dim3(ceil_div(F * kC, 256)), dim3(256), 0, st, w1, kC, F, 0, F, w1t);
-  hipLaunchKernelGGL(vfe_transpose_kernel, dim3(ceil_div(kC * kC, 256)), dim3(256), 0, st, w2, kC, 2 * kC, 0, kC, w2at);
-  hipLaunchKernelGGL(vfe_transpose_kernel, dim3(ceil_div(kC * kC, 256)), dim3(256), 0, st, w2, kC, 2 * kC, kC, kC, w2bt);
+  ISF_TRY(a.alloc_n(&sc2, (size_t)kC));
+  ISF_TRY(a.alloc_n(&w2p, (size_t)4 * 4 * 128));
+  hipLaunchKernelGGL(vfe_prep_kernel, dim3(1), dim3(256), 0, st, w1, F, w2, scale2, w1t, w2p, sc2);
   int N = 0;
   ISF_TRY(read_int(occ.total, &N, st));  // the one host sync of the VFE: sizes every per-voxel buffer
   *n_host = N;
@@ -238,28 +369,33 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   }
   int32_t* pt2vox = pt2vox_out;
   if (!pt2vox) ISF_TRY(a.alloc_n(&pt2vox, (size_t)P));
-  long long* sums;
-  int32_t* cnt;
-  float *vmax1, *u;
-  ISF_TRY(a.alloc_n(&sums, (size_t)N * 3));
-  ISF_TRY(a.alloc_n(&cnt, (size_t)N));
+  int32_t *slot, *order;
+  uint32_t *cnt, *start;
+  float4* mean4;
+  float* vmax1;
+  ISF_TRY(a.alloc_n(&slot, (size_t)P));
+  ISF_TRY(a.alloc_n(&order, (size_t)P));
+  ISF_TRY(a.alloc_n(&cnt, (size_t)N + 1));
+  ISF_TRY(a.alloc_n(&start, (size_t)N + 2));
+  ISF_TRY(a.alloc_n(&mean4, (size_t)N));
   ISF_TRY(a.alloc_n(&vmax1, (size_t)N * kC));
-  ISF_TRY(a.alloc_n(&u, (size_t)N * kC));
-  ISF_HIP_TRY(hipMemsetAsync(sums, 0, (size_t)N * 3 * sizeof(long long), st));
-  ISF_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)N * sizeof(int32_t), st));
+  ISF_HIP_TRY(hipMemsetAsync(cnt, 0, ((size_t)N + 1) * sizeof(uint32_t), st));
   ISF_HIP_TRY(hipMemsetAsync(vmax1, 0, (size_t)N * kC * sizeof(float), st));
   ISF_HIP_TRY(hipMemsetAsync(voxel_feats, 0, (size_t)N * kC * sizeof(float), st));
   ISF_TRY(occ_compact_coords4(occ, voxel_coors, st));
-  hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, coors4, P,
-                     occ.D, occ.H, occ.W, occ.bits, occ.prefix, pt2vox, sums, cnt);
-  const int pblocks = ceil_div(P, kVfeThreads);
-  hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(pblocks), dim3(kVfeThreads), 0, st, points, coors4, P,
-                     pt2vox, sums, cnt, g, w1t, scale1, shift1, reinterpret_cast<int*>(vmax1));
-  hipLaunchKernelGGL(vfe_voxel_term_kernel, dim3(ceil_div(N, kVfeThreads)), dim3(kVfeThreads), 0, st,
-                     vmax1, occ.total, w2bt, u);
-  hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(pblocks), dim3(kVfeThreads), 0, st, points, coors4, P,
-                     pt2vox, sums, cnt, g, w1t, scale1, shift1, w2at, u, scale2, shift2,
-                     reinterpret_cast<int*>(voxel_feats));
+  hipLaunchKernelGGL(vfe_count_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, coors4, P, occ.D, occ.H, occ.W,
+                     occ.bits, occ.prefix, pt2vox, slot, cnt);
+  ISF_LAUNCH_CHECK();
+  ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
+  hipLaunchKernelGGL(vfe_order_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, pt2vox, slot, P, start, order);
+  hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(N, 256)), dim3(256), 0, st, points, order, start, N,
+                     mean4);
+  const int* n_valid = reinterpret_cast<const int*>(start + N);
+  hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, points,
+                     coors4, order, pt2vox, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1);
+  hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st,
+                     points, coors4, order, pt2vox, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1, w2p, sc2,
+                     shift2, voxel_feats);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
