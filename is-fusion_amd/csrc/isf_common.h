@@ -75,7 +75,10 @@ struct OccIndex {
   int* total;                // device scalar: number of set bits
 };
 
-int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st);  // zeroed bits
+int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st, bool zero = true);
+// atomic-free marking through persistent byte maps (writes EVERY bitmap word: create with zero = false)
+int occ_mark_coords4_bytemap(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
+int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
 int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st);                           // prefix + total
 int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
 // coords of all set bits in rank order -> out [total,4]
@@ -107,7 +110,7 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
 // isf_rulebook.hip
 int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int32_t** perm_out,
                hipStream_t st);
-int launch_nbr(const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
+int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
                const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
                int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_);
 int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], const int ks[3],

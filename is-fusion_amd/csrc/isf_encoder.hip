@@ -209,7 +209,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         ISF_TRY(ensure_occ(a, L, B, st));
         stride = isf_nbr_stride(L.n);
         ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
-        ISF_TRY(launch_nbr(L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
+        ISF_TRY(launch_nbr(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
                            stride, pair_counts + i, st));
         L.cache_nbr = nbr;
         L.cache_stride = stride;
@@ -237,7 +237,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       Nx.coors = nc;
       stride = isf_nbr_stride(Nx.n);
       ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
-      ISF_TRY(launch_nbr(Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
+      ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
                          stride, pair_counts + i, st));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_nbr = nullptr;

@@ -27,80 +27,76 @@ __global__ void rb_perm_kernel(const int32_t* __restrict__ coors4, int n, int D,
   if (r >= 0) perm[r] = i;
 }
 
-// thread per output row (rows >= n_out up to nbr_stride are filled with -1)
+// one thread per (output row, tap): grid (ceil(stride/256), K).  Rows are sorted, so the 256 probes of a
+// block hit neighbouring bitmap words; the two dependent loads of a probe are the whole critical path.
+// Rows >= n_out up to nbr_stride are filled with -1.
 __global__ __launch_bounds__(256) void rb_nbr_kernel(const int32_t* __restrict__ out_coors4, int n_out,
                                                      RbGeom g,
                                                      const unsigned long long* __restrict__ in_bits,
                                                      const uint32_t* __restrict__ in_prefix,
                                                      const int32_t* __restrict__ perm,
                                                      int32_t* __restrict__ nbr, int nbr_stride,
-                                                     unsigned long long* __restrict__ pair_count) {
+                                                     uint32_t* __restrict__ block_pairs) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  int found = 0;
-  if (o < nbr_stride) {
-    const int K = g.ks[0] * g.ks[1] * g.ks[2];
-    if (o >= n_out) {
-      for (int k = 0; k < K; ++k) nbr[(size_t)k * nbr_stride + o] = -1;
-    } else {
-      const int4 c = reinterpret_cast<const int4*>(out_coors4)[o];
-      const unsigned long long bbase = (unsigned long long)c.x * g.in_shape[0];
-      int k = 0;
-      for (int kz = 0; kz < g.ks[0]; ++kz) {
-        const int iz = c.y * g.st[0] - g.pd[0] + kz;
-        for (int ky = 0; ky < g.ks[1]; ++ky) {
-          const int iy = c.z * g.st[1] - g.pd[1] + ky;
-          for (int kx = 0; kx < g.ks[2]; ++kx, ++k) {
-            const int ix = c.w * g.st[2] - g.pd[2] + kx;
-            int r = -1;
-            if (iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && ix >= 0 &&
-                ix < g.in_shape[2]) {
-              r = occ_lookup(in_bits, in_prefix, ((bbase + iz) * g.in_shape[1] + iy) * g.in_shape[2] + ix);
-              if (r >= 0 && perm) r = perm[r];
-            }
-            found += (r >= 0);
-            nbr[(size_t)k * nbr_stride + o] = r;
-          }
-        }
-      }
+  const int k = blockIdx.y;
+  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
+  int r = -1;
+  if (o < n_out) {
+    const int4 c = reinterpret_cast<const int4*>(out_coors4)[o];
+    const int iz = c.y * g.st[0] - g.pd[0] + kz;
+    const int iy = c.z * g.st[1] - g.pd[1] + ky;
+    const int ix = c.w * g.st[2] - g.pd[2] + kx;
+    if (iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && ix >= 0 && ix < g.in_shape[2]) {
+      r = occ_lookup(in_bits, in_prefix,
+                     (((unsigned long long)c.x * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2] + ix);
+      if (r >= 0 && perm) r = perm[r];
     }
   }
-  if (pair_count) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d, 64);
-    if ((threadIdx.x & 63) == 0 && found) atomicAdd(pair_count, (unsigned long long)found);
+  if (o < nbr_stride) nbr[(size_t)k * nbr_stride + o] = r;
+  if (block_pairs) {  // per-block partial, no atomics: a single counter word serialises at ~88 updates/us
+    __shared__ int wsum[4];
+    const unsigned long long m = __ballot(r >= 0);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      block_pairs[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (uint32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
   }
 }
 
-// strided conv: every input voxel marks the outputs it feeds
+__global__ __launch_bounds__(1024) void rb_sum_pairs_kernel(const uint32_t* __restrict__ block_pairs, int n,
+                                                            unsigned long long* __restrict__ pair_count) {
+  __shared__ unsigned long long ws[16];
+  unsigned long long s = 0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += block_pairs[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 16; ++w) t += ws[w];
+    *pair_count = t;
+  }
+}
+
+// strided conv: every (input voxel, tap) marks the output it feeds; grid (ceil(n_in/256), K)
 __global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restrict__ in_coors4, int n_in,
                                                           RbGeom g,
                                                           unsigned long long* __restrict__ out_bits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_in) return;
+  const int k = blockIdx.y;
+  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
   const int4 c = reinterpret_cast<const int4*>(in_coors4)[i];
-  const unsigned long long bbase = (unsigned long long)c.x * g.out_shape[0];
-  for (int kz = 0; kz < g.ks[0]; ++kz) {
-    const int tz = c.y + g.pd[0] - kz;
-    if (tz < 0 || tz % g.st[0]) continue;
-    const int oz = tz / g.st[0];
-    if (oz >= g.out_shape[0]) continue;
-    for (int ky = 0; ky < g.ks[1]; ++ky) {
-      const int ty = c.z + g.pd[1] - ky;
-      if (ty < 0 || ty % g.st[1]) continue;
-      const int oy = ty / g.st[1];
-      if (oy >= g.out_shape[1]) continue;
-      for (int kx = 0; kx < g.ks[2]; ++kx) {
-        const int tx = c.w + g.pd[2] - kx;
-        if (tx < 0 || tx % g.st[2]) continue;
-        const int ox = tx / g.st[2];
-        if (ox >= g.out_shape[2]) continue;
-        const unsigned long long cell = ((bbase + oz) * g.out_shape[1] + oy) * g.out_shape[2] + ox;
-        const unsigned long long bit = 1ull << (cell & 63);
-        unsigned long long* p = out_bits + (cell >> 6);
-        if (!(*p & bit)) atomicOr(p, bit);
-      }
-    }
-  }
+  const int tz = c.y + g.pd[0] - kz, ty = c.z + g.pd[1] - ky, tx = c.w + g.pd[2] - kx;
+  if (tz < 0 || ty < 0 || tx < 0 || tz % g.st[0] || ty % g.st[1] || tx % g.st[2]) return;
+  const int oz = tz / g.st[0], oy = ty / g.st[1], ox = tx / g.st[2];
+  if (oz >= g.out_shape[0] || oy >= g.out_shape[1] || ox >= g.out_shape[2]) return;
+  const unsigned long long cell =
+      (((unsigned long long)c.x * g.out_shape[0] + oz) * g.out_shape[1] + oy) * g.out_shape[2] + ox;
+  const unsigned long long bit = 1ull << (cell & 63);
+  unsigned long long* p = out_bits + (cell >> 6);
+  if (!(*p & bit)) atomicOr(p, bit);
 }
 
 static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[3], const int pd[3],
@@ -116,12 +112,17 @@ static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[
   return g;
 }
 
-int launch_nbr(const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
+int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
                const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
                int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_) {
   const RbGeom g = make_rb_geom(in_shape, ks, st, pd, subm);
-  hipLaunchKernelGGL(rb_nbr_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st_, out_coors4,
-                     n_out, g, in_occ.bits, in_occ.prefix, perm, nbr, nbr_stride, pair_count);
+  const int K = ks[0] * ks[1] * ks[2], nbx = ceil_div(nbr_stride, 256);
+  uint32_t* block_pairs = nullptr;
+  if (pair_count) ISF_TRY(a.alloc_n(&block_pairs, (size_t)K * nbx));
+  hipLaunchKernelGGL(rb_nbr_kernel, dim3(nbx, K), dim3(256), 0, st_, out_coors4, n_out, g, in_occ.bits,
+                     in_occ.prefix, perm, nbr, nbr_stride, block_pairs);
+  if (pair_count)
+    hipLaunchKernelGGL(rb_sum_pairs_kernel, dim3(1), dim3(1024), 0, st_, block_pairs, K * nbx, pair_count);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -130,8 +131,8 @@ int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], c
                     const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_) {
   if (n_in <= 0) return ISF_OK;
   const RbGeom g = make_rb_geom(in_shape, ks, st, pd, false);
-  hipLaunchKernelGGL(rb_mark_out_kernel, dim3(ceil_div(n_in, 256)), dim3(256), 0, st_, in_coors4, n_in, g,
-                     out_occ.bits);
+  hipLaunchKernelGGL(rb_mark_out_kernel, dim3(ceil_div(n_in, 256), ks[0] * ks[1] * ks[2]), dim3(256), 0, st_,
+                     in_coors4, n_in, g, out_occ.bits);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -245,7 +246,7 @@ int isf_build_rulebook(const int32_t* indices, int num_in, int batch_size, const
   ISF_TRY(build_perm(a, in_occ, indices, num_in, &perm, st));
   if (subm) {
     ISF_REQUIRE(nbr_stride >= isf_nbr_stride(num_in), ISF_ERR_CAPACITY, "build_rulebook: nbr_stride too small");
-    ISF_TRY(launch_nbr(indices, num_in, spatial_shape_host, ksize_host, stride_host, padding_host, true,
+    ISF_TRY(launch_nbr(a, indices, num_in, spatial_shape_host, ksize_host, stride_host, padding_host, true,
                        in_occ, perm, nbr, nbr_stride, nullptr, st));
     if (out_indices && out_indices != indices)
       ISF_HIP_TRY(hipMemcpyAsync(out_indices, indices, (size_t)num_in * 4 * sizeof(int32_t),
@@ -268,7 +269,7 @@ int isf_build_rulebook(const int32_t* indices, int num_in, int batch_size, const
               "build_rulebook: %d outputs exceed out_capacity %d", n_out, out_capacity);
   ISF_REQUIRE(nbr_stride >= isf_nbr_stride(n_out), ISF_ERR_CAPACITY, "build_rulebook: nbr_stride too small");
   ISF_TRY(occ_compact_coords4(out_occ, out_indices, st));
-  ISF_TRY(launch_nbr(out_indices, n_out, spatial_shape_host, ksize_host, stride_host, padding_host, false,
+  ISF_TRY(launch_nbr(a, out_indices, n_out, spatial_shape_host, ksize_host, stride_host, padding_host, false,
                      in_occ, perm, nbr, nbr_stride, nullptr, st));
   *num_out_host = n_out;
   return ISF_OK;

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void vfe_count_kernel(const int32_t* __restric
                                                         const uint32_t* __restrict__ prefix,
                                                         int32_t* __restrict__ pt2vox,
                                                         int32_t* __restrict__ slot,
-                                                        uint32_t* __restrict__ cnt) {
+                                                        uint32_t* __restrict__ cnt,
+                                                        int32_t* __restrict__ voxel_coors) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const int4 c = reinterpret_cast<const int4*>(coors4)[i];
@@ -95,7 +96,11 @@ __global__ __launch_bounds__(256) void vfe_count_kernel(const int32_t* __restric
   if (c.y >= 0 && c.z >= 0 && c.w >= 0)
     v = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
   pt2vox[i] = v;
-  if (v >= 0) slot[i] = (int32_t)atomicAdd(&cnt[v], 1u);
+  if (v >= 0) {
+    const uint32_t s = atomicAdd(&cnt[v], 1u);
+    slot[i] = (int32_t)s;
+    if (s == 0) reinterpret_cast<int4*>(voxel_coors)[v] = c;  // exactly one point per voxel draws slot 0
+  }
 }
 
 __global__ __launch_bounds__(256) void vfe_order_kernel(const int32_t* __restrict__ pt2vox,
@@ -340,8 +345,6 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
 }
 
 // ------------------------------------------------------------------------------------------ driver
-int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
-
 template <int CIN>
 static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, int B, const int grid[3],
                    VfeGeom g, const float* w1, const float* scale1, const float* shift1, const float* w2,
@@ -350,8 +353,8 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   const int F = CIN + 6;
   OccIndex occ;
   // d_alloc > grid z lets the sparse encoder (sparse_shape[0] = grid z + 1) reuse this index for level 0
-  ISF_TRY(occ_create(a, &occ, B, d_alloc > grid[2] ? d_alloc : grid[2], grid[1], grid[0], st));
-  ISF_TRY(occ_mark_coords4(occ, coors4, P, st));
+  ISF_TRY(occ_create(a, &occ, B, d_alloc > grid[2] ? d_alloc : grid[2], grid[1], grid[0], st, false));
+  ISF_TRY(occ_mark_coords4_bytemap(occ, coors4, P, st));
   ISF_TRY(occ_scan(a, occ, st));
   float *w1t, *sc2;
   uint4* w2p;
@@ -382,9 +385,8 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_HIP_TRY(hipMemsetAsync(cnt, 0, ((size_t)N + 1) * sizeof(uint32_t), st));
   ISF_HIP_TRY(hipMemsetAsync(vmax1, 0, (size_t)N * kC * sizeof(float), st));
   ISF_HIP_TRY(hipMemsetAsync(voxel_feats, 0, (size_t)N * kC * sizeof(float), st));
-  ISF_TRY(occ_compact_coords4(occ, voxel_coors, st));
   hipLaunchKernelGGL(vfe_count_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, coors4, P, occ.D, occ.H, occ.W,
-                     occ.bits, occ.prefix, pt2vox, slot, cnt);
+                     occ.bits, occ.prefix, pt2vox, slot, cnt, voxel_coors);
   ISF_LAUNCH_CHECK();
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
   hipLaunchKernelGGL(vfe_order_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, pt2vox, slot, P, start, order);
