@@ -251,6 +251,82 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
                              float* spatial_features, int out_shape_host[4],
                              isf_encoder_stats* stats_host, int time_layers, isf_stream_t stream);
 
+/* ===================================================================================================
+ * HSF / IGF rows (A8, A10-A14).  Dense 3x3 convolutions around them stay stock
+ * PyTorch-ROCm ops (north_star); everything below is what the reference runs through custom CUDA ops
+ * or long chains of small torch kernels.
+ * =================================================================================================== */
+
+/* nn.Linear with fused epilogue -----------------------------------------------------------------------
+ * replaces F.linear + bias + {GELU | ReLU} + residual add + LayerNorm chains of
+ *   mmdet3d/models/sst/sst_basic_block_v2.py:104-126 (EncoderLayer), backbones/sst_v2.py:83 (linear0),
+ *   middle_encoders/fusion_encoder.py:560-600 (MSDeformAttn projections), :653-674 (decoder layer FFN),
+ *   :221-470 (MultiheadAttention in/out projections), :489-496 (Instane2SceneAtt).
+ * isf_pack_linear splits weight [out, in] (torch layout) once into f16 hi/lo MFMA fragments.
+ * y[r, :] = LN( act( x[r, :] . W^T + bias + row_table[row_table_index[r], :] ) + residual[r, :] )
+ *   activation: 0 none, 1 ReLU, 2 GELU(erf);  LN only when ln_gamma != NULL (out_features <= 256).
+ * in_features in {32,64,128,256}; out_features % 16 == 0; ldx % 8 == 0. */
+size_t isf_packed_linear_bytes(int out_features, int in_features);
+int isf_pack_linear(const float* weight, int out_features, int in_features, void* packed, isf_stream_t stream);
+int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, const void* packed_weight,
+                       int out_features, const float* bias, const float* row_table, const int32_t* row_table_index,
+                       int activation, const float* residual, const float* ln_gamma, const float* ln_beta,
+                       float ln_eps, float* y, int ldy, isf_stream_t stream);
+
+/* A10/A11  window attention on a dense token grid -------------------------------------------------------
+ * replaces get_window_coors / flat2window / nn.MultiheadAttention / window2flat of
+ *   mmdet3d/ops/sst/sst_ops.py:219-268, 63-143 and models/sst/sst_basic_block_v2.py:41-75
+ * for the fusion encoder's dense grids (fusion_encoder.py:1151-1189: every cell is a token, token row =
+ * (b*S + y)*S + x).  qkv [B*S*S, 3*d] = (q | k | v) projections (q, k of x + pos, v of x);
+ * shift 0: windows aligned at 0, shift 1: windows offset by -window/2 (partial edge windows attend among the
+ * cells they hold).  out [B*S*S, d] = softmax(q k^T / sqrt(hd)) v per head, heads concatenated. */
+int isf_window_attention_forward(const float* qkv, int batch_size, int grid_size, int embed_dims, int num_heads,
+                                 int window, int shift, float* out, isf_stream_t stream);
+
+/* A13/A14  multi-head attention core with few keys ------------------------------------------------------
+ * replaces the softmax(QK^T)V part of multi_head_attention_forward (fusion_encoder.py:371-470) for
+ * num_keys <= 512: q [B*Lq, ldq], k / v [B*Lk, ldkv] (already projected; head h = columns h*hd..),
+ * out [B*Lq, ldo]. */
+int isf_attention_forward(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
+                          int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
+                          isf_stream_t stream);
+
+/* A14  per-channel map attention -----------------------------------------------------------------------
+ * replaces fusion_encoder.py:497-502: for each of num_maps = B*C maps (size x size, row-major)
+ *   out = query_scene + softmax(query_scene . query_ins^T, dim=-1) . query_ins */
+int isf_channel_attention_forward(const float* query_scene, const float* query_ins, int num_maps, int size,
+                                  float* out, isf_stream_t stream);
+
+/* A8  Point-to-Grid sampling ------------------------------------------------------------------------------
+ * replaces ISFusionEncoder.img_fv_to_bev + img_point_sampling (fusion_encoder.py:965-1070).
+ * pillars [M, slots, pillar_ld] (x, y, z first; zero-padded slots are sampled like the reference does),
+ * pillar_coors [M, 4] (b, z, y, x); img_nhwc [B*num_cam, feat_h, feat_w, C]; cam_params [B*num_cam, 20]:
+ *   M(3x3) = lidar2img[:3,:3] . inv(lidar_aug[:3,:3]), v(3) = lidar2img[:3,3] - M . lidar_aug[:3,3],
+ *   A(2x3) = img_aug[:2,:3], a(2) = img_aug[:2,3]   (host-side 4x4 algebra, see fusion_ops.p2g_camera_params)
+ * out [B, C, bev, bev] is written completely (zeros where no pillar). */
+int isf_p2g_forward(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
+                    const float* img_nhwc, int batch_size, int num_cam, int feat_h, int feat_w, int channels,
+                    const float* cam_params, int input_h, int input_w, int bev_size, float* out,
+                    isf_stream_t stream);
+
+/* A12  instance mining: sigmoid + 3x3 NMS + top-k -------------------------------------------------------
+ * replaces fusion_encoder.py:1100-1131.  heatmap [B, K, H, W] logits; classes with bit set in
+ * pool1_class_mask use a 1x1 pool (every cell is its own maximum).  top_index [B, k] = flat index % (H*W),
+ * top_index_raw [B, k] = flat index over (K, H, W), both in descending score order (ties: ascending index);
+ * masked_heatmap [B, K*H*W] optional (NULL to skip). */
+int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int height, int width, int k,
+                      unsigned pool1_class_mask, int32_t* top_index, int32_t* top_index_raw, float* masked_heatmap,
+                      isf_stream_t stream);
+
+/* A13  multi-scale deformable attention (one level) -----------------------------------------------------
+ * replaces MultiScaleDeformableAttnFunction.forward (mmdet3d/ops/.../ms_deform_attn, called at
+ * fusion_encoder.py:597) plus the softmax / location arithmetic of :585-596.
+ * value [B, H*W, heads*hd]; sampling_offsets [B*Q, heads*P*2]; attention_logits [B*Q, heads*P] (pre-softmax);
+ * reference_points [B*Q, 2] (x, y) in [0, 1]; out [B*Q, heads*hd]. */
+int isf_msda_forward(const float* value, const float* sampling_offsets, const float* attention_logits,
+                     const float* reference_points, int batch_size, int num_queries, int num_heads, int head_dim,
+                     int num_points, int height, int width, float* out, isf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

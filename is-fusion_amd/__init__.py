@@ -6,6 +6,8 @@ it through the shim package ``isfusion_amd/`` at the repository root.  Everythin
 host-side mirror of the reference's mmdet3d operator / module interface.  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
+from .fusion_encoder import ISFusionEncoder  # noqa: F401
+from .fusion_modules import SECONDV2, SSTInputLayerV2, SSTv2  # noqa: F401
 from .lidar_branch import ISFUSION_0075, LidarBranch  # noqa: F401
 from .norm import NaiveSyncBatchNorm1d, NaiveSyncBatchNorm2d  # noqa: F401
 from .scatter_points import DynamicScatter, dynamic_scatter  # noqa: F401

@@ -105,6 +105,21 @@ SIGNATURES = {
     "isf_lidar_branch_forward": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), c_int,
                                          ctypes.POINTER(VfeParams), _I3, ctypes.POINTER(ConvLayer), c_int,
                                          c_void_p, _I4, ctypes.POINTER(EncoderStats), c_int, c_void_p]),
+    "isf_packed_linear_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "isf_pack_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "isf_linear_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_void_p]),
+    "isf_window_attention_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p]),
+    "isf_attention_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_void_p, c_int, c_void_p]),
+    "isf_channel_attention_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "isf_p2g_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_instance_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "isf_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,212 @@
+// isf_attention.hip -- the three softmax-attention cores of HSF Grid-to-Region (A10/A11) and IGF (A13/A14).
+//
+//  window_attention   36-token (win x win) windows of a DENSE S x S token grid; membership is arithmetic
+//                     (reference: get_window_coors + flat2window/window2flat gathers, sst_ops.py:219-268,
+//                     sst_basic_block_v2.py:41-75).  One wave per (window, head).
+//  small_key_attention  Lk <= 256 keys resident in LDS, one thread per query, online softmax: the 200 x 200
+//                     instance self-attention (fusion_encoder.py:664) and the 32400 x 200 instance-to-scene
+//                     cross attention (fusion_encoder.py:489-494).
+//  (the per-channel map attention of A14 lives in isf_channel_attn.hip)
+// All fp32 VALU: these are small (<= 3 GFLOP / sample) next to the projections, which run on MFMA
+// (isf_linear.hip).
+#include "isf_common.h"
+
+namespace isf {
+
+// ----------------------------------------------------------------------------------------------------------------
+// qkv [B*S*S, 3d] (q | k | v, head h at columns h*HD); token row = (b*S + y)*S + x.
+// window (wy, wx) covers y in [wy*win - off, +win), off = win (shift 0: aligned) or win/2 (shift 1) minus the
+// first window index; out [B*S*S, d].
+template <int HD, int WIN>
+__global__ __launch_bounds__(512) void window_attention_kernel(const float* __restrict__ qkv, int S, int d,
+                                                              int y_off, float scale, float* __restrict__ out) {
+  constexpr int T = WIN * WIN;
+  static_assert(T <= 64, "window must fit one wave");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float (*kv)[2][T][HD] = reinterpret_cast<float (*)[2][T][HD]>(smem);   // [8 heads][k|v][T][HD]
+  const int lane = threadIdx.x & 63;
+  const int head = threadIdx.x >> 6;
+  const int b = blockIdx.z;
+  const int y0 = (int)blockIdx.y * WIN - y_off, x0 = (int)blockIdx.x * WIN - y_off;
+  const int iy = lane / WIN, ix = lane % WIN;
+  const int y = y0 + iy, x = x0 + ix;
+  const bool valid = lane < T && y >= 0 && y < S && x >= 0 && x < S;
+  float q[HD];
+  const size_t row = ((size_t)b * S + (valid ? y : 0)) * S + (valid ? x : 0);
+  const float* base = qkv + row * (size_t)(3 * d) + head * HD;
+  if (lane < T) {
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      float4 qq = valid ? *reinterpret_cast<const float4*>(base + c) : make_float4(0, 0, 0, 0);
+      float4 kk = valid ? *reinterpret_cast<const float4*>(base + d + c) : make_float4(0, 0, 0, 0);
+      float4 vv = valid ? *reinterpret_cast<const float4*>(base + 2 * d + c) : make_float4(0, 0, 0, 0);
+      q[c] = qq.x * scale; q[c + 1] = qq.y * scale; q[c + 2] = qq.z * scale; q[c + 3] = qq.w * scale;
+      *reinterpret_cast<float4*>(&kv[head][0][lane][c]) = kk;
+      *reinterpret_cast<float4*>(&kv[head][1][lane][c]) = vv;
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  float s[T];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const int yy = y0 + j / WIN, xx = x0 + j % WIN;
+    const bool ok = yy >= 0 && yy < S && xx >= 0 && xx < S;   // wave-uniform
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kk = *reinterpret_cast<const float4*>(&kv[head][0][j][c]);
+      a = fmaf(q[c], kk.x, a); a = fmaf(q[c + 1], kk.y, a); a = fmaf(q[c + 2], kk.z, a); a = fmaf(q[c + 3], kk.w, a);
+    }
+    s[j] = ok ? a : -INFINITY;
+    m = fmaxf(m, s[j]);
+  }
+  float sum = 0.f;
+  float o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const float p = __expf(s[j] - m);   // masked: exp(-inf) = 0
+    sum += p;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 vv = *reinterpret_cast<const float4*>(&kv[head][1][j][c]);
+      o[c] = fmaf(p, vv.x, o[c]); o[c + 1] = fmaf(p, vv.y, o[c + 1]);
+      o[c + 2] = fmaf(p, vv.z, o[c + 2]); o[c + 3] = fmaf(p, vv.w, o[c + 3]);
+    }
+  }
+  const float inv = 1.f / sum;
+  float* orow = out + row * (size_t)d + head * HD;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4)
+    *reinterpret_cast<float4*>(orow + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// q [B*Lq, ldq], k/v [B*Lk, ldk] (column offsets applied by the host), head h at columns h*HD; out [B*Lq, ldo]
+template <int HD>
+__global__ __launch_bounds__(256) void small_key_attention_kernel(const float* __restrict__ q, int ldq,
+                                                                  const float* __restrict__ k,
+                                                                  const float* __restrict__ v, int ldk, int Lq,
+                                                                  int Lk, float scale, float* __restrict__ out,
+                                                                  int ldo) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ks = smem;               // [Lk][HD]
+  float* vs = smem + (size_t)Lk * HD;
+  const int head = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < Lk * (HD / 4); i += blockDim.x) {
+    const int j = i / (HD / 4), c = (i % (HD / 4)) * 4;
+    const size_t off = ((size_t)b * Lk + j) * ldk + head * HD + c;
+    *reinterpret_cast<float4*>(ks + j * HD + c) = *reinterpret_cast<const float4*>(k + off);
+    *reinterpret_cast<float4*>(vs + j * HD + c) = *reinterpret_cast<const float4*>(v + off);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= Lq) return;
+  float qr[HD], o[HD];
+  const float* qp = q + ((size_t)b * Lq + qi) * ldq + head * HD;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(qp + c);
+    qr[c] = t.x * scale; qr[c + 1] = t.y * scale; qr[c + 2] = t.z * scale; qr[c + 3] = t.w * scale;
+    o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
+  }
+  float m = -INFINITY, sum = 0.f;
+  for (int j = 0; j < Lk; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kk = *reinterpret_cast<const float4*>(ks + j * HD + c);
+      a = fmaf(qr[c], kk.x, a); a = fmaf(qr[c + 1], kk.y, a); a = fmaf(qr[c + 2], kk.z, a); a = fmaf(qr[c + 3], kk.w, a);
+    }
+    const float mn = fmaxf(m, a);
+    const float corr = __expf(m - mn);   // first step: exp(-inf) = 0
+    const float p = __expf(a - mn);
+    sum = sum * corr + p;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 vv = *reinterpret_cast<const float4*>(vs + j * HD + c);
+      o[c] = fmaf(p, vv.x, o[c] * corr); o[c + 1] = fmaf(p, vv.y, o[c + 1] * corr);
+      o[c + 2] = fmaf(p, vv.z, o[c + 2] * corr); o[c + 3] = fmaf(p, vv.w, o[c + 3] * corr);
+    }
+    m = mn;
+  }
+  const float inv = 1.f / sum;
+  float* op = out + ((size_t)b * Lq + qi) * ldo + head * HD;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4)
+    *reinterpret_cast<float4*>(op + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_window_attention_forward(const float* qkv, int batch_size, int grid_size, int embed_dims, int num_heads,
+                                 int window, int shift, float* out, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && grid_size > 0, ISF_ERR_ARG, "window_attention: bad sizes");
+  if (batch_size == 0) return ISF_OK;
+  ISF_REQUIRE(qkv && out, ISF_ERR_ARG, "window_attention: null pointer");
+  ISF_REQUIRE(num_heads == 8 && window == 6 && (embed_dims == 128 || embed_dims == 256), ISF_ERR_UNSUPPORTED,
+              "window_attention: built for 8 heads, 6x6 windows, d in {128, 256} (got %d heads, win %d, d %d)",
+              num_heads, window, embed_dims);
+  // sst_ops.py:236-248: shift 0 adds `win` to the coordinates, shift 1 adds win/2, then floor-divides.
+  // window index 0 of this launch is the first window that holds a grid cell.
+  const int y_off = shift ? window / 2 : 0;
+  const int nwin = shift ? (grid_size - 1 + window / 2) / window + 1 : (grid_size + window - 1) / window;
+  const dim3 grid(nwin, nwin, batch_size), block(512);
+  const int hd = embed_dims / num_heads;
+  const float scale = 1.0f / sqrtf((float)hd);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)8 * 2 * 36 * hd * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_kernel<32, 6>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set = true;
+  }
+  if (hd == 16)
+    hipLaunchKernelGGL((window_attention_kernel<16, 6>), grid, block, lds, st, qkv, grid_size, embed_dims, y_off, scale, out);
+  else
+    hipLaunchKernelGGL((window_attention_kernel<32, 6>), grid, block, lds, st, qkv, grid_size, embed_dims, y_off, scale, out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_attention_forward(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
+                          int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
+                          isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && num_queries >= 0 && num_keys > 0, ISF_ERR_ARG, "attention: bad sizes");
+  if (batch_size == 0 || num_queries == 0) return ISF_OK;
+  ISF_REQUIRE(q && k && v && out, ISF_ERR_ARG, "attention: null pointer");
+  ISF_REQUIRE(embed_dims % num_heads == 0 && ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0, ISF_ERR_ARG,
+              "attention: strides must be multiples of 4 floats");
+  const int hd = embed_dims / num_heads;
+  ISF_REQUIRE((hd == 16 || hd == 32) && num_keys <= 512, ISF_ERR_UNSUPPORTED,
+              "attention: built for head_dim 16/32 and <= 512 keys (got %d, %d)", hd, num_keys);
+  const dim3 grid(ceil_div(num_queries, 256), num_heads, batch_size), block(256);
+  const size_t lds = (size_t)num_keys * hd * 2 * sizeof(float);
+  const float scale = 1.0f / sqrtf((float)hd);
+  hipStream_t st = as_stream(stream);
+  static bool attr_set = false;
+  if (!attr_set) {   // 512 keys x 32 dims x (k, v) = 128 KB of the 160 KB LDS
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_key_attention_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_key_attention_kernel<32>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr_set = true;
+  }
+  if (hd == 16)
+    hipLaunchKernelGGL((small_key_attention_kernel<16>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries,
+                       num_keys, scale, out, ldo);
+  else
+    hipLaunchKernelGGL((small_key_attention_kernel<32>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries,
+                       num_keys, scale, out, ldo);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+}  // extern "C"

@@ -1,0 +1,343 @@
+// isf_fusion.hip -- HSF Point-to-Grid sampling (A8), IGF instance mining (A12) and the multi-scale deformable
+// attention gather (A13).
+#include "isf_common.h"
+
+namespace isf {
+
+// ----------------------------------------------------------------------------------------------------------------
+// A8  img_fv_to_bev + img_point_sampling (fusion_encoder.py:965-1070).  The reference loops over samples, builds
+// [cam, 3, N] projections with four batched matmuls and calls grid_sample once per camera on an NCHW map, then
+// sums over cameras and the T pillar slots and scatters into a zero canvas.  Here: one wave per pillar, lanes
+// own channels of an NHWC image map (1 KB contiguous per bilinear tap), the projection of each (slot, camera) is
+// wave-uniform scalar work, the (camera, slot) sum stays in registers and the canvas is written once.
+// cam[b*num_cam + k] = 20 floats: M (3x3 row-major) = lidar2img[:3,:3] . inv(lidar_aug[:3,:3]),
+//                      v (3) = lidar2img[:3,3] - M . lidar_aug[:3,3], A (2x3) = img_aug[:2,:3], a (2) = img_aug[:2,3]
+template <int CPL /* channels per lane */>
+__global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pillars, int pillar_ld, int T,
+                                                  const int32_t* __restrict__ coors, int M,
+                                                  const float* __restrict__ img /* [B*cam, H, W, C] */, int num_cam,
+                                                  int H, int W, int C, const float* __restrict__ cam, float in_h,
+                                                  float in_w, int bev, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= M) return;
+  const int b = coors[4 * p], y = coors[4 * p + 2], x = coors[4 * p + 3];
+  float acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+  const int c0 = lane * CPL;
+  for (int t = 0; t < T; ++t) {
+    const float* pt = pillars + ((size_t)p * T + t) * pillar_ld;
+    const float px = pt[0], py = pt[1], pz = pt[2];
+    for (int k = 0; k < num_cam; ++k) {
+      const float* m = cam + (size_t)(b * num_cam + k) * 20;
+      float cx = m[0] * px + m[1] * py + m[2] * pz + m[9];
+      float cy = m[3] * px + m[4] * py + m[5] * pz + m[10];
+      float cz = m[6] * px + m[7] * py + m[8] * pz + m[11];
+      cz = fminf(fmaxf(cz, 1e-5f), 1e5f);
+      cx /= cz;
+      cy /= cz;
+      const float u = m[12] * cx + m[13] * cy + m[14] * cz + m[18];
+      const float v = m[15] * cx + m[16] * cy + m[17] * cz + m[19];
+      // (u / in_w - 0.5) * 2 then grid_sample's align_corners=False un-normalisation
+      const float gx = (u / in_w - 0.5f) * 2.f, gy = (v / in_h - 0.5f) * 2.f;
+      const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+      if (!(ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H)) continue;   // all four taps outside
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float lx = ix - fx, ly = iy - fy;
+      const float* base = img + (size_t)(b * num_cam + k) * H * W * C + c0;
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
+        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+        const float wgt = ((tap & 1) ? lx : 1.f - lx) * ((tap >> 1) ? ly : 1.f - ly);
+        const float* src = base + ((size_t)yy * W + xx) * C;
+        if (CPL == 4) {
+          const float4 f = *reinterpret_cast<const float4*>(src);
+          acc[0] = fmaf(wgt, f.x, acc[0]); acc[1] = fmaf(wgt, f.y, acc[1]);
+          acc[2] = fmaf(wgt, f.z, acc[2]); acc[3] = fmaf(wgt, f.w, acc[3]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) acc[c] = fmaf(wgt, src[c], acc[c]);
+        }
+      }
+    }
+  }
+  float* o = out + ((size_t)b * C + c0) * bev * bev + (size_t)y * bev + x;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) o[(size_t)c * bev * bev] = acc[c];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// A12  sigmoid -> 3x3 local-maximum suppression (1x1 for the listed classes) -> top-k over all classes
+// (fusion_encoder.py:1100-1131).  The reference materialises the suppressed map and argsorts all K*H*W
+// values per sample.  Here the suppression kernel compacts the surviving local maxima (typically ~1/9 of the
+// cells) into a candidate list of 50-bit keys (value bits | reversed index: unique, ties broken by ascending
+// flat index) and one workgroup per sample radix-selects the k-th key, collects the k winners and bitonic-sorts
+// them.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ hm, int K, int H, int W,
+                                                             unsigned pool1_mask, unsigned long long* __restrict__ cand,
+                                                             int* __restrict__ cand_count, float* __restrict__ masked) {
+  const int b = blockIdx.y;
+  const int n = K * H * W;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool keep = false;
+  float hv = 0.f;
+  if (i < n) {
+    const int x = i % W, y = (i / W) % H, c = i / (W * H);
+    const float* plane = hm + ((size_t)b * K + c) * H * W;
+    hv = sigmoidf_(plane[y * W + x]);
+    if ((pool1_mask >> c) & 1u) {
+      keep = true;
+    } else if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
+      float mx = hv;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) mx = fmaxf(mx, sigmoidf_(plane[(y + dy) * W + x + dx]));
+      keep = hv == mx;
+    }
+    if (masked) masked[(size_t)b * n + i] = keep ? hv : 0.f;
+    keep = keep && hv > 0.f;
+  }
+  // block-aggregated append
+  __shared__ int wave_cnt[4], wave_base[4];
+  const unsigned long long bal = __ballot(keep);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    int base = tot ? atomicAdd(cand_count + b, tot) : 0;
+    for (int w = 0; w < 4; ++w) { wave_base[w] = base; base += wave_cnt[w]; }
+  }
+  __syncthreads();
+  if (keep) {
+    const int pos = wave_base[wave] + __popcll(bal & ((1ull << lane) - 1));
+    cand[(size_t)b * n + pos] = ((unsigned long long)__float_as_uint(hv) << 19) | (unsigned long long)(0x7FFFF - i);
+  }
+}
+
+// one workgroup (1024 threads) per sample; k <= 1024
+__global__ __launch_bounds__(1024) void topk_select_kernel(const unsigned long long* __restrict__ cand,
+                                                           const int* __restrict__ cand_count, int n, int HW, int k,
+                                                           int32_t* __restrict__ top_mod, int32_t* __restrict__ top_raw) {
+  __shared__ int hist[1024];
+  __shared__ int scan[1024];
+  __shared__ unsigned long long sel[1024];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_need, s_cnt;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const unsigned long long* c = cand + (size_t)b * n;
+  const int nc = cand_count[b];
+  const int kk = nc < k ? nc : k;
+  unsigned long long thr = 0;
+  if (nc > k) {
+    if (t == 0) { s_prefix = 0; s_need = k; }
+    __syncthreads();
+    // 50-bit keys, 5 digits of 10 bits from the top
+    for (int shift = 40; shift >= 0; shift -= 10) {
+      hist[t] = 0;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      const int need = s_need;
+      for (int i = t; i < nc; i += 1024) {
+        const unsigned long long key = c[i];
+        if (shift == 40 || (key >> (shift + 10)) == prefix) atomicAdd(&hist[(int)((key >> shift) & 1023)], 1);
+      }
+      __syncthreads();
+      // inclusive suffix sum over bins (bin 1023 first)
+      scan[t] = hist[t];
+      __syncthreads();
+      for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t + d < 1024 ? scan[t + d] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+      }
+      const int incl = scan[t], excl = incl - hist[t];
+      if (excl < need && need <= incl) {   // exactly one bin
+        s_prefix = (prefix << 10) | (unsigned long long)t;
+        s_need = need - excl;
+      }
+      __syncthreads();
+    }
+    thr = s_prefix;   // the k-th largest key (keys are unique)
+  }
+  if (t == 0) s_cnt = 0;
+  sel[t] = 0;
+  __syncthreads();
+  for (int i = t; i < nc; i += 1024) {
+    const unsigned long long key = c[i];
+    if (key >= thr) {
+      const int pos = atomicAdd(&s_cnt, 1);
+      if (pos < 1024) sel[pos] = key;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending (unused slots hold key 0 = smallest)
+  for (int size = 2; size <= 1024; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = t ^ stride;
+      if (partner > t) {
+        const bool desc = (t & size) == 0;
+        const unsigned long long a = sel[t], bb = sel[partner];
+        if ((a < bb) == desc) { sel[t] = bb; sel[partner] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < kk) {
+    const int idx = 0x7FFFF - (int)(sel[t] & 0x7FFFF);
+    top_raw[(size_t)b * k + t] = idx;
+    top_mod[(size_t)b * k + t] = idx % HW;
+  }
+  // fewer than k positive local maxima: the reference's argsort continues into the zeros (tie order
+  // unspecified there); continue with the smallest flat indices that are not already selected.
+  if (kk < k && t == 0) {
+    int filled = kk, idx = 0;
+    while (filled < k && idx < n) {
+      bool used = false;
+      for (int j = 0; j < kk; ++j) used |= (0x7FFFF - (int)(sel[j] & 0x7FFFF)) == idx;
+      if (!used) {
+        top_raw[(size_t)b * k + filled] = idx;
+        top_mod[(size_t)b * k + filled] = idx % HW;
+        ++filled;
+      }
+      ++idx;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// A13  multi-scale deformable attention forward, single level (ops/src/cuda/ms_deform_im2col_cuda.cuh:33-84,
+// 237-299 in the reference) with the softmax over the sampling points and the location arithmetic of
+// MSDeformAttn.forward (fusion_encoder.py:585-596) folded in.
+// value [B, H*W, heads*D]; offsets [B*Q, heads*P*2]; logits [B*Q, heads*P]; ref [B*Q, 2] (x, y in [0,1]);
+// out [B*Q, heads*D].  One thread per (b, q, head, d); the 16 lanes of a head share the tap geometry.
+template <int D, int P>
+__global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ value, const float* __restrict__ offsets,
+                                                   const float* __restrict__ logits, const float* __restrict__ ref,
+                                                   int B, int Q, int heads, int H, int W, float* __restrict__ out) {
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * Q * heads * D;
+  if (tid >= total) return;
+  const int dch = (int)(tid % D);
+  const int h = (int)((tid / D) % heads);
+  const long long bq = tid / ((long long)D * heads);
+  const int b = (int)(bq / Q);
+  const float* lg = logits + bq * heads * P + h * P;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < P; ++p) mx = fmaxf(mx, lg[p]);
+  float e[P], sum = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) { e[p] = expf(lg[p] - mx); sum += e[p]; }
+  const float rx = ref[bq * 2], ry = ref[bq * 2 + 1];
+  const float* off = offsets + bq * heads * P * 2 + h * P * 2;
+  const float* vb = value + (size_t)b * H * W * heads * D + h * D + dch;
+  const size_t vstride = (size_t)heads * D;
+  float acc = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const float lx = rx + off[2 * p] / (float)W, ly = ry + off[2 * p + 1] / (float)H;
+    const float w_im = lx * (float)W - 0.5f, h_im = ly * (float)H - 0.5f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const float fh = floorf(h_im), fw = floorf(w_im);
+      const int h0 = (int)fh, w0 = (int)fw;
+      const float lh = h_im - fh, lw = w_im - fw;
+      float s = 0.f;
+      if (h0 >= 0 && w0 >= 0) s += (1.f - lh) * (1.f - lw) * vb[((size_t)h0 * W + w0) * vstride];
+      if (h0 >= 0 && w0 + 1 <= W - 1) s += (1.f - lh) * lw * vb[((size_t)h0 * W + w0 + 1) * vstride];
+      if (h0 + 1 <= H - 1 && w0 >= 0) s += lh * (1.f - lw) * vb[((size_t)(h0 + 1) * W + w0) * vstride];
+      if (h0 + 1 <= H - 1 && w0 + 1 <= W - 1) s += lh * lw * vb[((size_t)(h0 + 1) * W + w0 + 1) * vstride];
+      acc += (e[p] / sum) * s;
+    }
+  }
+  out[tid] = acc;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_p2g_forward(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
+                    const float* img_nhwc, int batch_size, int num_cam, int feat_h, int feat_w, int channels,
+                    const float* cam_params, int input_h, int input_w, int bev_size, float* out,
+                    isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(num_pillars >= 0 && batch_size > 0 && slots > 0 && bev_size > 0, ISF_ERR_ARG, "p2g: bad sizes");
+  ISF_REQUIRE(out, ISF_ERR_ARG, "p2g: null output");
+  hipStream_t st = as_stream(stream);
+  ISF_HIP_TRY(hipMemsetAsync(out, 0, (size_t)batch_size * channels * bev_size * bev_size * sizeof(float), st));
+  if (num_pillars == 0) return ISF_OK;
+  ISF_REQUIRE(pillars && pillar_coors && img_nhwc && cam_params, ISF_ERR_ARG, "p2g: null pointer");
+  ISF_REQUIRE(channels % 64 == 0 && channels <= 512 && pillar_ld >= 3, ISF_ERR_UNSUPPORTED,
+              "p2g: channels %d (need %%64 == 0, <= 512)", channels);
+  const dim3 grid(ceil_div(num_pillars, 4)), block(256);
+#define ISF_P2G(CPL)                                                                                              \
+  hipLaunchKernelGGL((p2g_kernel<CPL>), grid, block, 0, st, pillars, pillar_ld, slots, pillar_coors, num_pillars, \
+                     img_nhwc, num_cam, feat_h, feat_w, channels, cam_params, (float)input_h, (float)input_w,      \
+                     bev_size, out)
+  switch (channels / 64) {
+    case 1: ISF_P2G(1); break;
+    case 2: ISF_P2G(2); break;
+    case 4: ISF_P2G(4); break;
+    case 8: ISF_P2G(8); break;
+    default: set_error("p2g: channels %d not built (64, 128, 256, 512)", channels); return ISF_ERR_UNSUPPORTED;
+  }
+#undef ISF_P2G
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int height, int width, int k,
+                      unsigned pool1_class_mask, int32_t* top_index, int32_t* top_index_raw, float* masked_heatmap,
+                      isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && num_classes > 0 && num_classes <= 32 && height >= 3 && width >= 3, ISF_ERR_ARG,
+              "instance_topk: bad sizes");
+  if (batch_size == 0) return ISF_OK;
+  ISF_REQUIRE(heatmap && top_index && top_index_raw, ISF_ERR_ARG, "instance_topk: null pointer");
+  const long long n = (long long)num_classes * height * width;
+  ISF_REQUIRE(k > 0 && k <= 1024 && k <= n && n <= 0x7FFFF, ISF_ERR_UNSUPPORTED,
+              "instance_topk: k %d (<= 1024) over %lld cells (<= 524287)", k, n);
+  hipStream_t st = as_stream(stream);
+  Arena& a = arena_for_current_device();
+  ISF_TRY(a.reset());
+  unsigned long long* cand = nullptr;
+  int* count = nullptr;
+  ISF_TRY(a.alloc_n(&cand, (size_t)batch_size * n));
+  ISF_TRY(a.alloc_n(&count, (size_t)batch_size + 16));
+  ISF_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * batch_size, st));
+  hipLaunchKernelGGL(nms_candidates_kernel, dim3(ceil_div(n, 256), batch_size), dim3(256), 0, st, heatmap,
+                     num_classes, height, width, pool1_class_mask, cand, count, masked_heatmap);
+  ISF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(topk_select_kernel, dim3(batch_size), dim3(1024), 0, st, cand, count, (int)n, height * width, k,
+                     top_index, top_index_raw);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_msda_forward(const float* value, const float* sampling_offsets, const float* attention_logits,
+                     const float* reference_points, int batch_size, int num_queries, int num_heads, int head_dim,
+                     int num_points, int height, int width, float* out, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && num_queries >= 0, ISF_ERR_ARG, "msda: bad sizes");
+  if (batch_size == 0 || num_queries == 0) return ISF_OK;
+  ISF_REQUIRE(value && sampling_offsets && attention_logits && reference_points && out, ISF_ERR_ARG,
+              "msda: null pointer");
+  ISF_REQUIRE(head_dim == 16 && num_points == 16, ISF_ERR_UNSUPPORTED,
+              "msda: built for head_dim 16, 16 points, one level (got %d, %d)", head_dim, num_points);
+  const long long total = (long long)batch_size * num_queries * num_heads * head_dim;
+  hipLaunchKernelGGL((msda_kernel<16, 16>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), value,
+                     sampling_offsets, attention_logits, reference_points, batch_size, num_queries, num_heads, height,
+                     width, out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// isf_linear.hip -- fused row GEMM  Y = epilogue(X . W^T + b)  for the transformer pieces of HSF / IGF
+// (SST window-attention encoder layers A10/A11, MSDeformAttn projections A13, instance-to-scene attention A14).
+//
+// Reference: separate cuBLAS GEMM + bias + LayerNorm / GELU / residual kernels per nn.Linear
+// (sst_basic_block_v2.py:104-126, fusion_encoder.py:560-674).  Here one launch per Linear:
+//   arithmetic  f16 hi/lo split of both operands, 3 x v_mfma_f32_16x16x32_f16, fp32 accumulate
+//               (fp32-class accuracy, see isf_spconv16.hip); weights pre-split once (isf_pack_linear);
+//   tiling      wave = 16 rows x all N (N processed in chunks of <= 256 columns), A fragments converted once
+//               and kept in registers for the whole K (K <= 256), B fragments straight from L2 (weights are
+//               <= 0.4 MB and shared by every wave);
+//   epilogue    + bias, + per-row table add (T[idx[r]]: the window position-embedding contribution pos.Wq),
+//               activation (ReLU / exact GELU), + residual, LayerNorm over the row (needs the whole row in
+//               one chunk: N <= 256), written once.
+#include "isf_common.h"
+
+namespace isf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void lin_split8(const f32x8 v, h8& hi, h8& lo) {
+  hi = __builtin_convertvector(v, h8);
+  const f32x8 r = v - __builtin_convertvector(hi, f32x8);
+  lo = __builtin_convertvector(r, h8);
+}
+
+struct LinearEpilogue {
+  const float* bias;       // [N] or null
+  const float* table;      // [T, N] or null: y += table[idx[r]]
+  const int32_t* idx;      // [M]
+  const float* residual;   // [M, N] or null
+  const float* ln_gamma;   // [N] or null -> LayerNorm(eps)
+  const float* ln_beta;
+  float ln_eps;
+  int act;                 // 0 none, 1 relu, 2 gelu (erf)
+};
+
+// packedW[kc][nt][hi|lo][lane][8 halves]: element jj = W[16 nt + (lane&15)][32 kc + 8 (lane>>4) + jj] * 2^sw
+// header after the data: float 2^-sw
+template <int KC /* K/32 */, int CT /* column tiles per chunk */>
+__global__ __launch_bounds__(256) void linear_f16x3_kernel(const float* __restrict__ x, int M, int ldx,
+                                                           const uint4* __restrict__ wp,
+                                                           const float* __restrict__ w_inv_scale, int N,
+                                                           LinearEpilogue ep, float* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int col = lane & 15, kg = lane >> 4;
+  const int r0 = (blockIdx.x * 4 + wave) * 16;
+  if (r0 >= M) return;
+  const int ntiles = N >> 4;
+  // A fragments: row r0 + col, channels 32 kc + 8 kg .. +8
+  h8 ah[KC], al[KC];
+  {
+    const int r = r0 + col;
+    const float* xr = x + (size_t)(r < M ? r : M - 1) * ldx + kg * 8;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      f32x8 v = *reinterpret_cast<const f32x8*>(xr + kc * 32);
+      if (r >= M) v = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+      lin_split8(v, ah[kc], al[kc]);
+    }
+  }
+  const float winv = *w_inv_scale;
+  for (int c0 = 0; c0 < ntiles; c0 += CT) {
+    f32x4 acc[CT];
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt) {
+        if (c0 + nt < ntiles) {
+          const uint4 bhu = wp[((size_t)kc * ntiles + c0 + nt) * 128 + lane];
+          const uint4 blu = wp[((size_t)kc * ntiles + c0 + nt) * 128 + 64 + lane];
+          const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+          const h8 bl = *reinterpret_cast<const h8*>(&blu);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kc], bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bl, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bh, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue on the C/D layout: this lane holds rows r0 + 4 kg + t (t = 0..3), column 16 (c0+nt) + col
+    float v[CT][4];
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+      const int n = (c0 + nt) * 16 + col;
+      const bool cok = c0 + nt < ntiles;
+      const float b = (ep.bias && cok) ? ep.bias[n] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = r0 + 4 * kg + t;
+        float z = acc[nt][t] * winv + b;
+        if (cok && r < M) {
+          if (ep.table) z += ep.table[(size_t)ep.idx[r] * N + n];
+          if (ep.act == 1) z = fmaxf(z, 0.f);
+          else if (ep.act == 2) z = 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+          if (ep.residual) z += ep.residual[(size_t)r * N + n];
+        } else {
+          z = 0.f;
+        }
+        v[nt][t] = z;
+      }
+    }
+    if (ep.ln_gamma) {  // whole row in this chunk (host guarantees ntiles <= CT)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) s += v[nt][t];
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 64);
+        const float mean = s / (float)N;
+        float q = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) {
+          const float dlt = (c0 + nt < ntiles) ? v[nt][t] - mean : 0.f;
+          q += dlt * dlt;
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) q += __shfl_xor(q, d, 64);
+        const float rstd = rsqrtf(q / (float)N + ep.ln_eps);
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) {
+          if (c0 + nt < ntiles) {
+            const int n = (c0 + nt) * 16 + col;
+            v[nt][t] = (v[nt][t] - mean) * rstd * ep.ln_gamma[n] + ep.ln_beta[n];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < CT; ++nt) {
+      if (c0 + nt < ntiles) {
+        const int n = (c0 + nt) * 16 + col;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = r0 + 4 * kg + t;
+          if (r < M) y[(size_t)r * ldy + n] = v[nt][t];
+        }
+      }
+    }
+  }
+}
+
+__global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, const unsigned* __restrict__ amax_bits,
+                                   uint4* __restrict__ packed, float* __restrict__ header) {
+  const float amax = __uint_as_float(*amax_bits);
+  int e = 0;
+  if (amax > 0.f) (void)frexpf(amax, &e);
+  const int sw = amax > 0.f ? 13 - e : 0;
+  const float s = ldexpf(1.f, sw);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) header[0] = ldexpf(1.f, -sw);
+  const int ntiles = N >> 4, kcs = K >> 5;
+  if (t >= (long long)kcs * ntiles * 64) return;
+  const int lane = (int)(t & 63);
+  const int nt = (int)((t >> 6) % ntiles);
+  const int kc = (int)((t >> 6) / ntiles);
+  f32x8 v;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) v[jj] = w[(size_t)(16 * nt + (lane & 15)) * K + 32 * kc + 8 * (lane >> 4) + jj] * s;
+  h8 hi, lo;
+  lin_split8(v, hi, lo);
+  const size_t base = ((size_t)kc * ntiles + nt) * 128;
+  packed[base + lane] = *reinterpret_cast<const uint4*>(&hi);
+  packed[base + 64 + lane] = *reinterpret_cast<const uint4*>(&lo);
+}
+
+__global__ void absmax_kernel2(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float m = 0.f;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+template <int KC>
+static int launch_linear(const float* x, int M, int ldx, const void* packed, int N, int K, const LinearEpilogue& ep,
+                         float* y, int ldy, hipStream_t st) {
+  const uint4* wp = reinterpret_cast<const uint4*>(packed);
+  const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + (size_t)N * K * 4);
+  const dim3 grid(ceil_div(M, 64)), block(256);
+  const int ntiles = N / 16;
+  if (ntiles <= 8)
+    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 8>), grid, block, 0, st, x, M, ldx, wp, winv, N, ep, y, ldy);
+  else
+    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 16>), grid, block, 0, st, x, M, ldx, wp, winv, N, ep, y, ldy);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+size_t isf_packed_linear_bytes(int out_features, int in_features) {
+  return (size_t)out_features * in_features * 4 + 64;
+}
+
+int isf_pack_linear(const float* weight, int out_features, int in_features, void* packed, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(weight && packed && out_features % 16 == 0 && in_features % 32 == 0 && out_features > 0 && in_features > 0,
+              ISF_ERR_ARG, "pack_linear: need out %% 16 == 0 and in %% 32 == 0 (got %d, %d)", out_features, in_features);
+  hipStream_t st = as_stream(stream);
+  Arena& a = arena_for_current_device();
+  ISF_TRY(a.reset());
+  unsigned* amax = nullptr;
+  ISF_TRY(a.alloc_n(&amax, 64));
+  ISF_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
+  const size_t n = (size_t)out_features * in_features;
+  hipLaunchKernelGGL(absmax_kernel2, dim3(ceil_div((long long)n, 1024) < 256 ? ceil_div((long long)n, 1024) : 256),
+                     dim3(256), 0, st, weight, n, amax);
+  const long long total = (long long)(in_features / 32) * (out_features / 16) * 64;
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, weight, out_features,
+                     in_features, amax, reinterpret_cast<uint4*>(packed),
+                     reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + n * 4));
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, const void* packed_weight,
+                       int out_features, const float* bias, const float* row_table, const int32_t* row_table_index,
+                       int activation, const float* residual, const float* ln_gamma, const float* ln_beta,
+                       float ln_eps, float* y, int ldy, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(num_rows >= 0 && in_features > 0 && out_features > 0, ISF_ERR_ARG, "linear_forward: bad sizes");
+  if (num_rows == 0) return ISF_OK;
+  ISF_REQUIRE(x && packed_weight && y, ISF_ERR_ARG, "linear_forward: null pointer");
+  ISF_REQUIRE(in_features % 32 == 0 && in_features <= 256 && out_features % 16 == 0, ISF_ERR_UNSUPPORTED,
+              "linear_forward: in_features %d (need %%32, <= 256), out_features %d (need %%16)", in_features,
+              out_features);
+  ISF_REQUIRE(ldx % 8 == 0 && ldx >= in_features && ldy >= out_features, ISF_ERR_ARG, "linear_forward: bad strides");
+  ISF_REQUIRE(!ln_gamma || (out_features <= 256 && ln_beta), ISF_ERR_UNSUPPORTED,
+              "linear_forward: LayerNorm epilogue needs out_features <= 256");
+  ISF_REQUIRE((row_table == nullptr) == (row_table_index == nullptr), ISF_ERR_ARG, "linear_forward: table/index");
+  ISF_REQUIRE(!residual || ldy == out_features, ISF_ERR_ARG, "linear_forward: residual needs a dense output");
+  LinearEpilogue ep{bias, row_table, row_table_index, residual, ln_gamma, ln_beta, ln_eps, activation};
+  hipStream_t st = as_stream(stream);
+  switch (in_features / 32) {
+    case 1: return launch_linear<1>(x, num_rows, ldx, packed_weight, out_features, in_features, ep, y, ldy, st);
+    case 2: return launch_linear<2>(x, num_rows, ldx, packed_weight, out_features, in_features, ep, y, ldy, st);
+    case 4: return launch_linear<4>(x, num_rows, ldx, packed_weight, out_features, in_features, ep, y, ldy, st);
+    case 8: return launch_linear<8>(x, num_rows, ldx, packed_weight, out_features, in_features, ep, y, ldy, st);
+  }
+  set_error("linear_forward: in_features %d not built (32, 64, 128, 256)", in_features);
+  return ISF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

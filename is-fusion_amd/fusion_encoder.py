@@ -1,0 +1,98 @@
+"""ISFusionEncoder (drop-in for mmdet3d/models/middle_encoders/fusion_encoder.py:833-1189): HSF Point-to-Grid
+(A8), Grid-to-Region window attention (A10/A11), IGF instance mining (A12), instance context attention with
+multi-scale deformable attention (A13) and instance-to-scene attention (A14).
+
+Same constructor kwargs, sub-module / parameter names and ``forward`` signature
+    forward(img_mlvl_feats, lidar_feats, bs, **kwargs{pts_metas, img_metas, pts_backbone, lidar2img,
+            img_aug_matrix, lidar_aug_matrix}) -> ([f1 [B,128,S,S], f2 [B,256,S/2,S/2]], ins_hm [B,10,S,S])
+Custom arithmetic runs in libisf_hip.so (``fusion_ops``); the 3x3 dense convolutions (conv_fusion, heatmap
+head, conv_scene, conv_ins, SECONDV2) stay on PyTorch-ROCm as the north_star prescribes.  Inference only
+(eval-mode BN, dropout off); the training-only ``random_noise`` branch (:992-995) is not built.
+"""
+import torch
+from torch import nn
+
+from . import fusion_ops as ops
+from .fusion_modules import (ConvModule, InsContextAtt, Instane2SceneAtt, SSTInputLayerV2, SSTv2)
+
+
+class ISFusionEncoder(nn.Module):
+
+    def __init__(self, num_points_in_pillar=10, embed_dims=256, num_classes=10, **kwargs):
+        super().__init__()
+        self.num_points_in_pillar = num_points_in_pillar
+        self.bev_size = kwargs.get("bev_size", 180)
+        self.num_views = kwargs.get("num_views", 6)
+        region_shape = kwargs.get("region_shape", None)
+        grid_size = kwargs.get("grid_size", None)
+        region_drop_info = kwargs.get("region_drop_info", None) or [None] * len(region_shape)
+        self.embed_dims = embed_dims
+        E = embed_dims // 2
+        self.conv_fusion = ConvModule(embed_dims * 3, E)
+        self.get_regions = nn.ModuleList()
+        self.grid2region_att = nn.ModuleList()
+        for l in range(len(region_shape)):
+            d = E * (l + 1)
+            assert tuple(region_shape[l][:2]) == (region_shape[l][0],) * 2, "square windows only"
+            self.get_regions.append(SSTInputLayerV2(window_shape=region_shape[l], sparse_shape=grid_size[l],
+                                                    drop_info=region_drop_info[l], pos_temperature=1000,
+                                                    pos_embed=d))
+            self.grid2region_att.append(SSTv2(d_model=[d] * 4, nhead=[8] * 4, num_blocks=1,
+                                              dim_feedforward=[d] * 4, output_shape=grid_size[l][:2],
+                                              in_channel=E if l == 0 else None))
+        self.instance_num = kwargs.get("instance_num", 200)
+        self.nms_kernel_size = 3
+        self.conv_ins = ConvModule(E, E)
+        self.conv_scene = ConvModule(E, E)
+        self.conv_heatmap = ConvModule(E, E)
+        self.heatmap_head_1 = ConvModule(E, embed_dims // 4)
+        self.heatmap_head_2 = ConvModule(embed_dims // 4, embed_dims // 4)
+        self.heatmap_head_3 = nn.Conv2d(embed_dims // 4, num_classes, kernel_size=3, stride=1, padding=1)
+        self.instance_att = InsContextAtt(num_layers=2, embed_dims=E, bev_size=self.bev_size)
+        self.instance_to_scene_att = Instane2SceneAtt(d_model=E)
+
+    # --------------------------------------------------------------------------------------------- pieces
+    def img_fv_to_bev(self, mlvl_feats, bs, **kwargs):
+        """A8 Point-to-Grid: one kernel over (pillar, slot, camera) instead of B*6 grid_sample calls."""
+        pm = kwargs["pts_metas"]
+        return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs["lidar2img"],
+                              kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
+                              kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views)
+
+    def grid2region(self, level, bev):
+        """A10/A11: SSTInputLayerV2 + SSTv2 on the dense [B, C, S, S] grid."""
+        win = self.get_regions[level].window_shape[0]
+        return ops.sstv2_forward(self.grid2region_att[level], bev, win,
+                                 float(self.get_regions[level].pos_temperature))
+
+    def instance_fusion(self, bev_feats, scene_feats, bs, **kwargs):
+        """A12-A14 (fusion_encoder.py:1090-1149)."""
+        out = bev_feats.permute(0, 1, 3, 2).contiguous()
+        hm = self.heatmap_head_3(self.heatmap_head_2(self.heatmap_head_1(self.conv_heatmap(out))))
+        top_idx = ops.instance_topk(hm, self.instance_num, self.nms_kernel_size,
+                                    (8, 9) if self.num_views == 6 else (1, 2))
+        self.last_top_idx = top_idx   # [B, instance_num] flat BEV cell of every mined instance (for inspection)
+        x_scene = self.conv_scene(out)
+        x_ins, query_pos = ops.gather_instances(x_scene, top_idx, self.bev_size)
+        x_ins = ops.ins_context_att(self.instance_att, x_ins, query_pos, x_scene, self.bev_size)
+        q = self.conv_ins(bev_feats)
+        ret = ops.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, self.bev_size)
+        return ret, hm
+
+    @torch.no_grad()
+    def forward(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
+        assert not self.training, "isfusion_amd.ISFusionEncoder is the inference path (eval mode)"
+        img_bev = self.img_fv_to_bev([img_mlvl_feats[1]], bs, **kwargs)
+        bev_feats = self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
+        pts_backbone = kwargs.get("pts_backbone", None)
+        x = bev_feats
+        ins_hm = None
+        feats = []
+        for i in range(len(self.get_regions)):
+            x = self.grid2region(i, x)
+            if i == 0:
+                x, ins_hm = self.instance_fusion(bev_feats, x, bs, **kwargs)
+            nxt, _, this_feat = pts_backbone([x], "stage{}".format(i + 1))
+            feats.append(this_feat)
+            x = nxt
+        return feats, ins_hm

@@ -1,0 +1,193 @@
+"""Parameter containers of the HSF / IGF modules with the REFERENCE's sub-module and parameter names, so that
+``state_dict()`` keys equal those of mmdet3d/models/middle_encoders/fusion_encoder.py, models/sst/*,
+models/backbones/{sst_v2,second}.py and a released IS-Fusion checkpoint loads unchanged.  The arithmetic lives in
+``fusion_encoder.py`` (HIP kernels through the C ABI); the stock 3x3 convolutions stay on PyTorch-ROCm / MIOpen as
+the north_star prescribes.
+"""
+import torch
+from torch import nn
+
+
+class ConvModule(nn.Sequential):
+    """mmcv ConvModule(conv_cfg=Conv2d, norm_cfg=BN2d) as the path uses it: sub-modules ``conv`` (no bias), ``bn``,
+    ``activate`` (fusion_encoder.py:862-869)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.add_module("conv", nn.Conv2d(in_channels, out_channels, kernel_size, 1, padding, bias=False))
+        self.add_module("bn", nn.BatchNorm2d(out_channels, eps=eps, momentum=momentum))
+        self.add_module("activate", nn.ReLU(inplace=True))
+
+
+class _SelfAttn(nn.Module):
+    """holder named like nn.MultiheadAttention: in_proj_weight/in_proj_bias/out_proj.{weight,bias}"""
+
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, d, nhead):
+        super().__init__()
+        self.nhead = nhead
+        self.self_attn = _SelfAttn(d)
+
+
+class EncoderLayer(nn.Module):
+    """sst_basic_block_v2.py:77-126 (post-norm, LayerNorm, GELU)."""
+
+    def __init__(self, d, nhead, dim_feedforward):
+        super().__init__()
+        self.win_attn = WindowAttention(d, nhead)
+        self.linear1 = nn.Linear(d, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+
+
+class BasicShiftBlockV2(nn.Module):
+    def __init__(self, d, nhead, dim_feedforward):
+        super().__init__()
+        self.encoder_list = nn.ModuleList([EncoderLayer(d, nhead, dim_feedforward) for _ in range(2)])
+
+
+class SSTv2(nn.Module):
+    """backbones/sst_v2.py:11-63 parameter layout (linear0 only when in_channel is given)."""
+
+    def __init__(self, d_model, nhead, num_blocks, dim_feedforward, output_shape, in_channel=None):
+        super().__init__()
+        self.d_model, self.nhead, self.output_shape = d_model, nhead, output_shape
+        if in_channel is not None:
+            self.linear0 = nn.Linear(in_channel, d_model[0])
+        self.block_list = nn.ModuleList([BasicShiftBlockV2(d_model[i], nhead[i], dim_feedforward[i])
+                                         for i in range(num_blocks)])
+        for name, p in self.named_parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class SSTInputLayerV2(nn.Module):
+    """models/sst/sst_input_layer_v2.py: no parameters; on a dense grid window membership is arithmetic."""
+
+    def __init__(self, window_shape, sparse_shape, drop_info=None, shuffle_voxels=True, pos_temperature=1000,
+                 normalize_pos=False, pos_embed=None, **kwargs):
+        super().__init__()
+        self.window_shape, self.sparse_shape = window_shape, sparse_shape
+        self.pos_temperature, self.pos_embed_channels = pos_temperature, pos_embed
+        assert not normalize_pos
+
+
+class PositionEmbeddingLearned(nn.Module):
+    def __init__(self, input_channel, num_pos_feats):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1), nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True), nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model, n_levels, n_heads, n_points):
+        super().__init__()
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = _SelfAttn(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+
+
+class InsContextAtt(nn.Module):
+    def __init__(self, num_layers=1, embed_dims=128, bev_size=180, n_points=16):
+        super().__init__()
+        self.bev_size, self.num_layers, self.n_points = bev_size, num_layers, n_points
+        self.layers = nn.ModuleList([DeformableTransformerDecoderLayer(embed_dims, embed_dims, 1, 8, n_points)
+                                     for _ in range(num_layers)])
+        self.query_pos_embed = PositionEmbeddingLearned(2, embed_dims)
+        self.key_pos_embed = PositionEmbeddingLearned(2, embed_dims)
+
+
+class Instane2SceneAtt(nn.Module):
+    def __init__(self, d_model, nhead=8):
+        super().__init__()
+        self.nhead = nhead
+        self.multihead_attn = _SelfAttn(d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class SECONDV2(nn.Module):
+    """backbones/second.py:98-238: stock Conv2d(bias=False)+BN(eps 1e-3)+ReLU stacks, invoked stage-wise from the
+    fusion encoder.  Convolutions stay on PyTorch-ROCm (MIOpen)."""
+
+    def __init__(self, in_channels=128, out_channels=(128, 128, 256), layer_nums=(3, 5, 5), layer_strides=(2, 2, 2),
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False), **kw):
+        super().__init__()
+        eps, mom = norm_cfg.get("eps", 1e-3), norm_cfg.get("momentum", 0.01)
+        in_filters = [in_channels, *out_channels[:-1]]
+        blocks = []
+        for i, n in enumerate(layer_nums):
+            block = []
+            first = [nn.Conv2d(in_filters[i], out_channels[i], 3, stride=layer_strides[i], padding=1, bias=False),
+                     nn.BatchNorm2d(out_channels[i], eps=eps, momentum=mom), nn.ReLU(inplace=True)]
+            if layer_strides[i] == 2:
+                self.ds_layer = nn.Sequential(*first)
+            else:
+                block = first
+            for _ in range(n):
+                block += [nn.Conv2d(out_channels[i], out_channels[i], 3, padding=1, bias=False),
+                          nn.BatchNorm2d(out_channels[i], eps=eps, momentum=mom), nn.ReLU(inplace=True)]
+            blocks.append(nn.Sequential(*block))
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x, stage=None):
+        """(tokens, coords, feature) like the reference; tokens/coords of the dense grid are implicit here, so the
+        HIP fusion encoder consumes the [B, C, H, W] tensor directly: stage1 -> (ds_layer output, None, feature)."""
+        if stage == "stage1":
+            feat = self.blocks[0](x[0] if isinstance(x, (list, tuple)) else x)
+            return self.ds_layer(feat), None, feat
+        if stage == "stage2":
+            return None, None, self.blocks[1](x[0] if isinstance(x, (list, tuple)) else x)
+        x1 = self.blocks[0](x)
+        return x1, self.blocks[1](self.ds_layer(x1))
+
+
+def seeded_state_dict(module, seed):
+    """Deterministic, well-conditioned random values for every parameter / buffer of ``module`` (keyed by name, so
+    it does not depend on construction order).  Used by the golden generator (loaded into the REFERENCE modules)
+    and by the GPU tests (loaded into these modules)."""
+    import hashlib
+    sd = {}
+    for k, v in module.state_dict().items():
+        h = int(hashlib.sha256((str(seed) + "/" + k).encode()).hexdigest()[:8], 16)
+        g = torch.Generator().manual_seed(h)
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif v.dim() == 1 and (k.endswith("norm.weight") or ".norm" in k and k.endswith(".weight")
+                               or ".bn.weight" in k or k.endswith(".1.weight") and v.dim() == 1):
+            sd[k] = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        elif v.dim() == 1:
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        else:
+            fan_in = v[0].numel()
+            sd[k] = torch.randn(v.shape, generator=g) * (1.0 / fan_in) ** 0.5
+        if k.endswith("sampling_offsets.bias"):  # keep sampling points a few cells around the reference point
+            sd[k] = torch.randn(v.shape, generator=g) * 2.0
+    return sd

@@ -1,0 +1,313 @@
+"""Host side of the HSF / IGF rows (A8, A10-A14): thin wrappers that hand device pointers to
+libisf_hip.so.  No CPU fallback: every function raises when its tensors are not on a GPU or the library is missing.
+
+Layout conventions: a dense BEV grid [B, C, S, S] becomes a token matrix [B*S*S, C] (row = (b*S + y)*S + x, the
+order fusion_encoder.py:1167-1173 builds); the transposes between the two are stock torch ops.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+# ---------------------------------------------------------------------------------------------------- linear
+class PackedLinear:
+    """nn.Linear weights split once into f16 hi/lo MFMA fragments (isf_pack_linear)."""
+
+    def __init__(self, weight, bias=None):
+        _lib.require_cuda(weight)
+        w = weight.detach().float().contiguous()
+        self.out_features, self.in_features = w.shape
+        lib = _lib.load()
+        self.packed = torch.empty(lib.isf_packed_linear_bytes(self.out_features, self.in_features), dtype=torch.uint8,
+                                  device=w.device)
+        _lib.check(lib.isf_pack_linear(_lib.ptr(w), self.out_features, self.in_features, _lib.ptr(self.packed),
+                                       _lib.stream()), "isf_pack_linear")
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+
+
+def linear(x, pl, *, table=None, index=None, act=ACT_NONE, residual=None, ln=None):
+    """y = LN(act(x W^T + b + table[index]) + residual); x [M, K] fp32 row-major."""
+    _lib.require_cuda(x)
+    assert x.dim() == 2 and x.size(1) == pl.in_features and x.dtype == torch.float32
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty((x.size(0), pl.out_features), dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == y.shape
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln.weight.detach(), ln.bias.detach(), float(ln.eps)
+    _lib.check(_lib.load().isf_linear_forward(
+        _lib.ptr(x), x.size(0), pl.in_features, x.stride(0), _lib.ptr(pl.packed), pl.out_features,
+        _lib.ptr(pl.bias) if pl.bias is not None else None,
+        _lib.ptr(table) if table is not None else None, _lib.ptr(index) if index is not None else None, act,
+        _lib.ptr(residual) if residual is not None else None, _lib.ptr(g) if g is not None else None,
+        _lib.ptr(b) if b is not None else None, eps, _lib.ptr(y), y.stride(0), _lib.stream()), "isf_linear_forward")
+    return y
+
+
+def _cache(module, device):
+    c = getattr(module, "_isf_cache", None)
+    if c is None or c.get("device") != device:
+        c = {"device": device}
+        module._isf_cache = c
+    return c
+
+
+def to_tokens(x):
+    """[B, C, H, W] -> [B*H*W, C]"""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def from_tokens(t, B, H, W):
+    return t.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ A10 / A11
+def _window_tables(S, win, shift, d, temperature, device):
+    """In-window token index per grid cell and the sinusoidal window position embedding
+    (sst_ops.py:219-268 shifts, sst_input_layer_v2.py:224-290 embedding; 2-D, normalize_pos False)."""
+    off = win // 2 if shift else win
+    c = (torch.arange(S) + off) % win
+    iy, ix = torch.meshgrid(c, c, indexing="ij")
+    index = (iy * win + ix).reshape(-1).to(torch.int32)                     # [S*S]
+    k = torch.arange(win * win)
+    y = (k // win).double() - win / 2
+    x = (k % win).double() - win / 2
+    half = d // 2
+    inv = torch.arange(half, dtype=torch.float32)
+    inv = (torch.tensor(float(temperature)) ** (2 * (inv // 2) / half)).double()
+    ex, ey = x[:, None].float() / inv.float(), y[:, None].float() / inv.float()
+    ex = torch.stack([ex[:, ::2].sin(), ex[:, 1::2].cos()], dim=-1).flatten(-2)
+    ey = torch.stack([ey[:, ::2].sin(), ey[:, 1::2].cos()], dim=-1).flatten(-2)
+    pos = torch.cat([ex, ey], dim=-1)                                        # [win*win, d]
+    return index.to(device), pos.to(device)
+
+
+def _encoder_layer_cache(layer, S, win, shift, temperature, device, B):
+    c = _cache(layer, device)
+    key = ("win", S, win, shift, B)
+    if key not in c:
+        attn = layer.win_attn.self_attn
+        d = attn.out_proj.in_features
+        index, pos = _window_tables(S, win, shift, d, temperature, device)
+        w, b = attn.in_proj_weight.detach().float(), attn.in_proj_bias.detach().float()
+        # (x + pos) Wq = x Wq + pos Wq: the position term becomes a 36-row table added in the GEMM epilogue
+        tab = torch.zeros((win * win, 3 * d), dtype=torch.float32, device=device)
+        tab[:, :2 * d] = (pos.double() @ w[:2 * d].double().t()).float()
+        c[key] = dict(index=index.repeat(B).contiguous(), table=tab.contiguous(), qkv=PackedLinear(w, b),
+                      out=PackedLinear(attn.out_proj.weight, attn.out_proj.bias),
+                      l1=PackedLinear(layer.linear1.weight, layer.linear1.bias),
+                      l2=PackedLinear(layer.linear2.weight, layer.linear2.bias))
+    return c[key]
+
+
+def window_attention(qkv, B, S, d, nhead, win, shift):
+    out = torch.empty((qkv.size(0), d), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.load().isf_window_attention_forward(_lib.ptr(qkv), B, S, d, nhead, win, shift, _lib.ptr(out),
+                                                        _lib.stream()), "isf_window_attention_forward")
+    return out
+
+
+def sstv2_forward(sst, bev, win, temperature=1000.0):
+    """get_regions[i] + grid2region_att[i] (sst_v2.py:65-133) on a dense grid: [B, C, S, S] -> [B, d, S, S]."""
+    _lib.require_cuda(bev)
+    B, C, S, _ = bev.shape
+    x = to_tokens(bev.float())
+    if hasattr(sst, "linear0"):
+        c = _cache(sst, bev.device)
+        if "linear0" not in c:
+            c["linear0"] = PackedLinear(sst.linear0.weight, sst.linear0.bias)
+        x = linear(x, c["linear0"])
+    d = x.size(1)
+    for block in sst.block_list:
+        for shift, layer in enumerate(block.encoder_list):
+            p = _encoder_layer_cache(layer, S, win, shift, temperature, bev.device, B)
+            qkv = linear(x, p["qkv"], table=p["table"], index=p["index"])
+            att = window_attention(qkv, B, S, d, layer.win_attn.nhead, win, shift)
+            y = linear(att, p["out"], residual=x, ln=layer.norm1)
+            h = linear(y, p["l1"], act=ACT_GELU)
+            x = linear(h, p["l2"], residual=y, ln=layer.norm2)
+    return from_tokens(x, B, S, S)
+
+
+# ------------------------------------------------------------------------------------------------------ A8
+def p2g_camera_params(lidar2img, img_aug, lidar_aug):
+    """Fold the per-(sample, camera) 4x4 chain of img_point_sampling (fusion_encoder.py:1030-1047) into the 20
+    floats isf_p2g_forward takes (float64 on the host, rounded once)."""
+    l2i = torch.as_tensor(lidar2img).detach().double().cpu()
+    ia = torch.as_tensor(img_aug).detach().double().cpu()
+    la = torch.as_tensor(lidar_aug).detach().double().cpu()
+    B, ncam = l2i.shape[:2]
+    out = torch.empty((B, ncam, 20), dtype=torch.float64)
+    for b in range(B):
+        rinv = torch.inverse(la[b, :3, :3])
+        for k in range(ncam):
+            m = l2i[b, k, :3, :3] @ rinv
+            v = l2i[b, k, :3, 3] - m @ la[b, :3, 3]
+            out[b, k, :9] = m.reshape(-1)
+            out[b, k, 9:12] = v
+            out[b, k, 12:18] = ia[b, k, :2, :3].reshape(-1)
+            out[b, k, 18:20] = ia[b, k, :2, 3]
+    return out.float().reshape(B * ncam, 20)
+
+
+def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, input_shape, bs, bev, num_cam=6):
+    """img_fv_to_bev (fusion_encoder.py:965-1013): pillars [M, T, >=3], pillar_coors [M, 4] (b, z, y, x),
+    img_feat [bs*num_cam, C, H, W] -> [bs, C, bev, bev]."""
+    _lib.require_cuda(img_feat)
+    dev = img_feat.device
+    pillars = pillars.float().contiguous()
+    coors = pillar_coors.to(torch.int32).contiguous()
+    nhwc = img_feat.float().permute(0, 2, 3, 1).contiguous()
+    cam = p2g_camera_params(lidar2img, img_aug, lidar_aug).to(dev)
+    C, H, W = img_feat.shape[1:]
+    out = torch.empty((bs, C, bev, bev), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().isf_p2g_forward(_lib.ptr(pillars), pillars.size(2), pillars.size(1), _lib.ptr(coors),
+                                           pillars.size(0), _lib.ptr(nhwc), bs, num_cam, H, W, C, _lib.ptr(cam),
+                                           int(input_shape[0]), int(input_shape[1]), bev, _lib.ptr(out),
+                                           _lib.stream()), "isf_p2g_forward")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------- A12
+def instance_topk(heatmap, k=200, nms_kernel=3, pool1_classes=(8, 9), return_masked=False):
+    """fusion_encoder.py:1100-1131 -> top index % (H*W) [B, k] int64 (and the suppressed map when asked)."""
+    _lib.require_cuda(heatmap)
+    assert nms_kernel == 3
+    hm = heatmap.float().contiguous()
+    B, K, H, W = hm.shape
+    mask = 0
+    for c in pool1_classes:
+        mask |= 1 << c
+    top = torch.empty((B, k), dtype=torch.int32, device=hm.device)
+    raw = torch.empty((B, k), dtype=torch.int32, device=hm.device)
+    masked = torch.empty((B, K * H * W), dtype=torch.float32, device=hm.device) if return_masked else None
+    _lib.check(_lib.load().isf_instance_topk(_lib.ptr(hm), B, K, H, W, k, mask, _lib.ptr(top), _lib.ptr(raw),
+                                             _lib.ptr(masked) if masked is not None else None, _lib.stream()),
+               "isf_instance_topk")
+    if return_masked:
+        return top.long(), raw.long(), masked
+    return top.long()
+
+
+def gather_instances(x_scene, top_idx, bev_size):
+    """x_ins [B, E, Q] and the (x, y) query positions of fusion_encoder.py:1133-1141 (create_2D_grid cell centres,
+    axes swapped)."""
+    B, E = x_scene.shape[:2]
+    x_ins = x_scene.reshape(B, E, -1).gather(2, top_idx[:, None, :].expand(-1, E, -1))
+    qx = (top_idx % bev_size).float() + 0.5
+    qy = torch.div(top_idx, bev_size, rounding_mode="floor").float() + 0.5
+    return x_ins, torch.stack([qx, qy], dim=-1)
+
+
+# ----------------------------------------------------------------------------------------------------- A13
+def attention(q, k, v, B, Lq, Lk, E, nhead, ldkv=None):
+    out = torch.empty((B * Lq, E), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().isf_attention_forward(_lib.ptr(q), q.stride(0), _lib.ptr(k), _lib.ptr(v),
+                                                 ldkv if ldkv is not None else k.stride(0), B, Lq, Lk, E, nhead,
+                                                 _lib.ptr(out), out.stride(0), _lib.stream()), "isf_attention_forward")
+    return out
+
+
+def msda(value, offsets, logits, ref, B, Q, nhead, hd, npts, H, W):
+    out = torch.empty((B * Q, nhead * hd), dtype=torch.float32, device=value.device)
+    _lib.check(_lib.load().isf_msda_forward(_lib.ptr(value), _lib.ptr(offsets), _lib.ptr(logits), _lib.ptr(ref), B, Q,
+                                            nhead, hd, npts, H, W, _lib.ptr(out), _lib.stream()), "isf_msda_forward")
+    return out
+
+
+def _pos_embed(mod, xy):
+    """PositionEmbeddingLearned (fusion_encoder.py:173-189): stock Conv1d/BN1d stack on [B, N, 2] -> [B, N, E]"""
+    return mod.position_embedding_head(xy.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
+
+
+def ins_context_att(mod, x_ins, query_pos, x_scene, bev_size):
+    """InsContextAtt.forward (fusion_encoder.py:795-830), eval mode.  x_ins [B, E, Q], query_pos [B, Q, 2] (x, y),
+    x_scene [B, E, H, W] -> [B, E, Q]."""
+    _lib.require_cuda(x_scene)
+    dev = x_scene.device
+    B, E, Q = x_ins.shape
+    c = _cache(mod, dev)
+    if "key_pos" not in c:
+        g = torch.linspace(0, bev_size - 1, bev_size, device=dev) + 0.5
+        bx, by = torch.meshgrid(g, g, indexing="ij")
+        bev_pos = torch.stack([bx, by], 0).view(1, 2, -1).permute(0, 2, 1)
+        c["key_pos"] = _pos_embed(mod.key_pos_embed, bev_pos / bev_size)[0].contiguous()          # [HW, E]
+        c["layers"] = []
+        for l in mod.layers:
+            sa, ca = l.self_attn, l.cross_attn
+            w, b = sa.in_proj_weight.detach().float(), sa.in_proj_bias.detach().float()
+            c["layers"].append(dict(
+                qk=PackedLinear(w[:2 * E], b[:2 * E]), v=PackedLinear(w[2 * E:], b[2 * E:]),
+                out=PackedLinear(sa.out_proj.weight, sa.out_proj.bias),
+                value=PackedLinear(ca.value_proj.weight, ca.value_proj.bias),
+                off=PackedLinear(ca.sampling_offsets.weight, ca.sampling_offsets.bias),
+                aw=PackedLinear(ca.attention_weights.weight, ca.attention_weights.bias),
+                oproj=PackedLinear(ca.output_proj.weight, ca.output_proj.bias),
+                l1=PackedLinear(l.linear1.weight, l.linear1.bias), l2=PackedLinear(l.linear2.weight, l.linear2.bias)))
+    scene = x_scene.permute(0, 1, 3, 2)
+    H, W = scene.shape[2:]
+    src = (scene.flatten(2).transpose(1, 2) + c["key_pos"][None]).reshape(B * H * W, E).contiguous()
+    out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
+    ref = (query_pos / bev_size).reshape(B * Q, 2).contiguous()
+    qpe = _pos_embed(mod.query_pos_embed, ref.view(B, Q, 2)).reshape(B * Q, E)
+    for l, p in zip(mod.layers, c["layers"]):
+        nhead, npts = l.cross_attn.n_heads, l.cross_attn.n_points
+        qk_in = out + qpe
+        qk = linear(qk_in, p["qk"])
+        v = linear(out, p["v"])
+        # q = columns [0, E), k = columns [E, 2E) of qk (row stride 2E); v has row stride E, and the C entry takes
+        # one stride for k and v -> give k its own buffer (200 rows)
+        att = attention(qk, qk[:, E:].contiguous(), v, B, Q, Q, E, nhead)
+        out = linear(att, p["out"], residual=out, ln=l.norm2)
+        q = out + qpe
+        value = linear(src, p["value"])
+        off = linear(q, p["off"])
+        aw = linear(q, p["aw"])
+        t2 = msda(value, off, aw, ref, B, Q, nhead, E // nhead, npts, H, W)
+        out = linear(t2, p["oproj"], residual=out, ln=l.norm1)
+        h = linear(out, p["l1"], act=ACT_RELU)
+        out = linear(h, p["l2"], residual=out, ln=l.norm3)
+    return out.view(B, Q, E).transpose(1, 2).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------- A14
+def channel_attention(query_scene, query_ins):
+    _lib.require_cuda(query_scene)
+    qs, qi = query_scene.float().contiguous(), query_ins.float().contiguous()
+    B, C, H, W = qs.shape
+    assert H == W and qi.shape == qs.shape
+    out = torch.empty_like(qs)
+    _lib.check(_lib.load().isf_channel_attention_forward(_lib.ptr(qs), _lib.ptr(qi), B * C, H, _lib.ptr(out),
+                                                         _lib.stream()), "isf_channel_attention_forward")
+    return out
+
+
+def instance_to_scene(mod, query, x_ins, scene_feats, bev_size):
+    """Instane2SceneAtt.forward (fusion_encoder.py:480-502), eval mode: query [B, E, H, W] = conv_ins(bev),
+    x_ins [B, E, Q], scene_feats [B, E, H, W] (the Grid-to-Region output)."""
+    _lib.require_cuda(query)
+    B, E, H, W = query.shape
+    Q = x_ins.size(2)
+    c = _cache(mod, query.device)
+    if "q" not in c:
+        a = mod.multihead_attn
+        w, b = a.in_proj_weight.detach().float(), a.in_proj_bias.detach().float()
+        c["q"] = PackedLinear(w[:E], b[:E])
+        c["kv"] = PackedLinear(w[E:], b[E:])
+        c["out"] = PackedLinear(a.out_proj.weight, a.out_proj.bias)
+    xq = to_tokens(query.float())
+    xk = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
+    qp = linear(xq, c["q"])
+    kv = linear(xk, c["kv"])
+    att = attention(qp, kv, kv[:, E:], B, H * W, Q, E, mod.nhead, ldkv=2 * E)   # k | v share rows of kv
+    y = linear(att, c["out"], residual=xq, ln=mod.norm)
+    query_ins = from_tokens(y, B, H, W)
+    return channel_attention(scene_feats, query_ins)

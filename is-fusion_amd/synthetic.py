@@ -90,3 +90,69 @@ def batch(cfg_id, batch_size, num_points, kind="lidar"):
     """SURVEY.md section 8d seeding: seed = 1234 + 1000*cfg + sample_idx."""
     fn = lidar_sweeps if kind == "lidar" else uniform_cloud
     return [fn(1234 + 1000 * cfg_id + i, num_points) for i in range(batch_size)]
+
+
+def camera_matrices(batch_size, num_cam=6, image_hw=(384, 1056), seed=0):
+    """SURVEY.md section 8d cfg 3: num_cam pinhole cameras at 360/num_cam degree yaw spacing, fx = fy = 1266*0.48,
+    principal point at the image centre, mounted 1.5 m above the LiDAR origin.  -> (lidar2img [B,cam,4,4],
+    img_aug [B,cam,4,4] = small scale/shift augmentation, lidar_aug [B,4,4] = small yaw rotation + translation)."""
+    rng = np.random.default_rng(seed)
+    H, W = image_hw
+    f = 1266.0 * 0.48
+    K = np.array([[f, 0, W / 2, 0], [0, f, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float64)
+    l2i = np.zeros((batch_size, num_cam, 4, 4), np.float32)
+    for c in range(num_cam):
+        yaw = 2 * np.pi * c / num_cam
+        # camera axes in the lidar frame: z forward (cos yaw, sin yaw, 0), x right, y down
+        fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+        right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+        down = np.array([0.0, 0.0, -1.0])
+        R = np.stack([right, down, fwd], 0)          # lidar -> camera
+        t = -R @ np.array([0.0, 0.0, 1.5])
+        E = np.eye(4)
+        E[:3, :3], E[:3, 3] = R, t
+        l2i[:, c] = (K @ E).astype(np.float32)
+    img_aug = np.tile(np.eye(4, dtype=np.float32), (batch_size, num_cam, 1, 1))
+    lidar_aug = np.tile(np.eye(4, dtype=np.float32), (batch_size, 1, 1))
+    for b in range(batch_size):
+        s = 1.0 + 0.05 * rng.standard_normal()
+        img_aug[b, :, 0, 0] = img_aug[b, :, 1, 1] = s
+        img_aug[b, :, 0, 3], img_aug[b, :, 1, 3] = 4.0 * rng.standard_normal(), 3.0 * rng.standard_normal()
+        a = 0.1 * rng.standard_normal()
+        lidar_aug[b, :2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        lidar_aug[b, :3, 3] = 0.3 * rng.standard_normal(3)
+    return l2i, img_aug, lidar_aug
+
+
+def fusion_inputs(seed, batch_size, bev_size=180, num_pillars=1500, num_cam=6, image_hw=(384, 1056), embed=256):
+    """Random inputs of ISFusionEncoder.forward (BASELINE config 3: camera features random, LiDAR BEV random):
+    img feats (two FPN levels, stride 8 / 16), lidar BEV features, pillars (T = 12 slots, zero padded),
+    pillar coords (b, 0, y, x) unique per sample, camera / augmentation matrices."""
+    rng = np.random.default_rng(seed)
+    H, W = image_hw
+    B = batch_size
+    img0 = rng.standard_normal((B * num_cam, embed, H // 8, W // 8), dtype=np.float32)
+    img1 = rng.standard_normal((B * num_cam, embed, H // 16, W // 16), dtype=np.float32)
+    lidar = (rng.standard_normal((B, 2 * embed, bev_size, bev_size), dtype=np.float32) * 0.5)
+    lidar *= (rng.random((B, 1, bev_size, bev_size)) < 0.35)  # sparse like a real BEV map
+    coors, pillars = [], []
+    cell = 108.0 / bev_size
+    for b in range(B):
+        lin = rng.choice(bev_size * bev_size, min(num_pillars, bev_size * bev_size), replace=False)
+        y, x = lin // bev_size, lin % bev_size
+        coors.append(np.stack([np.full_like(y, b), np.zeros_like(y), y, x], 1))
+        n = rng.integers(1, 13, len(lin))
+        p = np.zeros((len(lin), 12, 5), np.float32)
+        cx, cy = -54.0 + (x + 0.5) * cell, -54.0 + (y + 0.5) * cell
+        for t in range(12):
+            m = n > t
+            p[m, t, 0] = cx[m] + rng.uniform(-cell / 2, cell / 2, m.sum())
+            p[m, t, 1] = cy[m] + rng.uniform(-cell / 2, cell / 2, m.sum())
+            p[m, t, 2] = rng.uniform(-3.0, 1.0, m.sum())
+            p[m, t, 3:] = rng.random((m.sum(), 2))
+        pillars.append(p)
+    l2i, img_aug, lidar_aug = camera_matrices(B, num_cam, image_hw, seed + 1)
+    return dict(img_feats=(img0, img1), lidar_feats=lidar.astype(np.float32),
+                pillars=np.concatenate(pillars).astype(np.float32),
+                pillar_coors=np.concatenate(coors).astype(np.int32), lidar2img=l2i, img_aug_matrix=img_aug,
+                lidar_aug_matrix=lidar_aug, input_shape=tuple(image_hw))

@@ -1,0 +1,203 @@
+"""Import the REFERENCE's Python modules for the HSF / IGF rows in the authoring container (no mmcv / mmdet /
+spconv / cv2 / ipdb installed, no GPU) so that their own code can generate golden vectors.
+
+Only third-party packages that are ABSENT are stubbed (registries, decorators, ConvModule = Conv2d+BN+ReLU,
+...).  Every mmdet3d module is loaded from its real file under /root/reference; nothing is copied.  The two
+compiled ops the path needs are replaced by the reference's own pure-torch implementations:
+  * mmcv _ext.ms_deform_attn_forward  -> ops/functions/ms_deform_attn_func.py:ms_deform_attn_core_pytorch
+  * TorchEx ingroup_indices.forward   -> first-come rank inside each group (the CUDA kernel's atomic order is
+                                         arbitrary; any rank order is valid because windows never overflow)
+Used by tests/golden/make_golden_fusion.py.  Not importable on the GPU box (there is no /root/reference there).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+from torch import nn
+
+REF = os.environ.get("ISF_REFERENCE_ROOT", "/root/reference")
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path=None, **attrs):
+    m = _mod(name, **attrs)
+    m.__path__ = [path] if path else []
+    return m
+
+
+class _Registry:
+    def __init__(self, name):
+        self.name = name
+        self.module_dict = {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+        return deco(module) if module is not None else deco
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.module_dict[cfg.pop("type")](**cfg)
+
+
+def _identity_decorator(*a, **k):
+    def deco(fn):
+        return fn
+    return deco
+
+
+class ConvModule(nn.Sequential):
+    """mmcv.cnn.ConvModule for the configuration the path uses: Conv2d(bias=False) + BN2d + ReLU, with the
+    sub-module names mmcv gives them (conv / bn / activate)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type="ReLU"), **kw):
+        super().__init__()
+        self.add_module("conv", nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding,
+                                          bias=norm_cfg is None))
+        if norm_cfg is not None:
+            self.add_module("bn", nn.BatchNorm2d(out_channels, eps=norm_cfg.get("eps", 1e-5),
+                                                 momentum=norm_cfg.get("momentum", 0.1)))
+        if act_cfg is not None:
+            self.add_module("activate", nn.ReLU(inplace=True))
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    cfg = dict(cfg or dict(type="Conv2d"))
+    t = cfg.pop("type")
+    assert t in ("Conv2d", None)
+    return nn.Conv2d(*args, **kwargs, **cfg)
+
+
+def build_norm_layer(cfg, num_features, postfix=""):
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    cfg.pop("requires_grad", None)
+    cls = {"BN": nn.BatchNorm2d, "BN2d": nn.BatchNorm2d, "BN1d": nn.BatchNorm1d, "LN": nn.LayerNorm,
+           "naiveSyncBN1d": nn.BatchNorm1d, "naiveSyncBN2d": nn.BatchNorm2d}[t]
+    return "bn" + str(postfix), cls(num_features, **cfg)
+
+
+def _load(name, relpath):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+_installed = {}
+
+
+def install():
+    """Install the stubs and load the reference modules; returns a dict of the loaded modules."""
+    if _installed:
+        return _installed
+    if not os.path.isdir(os.path.join(REF, "mmdet3d")):
+        raise RuntimeError("reference tree not available")
+    _mod("ipdb", set_trace=lambda *a, **k: None)
+    _mod("cv2")
+    regs = {n: _Registry(n) for n in ("ATTENTION", "TRANSFORMER_LAYER", "TRANSFORMER_LAYER_SEQUENCE", "BACKBONES",
+                                      "MIDDLE_ENCODERS", "FUSION_LAYERS")}
+    mmcv = _pkg("mmcv")
+    _pkg("mmcv.cnn", ConvModule=ConvModule, build_conv_layer=build_conv_layer, build_norm_layer=build_norm_layer)
+    _pkg("mmcv.cnn.bricks")
+    _mod("mmcv.cnn.bricks.registry", ATTENTION=regs["ATTENTION"], TRANSFORMER_LAYER=regs["TRANSFORMER_LAYER"],
+         TRANSFORMER_LAYER_SEQUENCE=regs["TRANSFORMER_LAYER_SEQUENCE"])
+
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    _pkg("mmcv.runner", force_fp32=_identity_decorator, auto_fp16=_identity_decorator, BaseModule=BaseModule)
+    _mod("mmcv.runner.base_module", BaseModule=BaseModule, ModuleList=nn.ModuleList, Sequential=nn.Sequential)
+    # the pure-torch MS-deformable attention of the reference's own ops/ tree stands in for the CUDA extension
+    _mod("MultiScaleDeformableAttention")
+    core = _load("isf_ref_ms_deform_attn_func", "ops/functions/ms_deform_attn_func.py")
+
+    class _Ext:
+        @staticmethod
+        def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
+                                   im2col_step=64):
+            return core.ms_deform_attn_core_pytorch(value, spatial_shapes, sampling_locations, attention_weights)
+
+        @staticmethod
+        def ms_deform_attn_backward(*a, **k):
+            raise NotImplementedError
+
+    _pkg("mmcv.utils", ext_loader=types.SimpleNamespace(load_ext=lambda *a, **k: _Ext), ConfigDict=dict,
+         build_from_cfg=None, deprecated_api_warning=_identity_decorator, to_2tuple=lambda x: (x, x))
+    _pkg("mmcv.ops", SparseConvTensor=object, SparseSequential=nn.Sequential)
+    _mod("mmcv.ops.multi_scale_deform_attn", multi_scale_deformable_attn_pytorch=core.ms_deform_attn_core_pytorch)
+    mmcv.__version__ = "stub"
+    _pkg("mmdet")
+    _pkg("mmdet.models", BACKBONES=regs["BACKBONES"])
+
+    base = os.path.join(REF, "mmdet3d")
+    _pkg("mmdet3d", base)
+    _mod("mmdet3d.core", draw_heatmap_gaussian=None, gaussian_radius=None)
+    builder = _mod("mmdet3d.models.builder", FUSION_LAYERS=regs["FUSION_LAYERS"],
+                   MIDDLE_ENCODERS=regs["MIDDLE_ENCODERS"],
+                   build_middle_encoder=lambda cfg: regs["MIDDLE_ENCODERS"].build(cfg),
+                   build_backbone=lambda cfg: regs["BACKBONES"].build(cfg))
+    _pkg("mmdet3d.models", os.path.join(base, "models"), builder=builder)
+    _pkg("mmdet3d.models.middle_encoders", os.path.join(base, "models", "middle_encoders"))
+    _pkg("mmdet3d.models.sst", os.path.join(base, "models", "sst"))
+    _pkg("mmdet3d.models.backbones", os.path.join(base, "models", "backbones"))
+    ops = _pkg("mmdet3d.ops", os.path.join(base, "ops"), SparseBasicBlock=None, make_sparse_convmodule=None)
+    _pkg("mmdet3d.ops.spconv", IS_SPCONV2_AVAILABLE=False)
+    ops.spconv = sys.modules["mmdet3d.ops.spconv"]
+
+    # TorchEx ingroup_indices: rank of every element inside its group, first come first served
+    def _ingroup_forward(group_inds, out_inds):
+        g = group_inds.cpu()
+        order = torch.argsort(g, stable=True)
+        gs = g[order]
+        start = torch.ones_like(gs, dtype=torch.bool)
+        start[1:] = gs[1:] != gs[:-1]
+        first = torch.cummax(torch.where(start, torch.arange(len(gs)), torch.zeros_like(gs)), 0).values
+        rank = torch.arange(len(gs)) - first
+        out_inds[order.to(out_inds.device)] = rank.to(out_inds.device)
+
+    _mod("ingroup_indices", forward=_ingroup_forward)
+    sst_ops = _load("mmdet3d.ops.sst.sst_ops", "mmdet3d/ops/sst/sst_ops.py")
+    if not torch.cuda.is_available():
+        _orig = sst_ops.IngroupIndicesFunction.forward
+
+        def _cpu_forward(ctx, group_inds):
+            out = torch.zeros_like(group_inds) - 1
+            _ingroup_forward(group_inds, out)
+            ctx.mark_non_differentiable(out)
+            return out
+        sst_ops.IngroupIndicesFunction.forward = staticmethod(_cpu_forward)
+        sst_ops.get_inner_win_inds = sst_ops.IngroupIndicesFunction.apply
+    for n in ("flat2window_v2", "window2flat_v2", "make_continuous_inds", "get_flat2win_inds_v2", "get_window_coors",
+              "get_inner_win_inds", "flat2window", "window2flat", "get_flat2win_inds"):
+        setattr(ops, n, getattr(sst_ops, n))
+    m = {}
+    m["sst_ops"] = sst_ops
+    m["sst_input_layer_v2"] = _load("mmdet3d.models.sst.sst_input_layer_v2", "mmdet3d/models/sst/sst_input_layer_v2.py")
+    m["sst_basic_block_v2"] = _load("mmdet3d.models.sst.sst_basic_block_v2", "mmdet3d/models/sst/sst_basic_block_v2.py")
+    m["sst_v2"] = _load("mmdet3d.models.backbones.sst_v2", "mmdet3d/models/backbones/sst_v2.py")
+    m["second"] = _load("mmdet3d.models.backbones.second", "mmdet3d/models/backbones/second.py")
+    m["msda_fn"] = _load("mmdet3d.models.middle_encoders.multi_scale_deformable_attn_function",
+                         "mmdet3d/models/middle_encoders/multi_scale_deformable_attn_function.py")
+    m["fusion_encoder"] = _load("mmdet3d.models.middle_encoders.fusion_encoder",
+                                "mmdet3d/models/middle_encoders/fusion_encoder.py")
+    m["ms_deform_core"] = core
+    _installed.update(m)
+    return m
+
+
+if __name__ == "__main__":
+    mods = install()
+    print({k: v.__name__ for k, v in mods.items()})

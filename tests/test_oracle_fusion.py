@@ -1,0 +1,57 @@
+"""CPU tests: the restatement of the HSF / IGF rows (oracle/fusion_ops.py) against the golden vectors the
+reference's own Python produced (tests/golden/make_golden_fusion.py -> fusion_ref.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from fusion_common import CONFIGS, check_sample, state_dicts, torch_inputs
+
+
+def oracle_forward(cfg):
+    """ISFusionEncoder.forward + SECONDV2 stages through the restatement -> dict of stage outputs"""
+    from oracle import fusion_ops as orc
+    sd, sdb = state_dicts(cfg)
+    t = torch_inputs(cfg)
+    B, bev = cfg["B"], cfg["bev"]
+    out = {}
+    with torch.no_grad():
+        out["img_bev"] = orc.p2g_sample(t["pillars"][..., :3], t["pillar_coors"], t["img_feats"][1], t["lidar2img"],
+                                        t["img_aug_matrix"], t["lidar_aug_matrix"], t["input_shape"], B, bev)
+        out["bev_feats"] = orc.conv_module(torch.cat([out["img_bev"], t["lidar_feats"]], 1), sd, "conv_fusion")
+        out["g2r0"] = orc.sstv2_forward(out["bev_feats"], sd, "grid2region_att.0")
+        out["ins_fusion"], out["hm"], out["top_idx"] = orc.instance_fusion(out["bev_feats"], out["g2r0"], sd, B, bev,
+                                                                            cfg["instance_num"])
+        nxt, out["feat0"] = orc.secondv2_stage(out["ins_fusion"], sdb, "bb", "stage1")
+        out["g2r1"] = orc.sstv2_forward(nxt, sd, "grid2region_att.1")
+        _, out["feat1"] = orc.secondv2_stage(out["g2r1"], sdb, "bb", "stage2")
+    return out
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_restatement_matches_reference_outputs(golden, name):
+    g = golden("fusion_ref.npz")
+    out = oracle_forward(CONFIGS[name])
+    assert np.array_equal(out["top_idx"].numpy(), g[name + ".top_idx"])
+    for key, tol in (("img_bev", 1e-5), ("bev_feats", 1e-4), ("g2r0", 2e-4), ("hm", 1e-4), ("ins_fusion", 3e-4),
+                     ("feat0", 5e-4), ("g2r1", 5e-4), ("feat1", 1e-3)):
+        check_sample(g, f"{name}.{key}", out[key], tol)
+
+
+def test_window_geometry_matches_reference_window_count():
+    """sst_ops.get_window_coors: shift 0 -> ceil(S/6) windows per side hold cells, shift 1 -> one more"""
+    from oracle import fusion_ops as orc
+    for S, n0, n1 in ((180, 30, 31), (90, 15, 16), (36, 6, 7)):
+        w0, _, _ = orc.window_geometry(S, 6, 0)
+        w1, _, _ = orc.window_geometry(S, 6, 1)
+        assert len(torch.unique(w0)) == n0 * n0 and len(torch.unique(w1)) == n1 * n1
+
+
+def test_instance_topk_edge_cases():
+    from oracle import fusion_ops as orc
+    hm = torch.full((1, 10, 8, 8), -20.0)
+    hm[0, 3, 4, 4] = 5.0
+    hm[0, 8, 0, 0] = 4.0   # class 8 uses a 1x1 pool: border cells are candidates there
+    hm[0, 2, 0, 0] = 9.0   # 3x3 classes never keep border cells
+    flat, top, raw = orc.instance_topk(hm, 2)
+    assert raw[0].tolist() == [3 * 64 + 36, 8 * 64] and top[0].tolist() == [36, 0]
+    assert flat[0, 2 * 64] == 0
