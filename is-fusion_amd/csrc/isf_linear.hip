@@ -5,9 +5,9 @@
 // (sst_basic_block_v2.py:104-126, fusion_encoder.py:560-674).  Here one launch per Linear:
 //   arithmetic  f16 hi/lo split of both operands, 3 x v_mfma_f32_16x16x32_f16, fp32 accumulate
 //               (fp32-class accuracy, see isf_spconv16.hip); weights pre-split once (isf_pack_linear);
-//   tiling      wave = 16 rows x all N (N processed in chunks of <= 256 columns), A fragments converted once
-//               and kept in registers for the whole K (K <= 256), B fragments straight from L2 (weights are
-//               <= 0.4 MB and shared by every wave);
+//   tiling      workgroup = 64 or 128 rows x all N (N in chunks of 128 or 256 columns); A fragments converted
+//               once and kept in registers for the whole K (K <= 256); B fragments staged once per workgroup
+//               through a double-buffered LDS ring;
 //   epilogue    + bias, + per-row table add (T[idx[r]]: the window position-embedding contribution pos.Wq),
 //               activation (ReLU / exact GELU), + residual, LayerNorm over the row (needs the whole row in
 //               one chunk: N <= 256), written once.
@@ -38,106 +38,147 @@ struct LinearEpilogue {
 
 // packedW[kc][nt][hi|lo][lane][8 halves]: element jj = W[16 nt + (lane&15)][32 kc + 8 (lane>>4) + jj] * 2^sw
 // header after the data: float 2^-sw
-template <int KC /* K/32 */, int CT /* column tiles per chunk */>
-__global__ __launch_bounds__(256) void linear_f16x3_kernel(const float* __restrict__ x, int M, int ldx,
+//
+// Workgroup = 4 waves x RG row groups of 16 rows (64 RG rows).  The B fragments of one (k chunk, column chunk)
+// step -- CT tiles x 2 KB, contiguous in the packed layout -- are staged once per workgroup through a
+// double-buffered LDS ring (global -> registers during the MFMAs of the previous step -> ds_write), so the L2
+// sees each weight byte once per 64 RG rows instead of once per 16.
+template <int KC /* K/32 */, int CT /* column tiles per chunk */, int RG /* row groups per wave */>
+__global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16x3_kernel(const float* __restrict__ x, int M, int ldx,
                                                            const uint4* __restrict__ wp,
                                                            const float* __restrict__ w_inv_scale, int N,
                                                            LinearEpilogue ep, float* __restrict__ y, int ldy) {
+  constexpr int STEP_U4 = CT * 128;          // uint4 per staged step
+  constexpr int PF = STEP_U4 / 256;          // uint4 per thread per step
+  __shared__ uint4 bbuf[2][STEP_U4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int col = lane & 15, kg = lane >> 4;
-  const int r0 = (blockIdx.x * 4 + wave) * 16;
-  if (r0 >= M) return;
+  const int r0 = (blockIdx.x * 4 + wave) * 16 * RG;
   const int ntiles = N >> 4;
-  // A fragments: row r0 + col, channels 32 kc + 8 kg .. +8
-  h8 ah[KC], al[KC];
-  {
-    const int r = r0 + col;
+  const int nchunks = (ntiles + CT - 1) / CT;
+  // A fragments: row r0 + 16 g + col, channels 32 kc + 8 kg .. +8
+  h8 ah[RG][KC], al[RG][KC];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int r = r0 + 16 * g + col;
     const float* xr = x + (size_t)(r < M ? r : M - 1) * ldx + kg * 8;
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
       f32x8 v = *reinterpret_cast<const f32x8*>(xr + kc * 32);
       if (r >= M) v = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
-      lin_split8(v, ah[kc], al[kc]);
+      lin_split8(v, ah[g][kc], al[g][kc]);
     }
   }
   const float winv = *w_inv_scale;
-  for (int c0 = 0; c0 < ntiles; c0 += CT) {
-    f32x4 acc[CT];
+  // prefetch registers for the next step
+  uint4 pf[PF];
+  auto fetch = [&](int chunk, int kc) {
+    const int c0 = chunk * CT;
+    const int valid_u4 = (ntiles - c0 < CT ? ntiles - c0 : CT) * 128;
+    const uint4* src = wp + ((size_t)kc * ntiles + c0) * 128;
 #pragma unroll
-    for (int nt = 0; nt < CT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < PF; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      pf[i] = idx < valid_u4 ? src[idx] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto commit = [&](int buf) {
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
+    for (int i = 0; i < PF; ++i) bbuf[buf][threadIdx.x + 256 * i] = pf[i];
+  };
+  fetch(0, 0);
+  commit(0);
+  __syncthreads();
+  int step = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int c0 = chunk * CT;
+    f32x4 acc[RG][CT];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int nt = 0; nt < CT; ++nt) acc[g][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc, ++step) {
+      const int buf = step & 1;
+      const bool more = !(chunk == nchunks - 1 && kc == KC - 1);
+      if (more) fetch(kc == KC - 1 ? chunk + 1 : chunk, kc == KC - 1 ? 0 : kc + 1);
 #pragma unroll
       for (int nt = 0; nt < CT; ++nt) {
-        if (c0 + nt < ntiles) {
-          const uint4 bhu = wp[((size_t)kc * ntiles + c0 + nt) * 128 + lane];
-          const uint4 blu = wp[((size_t)kc * ntiles + c0 + nt) * 128 + 64 + lane];
-          const h8 bh = *reinterpret_cast<const h8*>(&bhu);
-          const h8 bl = *reinterpret_cast<const h8*>(&blu);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kc], bh, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bl, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bh, acc[nt], 0, 0, 0);
+        const uint4 bhu = bbuf[buf][nt * 128 + lane];
+        const uint4 blu = bbuf[buf][nt * 128 + 64 + lane];
+        const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+        const h8 bl = *reinterpret_cast<const h8*>(&blu);
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[g][kc], bh, acc[g][nt], 0, 0, 0);
+          acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kc], bl, acc[g][nt], 0, 0, 0);
+          acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[g][kc], bh, acc[g][nt], 0, 0, 0);
         }
       }
+      if (more) commit(buf ^ 1);   // the other buffer was last read before the previous barrier
+      __syncthreads();
     }
-    // epilogue on the C/D layout: this lane holds rows r0 + 4 kg + t (t = 0..3), column 16 (c0+nt) + col
-    float v[CT][4];
+    // epilogue on the C/D layout: this lane holds rows r0 + 16 g + 4 kg + t (t = 0..3), column 16 (c0+nt) + col
 #pragma unroll
-    for (int nt = 0; nt < CT; ++nt) {
-      const int n = (c0 + nt) * 16 + col;
-      const bool cok = c0 + nt < ntiles;
-      const float b = (ep.bias && cok) ? ep.bias[n] : 0.f;
+    for (int g = 0; g < RG; ++g) {
+      float v[CT][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = r0 + 4 * kg + t;
-        float z = acc[nt][t] * winv + b;
-        if (cok && r < M) {
-          if (ep.table) z += ep.table[(size_t)ep.idx[r] * N + n];
-          if (ep.act == 1) z = fmaxf(z, 0.f);
-          else if (ep.act == 2) z = 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
-          if (ep.residual) z += ep.residual[(size_t)r * N + n];
-        } else {
-          z = 0.f;
+      for (int nt = 0; nt < CT; ++nt) {
+        const int n = (c0 + nt) * 16 + col;
+        const bool cok = c0 + nt < ntiles;
+        const float b = (ep.bias && cok) ? ep.bias[n] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int r = r0 + 16 * g + 4 * kg + t;
+          float z = acc[g][nt][t] * winv + b;
+          if (cok && r < M) {
+            if (ep.table) z += ep.table[(size_t)ep.idx[r] * N + n];
+            if (ep.act == 1) z = fmaxf(z, 0.f);
+            else if (ep.act == 2) z = 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+            if (ep.residual) z += ep.residual[(size_t)r * N + n];
+          } else {
+            z = 0.f;
+          }
+          v[nt][t] = z;
         }
-        v[nt][t] = z;
       }
-    }
-    if (ep.ln_gamma) {  // whole row in this chunk (host guarantees ntiles <= CT)
+      if (ep.ln_gamma) {  // whole row in this chunk (host guarantees ntiles <= CT)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float s = 0.f;
+        for (int t = 0; t < 4; ++t) {
+          float s = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < CT; ++nt) s += v[nt][t];
+          for (int nt = 0; nt < CT; ++nt) s += v[nt][t];
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 64);
-        const float mean = s / (float)N;
-        float q = 0.f;
+          for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 64);
+          const float mean = s / (float)N;
+          float q = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < CT; ++nt) {
-          const float dlt = (c0 + nt < ntiles) ? v[nt][t] - mean : 0.f;
-          q += dlt * dlt;
-        }
+          for (int nt = 0; nt < CT; ++nt) {
+            const float dlt = (c0 + nt < ntiles) ? v[nt][t] - mean : 0.f;
+            q += dlt * dlt;
+          }
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) q += __shfl_xor(q, d, 64);
-        const float rstd = rsqrtf(q / (float)N + ep.ln_eps);
+          for (int d = 1; d < 16; d <<= 1) q += __shfl_xor(q, d, 64);
+          const float rstd = rsqrtf(q / (float)N + ep.ln_eps);
 #pragma unroll
-        for (int nt = 0; nt < CT; ++nt) {
-          if (c0 + nt < ntiles) {
-            const int n = (c0 + nt) * 16 + col;
-            v[nt][t] = (v[nt][t] - mean) * rstd * ep.ln_gamma[n] + ep.ln_beta[n];
+          for (int nt = 0; nt < CT; ++nt) {
+            if (c0 + nt < ntiles) {
+              const int n = (c0 + nt) * 16 + col;
+              v[nt][t] = (v[nt][t] - mean) * rstd * ep.ln_gamma[n] + ep.ln_beta[n];
+            }
           }
         }
       }
-    }
 #pragma unroll
-    for (int nt = 0; nt < CT; ++nt) {
-      if (c0 + nt < ntiles) {
-        const int n = (c0 + nt) * 16 + col;
+      for (int nt = 0; nt < CT; ++nt) {
+        if (c0 + nt < ntiles) {
+          const int n = (c0 + nt) * 16 + col;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int r = r0 + 4 * kg + t;
-          if (r < M) y[(size_t)r * ldy + n] = v[nt][t];
+          for (int t = 0; t < 4; ++t) {
+            const int r = r0 + 16 * g + 4 * kg + t;
+            if (r < M) y[(size_t)r * ldy + n] = v[nt][t];
+          }
         }
       }
     }
@@ -182,12 +223,18 @@ static int launch_linear(const float* x, int M, int ldx, const void* packed, int
                          float* y, int ldy, hipStream_t st) {
   const uint4* wp = reinterpret_cast<const uint4*>(packed);
   const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) + (size_t)N * K * 4);
-  const dim3 grid(ceil_div(M, 64)), block(256);
+  const dim3 block(256);
   const int ntiles = N / 16;
-  if (ntiles <= 8)
-    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 8>), grid, block, 0, st, x, M, ldx, wp, winv, N, ep, y, ldy);
+  const bool wide_ln = ep.ln_gamma && ntiles > 8;   // LayerNorm needs the whole row in one column chunk
+  if (wide_ln)
+    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 16, 1>), dim3(ceil_div(M, 64)), block, 0, st, x, M, ldx, wp, winv, N,
+                       ep, y, ldy);
+  else if (M <= 4096 || KC == 8)   // few rows: more, smaller workgroups; K = 256: A fragments fill the registers
+    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 8, 1>), dim3(ceil_div(M, 64)), block, 0, st, x, M, ldx, wp, winv, N,
+                       ep, y, ldy);
   else
-    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 16>), grid, block, 0, st, x, M, ldx, wp, winv, N, ep, y, ldy);
+    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 8, 2>), dim3(ceil_div(M, 128)), block, 0, st, x, M, ldx, wp, winv, N,
+                       ep, y, ldy);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

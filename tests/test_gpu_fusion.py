@@ -189,7 +189,9 @@ def test_msda_matches_restatement(dev, B, Q, H):
     loc = ref_pts.view(B, Q, 1, 1, 1, 2) + off.view(B, Q, 8, 1, 16, 2) / torch.tensor([H, H], dtype=torch.float32)
     aw = logits.view(B, Q, 8, 16).softmax(-1).view(B, Q, 8, 1, 16)
     ref = orc.msda_core(value, torch.tensor([[H, H]]), loc, aw).reshape(B * Q, 128)
-    assert (out - ref).abs().max().item() < 1e-5
+    # pixel coordinates up to H = 180 carry an fp32 ulp of 1.5e-5: bilinear weights differ by that much between
+    # two correctly rounded evaluation orders, times O(1) values
+    assert (out - ref).abs().max().item() < 5e-5
 
 
 # -------------------------------------------------------------------------------------- module-level parity
