@@ -271,7 +271,10 @@ int isf_pack_linear(const float* weight, int out_features, int in_features, void
 int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, const void* packed_weight,
                        int out_features, const float* bias, const float* row_table, const int32_t* row_table_index,
                        int activation, const float* residual, const float* ln_gamma, const float* ln_beta,
-                       float ln_eps, float* y, int ldy, isf_stream_t stream);
+                       float ln_eps, float* y, int ldy, int x_hw, int residual_hw, int y_hw, isf_stream_t stream);
+/* x_hw / residual_hw / y_hw: 0 = row-major [num_rows, C]; hw > 0 = the tensor is channels-first [B, C, hw] with row
+ * r = b*hw + pos (a BEV map [B, C, H, W], hw = H*W, hw % 4 == 0): the NCHW <-> token transposes of
+ * fusion_encoder.py:1163, sst_v2.py:97-133 and :480-496 happen inside the GEMM's loads / stores. */
 
 /* A10/A11  window attention on a dense token grid -------------------------------------------------------
  * replaces get_window_coors / flat2window / nn.MultiheadAttention / window2flat of

@@ -108,7 +108,8 @@ SIGNATURES = {
     "isf_packed_linear_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "isf_pack_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "isf_linear_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                   c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_void_p]),
+                                   c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_void_p]),
     "isf_window_attention_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                              c_void_p]),
     "isf_attention_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -7,9 +7,10 @@ namespace isf {
 // ----------------------------------------------------------------------------------------------------------------
 // A8  img_fv_to_bev + img_point_sampling (fusion_encoder.py:965-1070).  The reference loops over samples, builds
 // [cam, 3, N] projections with four batched matmuls and calls grid_sample once per camera on an NCHW map, then
-// sums over cameras and the T pillar slots and scatters into a zero canvas.  Here: one wave per pillar, lanes
-// own channels of an NHWC image map (1 KB contiguous per bilinear tap), the projection of each (slot, camera) is
-// wave-uniform scalar work, the (camera, slot) sum stays in registers and the canvas is written once.
+// sums over cameras and the T pillar slots and scatters into a zero canvas.  Here: one wave per pillar; the
+// T x num_cam projections are computed one per lane, the in-view ones (ballot) are then visited wave-uniformly with
+// lanes owning channels of an NHWC image map (1 KB contiguous per bilinear tap); the (camera, slot) sum stays in
+// registers and the canvas is written once.
 // cam[b*num_cam + k] = 20 floats: M (3x3 row-major) = lidar2img[:3,:3] . inv(lidar_aug[:3,:3]),
 //                      v (3) = lidar2img[:3,3] - M . lidar_aug[:3,3], A (2x3) = img_aug[:2,:3], a (2) = img_aug[:2,3]
 template <int CPL /* channels per lane */>
@@ -26,10 +27,18 @@ __global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pill
 #pragma unroll
   for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
   const int c0 = lane * CPL;
-  for (int t = 0; t < T; ++t) {
-    const float* pt = pillars + ((size_t)p * T + t) * pillar_ld;
-    const float px = pt[0], py = pt[1], pz = pt[2];
-    for (int k = 0; k < num_cam; ++k) {
+  // projection: one (slot, camera) pair per lane; the in-view pairs are then visited wave-uniformly
+  const int pairs = T * num_cam;
+  for (int base0 = 0; base0 < pairs; base0 += 64) {
+    const int pr = base0 + lane;
+    bool ok = false;
+    float ix = 0.f, iy = 0.f;
+    int k = 0;
+    if (pr < pairs) {
+      const int t = pr / num_cam;
+      k = pr - t * num_cam;
+      const float* pt = pillars + ((size_t)p * T + t) * pillar_ld;
+      const float px = pt[0], py = pt[1], pz = pt[2];
       const float* m = cam + (size_t)(b * num_cam + k) * 20;
       float cx = m[0] * px + m[1] * py + m[2] * pz + m[9];
       float cy = m[3] * px + m[4] * py + m[5] * pz + m[10];
@@ -41,12 +50,20 @@ __global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pill
       const float v = m[15] * cx + m[16] * cy + m[17] * cz + m[19];
       // (u / in_w - 0.5) * 2 then grid_sample's align_corners=False un-normalisation
       const float gx = (u / in_w - 0.5f) * 2.f, gy = (v / in_h - 0.5f) * 2.f;
-      const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
-      if (!(ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H)) continue;   // all four taps outside
-      const float fx = floorf(ix), fy = floorf(iy);
+      ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+      iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+      ok = ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H;   // else all four taps are outside
+    }
+    unsigned long long live = __ballot(ok);
+    while (live) {
+      const int src_lane = __ffsll((long long)live) - 1;
+      live &= live - 1;
+      const float sx = __shfl(ix, src_lane, 64), sy = __shfl(iy, src_lane, 64);
+      const int sk = __shfl(k, src_lane, 64);
+      const float fx = floorf(sx), fy = floorf(sy);
       const int x0 = (int)fx, y0 = (int)fy;
-      const float lx = ix - fx, ly = iy - fy;
-      const float* base = img + (size_t)(b * num_cam + k) * H * W * C + c0;
+      const float lx = sx - fx, ly = sy - fy;
+      const float* base = img + (size_t)(b * num_cam + sk) * H * W * C + c0;
 #pragma unroll
       for (int tap = 0; tap < 4; ++tap) {
         const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);

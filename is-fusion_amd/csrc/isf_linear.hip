@@ -34,6 +34,8 @@ struct LinearEpilogue {
   const float* ln_beta;
   float ln_eps;
   int act;                 // 0 none, 1 relu, 2 gelu (erf)
+  // channels-first addressing (0 = row-major [M, C]; hw > 0 = tensor [B, C, hw] with row r = b*hw + pos):
+  int x_hw, res_hw, y_hw;
 };
 
 // packedW[kc][nt][hi|lo][lane][8 halves]: element jj = W[16 nt + (lane&15)][32 kc + 8 (lane>>4) + jj] * 2^sw
@@ -43,7 +45,8 @@ struct LinearEpilogue {
 // step -- CT tiles x 2 KB, contiguous in the packed layout -- are staged once per workgroup through a
 // double-buffered LDS ring (global -> registers during the MFMAs of the previous step -> ds_write), so the L2
 // sees each weight byte once per 64 RG rows instead of once per 16.
-template <int KC /* K/32 */, int CT /* column tiles per chunk */, int RG /* row groups per wave */>
+template <int KC /* K/32 */, int CT /* column tiles per chunk */, int RG /* row groups per wave */,
+          bool CF /* some operand is channels-first */>
 __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16x3_kernel(const float* __restrict__ x, int M, int ldx,
                                                            const uint4* __restrict__ wp,
                                                            const float* __restrict__ w_inv_scale, int N,
@@ -57,17 +60,50 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
   const int r0 = (blockIdx.x * 4 + wave) * 16 * RG;
   const int ntiles = N >> 4;
   const int nchunks = (ntiles + CT - 1) / CT;
+  // channels-first input: the workgroup's [K x 64 RG rows] tile is loaded with 16-byte loads along the rows (the
+  // contiguous direction of [B, K, hw]) into LDS and read back transposed
+  constexpr int XT_LD = 64 * RG + 4;
+  extern __shared__ __attribute__((aligned(16))) float xt[];   // [K][XT_LD], only when ep.x_hw
+  if (CF && ep.x_hw) {
+    constexpr int QUADS = 16 * RG;   // row quads per tile
+    const int R0 = blockIdx.x * 64 * RG;
+    for (int idx = threadIdx.x; idx < KC * 32 * QUADS; idx += 256) {
+      const int c = idx / QUADS, q = idx - c * QUADS;
+      const int r = R0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < M) {
+        const int bb = r / ep.x_hw, pos = r - bb * ep.x_hw;
+        const float* p = x + ((size_t)bb * (KC * 32) + c) * ep.x_hw + pos;
+        if (r + 3 < M) v = *reinterpret_cast<const float4*>(p);
+        else { v.x = p[0]; if (r + 1 < M) v.y = p[1]; if (r + 2 < M) v.z = p[2]; }
+      }
+      *reinterpret_cast<float4*>(xt + c * XT_LD + 4 * q) = v;
+    }
+    __syncthreads();
+  }
   // A fragments: row r0 + 16 g + col, channels 32 kc + 8 kg .. +8
   h8 ah[RG][KC], al[RG][KC];
 #pragma unroll
   for (int g = 0; g < RG; ++g) {
     const int r = r0 + 16 * g + col;
-    const float* xr = x + (size_t)(r < M ? r : M - 1) * ldx + kg * 8;
+    const int rc = r < M ? r : M - 1;
+    if (!CF || ep.x_hw == 0) {
+      const float* xr = x + (size_t)rc * ldx + kg * 8;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-      f32x8 v = *reinterpret_cast<const f32x8*>(xr + kc * 32);
-      if (r >= M) v = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
-      lin_split8(v, ah[g][kc], al[g][kc]);
+      for (int kc = 0; kc < KC; ++kc) {
+        f32x8 v = *reinterpret_cast<const f32x8*>(xr + kc * 32);
+        if (r >= M) v = f32x8{0, 0, 0, 0, 0, 0, 0, 0};
+        lin_split8(v, ah[g][kc], al[g][kc]);
+      }
+    } else {   // [B, K, hw] tile staged through LDS (see below)
+      const int rl = (wave * RG + g) * 16 + col;   // row inside the workgroup tile
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        f32x8 v;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = xt[(kc * 32 + kg * 8 + jj) * XT_LD + rl];
+        lin_split8(v, ah[g][kc], al[g][kc]);
+      }
     }
   }
   const float winv = *w_inv_scale;
@@ -128,15 +164,24 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
         const int n = (c0 + nt) * 16 + col;
         const bool cok = c0 + nt < ntiles;
         const float b = (ep.bias && cok) ? ep.bias[n] : 0.f;
+        const int rq = r0 + 16 * g + 4 * kg;   // 4 consecutive rows; hw % 4 == 0 keeps them in one sample
+        float4 res4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CF && ep.residual && ep.res_hw && cok && rq < M) {
+          const int bb = rq / ep.res_hw, pos = rq - bb * ep.res_hw;
+          const float* rp = ep.residual + ((size_t)bb * N + n) * ep.res_hw + pos;
+          if (rq + 3 < M) res4 = *reinterpret_cast<const float4*>(rp);
+          else { res4.x = rp[0]; if (rq + 1 < M) res4.y = rp[1]; if (rq + 2 < M) res4.z = rp[2]; }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int r = r0 + 16 * g + 4 * kg + t;
+          const int r = rq + t;
           float z = acc[g][nt][t] * winv + b;
           if (cok && r < M) {
             if (ep.table) z += ep.table[(size_t)ep.idx[r] * N + n];
             if (ep.act == 1) z = fmaxf(z, 0.f);
             else if (ep.act == 2) z = 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
-            if (ep.residual) z += ep.residual[(size_t)r * N + n];
+            if (ep.residual) z += (CF && ep.res_hw) ? (t == 0 ? res4.x : t == 1 ? res4.y : t == 2 ? res4.z : res4.w)
+                                            : ep.residual[(size_t)r * N + n];
           } else {
             z = 0.f;
           }
@@ -174,10 +219,20 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
       for (int nt = 0; nt < CT; ++nt) {
         if (c0 + nt < ntiles) {
           const int n = (c0 + nt) * 16 + col;
+          const int rq = r0 + 16 * g + 4 * kg;
+          if (CF && ep.y_hw) {   // [B, N, hw]: this lane's 4 rows are 4 consecutive floats of channel n
+            if (rq < M) {
+              const int bb = rq / ep.y_hw, pos = rq - bb * ep.y_hw;
+              float* yp = y + ((size_t)bb * N + n) * ep.y_hw + pos;
+              if (rq + 3 < M) *reinterpret_cast<float4*>(yp) = make_float4(v[nt][0], v[nt][1], v[nt][2], v[nt][3]);
+              else { yp[0] = v[nt][0]; if (rq + 1 < M) yp[1] = v[nt][1]; if (rq + 2 < M) yp[2] = v[nt][2]; }
+            }
+          } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int r = r0 + 16 * g + 4 * kg + t;
-            if (r < M) y[(size_t)r * ldy + n] = v[nt][t];
+            for (int t = 0; t < 4; ++t) {
+              const int r = rq + t;
+              if (r < M) y[(size_t)r * ldy + n] = v[nt][t];
+            }
           }
         }
       }
@@ -226,15 +281,27 @@ static int launch_linear(const float* x, int M, int ldx, const void* packed, int
   const dim3 block(256);
   const int ntiles = N / 16;
   const bool wide_ln = ep.ln_gamma && ntiles > 8;   // LayerNorm needs the whole row in one column chunk
-  if (wide_ln)
-    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 16, 1>), dim3(ceil_div(M, 64)), block, 0, st, x, M, ldx, wp, winv, N,
-                       ep, y, ldy);
-  else if (M <= 4096 || KC == 8)   // few rows: more, smaller workgroups; K = 256: A fragments fill the registers
-    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 8, 1>), dim3(ceil_div(M, 64)), block, 0, st, x, M, ldx, wp, winv, N,
-                       ep, y, ldy);
-  else
-    hipLaunchKernelGGL((linear_f16x3_kernel<KC, 8, 2>), dim3(ceil_div(M, 128)), block, 0, st, x, M, ldx, wp, winv, N,
-                       ep, y, ldy);
+  const bool cf = ep.x_hw || ep.res_hw || ep.y_hw;
+  static bool attr_set = false;
+  if (!attr_set) {   // channels-first input stages a [K][rows + 4] fp32 tile in dynamic LDS on top of the weight ring
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<KC, 16, 1, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, KC * 32 * 68 * 4));
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<KC, 8, 1, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, KC * 32 * 68 * 4));
+    attr_set = true;
+  }
+  const size_t lds1 = ep.x_hw ? (size_t)KC * 32 * 68 * 4 : 0;
+#define ISF_LIN(CT_, RG_, CF_, ROWS_, LDS_)                                                                        \
+  hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, RG_, CF_>), dim3(ceil_div(M, ROWS_)), block, LDS_, st, x, M, ldx, \
+                     wp, winv, N, ep, y, ldy)
+  if (wide_ln) {
+    if (cf) ISF_LIN(16, 1, true, 64, lds1); else ISF_LIN(16, 1, false, 64, 0);
+  } else if (M <= 4096 || KC == 8) {   // few rows: more, smaller workgroups; K = 256: A fragments fill the registers
+    if (cf) ISF_LIN(8, 1, true, 64, lds1); else ISF_LIN(8, 1, false, 64, 0);
+  } else {
+    if (cf) ISF_LIN(8, 1, true, 64, lds1); else ISF_LIN(8, 2, false, 128, 0);   // CF + 2 row groups spills
+  }
+#undef ISF_LIN
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -271,7 +338,7 @@ int isf_pack_linear(const float* weight, int out_features, int in_features, void
 int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, const void* packed_weight,
                        int out_features, const float* bias, const float* row_table, const int32_t* row_table_index,
                        int activation, const float* residual, const float* ln_gamma, const float* ln_beta,
-                       float ln_eps, float* y, int ldy, isf_stream_t stream) {
+                       float ln_eps, float* y, int ldy, int x_hw, int residual_hw, int y_hw, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(num_rows >= 0 && in_features > 0 && out_features > 0, ISF_ERR_ARG, "linear_forward: bad sizes");
   if (num_rows == 0) return ISF_OK;
@@ -279,12 +346,17 @@ int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, c
   ISF_REQUIRE(in_features % 32 == 0 && in_features <= 256 && out_features % 16 == 0, ISF_ERR_UNSUPPORTED,
               "linear_forward: in_features %d (need %%32, <= 256), out_features %d (need %%16)", in_features,
               out_features);
-  ISF_REQUIRE(ldx % 8 == 0 && ldx >= in_features && ldy >= out_features, ISF_ERR_ARG, "linear_forward: bad strides");
+  ISF_REQUIRE((x_hw || (ldx % 8 == 0 && ldx >= in_features)) && (y_hw || ldy >= out_features), ISF_ERR_ARG,
+              "linear_forward: bad strides");
+  ISF_REQUIRE(x_hw >= 0 && residual_hw >= 0 && y_hw >= 0 && x_hw % 4 == 0 && residual_hw % 4 == 0 && y_hw % 4 == 0,
+              ISF_ERR_UNSUPPORTED, "linear_forward: channels-first tensors need hw %% 4 == 0");
+  ISF_REQUIRE((!x_hw || num_rows % x_hw == 0) && (!residual_hw || num_rows % residual_hw == 0) &&
+                  (!y_hw || num_rows % y_hw == 0), ISF_ERR_ARG, "linear_forward: num_rows is not a multiple of hw");
   ISF_REQUIRE(!ln_gamma || (out_features <= 256 && ln_beta), ISF_ERR_UNSUPPORTED,
               "linear_forward: LayerNorm epilogue needs out_features <= 256");
   ISF_REQUIRE((row_table == nullptr) == (row_table_index == nullptr), ISF_ERR_ARG, "linear_forward: table/index");
-  ISF_REQUIRE(!residual || ldy == out_features, ISF_ERR_ARG, "linear_forward: residual needs a dense output");
-  LinearEpilogue ep{bias, row_table, row_table_index, residual, ln_gamma, ln_beta, ln_eps, activation};
+  LinearEpilogue ep{bias, row_table, row_table_index, residual, ln_gamma, ln_beta, ln_eps, activation,
+                    x_hw, residual_hw, y_hw};
   hipStream_t st = as_stream(stream);
   switch (in_features / 32) {
     case 1: return launch_linear<1>(x, num_rows, ldx, packed_weight, out_features, in_features, ep, y, ldy, st);

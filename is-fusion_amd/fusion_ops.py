@@ -29,25 +29,46 @@ class PackedLinear:
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 
-def linear(x, pl, *, table=None, index=None, act=ACT_NONE, residual=None, ln=None):
-    """y = LN(act(x W^T + b + table[index]) + residual); x [M, K] fp32 row-major."""
+def linear(x, pl, *, table=None, index=None, act=ACT_NONE, residual=None, ln=None, out_nchw=None):
+    """y = LN(act(x W^T + b + table[index]) + residual).
+    x: [M, K] fp32 row-major, or a BEV map [B, K, H, W] read as its B*H*W tokens (no transpose pass);
+    residual: [M, N] or [B, N, H, W] likewise; out_nchw=(B, H, W) writes y as [B, N, H, W] instead of [M, N]."""
     _lib.require_cuda(x)
-    assert x.dim() == 2 and x.size(1) == pl.in_features and x.dtype == torch.float32
+    assert x.dtype == torch.float32
     x = x if x.is_contiguous() else x.contiguous()
-    y = torch.empty((x.size(0), pl.out_features), dtype=torch.float32, device=x.device)
+    x_hw = res_hw = y_hw = 0
+    if x.dim() == 4:
+        assert x.size(1) == pl.in_features
+        M, x_hw, ldx = x.size(0) * x.size(2) * x.size(3), x.size(2) * x.size(3), 0
+    else:
+        assert x.dim() == 2 and x.size(1) == pl.in_features
+        M, ldx = x.size(0), x.stride(0)
+    if out_nchw is not None:
+        B, H, W = out_nchw
+        assert B * H * W == M
+        y = torch.empty((B, pl.out_features, H, W), dtype=torch.float32, device=x.device)
+        y_hw, ldy = H * W, 0
+    else:
+        y = torch.empty((M, pl.out_features), dtype=torch.float32, device=x.device)
+        ldy = y.stride(0)
     if residual is not None:
         residual = residual.contiguous()
-        assert residual.shape == y.shape
+        if residual.dim() == 4:
+            assert residual.size(1) == pl.out_features and residual.numel() == M * pl.out_features
+            res_hw = residual.size(2) * residual.size(3)
+        else:
+            assert tuple(residual.shape) == (M, pl.out_features)
     g = b = None
     eps = 0.0
     if ln is not None:
         g, b, eps = ln.weight.detach(), ln.bias.detach(), float(ln.eps)
     _lib.check(_lib.load().isf_linear_forward(
-        _lib.ptr(x), x.size(0), pl.in_features, x.stride(0), _lib.ptr(pl.packed), pl.out_features,
+        _lib.ptr(x), M, pl.in_features, ldx, _lib.ptr(pl.packed), pl.out_features,
         _lib.ptr(pl.bias) if pl.bias is not None else None,
         _lib.ptr(table) if table is not None else None, _lib.ptr(index) if index is not None else None, act,
         _lib.ptr(residual) if residual is not None else None, _lib.ptr(g) if g is not None else None,
-        _lib.ptr(b) if b is not None else None, eps, _lib.ptr(y), y.stride(0), _lib.stream()), "isf_linear_forward")
+        _lib.ptr(b) if b is not None else None, eps, _lib.ptr(y), ldy, x_hw, res_hw, y_hw, _lib.stream()),
+        "isf_linear_forward")
     return y
 
 
@@ -119,22 +140,25 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
     """get_regions[i] + grid2region_att[i] (sst_v2.py:65-133) on a dense grid: [B, C, S, S] -> [B, d, S, S]."""
     _lib.require_cuda(bev)
     B, C, S, _ = bev.shape
-    x = to_tokens(bev.float())
+    fused_io = (S * S) % 4 == 0          # channels-first loads / stores inside the GEMM need hw % 4 == 0
     if hasattr(sst, "linear0"):
         c = _cache(sst, bev.device)
         if "linear0" not in c:
             c["linear0"] = PackedLinear(sst.linear0.weight, sst.linear0.bias)
-        x = linear(x, c["linear0"])
+        x = linear(bev.float() if fused_io else to_tokens(bev.float()), c["linear0"])
+    else:   # the first layer reads the map channels-first both as GEMM input and as residual
+        x = bev.float().contiguous() if fused_io else to_tokens(bev.float())
     d = x.size(1)
-    for block in sst.block_list:
-        for shift, layer in enumerate(block.encoder_list):
-            p = _encoder_layer_cache(layer, S, win, shift, temperature, bev.device, B)
-            qkv = linear(x, p["qkv"], table=p["table"], index=p["index"])
-            att = window_attention(qkv, B, S, d, layer.win_attn.nhead, win, shift)
-            y = linear(att, p["out"], residual=x, ln=layer.norm1)
-            h = linear(y, p["l1"], act=ACT_GELU)
-            x = linear(h, p["l2"], residual=y, ln=layer.norm2)
-    return from_tokens(x, B, S, S)
+    layers = [(shift, layer) for block in sst.block_list for shift, layer in enumerate(block.encoder_list)]
+    for li, (shift, layer) in enumerate(layers):
+        p = _encoder_layer_cache(layer, S, win, shift, temperature, bev.device, B)
+        qkv = linear(x, p["qkv"], table=p["table"], index=p["index"])
+        att = window_attention(qkv, B, S, d, layer.win_attn.nhead, win, shift)
+        y = linear(att, p["out"], residual=x, ln=layer.norm1)
+        h = linear(y, p["l1"], act=ACT_GELU)
+        last = li == len(layers) - 1 and fused_io
+        x = linear(h, p["l2"], residual=y, ln=layer.norm2, out_nchw=(B, S, S) if last else None)
+    return x if fused_io else from_tokens(x, B, S, S)
 
 
 # ------------------------------------------------------------------------------------------------------ A8
@@ -303,11 +327,12 @@ def instance_to_scene(mod, query, x_ins, scene_feats, bev_size):
         c["q"] = PackedLinear(w[:E], b[:E])
         c["kv"] = PackedLinear(w[E:], b[E:])
         c["out"] = PackedLinear(a.out_proj.weight, a.out_proj.bias)
-    xq = to_tokens(query.float())
+    fused_io = (H * W) % 4 == 0
+    xq = query.float().contiguous() if fused_io else to_tokens(query.float())   # read channels-first in the GEMMs
     xk = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
     qp = linear(xq, c["q"])
     kv = linear(xk, c["kv"])
     att = attention(qp, kv, kv[:, E:], B, H * W, Q, E, mod.nhead, ldkv=2 * E)   # k | v share rows of kv
-    y = linear(att, c["out"], residual=xq, ln=mod.norm)
-    query_ins = from_tokens(y, B, H, W)
+    y = linear(att, c["out"], residual=xq, ln=mod.norm, out_nchw=(B, H, W) if fused_io else None)
+    query_ins = y if fused_io else from_tokens(y, B, H, W)
     return channel_attention(scene_feats, query_ins)

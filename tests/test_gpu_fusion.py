@@ -48,6 +48,24 @@ def test_linear_fused_epilogue(dev, act, N):
     assert (y.cpu() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,K,N", [(2, 18, 18, 256, 256), (1, 180, 180, 128, 128), (3, 6, 10, 64, 384)])
+def test_linear_channels_first_io(dev, B, H, W, K, N):
+    """GEMM input / residual read from, and output written to, [B, C, H, W] maps (no transpose passes)"""
+    from isfusion_amd import fusion_ops as ops
+    x, w, b = rnd((B, K, H, W), 12), rnd((N, K), 13, K ** -0.5), rnd((N,), 14, 0.1)
+    res = rnd((B, N, H, W), 15)
+    ln = torch.nn.LayerNorm(N) if N <= 256 else None
+    pl = ops.PackedLinear(w.to(dev), b.to(dev))
+    y = ops.linear(x.to(dev), pl, residual=res.to(dev), ln=ln.to(dev) if ln else None, out_nchw=(B, H, W)).cpu()
+    z = F.linear(x.permute(0, 2, 3, 1), w, b) + res.permute(0, 2, 3, 1)
+    if ln:
+        z = F.layer_norm(z, (N,), ln.weight.cpu(), ln.bias.cpu(), ln.eps)
+    assert y.shape == (B, N, H, W)
+    assert (y - z.permute(0, 3, 1, 2)).abs().max().item() < 2e-5
+    y2 = ops.linear(x.to(dev), pl).cpu()                       # channels-first in, token-major out
+    assert (y2 - F.linear(x.permute(0, 2, 3, 1), w, b).reshape(-1, N)).abs().max().item() < 2e-5
+
+
 def test_linear_rejects_bad_shapes(dev):
     from isfusion_amd import fusion_ops as ops
     from isfusion_amd._lib import IsfError
