@@ -25,13 +25,14 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace isf {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
-static constexpr int kTM = 128;
 static constexpr int kMaxTaps = 27;
 
 // LDS-DMA of 16 B per lane: LDS[lds_base + lane*16] = *gsrc.  Issued through inline asm on purpose: when hipcc
@@ -70,9 +71,13 @@ __device__ __forceinline__ f32x8 join8(const uint4 hi, const uint4 lo) {
   return __builtin_convertvector(h, f32x8) + __builtin_convertvector(l, f32x8);
 }
 
-template <int NT>
+// one all-zero 64-byte line: the gather address of rows that have no neighbour through a tap
+__device__ uint4 g_zero_line[4];
+
+template <int NT, int RG>
 struct Conv16Smem {
-  static constexpr int nbr_bytes = kMaxTaps * kTM * 4;
+  static constexpr int TM = 64 * RG;                                     // rows per workgroup
+  static constexpr int nbr_bytes = kMaxTaps * TM * 4;
   static constexpr int bbuf_bytes = 2 * NT * 2048;                       // double-buffered weight stage
   static constexpr int EPN = NT > 8 ? 8 : NT;                            // column tiles per epilogue pass
   static constexpr int epi_bytes = 4 * 16 * (16 * EPN + 4) * 4;          // per-wave 16 x (16*EPN+4) fp32
@@ -80,18 +85,20 @@ struct Conv16Smem {
   static constexpr int bytes = nbr_bytes + work_bytes + 256;
 };
 
-template <int CIN, int NT>
-__global__ __launch_bounds__(256, (NT > 8 ? 2 : 3)) void spconv_f16x3_kernel(
+template <int CIN, int NT, int RG>
+__global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
-    uint4* __restrict__ ys, int n_out, int relu) {
-  using S = Conv16Smem<NT>;
+    uint4* __restrict__ ys, int n_out, int relu, int row_tiles) {
+  using S = Conv16Smem<NT, RG>;
+  constexpr int TM = S::TM;
+  constexpr int WR = 16 * RG;         // rows per wave
   constexpr int NCH = CIN / 32;       // 32-channel chunks
   constexpr int CH8 = CIN / 8;        // 8-channel (32-byte) units per input row
   constexpr int BN = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* nbr_l = reinterpret_cast<int*>(smem);                                  // [27][128]
+  int* nbr_l = reinterpret_cast<int*>(smem);                                  // [27][TM]
   uint4* bbuf = reinterpret_cast<uint4*>(smem + S::nbr_bytes);                // [2][NT][2][64]
   int* misc = reinterpret_cast<int*>(smem + S::nbr_bytes + S::work_bytes);    // [4] wave masks
 
@@ -99,61 +106,94 @@ __global__ __launch_bounds__(256, (NT > 8 ? 2 : 3)) void spconv_f16x3_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
-  const int row0 = blockIdx.x * kTM;
-  const int cb = blockIdx.y;
+  // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2) in
+  // linear-id order.  With two column blocks, XCD x only ever works on column block x & 1, so the weights
+  // it streams (27 taps x CIN x 128 columns) are half of the layer's and stay resident in its L2.
+  const int ncb = cout / BN;
+  int cb, tile;
+  if (ncb == 2) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    cb = xcd & 1;
+    tile = j * 4 + (xcd >> 1);
+  } else {
+    cb = blockIdx.x % ncb;
+    tile = blockIdx.x / ncb;
+  }
+  if (tile >= row_tiles) return;
+  const int row0 = tile * TM;
   const int ntiles_total = cout >> 4;
 
-  // ---- prologue: neighbour tile -> LDS, per-row-group tap masks
-  for (int i = tid; i < K * kTM; i += 256) {
-    const int k = i >> 7, r = i & 127;
-    nbr_l[i] = nbr[(size_t)k * nbr_stride + row0 + r];
+  // ---- prologue: neighbour tile -> LDS, per-wave tap mask
+  for (int i = tid; i < K * TM; i += 256) {
+    const int k = i / TM, r = i - k * TM;
+    nbr_l[i] = row0 + r < nbr_stride ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;   // stride = round_up(n, 128)
   }
   __syncthreads();
-  unsigned mask0 = 0, mask1 = 0;
+  // per-row-group tap masks (bit k: some row of the 16-row group has a neighbour through tap k), wave-uniform
+  unsigned rgm[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) rgm[rg] = 0;
   for (int k = 0; k < K; ++k) {
-    const int v = nbr_l[k * kTM + wave * 32 + (lane & 31)];
-    const unsigned long long m = __ballot(v >= 0);
-    mask0 |= ((m & 0xffffull) ? 1u : 0u) << k;
-    mask1 |= ((m & 0xffff0000ull) ? 1u : 0u) << k;
+#pragma unroll
+    for (int rg = 0; rg < RG; rg += 4) {   // 64 lanes cover 4 row groups per ballot
+      const int r = rg * 16 + lane;
+      const bool has = r < WR && nbr_l[k * TM + wave * WR + r] >= 0;
+      const unsigned long long m = __ballot(has);
+#pragma unroll
+      for (int j = 0; j < 4 && rg + j < RG; ++j) rgm[rg + j] |= (((m >> (16 * j)) & 0xffffull) ? 1u : 0u) << k;
+    }
   }
-  if (lane == 0) misc[wave] = (int)(mask0 | mask1);
+  unsigned wmask = 0;
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    rgm[rg] = __builtin_amdgcn_readfirstlane(rgm[rg]);
+    wmask |= rgm[rg];
+  }
+  if (lane == 0) misc[wave] = (int)wmask;
   __syncthreads();
   unsigned wg_mask = (unsigned)(misc[0] | misc[1] | misc[2] | misc[3]);
   wg_mask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int ntaps = __popc(wg_mask);
   const int nsteps = ntaps * NCH;
 
-  f32x4 acc[2][NT];
+  f32x4 acc[RG][NT];
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg)
+  for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // step s -> (chunk, tap): CHUNK-OUTER, taps (set bits of wg_mask, increasing) inner.  An input row is the
   // tap-k neighbour of up to ~15 output rows of this tile and its neighbours, so with the taps innermost the
   // same 128-byte row segment is re-gathered within a few steps (L1/L2 hits) instead of 8 chunks later.
-  unsigned rem_mask = 0;         // taps of the current chunk not yet started (prefetch cursor)
-  int pf_tap = -1, pf_ch = -1;   // prefetch cursor
-  auto advance = [&]() {
-    if (rem_mask == 0) {
-      rem_mask = wg_mask;
-      ++pf_ch;
+  struct Cursor {
+    unsigned rem;   // taps of the current chunk not yet visited
+    int tap, ch;
+  };
+  auto advance = [&](Cursor& c) {
+    if (c.rem == 0) {
+      c.rem = wg_mask;
+      ++c.ch;
     }
-    pf_tap = __ffs(rem_mask) - 1;
-    rem_mask &= rem_mask - 1;
+    c.tap = __ffs(c.rem) - 1;
+    c.rem &= c.rem - 1;
   };
 
-  uint4 a_nxt[2][2];  // [row group][hi, lo]
+  // Prefetch pipeline: weights (LDS double buffer, DMA) and A fragments (registers) are both fetched ONE step
+  // ahead, issued right after the barrier so that they fly during the MFMAs of the current step.  A 16-row
+  // group that has no neighbour through the tap neither gathers nor multiplies (wave-uniform branches).
+  uint4 a_nxt[RG][2];  // [row group][hi, lo]
   auto load_A = [&](int tap, int ch) {
 #pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {
-      const int idx = nbr_l[tap * kTM + wave * 32 + rg * 16 + col];
-      a_nxt[rg][0] = make_uint4(0, 0, 0, 0);
-      a_nxt[rg][1] = make_uint4(0, 0, 0, 0);
-      if (idx >= 0) {
-        const uint4* p = xs + ((size_t)idx * CH8 + ch * 4 + kg) * 2;
-        a_nxt[rg][0] = p[0];
-        a_nxt[rg][1] = p[1];
+    for (int rg = 0; rg < RG; ++rg) {
+      if ((rgm[rg] >> tap) & 1u) {
+        const int idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
+        a_nxt[rg][0] = make_uint4(0, 0, 0, 0);
+        a_nxt[rg][1] = make_uint4(0, 0, 0, 0);
+        if (idx >= 0) {
+          const uint4* p = xs + ((size_t)idx * CH8 + ch * 4 + kg) * 2;
+          a_nxt[rg][0] = p[0];
+          a_nxt[rg][1] = p[1];
+        }
       }
     }
   };
@@ -165,73 +205,82 @@ __global__ __launch_bounds__(256, (NT > 8 ? 2 : 3)) void spconv_f16x3_kernel(
     for (int i = 0; i < (NT * 128) / 256; ++i) glds16(src + i * 256 + tid, dst + (unsigned)i * 4096u);
   };
 
-  if (nsteps > 0) {
-    advance();
-    load_A(pf_tap, pf_ch);
-    stage_B(pf_tap, pf_ch, 0);
-  }
-  for (int s = 0; s < nsteps; ++s) {
-    const int tap = pf_tap;
-    uint4 a_cur[2][2];
-#pragma unroll
-    for (int rg = 0; rg < 2; ++rg) { a_cur[rg][0] = a_nxt[rg][0]; a_cur[rg][1] = a_nxt[rg][1]; }
-    // this wave's share of B(s) (and its A(s) rows) must have landed before anyone reads the buffer
-    // (the builtin, not inline asm, so that hipcc's own scoreboard knows every tracked load has landed too and
-    //  does not re-wait for the A(s) registers in the middle of the next prefetch; simm16 0x0F70 = vmcnt(0))
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();  // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
-    if (s + 1 < nsteps) {
-      advance();
-      load_A(pf_tap, pf_ch);
-      stage_B(pf_tap, pf_ch, (s + 1) & 1);
+  {
+    Cursor cur{0u, -1, -1};
+    if (nsteps > 0) {
+      advance(cur);
+      load_A(cur.tap, cur.ch);
+      stage_B(cur.tap, cur.ch, 0);
     }
-    // A row group without a neighbour through this tap carries zero A fragments, so running it is harmless;
-    // the wave skips the tap only when neither of its row groups needs it (one code path, no divergence).
-    if (((mask0 | mask1) >> tap) & 1u) {
-      const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
-      const h8 ah0 = *reinterpret_cast<const h8*>(&a_cur[0][0]);
-      const h8 al0 = *reinterpret_cast<const h8*>(&a_cur[0][1]);
-      const h8 ah1 = *reinterpret_cast<const h8*>(&a_cur[1][0]);
-      const h8 al1 = *reinterpret_cast<const h8*>(&a_cur[1][1]);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const uint4 bhu = b[(nt * 2 + 0) * 64];
-        const uint4 blu = b[(nt * 2 + 1) * 64];
-        const h8 bh = *reinterpret_cast<const h8*>(&bhu);
-        const h8 bl = *reinterpret_cast<const h8*>(&blu);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acc[1][nt], 0, 0, 0);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acc[1][nt], 0, 0, 0);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acc[1][nt], 0, 0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+      const int tap = cur.tap;
+      uint4 a_cur[RG][2];
+  #pragma unroll
+      for (int rg = 0; rg < RG; ++rg) { a_cur[rg][0] = a_nxt[rg][0]; a_cur[rg][1] = a_nxt[rg][1]; }
+      // this wave's share of B(s) (and its A(s) rows) must have landed before anyone reads the buffer
+      // (the builtin, not inline asm, so that hipcc's own scoreboard knows every tracked load has landed too and
+      //  does not re-wait for the A(s) registers in the middle of the next prefetch; simm16 0x0F70 = vmcnt(0))
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();  // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
+      if (s + 1 < nsteps) {
+        advance(cur);
+        load_A(cur.tap, cur.ch);
+        stage_B(cur.tap, cur.ch, (s + 1) & 1);
+      }
+      if ((wmask >> tap) & 1u) {
+        const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
+        bool need[RG];
+  #pragma unroll
+        for (int rg = 0; rg < RG; ++rg) need[rg] = (rgm[rg] >> tap) & 1u;   // scalar (wave-uniform)
+        uint4 bhu_n = b[0], blu_n = b[64];   // tile nt+1's B fragments are read while tile nt multiplies
+  #pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const uint4 bhu = bhu_n, blu = blu_n;
+          if (nt + 1 < NT) {
+            bhu_n = b[((nt + 1) * 2 + 0) * 64];
+            blu_n = b[((nt + 1) * 2 + 1) * 64];
+          }
+          const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+          const h8 bl = *reinterpret_cast<const h8*>(&blu);
+  #pragma unroll
+          for (int rg = 0; rg < RG; ++rg) {
+            if (need[rg]) {
+              const h8 ah = *reinterpret_cast<const h8*>(&a_cur[rg][0]);
+              const h8 al = *reinterpret_cast<const h8*>(&a_cur[rg][1]);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
+            }
+          }
+        }
       }
     }
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
 
   // ---- epilogue: per row group, accumulator (col = lane&15, row = 4*(lane>>4)+t) -> LDS row-major ->
   //      one lane per (row, 8-channel unit): BN fold (incl. the weight scale), residual, ReLU, split, store
   constexpr int EPN = S::EPN;
   constexpr int RS = 16 * EPN + 4;
-  float* tile = reinterpret_cast<float*>(smem + S::nbr_bytes) + wave * 16 * RS;
+  float* tile_l = reinterpret_cast<float*>(smem + S::nbr_bytes) + wave * 16 * RS;
   const float winv = *w_inv_scale;
 #pragma unroll
-  for (int rg = 0; rg < 2; ++rg) {
+  for (int rg = 0; rg < RG; ++rg) {
 #pragma unroll
     for (int ps = 0; ps < NT / EPN; ++ps) {  // passes of EPN column tiles (keeps the transpose tile small)
 #pragma unroll
       for (int nt = 0; nt < EPN; ++nt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) tile[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][ps * EPN + nt][t];
+        for (int t = 0; t < 4; ++t) tile_l[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][ps * EPN + nt][t];
       // wave-private tile: a wave-level fence is enough (LDS ops of one wave complete in order)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       constexpr int UNITS = (16 * EPN) / 8;  // 8-channel units per row in this pass
       for (int i = lane; i < 16 * UNITS; i += 64) {
         const int r = i / UNITS, u = i % UNITS;
-        const int grow = row0 + wave * 32 + rg * 16 + r;
+        const int grow = row0 + wave * WR + rg * 16 + r;
         if (grow < n_out) {
-          const float* tp = tile + r * RS + u * 8;
+          const float* tp = tile_l + r * RS + u * 8;
           f32x8 v;
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = tp[j];
@@ -317,11 +366,15 @@ __global__ void pack_filters16_kernel(const float* __restrict__ w, int K, int ci
   packed[base + 64 + lane] = lo;
 }
 
-// Cout = 256: one 256-column workgroup (NT = 16, 128 accumulator registers, A gathered once) instead of two
-// 128-column workgroups.  Tuning switch (env ISF_CONV16_WIDE=0/1 read once).
+// Tuning switches, read once: ISF_CONV16_WIDE=1 -> one 256-column workgroup for Cout = 256 (NT = 16);
+// ISF_CONV16_RG=2|4 forces 128- or 256-row workgroups (default: see launch16_rows).
 static const bool g_conv16_wide = [] {
   const char* e = getenv("ISF_CONV16_WIDE");
   return e ? (e[0] != '0') : false;
+}();
+static const int g_conv16_rg = [] {
+  const char* e = getenv("ISF_CONV16_RG");
+  return e ? atoi(e) : 0;
 }();
 
 bool sparse_conv_f16x3_supported(int c_in, int c_out) {
@@ -329,23 +382,41 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
          (c_out == 32 || c_out == 64 || c_out == 128 || c_out == 256);
 }
 
-template <int CIN, int NT>
+template <int CIN, int NT, int RG>
 static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                     int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                     int relu, uint4* ys, hipStream_t st) {
-  using S = Conv16Smem<NT>;
-  auto kern = spconv_f16x3_kernel<CIN, NT>;
+  using S = Conv16Smem<NT, RG>;
+  auto kern = spconv_f16x3_kernel<CIN, NT, RG>;
   static bool attr_set = false;
   if (!attr_set && S::bytes > 48 * 1024) {
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, S::bytes));
     attr_set = true;
   }
-  dim3 grid(ceil_div(n_out, kTM), cout / (16 * NT));
-  hipLaunchKernelGGL(kern, grid, dim3(256), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K, cout, scale, shift,
-                     residual, ys, n_out, relu);
+  const int row_tiles = ceil_div(n_out, S::TM);
+  const int ncb = cout / (16 * NT);
+  const int blocks = ncb == 2 ? 8 * ceil_div(row_tiles, 4) : row_tiles * ncb;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K, cout, scale,
+                     shift, residual, ys, n_out, relu, row_tiles);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
+}
+
+template <int CIN, int NT>
+static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
+                         int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
+                         int relu, uint4* ys, hipStream_t st) {
+  // 256-row workgroups halve the weight bytes a CU pulls per MFMA (the kernel is co-limited by the per-CU vector
+  // memory path); measured: a win for 128 -> 128 at >= ~400 row tiles, a loss for the narrow shallow levels
+  // (fewer waves to hide the gather latency) and for the small deep levels (too few workgroups).
+  bool big = CIN == 128 && NT == 8 && ceil_div(n_out, 256) >= 400;
+  if (g_conv16_rg == 2) big = false;
+  if (g_conv16_rg == 4) big = true;
+  if (NT * 4 <= 32 && big)
+    return launch16<CIN, (NT * 4 <= 32 ? NT : 2), 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
+                                                     residual, relu, ys, st);
+  return launch16<CIN, NT, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
 }
 
 template <int CIN>
@@ -353,13 +424,13 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
                       int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                       int relu, uint4* ys, hipStream_t st) {
   switch (cout) {
-    case 32:  return launch16<CIN, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
-    case 64:  return launch16<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
-    case 128: return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 32:  return launch16_rows<CIN, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 64:  return launch16_rows<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
       if (g_conv16_wide)
-        return launch16<CIN, 16>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
-      return launch16<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+        return launch16<CIN, 16, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+      return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }
   return ISF_ERR_UNSUPPORTED;
 }
