@@ -47,6 +47,22 @@ def make_frames(rank, world, batch, num_points):
     return [synthetic.lidar_sweeps(1234 + 1000 * CFG_ID + f, num_points) for f in frames_for_rank(rank, world, batch)]
 
 
+def pmc_traffic(cin, cout):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_v5_traffic.json: FETCH_SIZE, corrected x2 for gfx950, + WRITE_SIZE; counters cannot be collected
+    from inside the timed process).  None when no summary is committed for that kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v5_traffic.json")
+    try:
+        per = json.load(open(path))["per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+    nt = min(cout // 16, 8)
+    for k, v in per.items():
+        if k.startswith(f"spconv_f16x3_kernel<{cin}, {nt},") and "fetch_bytes" in v and "write_bytes" in v:
+            return round(v["fetch_bytes"] + v["write_bytes"])
+    return None
+
+
 def conv_layer_bytes_flops(kind, cin, cout, K, n_in, n_out, pairs):
     """SURVEY.md section 8d algorithmic (compulsory) traffic of one sparse-conv layer, fp32."""
     s = 4
@@ -155,6 +171,7 @@ def main():
             g = groups.setdefault(f"spconv_mfma<cin={cin},cout={cout}>", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             g["ms"] += float(ms_layer[i]); g["flops"] += fl; g["bytes"] += by; g["launches"] += 1
         name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        cin_dom, cout_dom = [int(v) for v in __import__("re").findall(r"\d+", name)]
         t_s = dom["ms"] * 1e-3
         tflops = dom["flops"] / t_s / 1e12 if t_s > 0 else 0.0
         gbs = dom["bytes"] / t_s / 1e9 if t_s > 0 else 0.0
@@ -165,14 +182,18 @@ def main():
         t_roof_mfma = mult * dom["flops"] / (peak * 1e12)
         t_roof_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
         if t_roof_mfma >= t_roof_hbm:
-            roof = dict(bound="mfma", achieved=round(mult * tflops, 3), peak=peak, unit="TFLOP/s",
+            # achieved = ALGORITHMIC flops / launch time; the peak is what the matrix pipe can deliver per
+            # algorithmic flop with this arithmetic: dense f16 peak / 3 passes (or the fp32 MFMA peak)
+            roof = dict(bound="mfma", achieved=round(tflops, 3), peak=round(peak / mult, 1), unit="TFLOP/s",
                         frac=round(mult * tflops / peak, 4),
-                        arithmetic="f16x3 split MFMA (3 f16 passes per fp32 product, fp32 accumulate)"
-                        if split else "fp32 MFMA")
+                        arithmetic=f"f16x3 split MFMA: 3 f16 passes per fp32 product, fp32 accumulate; peak = "
+                                   f"{MFMA_F16_PEAK_TFLOPS:.0f} dense f16 TFLOP/s / 3" if split else "fp32 MFMA")
         else:
             roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(gbs / HBM_PEAK_GBS, 4))
-        roof.update(traffic=None, kernel=name, launches_per_step=dom["launches"],
+        roof.update(traffic=pmc_traffic(cin_dom, cout_dom), traffic_source="profiles/r01_v5_traffic.json (rocprofv3 --pmc "
+                    "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)",
+                    algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]), kernel=name, launches_per_step=dom["launches"],
                     avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
                     algorithmic_gbs=round(gbs, 1), algorithmic_tflops=round(tflops, 3),
                     conv_ms_per_step=round(float(ms_layer.sum()), 3),

@@ -74,57 +74,78 @@ __device__ __forceinline__ f32x8 join8(const uint4 hi, const uint4 lo) {
 // one all-zero 64-byte line: the gather address of rows that have no neighbour through a tap
 __device__ uint4 g_zero_line[4];
 
-template <int NT, int RG>
-struct Conv16Smem {
-  static constexpr int TM = 64 * RG;                                     // rows per workgroup
-  static constexpr int nbr_bytes = kMaxTaps * TM * 4;
-  static constexpr int bbuf_bytes = 2 * NT * 2048;                       // double-buffered weight stage
-  static constexpr int EPN = NT > 8 ? 8 : NT;                            // column tiles per epilogue pass
-  static constexpr int epi_bytes = 4 * 16 * (16 * EPN + 4) * 4;          // per-wave 16 x (16*EPN+4) fp32
-  static constexpr int work_bytes = bbuf_bytes > epi_bytes ? bbuf_bytes : epi_bytes;
-  static constexpr int bytes = nbr_bytes + work_bytes + 256;
+// narrow layers (CIN <= 64, <= 64 output columns) run all their 32-channel chunks in one step: half / the same
+// number of barriers for twice the MFMAs per barrier
+template <int CIN, int NT>
+struct Conv16Step {
+  static constexpr int KCH = (CIN <= 64 && NT <= 4) ? CIN / 32 : 1;      // 32-channel chunks per step
 };
 
-template <int CIN, int NT, int RG>
-__global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_kernel(
+template <int NT, int RG, int KCH, int NW>
+struct Conv16Smem {
+  static constexpr int TM = 16 * RG * NW;                                // rows per workgroup
+  static constexpr int nbr_bytes = kMaxTaps * TM * 4;
+  static constexpr int bbuf_bytes = 2 * KCH * NT * 2048;                 // double-buffered weight stage
+  static constexpr int EPN = NT > 4 ? 4 : NT;                            // column tiles per epilogue pass
+  static constexpr int epi_bytes = NW * 16 * (16 * EPN + 4) * 4;         // per-wave 16 x (16*EPN+4) fp32
+  // the epilogue tile overlays the neighbour table and the weight ring (both dead by then)
+  static constexpr int main_bytes = nbr_bytes + bbuf_bytes;
+  static constexpr int work_bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+  static constexpr int bytes = work_bytes + 256;
+};
+
+// NW waves per workgroup (4 or 16): all of them share one weight stage per step, so the weight bytes a CU pulls
+// through its vector memory path per MFMA fall with NW -- the measured wall of this kernel is the ~10 TB/s of
+// aggregate L2 -> CU traffic (weights re-streamed per workgroup + gathered rows), not the MFMA pipe.
+template <int CIN, int NT, int RG, int NW>
+__global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, int row_tiles) {
-  using S = Conv16Smem<NT, RG>;
+  constexpr int KCH = Conv16Step<CIN, NT>::KCH;
+  using S = Conv16Smem<NT, RG, KCH, NW>;
+  constexpr int NTHR = 64 * NW;
   constexpr int TM = S::TM;
   constexpr int WR = 16 * RG;         // rows per wave
   constexpr int NCH = CIN / 32;       // 32-channel chunks
+  constexpr int NCG = NCH / KCH;      // chunk groups (steps per tap)
   constexpr int CH8 = CIN / 8;        // 8-channel (32-byte) units per input row
   constexpr int BN = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* nbr_l = reinterpret_cast<int*>(smem);                                  // [27][TM]
   uint4* bbuf = reinterpret_cast<uint4*>(smem + S::nbr_bytes);                // [2][NT][2][64]
-  int* misc = reinterpret_cast<int*>(smem + S::nbr_bytes + S::work_bytes);    // [4] wave masks
+  int* misc = reinterpret_cast<int*>(smem + S::work_bytes);                   // [NW] wave masks
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
   // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2) in
-  // linear-id order.  With two column blocks, XCD x only ever works on column block x & 1, so the weights
-  // it streams (27 taps x CIN x 128 columns) are half of the layer's and stay resident in its L2.
+  // linear-id order.  XCD x works through ONE CONTIGUOUS range of row tiles (rows are (b,z,y,x)-sorted, so the
+  // y / z neighbours a tile gathers are rows of tiles the same XCD touches a little earlier or later: its L2
+  // holds that sliding window instead of every XCD fetching every row), and with two column blocks only ever
+  // on column block x & 1, so that the weights it streams are half of the layer's.
   const int ncb = cout / BN;
   int cb, tile;
-  if (ncb == 2) {
+  {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    cb = xcd & 1;
-    tile = j * 4 + (xcd >> 1);
-  } else {
-    cb = blockIdx.x % ncb;
-    tile = blockIdx.x / ncb;
+    if (ncb == 2) {
+      cb = xcd & 1;
+      tile = (xcd >> 1) * ((row_tiles + 3) >> 2) + j;
+      if (j >= ((row_tiles + 3) >> 2)) return;
+    } else {
+      cb = 0;
+      tile = xcd * ((row_tiles + 7) >> 3) + j;
+      if (j >= ((row_tiles + 7) >> 3)) return;
+    }
   }
   if (tile >= row_tiles) return;
   const int row0 = tile * TM;
   const int ntiles_total = cout >> 4;
 
   // ---- prologue: neighbour tile -> LDS, per-wave tap mask
-  for (int i = tid; i < K * TM; i += 256) {
+  for (int i = tid; i < K * TM; i += NTHR) {
     const int k = i / TM, r = i - k * TM;
     nbr_l[i] = row0 + r < nbr_stride ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;   // stride = round_up(n, 128)
   }
@@ -151,10 +172,12 @@ __global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_ker
   }
   if (lane == 0) misc[wave] = (int)wmask;
   __syncthreads();
-  unsigned wg_mask = (unsigned)(misc[0] | misc[1] | misc[2] | misc[3]);
+  unsigned wg_mask = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) wg_mask |= (unsigned)misc[w];
   wg_mask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int ntaps = __popc(wg_mask);
-  const int nsteps = ntaps * NCH;
+  const int nsteps = ntaps * NCG;
 
   f32x4 acc[RG][NT];
 #pragma unroll
@@ -181,28 +204,40 @@ __global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_ker
   // Prefetch pipeline: weights (LDS double buffer, DMA) and A fragments (registers) are both fetched ONE step
   // ahead, issued right after the barrier so that they fly during the MFMAs of the current step.  A 16-row
   // group that has no neighbour through the tap neither gathers nor multiplies (wave-uniform branches).
-  uint4 a_nxt[RG][2];  // [row group][hi, lo]
-  auto load_A = [&](int tap, int ch) {
+  uint4 a_nxt[RG][KCH][2];  // [row group][chunk of the step][hi, lo]
+  auto load_A = [&](int tap, int cg) {
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
       if ((rgm[rg] >> tap) & 1u) {
         const int idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
-        a_nxt[rg][0] = make_uint4(0, 0, 0, 0);
-        a_nxt[rg][1] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+          a_nxt[rg][kc][0] = make_uint4(0, 0, 0, 0);
+          a_nxt[rg][kc][1] = make_uint4(0, 0, 0, 0);
+        }
         if (idx >= 0) {
-          const uint4* p = xs + ((size_t)idx * CH8 + ch * 4 + kg) * 2;
-          a_nxt[rg][0] = p[0];
-          a_nxt[rg][1] = p[1];
+#pragma unroll
+          for (int kc = 0; kc < KCH; ++kc) {
+            const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4 + kg) * 2;
+            a_nxt[rg][kc][0] = p[0];
+            a_nxt[rg][kc][1] = p[1];
+          }
         }
       }
     }
   };
   const unsigned bbuf_addr = __builtin_amdgcn_readfirstlane(lds_addr(bbuf));
-  auto stage_B = [&](int tap, int ch, int buf) {
-    const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
-    const unsigned dst = bbuf_addr + (unsigned)(buf * (NT * 128) + wave * 64) * 16u;
+  auto stage_B = [&](int tap, int cg, int buf) {
 #pragma unroll
-    for (int i = 0; i < (NT * 128) / 256; ++i) glds16(src + i * 256 + tid, dst + (unsigned)i * 4096u);
+    for (int kc = 0; kc < KCH; ++kc) {
+      const uint4* src = wpk + (((size_t)tap * NCH + cg * KCH + kc) * ntiles_total + cb * NT) * 128;
+      const unsigned dst = bbuf_addr + (unsigned)((buf * KCH + kc) * (NT * 128)) * 16u;
+#pragma unroll
+      for (int i = 0; i < (NT * 128 + NTHR - 1) / NTHR; ++i) {
+        const int base = i * NTHR + wave * 64;   // wave-uniform: this wave's 64 consecutive 16-byte pieces
+        if (base < NT * 128) glds16(src + base + lane, dst + (unsigned)base * 16u);
+      }
+    }
   };
 
   {
@@ -214,9 +249,11 @@ __global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_ker
     }
     for (int s = 0; s < nsteps; ++s) {
       const int tap = cur.tap;
-      uint4 a_cur[RG][2];
+      uint4 a_cur[RG][KCH][2];
   #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) { a_cur[rg][0] = a_nxt[rg][0]; a_cur[rg][1] = a_nxt[rg][1]; }
+      for (int rg = 0; rg < RG; ++rg)
+  #pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) { a_cur[rg][kc][0] = a_nxt[rg][kc][0]; a_cur[rg][kc][1] = a_nxt[rg][kc][1]; }
       // this wave's share of B(s) (and its A(s) rows) must have landed before anyone reads the buffer
       // (the builtin, not inline asm, so that hipcc's own scoreboard knows every tracked load has landed too and
       //  does not re-wait for the A(s) registers in the middle of the next prefetch; simm16 0x0F70 = vmcnt(0))
@@ -228,25 +265,26 @@ __global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_ker
         stage_B(cur.tap, cur.ch, (s + 1) & 1);
       }
       if ((wmask >> tap) & 1u) {
-        const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
+        const uint4* b = bbuf + (s & 1) * (KCH * NT * 128) + lane;
         bool need[RG];
   #pragma unroll
         for (int rg = 0; rg < RG; ++rg) need[rg] = (rgm[rg] >> tap) & 1u;   // scalar (wave-uniform)
-        uint4 bhu_n = b[0], blu_n = b[64];   // tile nt+1's B fragments are read while tile nt multiplies
+        uint4 bhu_n = b[0], blu_n = b[64];   // the next B fragments are read from LDS while these multiply
   #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int i = 0; i < KCH * NT; ++i) {   // i = kc * NT + nt
+          const int kc = i / NT, nt = i % NT;
           const uint4 bhu = bhu_n, blu = blu_n;
-          if (nt + 1 < NT) {
-            bhu_n = b[((nt + 1) * 2 + 0) * 64];
-            blu_n = b[((nt + 1) * 2 + 1) * 64];
+          if (i + 1 < KCH * NT) {
+            bhu_n = b[((i + 1) * 2 + 0) * 64];
+            blu_n = b[((i + 1) * 2 + 1) * 64];
           }
           const h8 bh = *reinterpret_cast<const h8*>(&bhu);
           const h8 bl = *reinterpret_cast<const h8*>(&blu);
   #pragma unroll
           for (int rg = 0; rg < RG; ++rg) {
             if (need[rg]) {
-              const h8 ah = *reinterpret_cast<const h8*>(&a_cur[rg][0]);
-              const h8 al = *reinterpret_cast<const h8*>(&a_cur[rg][1]);
+              const h8 ah = *reinterpret_cast<const h8*>(&a_cur[rg][kc][0]);
+              const h8 al = *reinterpret_cast<const h8*>(&a_cur[rg][kc][1]);
               acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
               acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
               acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
@@ -263,7 +301,7 @@ __global__ __launch_bounds__(256, (NT * RG >= 16 ? 2 : 3)) void spconv_f16x3_ker
   //      one lane per (row, 8-channel unit): BN fold (incl. the weight scale), residual, ReLU, split, store
   constexpr int EPN = S::EPN;
   constexpr int RS = 16 * EPN + 4;
-  float* tile_l = reinterpret_cast<float*>(smem + S::nbr_bytes) + wave * 16 * RS;
+  float* tile_l = reinterpret_cast<float*>(smem) + wave * 16 * RS;
   const float winv = *w_inv_scale;
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
@@ -367,10 +405,14 @@ __global__ void pack_filters16_kernel(const float* __restrict__ w, int K, int ci
 }
 
 // Tuning switches, read once: ISF_CONV16_WIDE=1 -> one 256-column workgroup for Cout = 256 (NT = 16);
-// ISF_CONV16_RG=2|4 forces 128- or 256-row workgroups (default: see launch16_rows).
+// ISF_CONV16_NW / ISF_CONV16_RG: see launch16_rows.
 static const bool g_conv16_wide = [] {
   const char* e = getenv("ISF_CONV16_WIDE");
   return e ? (e[0] != '0') : false;
+}();
+static const int g_conv16_nw = [] {
+  const char* e = getenv("ISF_CONV16_NW");
+  return e ? atoi(e) : 0;
 }();
 static const int g_conv16_rg = [] {
   const char* e = getenv("ISF_CONV16_RG");
@@ -382,12 +424,12 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
          (c_out == 32 || c_out == 64 || c_out == 128 || c_out == 256);
 }
 
-template <int CIN, int NT, int RG>
+template <int CIN, int NT, int RG, int NW>
 static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                     int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                     int relu, uint4* ys, hipStream_t st) {
-  using S = Conv16Smem<NT, RG>;
-  auto kern = spconv_f16x3_kernel<CIN, NT, RG>;
+  using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
+  auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW>;
   static bool attr_set = false;
   if (!attr_set && S::bytes > 48 * 1024) {
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -396,27 +438,34 @@ static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K,
   }
   const int row_tiles = ceil_div(n_out, S::TM);
   const int ncb = cout / (16 * NT);
-  const int blocks = ncb == 2 ? 8 * ceil_div(row_tiles, 4) : row_tiles * ncb;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K, cout, scale,
+  ISF_REQUIRE(ncb == 1 || ncb == 2, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d column blocks", ncb);
+  const int blocks = 8 * (ncb == 2 ? ceil_div(row_tiles, 4) : ceil_div(row_tiles, 8));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K, cout, scale,
                      shift, residual, ys, n_out, relu, row_tiles);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
 
+// Workgroup shape per layer.  16 waves x 32 rows (512-row tiles, one workgroup per CU) share each weight stage
+// 4x wider than 4 waves do.  Measured (B=4 x 300 k points): a win only for the 128-column layers of the large
+// levels (128 -> 128: 1.13 -> 1.03 ms per 4 launches, 64 -> 128: 0.173 -> 0.147 ms); the narrow layers lose
+// (fewer independent workgroups to hide the gather latency) and the small deep levels do not have enough tiles
+// for 256 CUs.  ISF_CONV16_NW=4|16 and ISF_CONV16_RG=2|4 override (tuning).
 template <int CIN, int NT>
 static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
-  // 256-row workgroups halve the weight bytes a CU pulls per MFMA (the kernel is co-limited by the per-CU vector
-  // memory path); measured: a win for 128 -> 128 at >= ~400 row tiles, a loss for the narrow shallow levels
-  // (fewer waves to hide the gather latency) and for the small deep levels (too few workgroups).
-  bool big = CIN == 128 && NT == 8 && ceil_div(n_out, 256) >= 400;
-  if (g_conv16_rg == 2) big = false;
-  if (g_conv16_rg == 4) big = true;
-  if (NT * 4 <= 32 && big)
-    return launch16<CIN, (NT * 4 <= 32 ? NT : 2), 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
+  const int ncb = cout / (16 * NT);
+  bool wide_wg = NT == 8 && CIN >= 64 && (long long)ceil_div(n_out, 512) * ncb >= 200;
+  if (g_conv16_nw == 4) wide_wg = false;
+  if (g_conv16_nw == 16) wide_wg = NT <= 8;
+  if (wide_wg)
+    return launch16<CIN, (NT <= 8 ? NT : 2), 2, 16>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
                                                      residual, relu, ys, st);
-  return launch16<CIN, NT, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+  if (g_conv16_rg == 4 && NT * 4 <= 32)
+    return launch16<CIN, (NT * 4 <= 32 ? NT : 2), 4, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
+                                                        residual, relu, ys, st);
+  return launch16<CIN, NT, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
 }
 
 template <int CIN>
@@ -429,7 +478,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
       if (g_conv16_wide)
-        return launch16<CIN, 16, 2>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+        return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }
   return ISF_ERR_UNSUPPORTED;
