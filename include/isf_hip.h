@@ -330,6 +330,24 @@ int isf_msda_forward(const float* value, const float* sampling_offsets, const fl
                      const float* reference_points, int batch_size, int num_queries, int num_heads, int head_dim,
                      int num_points, int height, int width, float* out, isf_stream_t stream);
 
+/* A9 / A15  dense 3x3 BEV convolutions on the sparse-conv kernel ------------------------
+ * replaces mmcv ConvModule / nn.Conv2d + BatchNorm2d + ReLU (fusion_encoder.py:862-960, backbones/second.py:126-165,
+ * MIOpen Winograd + 2 elementwise kernels per layer).  A dense B x H x W grid is a sparse tensor with every cell
+ * active: isf_dense_grid_rulebook writes its neighbour table arithmetically (tap k = ky*kernel_w + kx; with
+ * transpose_taps the taps are enumerated (kx, ky), which is the convolution of the SPATIALLY TRANSPOSED map expressed
+ * on the un-transposed tokens -- the bev_feats.permute(0,1,3,2) of fusion_encoder.py:1093 costs nothing);
+ * isf_sparse_conv_forward_f16x3 then runs Conv + BN + ReLU (+ partial sums of > 256 input channels through its
+ * residual input) in one launch.  nbr == NULL only queries out_hw_host.
+ * isf_nchw_to_split / isf_split_to_nchw convert between [B, C, hw] fp32 maps and split-format token matrices
+ * (token = b*hw + pos); x_channel_offset / channel_offset select a channel slice of the source map / destination
+ * rows (<= 256 channels per call). */
+int isf_dense_grid_rulebook(int batch_size, int height, int width, int kernel_h, int kernel_w, int stride, int padding,
+                            int transpose_taps, int32_t* nbr, int nbr_stride, int out_hw_host[2],
+                            isf_stream_t stream);
+int isf_nchw_to_split(const float* x, int batch_size, int x_channels, int x_channel_offset, int channels, int hw,
+                      void* out_split, int out_channels, int channel_offset, isf_stream_t stream);
+int isf_split_to_nchw(const void* x_split, int batch_size, int channels, int hw, float* out, isf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -121,6 +121,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     "isf_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p, c_void_p]),
+    "isf_dense_grid_rulebook": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                        c_int * 2, c_void_p]),
+    "isf_nchw_to_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "isf_split_to_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -5,14 +5,16 @@ multi-scale deformable attention (A13) and instance-to-scene attention (A14).
 Same constructor kwargs, sub-module / parameter names and ``forward`` signature
     forward(img_mlvl_feats, lidar_feats, bs, **kwargs{pts_metas, img_metas, pts_backbone, lidar2img,
             img_aug_matrix, lidar_aug_matrix}) -> ([f1 [B,128,S,S], f2 [B,256,S/2,S/2]], ins_hm [B,10,S,S])
-Custom arithmetic runs in libisf_hip.so (``fusion_ops``); the 3x3 dense convolutions (conv_fusion, heatmap
-head, conv_scene, conv_ins, SECONDV2) stay on PyTorch-ROCm as the north_star prescribes.  Inference only
-(eval-mode BN, dropout off); the training-only ``random_noise`` branch (:992-995) is not built.
+Custom arithmetic runs in libisf_hip.so (``fusion_ops``).  The 3x3 dense convolutions (conv_fusion, heatmap head,
+conv_scene, conv_ins) run on the sparse encoder's f16x3 MFMA kernel over the dense grid (``dense_conv``,
+SURVEY.md 8f #4; ``dense_conv="stock"`` keeps them on PyTorch-ROCm / MIOpen as the north_star's minimum prescribes).
+Inference only (eval-mode BN, dropout off); the training-only ``random_noise`` branch (:992-995) is not built.
 """
 import torch
 from torch import nn
 
 from . import fusion_ops as ops
+from .dense_conv import PackedConvBN, SplitMap
 from .fusion_modules import (ConvModule, InsContextAtt, Instane2SceneAtt, SSTInputLayerV2, SSTv2)
 
 
@@ -23,6 +25,7 @@ class ISFusionEncoder(nn.Module):
         self.num_points_in_pillar = num_points_in_pillar
         self.bev_size = kwargs.get("bev_size", 180)
         self.num_views = kwargs.get("num_views", 6)
+        self.dense_conv = kwargs.get("dense_conv", "hip")
         region_shape = kwargs.get("region_shape", None)
         grid_size = kwargs.get("grid_size", None)
         region_drop_info = kwargs.get("region_drop_info", None) or [None] * len(region_shape)
@@ -52,12 +55,30 @@ class ISFusionEncoder(nn.Module):
         self.instance_to_scene_att = Instane2SceneAtt(d_model=E)
 
     # --------------------------------------------------------------------------------------------- pieces
+    def _conv(self, name):
+        """ConvModule `name` packed for the f16x3 kernel (cached per device)"""
+        mod = getattr(self, name)
+        cache = self.__dict__.setdefault("_isf_packed", {})
+        dev = mod.conv.weight.device
+        if cache.get(name, (None,))[0] != dev:
+            cache[name] = (dev, PackedConvBN(mod.conv, mod.bn, relu=True))
+        return cache[name][1]
+
     def img_fv_to_bev(self, mlvl_feats, bs, **kwargs):
         """A8 Point-to-Grid: one kernel over (pillar, slot, camera) instead of B*6 grid_sample calls."""
         pm = kwargs["pts_metas"]
         return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs["lidar2img"],
                               kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
                               kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views)
+
+    def fuse(self, img_bev, lidar_feats):
+        """conv_fusion(cat([img_bev, lidar_feats])) (fusion_encoder.py:1163-1165) -> [B, E, S, S]"""
+        if self.dense_conv != "hip":
+            return self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
+        maps = [SplitMap.from_nchw(img_bev)]
+        for off in range(0, lidar_feats.size(1), 256):
+            maps.append(SplitMap.from_nchw(lidar_feats, off, min(256, lidar_feats.size(1) - off)))
+        return self._conv("conv_fusion")(maps).to_nchw()
 
     def grid2region(self, level, bev):
         """A10/A11: SSTInputLayerV2 + SSTv2 on the dense [B, C, S, S] grid."""
@@ -66,24 +87,38 @@ class ISFusionEncoder(nn.Module):
                                  float(self.get_regions[level].pos_temperature))
 
     def instance_fusion(self, bev_feats, scene_feats, bs, **kwargs):
-        """A12-A14 (fusion_encoder.py:1090-1149)."""
-        out = bev_feats.permute(0, 1, 3, 2).contiguous()
-        hm = self.heatmap_head_3(self.heatmap_head_2(self.heatmap_head_1(self.conv_heatmap(out))))
+        """A12-A14 (fusion_encoder.py:1090-1149).  The reference convolves the spatially transposed map
+        (`bev_feats.permute(0, 1, 3, 2)`, :1093,1139); the hip path applies the transposed 3x3 kernels to the
+        un-transposed tokens instead, so no transposed copy of the map is ever made."""
+        S = self.bev_size
+        if self.dense_conv == "hip":
+            m = SplitMap.from_nchw(bev_feats)
+            t = self._conv("heatmap_head_2")(self._conv("heatmap_head_1")(self._conv("conv_heatmap")(m, True), True),
+                                             True).to_nchw()                         # un-transposed orientation
+            hm = self.heatmap_head_3(t.permute(0, 1, 3, 2))                          # 64 -> 10 channels: stock conv
+            x_scene_t = self._conv("conv_scene")(m, True).to_nchw()                   # = conv_scene(out)^T
+            q = self._conv("conv_ins")(m).to_nchw()
+        else:
+            out = bev_feats.permute(0, 1, 3, 2).contiguous()
+            hm = self.heatmap_head_3(self.heatmap_head_2(self.heatmap_head_1(self.conv_heatmap(out))))
+            x_scene_t = self.conv_scene(out).permute(0, 1, 3, 2).contiguous()
+            q = self.conv_ins(bev_feats)
         top_idx = ops.instance_topk(hm, self.instance_num, self.nms_kernel_size,
                                     (8, 9) if self.num_views == 6 else (1, 2))
-        self.last_top_idx = top_idx   # [B, instance_num] flat BEV cell of every mined instance (for inspection)
-        x_scene = self.conv_scene(out)
-        x_ins, query_pos = ops.gather_instances(x_scene, top_idx, self.bev_size)
-        x_ins = ops.ins_context_att(self.instance_att, x_ins, query_pos, x_scene, self.bev_size)
-        q = self.conv_ins(bev_feats)
-        ret = ops.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, self.bev_size)
+        self.last_top_idx = top_idx   # [B, instance_num] flat cell (of the transposed map) of every mined instance
+        # cell n' = y'*S + x' of the transposed map is cell x'*S + y' of the un-transposed one
+        idx_t = (top_idx % S) * S + torch.div(top_idx, S, rounding_mode="floor")
+        x_ins, _ = ops.gather_instances(x_scene_t, idx_t, S)
+        _, query_pos = ops.gather_instances(x_scene_t, top_idx, S)
+        x_ins = ops.ins_context_att(self.instance_att, x_ins, query_pos, x_scene_t, S)
+        ret = ops.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, S)
         return ret, hm
 
     @torch.no_grad()
     def forward(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
         assert not self.training, "isfusion_amd.ISFusionEncoder is the inference path (eval mode)"
         img_bev = self.img_fv_to_bev([img_mlvl_feats[1]], bs, **kwargs)
-        bev_feats = self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
+        bev_feats = self.fuse(img_bev, lidar_feats)
         pts_backbone = kwargs.get("pts_backbone", None)
         x = bev_feats
         ins_hm = None

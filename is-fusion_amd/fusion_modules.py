@@ -153,16 +153,42 @@ class SECONDV2(nn.Module):
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
 
+    dense_conv = "hip"   # "hip": f16x3 MFMA kernel of the sparse encoder on the dense grid; "stock": MIOpen
+
+    def _packed(self, name, seq):
+        from .dense_conv import pack_sequential
+        cache = self.__dict__.setdefault("_isf_packed", {})
+        dev = next(seq.parameters()).device
+        if cache.get(name, (None,))[0] != dev:
+            cache[name] = (dev, pack_sequential(seq))
+        return cache[name][1]
+
+    def _run(self, name, seq, x):
+        """x: [B, C, H, W] fp32 or a dense_conv.SplitMap -> SplitMap (hip) / tensor (stock)"""
+        from .dense_conv import SplitMap
+        if self.dense_conv != "hip":
+            return seq(x)
+        m = x if isinstance(x, SplitMap) else SplitMap.from_nchw(x)
+        for layer in self._packed(name, seq):
+            m = layer(m)
+        return m
+
     def forward(self, x, stage=None):
         """(tokens, coords, feature) like the reference; tokens/coords of the dense grid are implicit here, so the
         HIP fusion encoder consumes the [B, C, H, W] tensor directly: stage1 -> (ds_layer output, None, feature)."""
+        from .dense_conv import SplitMap
+
+        def nchw(t):
+            return t.to_nchw() if isinstance(t, SplitMap) else t
+        if self.training:
+            raise RuntimeError("isfusion_amd.SECONDV2 is the inference path (eval mode)")
         if stage == "stage1":
-            feat = self.blocks[0](x[0] if isinstance(x, (list, tuple)) else x)
-            return self.ds_layer(feat), None, feat
+            feat = self._run("b0", self.blocks[0], x[0] if isinstance(x, (list, tuple)) else x)
+            return nchw(self._run("ds", self.ds_layer, feat)), None, nchw(feat)
         if stage == "stage2":
-            return None, None, self.blocks[1](x[0] if isinstance(x, (list, tuple)) else x)
-        x1 = self.blocks[0](x)
-        return x1, self.blocks[1](self.ds_layer(x1))
+            return None, None, nchw(self._run("b1", self.blocks[1], x[0] if isinstance(x, (list, tuple)) else x))
+        x1 = self._run("b0", self.blocks[0], x)
+        return nchw(x1), nchw(self._run("b1", self.blocks[1], self._run("ds", self.ds_layer, x1)))
 
 
 def seeded_state_dict(module, seed):

@@ -252,11 +252,12 @@ def _pos_embed(mod, xy):
     return mod.position_embedding_head(xy.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
 
 
-def ins_context_att(mod, x_ins, query_pos, x_scene, bev_size):
+def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
     """InsContextAtt.forward (fusion_encoder.py:795-830), eval mode.  x_ins [B, E, Q], query_pos [B, Q, 2] (x, y),
-    x_scene [B, E, H, W] -> [B, E, Q]."""
-    _lib.require_cuda(x_scene)
-    dev = x_scene.device
+    scene [B, E, H, W] = the reference's `x_scene.permute(0, 1, 3, 2)` (:806; the caller holds the map in that
+    orientation already) -> [B, E, Q]."""
+    _lib.require_cuda(scene)
+    dev = scene.device
     B, E, Q = x_ins.shape
     c = _cache(mod, dev)
     if "key_pos" not in c:
@@ -276,7 +277,6 @@ def ins_context_att(mod, x_ins, query_pos, x_scene, bev_size):
                 aw=PackedLinear(ca.attention_weights.weight, ca.attention_weights.bias),
                 oproj=PackedLinear(ca.output_proj.weight, ca.output_proj.bias),
                 l1=PackedLinear(l.linear1.weight, l.linear1.bias), l2=PackedLinear(l.linear2.weight, l.linear2.bias)))
-    scene = x_scene.permute(0, 1, 3, 2)
     H, W = scene.shape[2:]
     src = (scene.flatten(2).transpose(1, 2) + c["key_pos"][None]).reshape(B * H * W, E).contiguous()
     out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()

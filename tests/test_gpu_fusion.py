@@ -212,6 +212,59 @@ def test_msda_matches_restatement(dev, B, Q, H):
     assert (out - ref).abs().max().item() < 5e-5
 
 
+# ------------------------------------------------------------------------------- A9 / A15 dense convolutions
+@pytest.mark.parametrize("B,cin,cout,H,W,stride", [(2, 128, 128, 36, 36, 1), (1, 768, 128, 180, 180, 1),
+                                                  (2, 128, 256, 36, 36, 2), (1, 64, 64, 20, 30, 1),
+                                                  (1, 256, 256, 90, 90, 1), (1, 128, 64, 9, 7, 2)])
+def test_dense_conv_bn_relu_matches_torch(dev, B, cin, cout, H, W, stride):
+    from isfusion_amd.dense_conv import PackedConvBN, SplitMap
+    conv = torch.nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(cout, eps=1e-3).eval()
+    conv.weight.data = rnd(conv.weight.shape, 90, (9 * cin) ** -0.5)
+    bn.weight.data, bn.bias.data = rnd((cout,), 91, 0.2) + 1, rnd((cout,), 92, 0.1)
+    bn.running_mean.data, bn.running_var.data = rnd((cout,), 93, 0.1), rnd((cout,), 94, 0.1).abs() + 0.8
+    x = rnd((B, cin, H, W), 95)
+    with torch.no_grad():
+        ref = F.relu(bn(conv(x.double().float())))
+        reft = F.relu(bn(conv(x.permute(0, 1, 3, 2)))).permute(0, 1, 3, 2)
+    pc = PackedConvBN(conv.to(dev), bn.to(dev), relu=True)
+    xd = x.to(dev)
+    maps = [SplitMap.from_nchw(xd, off, min(256, cin - off)) for off in range(0, cin, 256)]
+    got = pc(maps).to_nchw().cpu()
+    assert got.shape == ref.shape
+    # fp32-class arithmetic; MIOpen / oneDNN fp32 differ from each other by this much on K = 9*cin sums
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    if stride == 1:
+        gott = pc(maps, transpose=True).to_nchw().cpu()
+        assert (gott - reft).abs().max().item() < 3e-5 * max(1.0, reft.abs().max().item())
+
+
+def test_split_map_roundtrip_and_slices(dev):
+    from isfusion_amd.dense_conv import SplitMap
+    x = rnd((2, 320, 13, 11), 96, 3.0).to(dev)
+    a = SplitMap.from_nchw(x, 0, 256).to_nchw()
+    b = SplitMap.from_nchw(x, 256, 64).to_nchw()
+    got = torch.cat([a, b], 1)
+    assert (got - x).abs().max().item() <= 3.0 * 8 * 2.0 ** -21   # hi + lo f16 halves keep 22 bits
+
+
+def test_secondv2_hip_matches_stock(dev):
+    cfg = CONFIGS["small"]
+    _, bb = build_modules(cfg, dev)
+    x = rnd((2, 128, 36, 36), 97, 0.5).relu().to(dev)
+    with torch.no_grad():
+        nxt, _, f0 = bb([x], "stage1")
+        type(bb).dense_conv = "stock"
+        try:
+            snxt, _, sf0 = bb([x], "stage1")
+            s1 = bb([snxt], "stage2")[2]
+        finally:
+            type(bb).dense_conv = "hip"
+        h1 = bb([snxt], "stage2")[2]
+    assert (f0 - sf0).abs().max().item() < 1e-4 and (nxt - snxt).abs().max().item() < 1e-4
+    assert (h1 - s1).abs().max().item() < 1e-4
+
+
 # -------------------------------------------------------------------------------------- module-level parity
 @pytest.mark.parametrize("name", ["small", "full"])
 def test_grid_to_region_matches_restatement(dev, name):
@@ -231,15 +284,20 @@ def test_grid_to_region_matches_restatement(dev, name):
     assert (got - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("name", ["small", "full"])
-def test_fusion_encoder_matches_reference_golden(dev, golden, name):
-    """whole ISFusionEncoder.forward + SECONDV2 stages against the reference's own outputs"""
+@pytest.mark.parametrize("name,dense", [("small", "hip"), ("full", "hip"), ("small", "stock")])
+def test_fusion_encoder_matches_reference_golden(dev, golden, name, dense):
+    """whole ISFusionEncoder.forward + SECONDV2 stages against the reference's own outputs; the 3x3 dense convs on the
+    f16x3 MFMA kernel (default) or on stock PyTorch-ROCm"""
     g = golden("fusion_ref.npz")
     cfg = CONFIGS[name]
     enc, bb = build_modules(cfg, dev)
+    enc.dense_conv = dense
+    bb.dense_conv = dense          # instance attribute shadows the class default
     t = torch_inputs(cfg, dev)
     stages = {}
-    hs = [enc.conv_fusion.register_forward_hook(lambda m, i, o: stages.__setitem__("bev_feats", o.clone()))]
+    fuse = enc.fuse
+    enc.fuse = lambda a, b: stages.setdefault("bev_feats", fuse(a, b))
+    hs = []
     feats, hm = enc(t["img_feats"], t["lidar_feats"], cfg["B"],
                     pts_metas=dict(pillars=t["pillars"], pillar_coors=t["pillar_coors"]),
                     img_metas=[dict(input_shape=t["input_shape"])], pts_backbone=bb, lidar2img=t["lidar2img"],

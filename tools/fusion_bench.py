@@ -46,8 +46,7 @@ def main():
         res["frames_per_s"] = B / ms * 1e3
         ms, img_bev = timed(lambda: enc.img_fv_to_bev([t["img_feats"][1]], B, **kw), a.steps)
         res["p2g_ms"] = ms
-        x = torch.cat([img_bev, t["lidar_feats"]], 1)
-        ms, bev = timed(lambda: enc.conv_fusion(x), a.steps)
+        ms, bev = timed(lambda: enc.fuse(img_bev, t["lidar_feats"]), a.steps)
         res["conv_fusion_ms"] = ms
         ms, g0 = timed(lambda: enc.grid2region(0, bev), a.steps)
         res["g2r0_ms"] = ms
