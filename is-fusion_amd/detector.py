@@ -1,0 +1,88 @@
+"""The point-cloud half of ``ISFusionDetector`` (mmdet3d/models/detectors/isfusion.py:83-121, 148-176): everything
+between the raw sweeps (+ camera feature maps from the stock image backbone / neck) and the multi-scale BEV features
+the detection neck / head consume.
+
+    ISFusionPtsPath.extract_pts_feat(pts, img_feats, img_metas, lidar2img=..., img_aug_matrix=..., lidar_aug_matrix=...)
+        -> [f1 [B,128,180,180], f2 [B,256,90,90]]   (+ the instance heat-map when ``return_heatmap``)
+
+Same method names (``dynamic_voxelize`` is folded into the one-call LiDAR branch, ``voxelize(points, 'pillar')``,
+``isfusion``, ``extract_pts_feat``), same sub-module attribute names (``pts_voxel_encoder``, ``pts_middle_encoder``,
+``pts_pillar_layer``, ``fusion_encoder``, ``pts_backbone``) so a released checkpoint's ``pts_*`` / ``fusion_encoder.*``
+keys load unchanged.  The image backbone / necks and the bbox head stay stock (out of scope).
+"""
+import torch
+from torch import nn
+
+from .fusion_encoder import ISFusionEncoder
+from .fusion_modules import SECONDV2
+from .lidar_branch import ISFUSION_0075, LidarBranch
+from .voxelize import Voxelization
+
+ISFUSION_0075_FUSION = dict(
+    out_size_factor=8,
+    fusion_encoder=dict(num_points_in_pillar=12, embed_dims=256, bev_size=180, num_views=6,
+                        region_shape=[(6, 6, 1), (6, 6, 1)], grid_size=[[180, 180, 1], [90, 90, 1]],
+                        region_drop_info=[{0: {"max_tokens": 36, "drop_range": (0, 100000)}},
+                                          {0: {"max_tokens": 36, "drop_range": (0, 100000)}}],
+                        instance_num=200),
+    pts_backbone=dict(in_channels=128, out_channels=[128, 256], layer_nums=[5, 5], layer_strides=[1, 2],
+                      norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False)),
+)
+
+
+class ISFusionPtsPath(nn.Module):
+
+    def __init__(self, voxel_size=None, pc_range=None, pts_voxel_encoder=None, pts_middle_encoder=None,
+                 fusion_encoder=None, pts_backbone=None, out_size_factor=None):
+        super().__init__()
+        cfg = ISFUSION_0075
+        self.voxel_size = list(voxel_size or cfg["voxel_size"])
+        self.pc_range = list(pc_range or cfg["point_cloud_range"])
+        lidar = LidarBranch(self.voxel_size, self.pc_range, pts_voxel_encoder, pts_middle_encoder)
+        # the one-call engine is kept OUT of the module tree; its two sub-modules are registered here under the
+        # reference's attribute names (shared objects), so state-dict keys are pts_voxel_encoder.* / pts_middle_encoder.*
+        object.__setattr__(self, "_lidar", lidar)
+        self.pts_voxel_encoder = lidar.pts_voxel_encoder
+        self.pts_middle_encoder = lidar.pts_middle_encoder
+        fe = dict(fusion_encoder or ISFUSION_0075_FUSION["fusion_encoder"])
+        fe.pop("type", None)
+        self.fusion_encoder = ISFusionEncoder(**fe)
+        bb = dict(pts_backbone or ISFUSION_0075_FUSION["pts_backbone"])
+        bb.pop("type", None)
+        self.pts_backbone = SECONDV2(**bb)
+        osf = out_size_factor or ISFUSION_0075_FUSION["out_size_factor"]
+        # isfusion.py:45-51
+        self.pillar_size = [self.voxel_size[0] * osf, self.voxel_size[1] * osf, self.pc_range[5] - self.pc_range[2]]
+        self.pts_pillar_layer = Voxelization(max_num_points=self.fusion_encoder.num_points_in_pillar,
+                                             voxel_size=self.pillar_size, max_voxels=(30000, 60000),
+                                             point_cloud_range=self.pc_range)
+
+    @torch.no_grad()
+    def voxelize(self, points, voxel_type="pillar"):
+        """isfusion.py:148-176 (pillar branch): per-sample hard voxelization, batch index prepended."""
+        assert voxel_type == "pillar", "the fine grid is voxelized dynamically inside the LiDAR branch"
+        voxels, coors, num_points = [], [], []
+        for i, res in enumerate(points):
+            v, c, n = self.pts_pillar_layer(res)
+            voxels.append(v)
+            num_points.append(n)
+            coors.append(torch.nn.functional.pad(c, (1, 0), mode="constant", value=i))
+        return torch.cat(voxels, 0), torch.cat(num_points, 0), torch.cat(coors, 0)
+
+    def isfusion(self, pts, pts_feats, img_feats, img_metas, batch_size, **kwargs):
+        """isfusion.py:83-101"""
+        pillars, pillars_num_points, pillar_coors = self.voxelize(pts, voxel_type="pillar")
+        pts_metas = dict(pillars=pillars, pillars_num_points=pillars_num_points, pillar_coors=pillar_coors, pts=pts,
+                         pillar_size=self.pillar_size)
+        kwargs.update(dict(pts_metas=pts_metas, img_metas=img_metas, pts_backbone=self.pts_backbone))
+        return self.fusion_encoder(img_feats, pts_feats, batch_size, **kwargs)
+
+    @torch.no_grad()
+    def extract_pts_feat(self, pts, img_feats, img_metas, return_heatmap=False, **kwargs):
+        """isfusion.py:103-121 without the neck: dynamic voxelize + DynamicVFE + SparseEncoder (one C call), pillar
+        voxelization, ISFusionEncoder with the SECONDV2 stages."""
+        assert not self.training, "inference path (eval mode)"
+        self._lidar.train(False)
+        x = self._lidar(pts)
+        feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)
+        return (feats, ins_heatmap) if return_heatmap else feats
