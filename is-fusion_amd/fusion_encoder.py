@@ -95,7 +95,12 @@ class ISFusionEncoder(nn.Module):
             m = SplitMap.from_nchw(bev_feats)
             t = self._conv("heatmap_head_2")(self._conv("heatmap_head_1")(self._conv("conv_heatmap")(m, True), True),
                                              True).to_nchw()                         # un-transposed orientation
-            hm = self.heatmap_head_3(t.permute(0, 1, 3, 2))                          # 64 -> 10 channels: stock conv
+            # 64 -> 10 channels (below the MFMA tile): stock conv, again with the transposed taps on the contiguous
+            # un-transposed map (a permuted *view* would send MIOpen to its naive non-packed kernel: 3 ms), then the
+            # 10-channel result is transposed into the orientation the reference returns
+            h3 = self.heatmap_head_3
+            hm = torch.nn.functional.conv2d(t, h3.weight.transpose(2, 3).contiguous(), h3.bias, 1, 1)
+            hm = hm.permute(0, 1, 3, 2).contiguous()
             x_scene_t = self._conv("conv_scene")(m, True).to_nchw()                   # = conv_scene(out)^T
             q = self._conv("conv_ins")(m).to_nchw()
         else:
