@@ -185,8 +185,10 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * Same contract as isf_sparse_conv_forward_packed, evaluated on the f16 matrix cores with fp32-equivalent
  * accuracy: operands are carried as hi + lo f16 halves (22 significant bits), products as
  * a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with fp32 accumulation.  Activations are exchanged in the SPLIT format:
- * row-major [N, C/8] units of 32 bytes = 8 x f16 hi followed by 8 x f16 lo (same 4 bytes/element as fp32);
- * isf_f32_to_split / isf_split_to_f32 convert.  |activation| must be < 65504.  Cin, Cout in {32,64,128,256}.
+ * row-major [N, C/32] chunks of 128 bytes, a chunk = 32 channels as 4 x (8 f16 hi) followed by 4 x (8 f16 lo)
+ * (same 4 bytes/element as fp32; the 16-byte pieces the four k-group lanes of an MFMA row fetch together are
+ * contiguous); isf_f32_to_split / isf_split_to_f32 convert ([N, C] row-major fp32, N*C a multiple of 32).
+ * |activation| must be < 65504.  Cin, Cout in {32,64,128,256}.
  * isf_set_conv_precision(0) (default): isf_sparse_encoder_forward / isf_lidar_branch_forward use this path
  * when every layer carries packed16; isf_set_conv_precision(1) forces the fp32 MFMA kernels. */
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);

@@ -95,6 +95,17 @@ __device__ __forceinline__ int occ_lookup(const unsigned long long* __restrict__
   return (int)(prefix[w] + (uint32_t)__popcll(word & (bit - 1)));
 }
 
+// ----------------------------------------------------------------------------- split activation format
+// Row-major [N][C/32] chunks of 128 bytes; a chunk holds 32 channels as 4 x (8 f16 hi) followed by 4 x (8 f16 lo)
+// (value = hi + lo).  The four 16-byte hi pieces of a chunk -- what the four k-group lanes of one MFMA row fetch
+// with ONE load instruction -- are contiguous (64 B), and so are the lo pieces: the texture addresser coalesces a
+// row's lanes into one request.  (Interleaving hi|lo per 8 channels made every lane a separate 16-byte request at
+// a 32-byte stride: 64 requests per gather instruction instead of 16.)
+// Index, in 16-byte units, of the hi piece of 8-channel unit u of `row` (c_units = C/8); the lo piece is +4.
+__host__ __device__ inline size_t split_hi_index(size_t row, int c_units, int u) {
+  return (row * (size_t)c_units + (size_t)(u & ~3)) * 2 + (size_t)(u & 3);
+}
+
 // ----------------------------------------------------------------------------- internal ops (arena-aware)
 // isf_voxelize.hip
 int dynamic_voxelize_impl(const float* points, int P, int C, const float vs[3], const float range[6],

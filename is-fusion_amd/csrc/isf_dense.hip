@@ -7,7 +7,7 @@
 // fp32 Winograd kernel + BatchNorm kernel + ReLU kernel per layer.
 //
 // This file: the arithmetic rulebook and the two layout kernels between [B, C, H, W] fp32 maps and the split-format
-// token matrix ([B*H*W, C/8] units of 8 f16 hi | 8 f16 lo) the conv kernel reads and writes.
+// token matrix (isf_common.h, "split activation format") the conv kernel reads and writes.
 #include "isf_common.h"
 
 namespace isf {
@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void nchw_to_split_kernel(const float* __restr
     const h8 hi = __builtin_convertvector(v, h8);
     const f32x8 r = v - __builtin_convertvector(hi, f32x8);
     const h8 lo = __builtin_convertvector(r, h8);
-    const size_t o = (((size_t)b * HW + p0 + p) * out_units + unit0 + u) * 2;
+    const size_t o = split_hi_index((size_t)b * HW + p0 + p, out_units, unit0 + u);
     out[o] = *reinterpret_cast<const uint4*>(&hi);
-    out[o + 1] = *reinterpret_cast<const uint4*>(&lo);
+    out[o + 4] = *reinterpret_cast<const uint4*>(&lo);
   }
 }
 
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void split_to_nchw_kernel(const uint4* __restr
   for (int i = threadIdx.x; i < 32 * units; i += 256) {
     const int p = i / units, u = i - p * units;
     if (p0 + p >= HW) continue;
-    const size_t o = (((size_t)b * HW + p0 + p) * units + u) * 2;
-    const uint4 hu = xs[o], lu = xs[o + 1];
+    const size_t o = split_hi_index((size_t)b * HW + p0 + p, units, u);
+    const uint4 hu = xs[o], lu = xs[o + 4];
     const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(&hu), f32x8) +
                     __builtin_convertvector(*reinterpret_cast<const h8*>(&lu), f32x8);
 #pragma unroll
@@ -115,10 +115,10 @@ int isf_nchw_to_split(const float* x, int batch_size, int x_channels, int x_chan
   ISF_REQUIRE(batch_size >= 0 && channels > 0 && hw > 0, ISF_ERR_ARG, "nchw_to_split: bad sizes");
   if (batch_size == 0) return ISF_OK;
   ISF_REQUIRE(x && out_split, ISF_ERR_ARG, "nchw_to_split: null pointer");
-  ISF_REQUIRE(channels % 8 == 0 && out_channels % 8 == 0 && channel_offset % 8 == 0 &&
+  ISF_REQUIRE(channels % 32 == 0 && out_channels % 32 == 0 && channel_offset % 32 == 0 &&
                   channel_offset + channels <= out_channels && channels <= 256 && x_channel_offset >= 0 &&
                   x_channel_offset + channels <= x_channels,
-              ISF_ERR_UNSUPPORTED, "nchw_to_split: channel counts must be multiples of 8, <= 256 per call");
+              ISF_ERR_UNSUPPORTED, "nchw_to_split: channel counts must be multiples of 32, <= 256 per call");
   hipLaunchKernelGGL(nchw_to_split_kernel, dim3(ceil_div(hw, 32), batch_size), dim3(256),
                      (size_t)32 * (channels + 1) * sizeof(float), as_stream(stream), x, x_channels, x_channel_offset,
                      channels, hw, reinterpret_cast<uint4*>(out_split), out_channels / 8, channel_offset / 8);
@@ -131,8 +131,8 @@ int isf_split_to_nchw(const void* x_split, int batch_size, int channels, int hw,
   ISF_REQUIRE(batch_size >= 0 && channels > 0 && hw > 0, ISF_ERR_ARG, "split_to_nchw: bad sizes");
   if (batch_size == 0) return ISF_OK;
   ISF_REQUIRE(x_split && out, ISF_ERR_ARG, "split_to_nchw: null pointer");
-  ISF_REQUIRE(channels % 8 == 0 && channels <= 256, ISF_ERR_UNSUPPORTED,
-              "split_to_nchw: channels must be a multiple of 8 (<= 256)");
+  ISF_REQUIRE(channels % 32 == 0 && channels <= 256, ISF_ERR_UNSUPPORTED,
+              "split_to_nchw: channels must be a multiple of 32 (<= 256)");
   hipLaunchKernelGGL(split_to_nchw_kernel, dim3(ceil_div(hw, 32), batch_size), dim3(256),
                      (size_t)32 * (channels + 1) * sizeof(float), as_stream(stream),
                      reinterpret_cast<const uint4*>(x_split), channels, hw, out);

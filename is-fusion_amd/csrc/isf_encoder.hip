@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__
           const int r = rows[xx];
           float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if (r >= 0 && c0 + u * 8 < C) {
-            const uint4* p = fs + ((size_t)r * (C >> 3) + (c0 >> 3) + u) * 2;
-            const uint4 hi = p[0], lo = p[1];
+            const size_t o = split_hi_index((size_t)r, C >> 3, (c0 >> 3) + u);
+            const uint4 hi = fs[o], lo = fs[o + 4];
             const _Float16* h = reinterpret_cast<const _Float16*>(&hi);
             const _Float16* l = reinterpret_cast<const _Float16*>(&lo);
 #pragma unroll
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__
 
 int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int32_t* indices, int n, int C,
                              int B, int D, int H, int W, float* out, const OccIndex* occ_in, hipStream_t st) {
-  ISF_REQUIRE(C % (split ? 8 : 4) == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of %d", C,
-              split ? 8 : 4);
+  ISF_REQUIRE(C % (split ? 32 : 4) == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of %d", C,
+              split ? 32 : 4);
   OccIndex occ;
   const int32_t* perm = nullptr;
   if (occ_in) {

@@ -7,7 +7,7 @@
 // MFMA pipe is 16x the fp32 MFMA rate on gfx950 (2.5 PFLOP/s vs 157 TFLOP/s dense), so three passes are
 // still 5.3x the fp32 matrix rate.  Weights are scaled by a power of two at pack time so their low halves
 // stay in the normal f16 range; activations are stored between layers already split (same 4 B/element as
-// fp32), so the inner loop has no conversions at all.  |activation| must stay below 65504 (f16 max):
+// fp32; layout: isf_common.h, "split activation format"), so the inner loop has no conversions at all.  |activation| must stay below 65504 (f16 max):
 // outside that range the result is inf/NaN, never silently wrong.
 //
 // Structure (register-stationary; differs from the fp32 kernel in isf_spconv.hip):
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         if (idx >= 0) {
 #pragma unroll
           for (int kc = 0; kc < KCH; ++kc) {
-            const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4 + kg) * 2;
-            a_nxt[rg][kc][0] = p[0];
-            a_nxt[rg][kc][1] = p[1];
+            const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4) * 2 + kg;   // chunk base + k-group
+            a_nxt[rg][kc][0] = p[0];   // 4 contiguous hi pieces per row and instruction
+            a_nxt[rg][kc][1] = p[4];   // 4 contiguous lo pieces
           }
         }
       }
@@ -329,8 +329,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
             const float sh = shift ? shift[gc + j] : 0.f;
             v[j] = fmaf(v[j], sc, sh);
           }
-          const size_t o = ((size_t)grow * (cout >> 3) + (gc >> 3)) * 2;
-          if (residual) v += join8(residual[o], residual[o + 1]);
+          const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
+          if (residual) v += join8(residual[o], residual[o + 4]);
           if (relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
           uint4 hi, lo;
           split8(v, hi, lo);
           ys[o] = hi;
-          ys[o + 1] = lo;
+          ys[o + 4] = lo;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -353,14 +353,16 @@ __global__ void f32_to_split_kernel(const float* __restrict__ x, size_t n8, uint
   const f32x8 v = *reinterpret_cast<const f32x8*>(x + i * 8);
   uint4 hi, lo;
   split8(v, hi, lo);
-  xs[i * 2] = hi;
-  xs[i * 2 + 1] = lo;
+  const size_t o = (i >> 2) * 8 + (i & 3);   // element counts are multiples of 32: chunks never straddle rows
+  xs[o] = hi;
+  xs[o + 4] = lo;
 }
 
 __global__ void split_to_f32_kernel(const uint4* __restrict__ xs, size_t n8, float* __restrict__ x) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
-  *reinterpret_cast<f32x8*>(x + i * 8) = join8(xs[i * 2], xs[i * 2 + 1]);
+  const size_t o = (i >> 2) * 8 + (i & 3);
+  *reinterpret_cast<f32x8*>(x + i * 8) = join8(xs[o], xs[o + 4]);
 }
 
 __global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
@@ -526,7 +528,7 @@ int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void
 
 int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st) {
   if (n_elems == 0) return ISF_OK;
-  ISF_REQUIRE(n_elems % 8 == 0, ISF_ERR_ARG, "f32_to_split: element count must be a multiple of 8");
+  ISF_REQUIRE(n_elems % 32 == 0, ISF_ERR_ARG, "f32_to_split: element count must be a multiple of 32");
   hipLaunchKernelGGL(f32_to_split_kernel, dim3(ceil_div((long long)(n_elems / 8), 256)), dim3(256), 0, st, x,
                      n_elems / 8, reinterpret_cast<uint4*>(xs));
   ISF_LAUNCH_CHECK();
@@ -535,7 +537,7 @@ int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st) 
 
 int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st) {
   if (n_elems == 0) return ISF_OK;
-  ISF_REQUIRE(n_elems % 8 == 0, ISF_ERR_ARG, "split_to_f32: element count must be a multiple of 8");
+  ISF_REQUIRE(n_elems % 32 == 0, ISF_ERR_ARG, "split_to_f32: element count must be a multiple of 32");
   hipLaunchKernelGGL(split_to_f32_kernel, dim3(ceil_div((long long)(n_elems / 8), 256)), dim3(256), 0, st,
                      reinterpret_cast<const uint4*>(xs), n_elems / 8, x);
   ISF_LAUNCH_CHECK();

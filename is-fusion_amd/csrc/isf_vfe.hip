@@ -103,19 +103,34 @@ __global__ __launch_bounds__(256) void vfe_count_kernel(const int32_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void vfe_order_kernel(const int32_t* __restrict__ pt2vox,
+// Points are copied ONCE into voxel-sorted 32-byte records {CIN features, voxel id}: the three per-point passes
+// (mean, layer 1, layer 2) then stream contiguous records instead of gathering points / coords / voxel ids through
+// an index (measured FETCH_SIZE of the gathering version: 146 + 328 + 437 MB for 24 MB of points).
+static constexpr int kRec = 8;   // floats per record
+template <int CIN>
+__global__ __launch_bounds__(256) void vfe_order_kernel(const float* __restrict__ points,
+                                                        const int32_t* __restrict__ pt2vox,
                                                         const int32_t* __restrict__ slot, int P,
                                                         const uint32_t* __restrict__ start,
-                                                        int32_t* __restrict__ order) {
+                                                        float* __restrict__ recs) {
+  static_assert(CIN + 1 <= kRec, "record too small");
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   const int v = pt2vox[i];
-  if (v >= 0) order[start[v] + slot[i]] = i;
+  if (v < 0) return;
+  float r[kRec];
+#pragma unroll
+  for (int k = 0; k < kRec; ++k) r[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < CIN; ++k) r[k] = points[(size_t)i * CIN + k];
+  r[kRec - 1] = __int_as_float(v);
+  float4* o = reinterpret_cast<float4*>(recs + (size_t)(start[v] + slot[i]) * kRec);
+  o[0] = make_float4(r[0], r[1], r[2], r[3]);
+  o[1] = make_float4(r[4], r[5], r[6], r[7]);
 }
 
 template <int CIN>
-__global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__ points,
-                                                       const int32_t* __restrict__ order,
+__global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__ recs,
                                                        const uint32_t* __restrict__ start, int N,
                                                        float4* __restrict__ mean4) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__
   const uint32_t j0 = start[v], j1 = start[v + 1];
   long long sx = 0, sy = 0, sz = 0;
   for (uint32_t j = j0; j < j1; ++j) {
-    const float* p = points + (size_t)order[j] * CIN;
+    const float* p = recs + (size_t)j * kRec;
     sx += __double2ll_rn((double)p[0] * kFix);
     sy += __double2ll_rn((double)p[1] * kFix);
     sz += __double2ll_rn((double)p[2] * kFix);
@@ -194,9 +209,8 @@ __device__ __forceinline__ void vfe_segmented_max(const int* __restrict__ vox, u
 
 template <int CIN>
 __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
-    const float* __restrict__ points, const int32_t* __restrict__ coors4, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ pt2vox, const int* __restrict__ n_valid, const uint32_t* __restrict__ start,
-    const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
+    const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
+    const uint32_t* __restrict__ start, const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
     const float* __restrict__ scale1, const float* __restrict__ shift1, float* __restrict__ vmax1) {
   __shared__ float tile[kL1Threads * kLdsStride];
   __shared__ int vox[kL1Threads];
@@ -204,10 +218,12 @@ __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
   const uint32_t j = blockIdx.x * kL1Threads + t;
   int v = -1;
   if (j < (uint32_t)*n_valid) {
-    const int i = order[j];
-    v = pt2vox[i];
+    float rec[kRec];
+    *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
+    *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
+    v = __float_as_int(rec[kRec - 1]);
     float f[CIN + 6], h[kC];
-    vfe_point_features<CIN>(points + (size_t)i * CIN, reinterpret_cast<const int4*>(coors4)[i], mean4[v], g, f);
+    vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
     vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
 #pragma unroll
     for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = h[o];
@@ -229,9 +245,8 @@ static constexpr int kL2WaveBytes = 64 * kLdsStride * 4;  // 16640 >= 16384
 
 template <int CIN>
 __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
-    const float* __restrict__ points, const int32_t* __restrict__ coors4, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ pt2vox, const int* __restrict__ n_valid, const uint32_t* __restrict__ start,
-    const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
+    const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
+    const uint32_t* __restrict__ start, const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
     const float* __restrict__ scale1, const float* __restrict__ shift1, const float* __restrict__ vmax1,
     const uint4* __restrict__ w2p, const float* __restrict__ sc2, const float* __restrict__ shift2,
     float* __restrict__ out) {
@@ -251,10 +266,12 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
   int v = -1;
   float h[kC];
   if (j < nv) {
-    const int i = order[j];
-    v = pt2vox[i];
+    float rec[kRec];
+    *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
+    *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
+    v = __float_as_int(rec[kRec - 1]);
     float f[CIN + 6];
-    vfe_point_features<CIN>(points + (size_t)i * CIN, reinterpret_cast<const int4*>(coors4)[i], mean4[v], g, f);
+    vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
     vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
   } else {
 #pragma unroll
@@ -372,12 +389,13 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   }
   int32_t* pt2vox = pt2vox_out;
   if (!pt2vox) ISF_TRY(a.alloc_n(&pt2vox, (size_t)P));
-  int32_t *slot, *order;
+  int32_t* slot;
+  float* recs;
   uint32_t *cnt, *start;
   float4* mean4;
   float* vmax1;
   ISF_TRY(a.alloc_n(&slot, (size_t)P));
-  ISF_TRY(a.alloc_n(&order, (size_t)P));
+  ISF_TRY(a.alloc_n(&recs, (size_t)P * kRec));
   ISF_TRY(a.alloc_n(&cnt, (size_t)N + 1));
   ISF_TRY(a.alloc_n(&start, (size_t)N + 2));
   ISF_TRY(a.alloc_n(&mean4, (size_t)N));
@@ -389,15 +407,14 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
                      occ.bits, occ.prefix, pt2vox, slot, cnt, voxel_coors);
   ISF_LAUNCH_CHECK();
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
-  hipLaunchKernelGGL(vfe_order_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, pt2vox, slot, P, start, order);
-  hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(N, 256)), dim3(256), 0, st, points, order, start, N,
-                     mean4);
+  hipLaunchKernelGGL(vfe_order_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, pt2vox, slot, P, start,
+                     recs);
+  hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(N, 256)), dim3(256), 0, st, recs, start, N, mean4);
   const int* n_valid = reinterpret_cast<const int*>(start + N);
-  hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, points,
-                     coors4, order, pt2vox, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1);
-  hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st,
-                     points, coors4, order, pt2vox, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1, w2p, sc2,
-                     shift2, voxel_feats);
+  hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, recs,
+                     voxel_coors, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1);
+  hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st, recs,
+                     voxel_coors, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1, w2p, sc2, shift2, voxel_feats);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
