@@ -145,9 +145,21 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   const int ntiles_total = cout >> 4;
 
   // ---- prologue: neighbour tile -> LDS, per-wave tap mask
-  for (int i = tid; i < K * TM; i += NTHR) {
-    const int k = i / TM, r = i - k * TM;
-    nbr_l[i] = row0 + r < nbr_stride ? nbr[(size_t)k * nbr_stride + row0 + r] : -1;   // stride = round_up(n, 128)
+  {   // all loads first, then all LDS stores (a load -> wait -> store loop costs one L2 round trip per iteration)
+    constexpr int NB_IT = (kMaxTaps * TM + NTHR - 1) / NTHR;
+    int tmp[NB_IT];
+#pragma unroll
+    for (int it = 0; it < NB_IT; ++it) {
+      const int i = tid + it * NTHR;
+      const int k = i / TM, r = i - k * TM;
+      tmp[it] = -1;   // stride = round_up(n, 128): rows beyond it have no neighbours
+      if (i < K * TM && row0 + r < nbr_stride) tmp[it] = nbr[(size_t)k * nbr_stride + row0 + r];
+    }
+#pragma unroll
+    for (int it = 0; it < NB_IT; ++it) {
+      const int i = tid + it * NTHR;
+      if (i < K * TM) nbr_l[i] = tmp[it];
+    }
   }
   __syncthreads();
   // per-row-group tap masks (bit k: some row of the 16-row group has a neighbour through tap k), wave-uniform
@@ -307,17 +319,35 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   for (int rg = 0; rg < RG; ++rg) {
 #pragma unroll
     for (int ps = 0; ps < NT / EPN; ++ps) {  // passes of EPN column tiles (keeps the transpose tile small)
+      constexpr int UNITS = (16 * EPN) / 8;           // 8-channel units per row in this pass
+      constexpr int ITEMS = (16 * UNITS + 63) / 64;   // (row, unit) items per lane
+      // the residual rows of this pass are requested before the LDS transpose, so their latency hides behind it
+      uint4 res_hi[ITEMS], res_lo[ITEMS];
+      if (residual) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+          const int i = lane + 64 * it;
+          const int grow = row0 + wave * WR + rg * 16 + i / UNITS;
+          res_hi[it] = make_uint4(0, 0, 0, 0);
+          res_lo[it] = make_uint4(0, 0, 0, 0);
+          if (i < 16 * UNITS && grow < n_out) {
+            const size_t o = split_hi_index((size_t)grow, cout >> 3, (cb * BN + ps * (16 * EPN)) / 8 + i % UNITS);
+            res_hi[it] = residual[o];
+            res_lo[it] = residual[o + 4];
+          }
+        }
+      }
 #pragma unroll
       for (int nt = 0; nt < EPN; ++nt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) tile_l[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][ps * EPN + nt][t];
       // wave-private tile: a wave-level fence is enough (LDS ops of one wave complete in order)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      constexpr int UNITS = (16 * EPN) / 8;  // 8-channel units per row in this pass
-      for (int i = lane; i < 16 * UNITS; i += 64) {
+      for (int it = 0; it < ITEMS; ++it) {
+        const int i = lane + 64 * it;
         const int r = i / UNITS, u = i % UNITS;
         const int grow = row0 + wave * WR + rg * 16 + r;
-        if (grow < n_out) {
+        if (i < 16 * UNITS && grow < n_out) {
           const float* tp = tile_l + r * RS + u * 8;
           f32x8 v;
 #pragma unroll
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
             v[j] = fmaf(v[j], sc, sh);
           }
           const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
-          if (residual) v += join8(residual[o], residual[o + 4]);
+          if (residual) v += join8(res_hi[it], res_lo[it]);
           if (relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
