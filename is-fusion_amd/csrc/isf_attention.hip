@@ -140,6 +140,89 @@ __global__ __launch_bounds__(256) void small_key_attention_kernel(const float* _
     *reinterpret_cast<float4*>(op + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Many keys, few queries (TransFusion head: 200 queries x 32400 BEV keys, transfusion_head_v2.py:104-106): the keys
+// are split into chunks of <= 512 (one workgroup per (query tile, head, batch x chunk), chunk resident in LDS); each
+// thread runs the online softmax of its query over the chunk and writes (max, sum, unnormalised output); a second
+// kernel merges the chunks.  part: [B][heads][nsplit][Lq][HD + 2].
+template <int HD>
+__global__ __launch_bounds__(256) void split_key_attention_kernel(const float* __restrict__ q, int ldq,
+                                                                  const float* __restrict__ k,
+                                                                  const float* __restrict__ v, int ldk, int Lq,
+                                                                  int Lk, int kps, int nsplit, float scale,
+                                                                  float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int head = blockIdx.y, b = blockIdx.z / nsplit, sp = blockIdx.z % nsplit;
+  const int k0 = sp * kps;
+  const int kn = min(kps, Lk - k0);
+  float* ks = smem;
+  float* vs = smem + (size_t)kps * HD;
+  for (int i = threadIdx.x; i < kn * (HD / 4); i += blockDim.x) {
+    const int j = i / (HD / 4), c = (i % (HD / 4)) * 4;
+    const size_t off = ((size_t)b * Lk + k0 + j) * ldk + head * HD + c;
+    *reinterpret_cast<float4*>(ks + j * HD + c) = *reinterpret_cast<const float4*>(k + off);
+    *reinterpret_cast<float4*>(vs + j * HD + c) = *reinterpret_cast<const float4*>(v + off);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= Lq) return;
+  float qr[HD], o[HD];
+  const float* qp = q + ((size_t)b * Lq + qi) * ldq + head * HD;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(qp + c);
+    qr[c] = t.x * scale; qr[c + 1] = t.y * scale; qr[c + 2] = t.z * scale; qr[c + 3] = t.w * scale;
+    o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
+  }
+  float m = -INFINITY, sum = 0.f;
+  for (int j = 0; j < kn; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 kk = *reinterpret_cast<const float4*>(ks + j * HD + c);
+      a = fmaf(qr[c], kk.x, a); a = fmaf(qr[c + 1], kk.y, a); a = fmaf(qr[c + 2], kk.z, a); a = fmaf(qr[c + 3], kk.w, a);
+    }
+    const float mn = fmaxf(m, a);
+    const float corr = __expf(m - mn);
+    const float p = __expf(a - mn);
+    sum = sum * corr + p;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      const float4 vv = *reinterpret_cast<const float4*>(vs + j * HD + c);
+      o[c] = fmaf(p, vv.x, o[c] * corr); o[c + 1] = fmaf(p, vv.y, o[c + 1] * corr);
+      o[c + 2] = fmaf(p, vv.z, o[c + 2] * corr); o[c + 3] = fmaf(p, vv.w, o[c + 3] * corr);
+    }
+    m = mn;
+  }
+  float* pp = part + ((((size_t)b * gridDim.y + head) * nsplit + sp) * Lq + qi) * (HD + 2);
+  pp[0] = m;
+  pp[1] = sum;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) pp[2 + c] = o[c];
+}
+
+template <int HD>
+__global__ void merge_key_splits_kernel(const float* __restrict__ part, int B, int heads, int nsplit, int Lq,
+                                        float* __restrict__ out, int ldo) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)B * heads * Lq * HD) return;
+  const int c = (int)(t % HD);
+  const int qi = (int)((t / HD) % Lq);
+  const int head = (int)((t / ((long long)HD * Lq)) % heads);
+  const int b = (int)(t / ((long long)HD * Lq * heads));
+  const float* pb = part + (((size_t)b * heads + head) * nsplit * Lq + qi) * (HD + 2);
+  const size_t sstride = (size_t)Lq * (HD + 2);
+  float M = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pb[s * sstride]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = __expf(pb[s * sstride] - M);
+    den = fmaf(pb[s * sstride + 1], w, den);
+    num = fmaf(pb[s * sstride + 2 + c], w, num);
+  }
+  out[((size_t)b * Lq + qi) * ldo + head * HD + c] = num / den;
+}
+
 }  // namespace isf
 
 extern "C" {
@@ -186,8 +269,40 @@ int isf_attention_forward(const float* q, int ldq, const float* k, const float* 
   ISF_REQUIRE(embed_dims % num_heads == 0 && ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0, ISF_ERR_ARG,
               "attention: strides must be multiples of 4 floats");
   const int hd = embed_dims / num_heads;
-  ISF_REQUIRE((hd == 16 || hd == 32) && num_keys <= 512, ISF_ERR_UNSUPPORTED,
-              "attention: built for head_dim 16/32 and <= 512 keys (got %d, %d)", hd, num_keys);
+  ISF_REQUIRE(hd == 16 || hd == 32, ISF_ERR_UNSUPPORTED, "attention: built for head_dim 16 / 32 (got %d)", hd);
+  if (num_keys > 512) {   // keys split into <= 512-key chunks + merge
+    hipStream_t st = as_stream(stream);
+    const int kps = 512, nsplit = ceil_div(num_keys, kps);
+    Arena& a = arena_for_current_device();
+    ISF_TRY(a.reset());
+    float* part = nullptr;
+    ISF_TRY(a.alloc_n(&part, (size_t)batch_size * num_heads * nsplit * num_queries * (hd + 2)));
+    static bool split_attr_set = false;
+    if (!split_attr_set) {
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&split_key_attention_kernel<16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&split_key_attention_kernel<32>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      split_attr_set = true;
+    }
+    const dim3 grid(ceil_div(num_queries, 256), num_heads, batch_size * nsplit), block(256);
+    const size_t lds = (size_t)kps * hd * 2 * sizeof(float);
+    const float scale = 1.0f / sqrtf((float)hd);
+    const long long total = (long long)batch_size * num_heads * num_queries * hd;
+    if (hd == 16) {
+      hipLaunchKernelGGL((split_key_attention_kernel<16>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries,
+                         num_keys, kps, nsplit, scale, part);
+      hipLaunchKernelGGL((merge_key_splits_kernel<16>), dim3(ceil_div(total, 256)), dim3(256), 0, st, part, batch_size,
+                         num_heads, nsplit, num_queries, out, ldo);
+    } else {
+      hipLaunchKernelGGL((split_key_attention_kernel<32>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries,
+                         num_keys, kps, nsplit, scale, part);
+      hipLaunchKernelGGL((merge_key_splits_kernel<32>), dim3(ceil_div(total, 256)), dim3(256), 0, st, part, batch_size,
+                         num_heads, nsplit, num_queries, out, ldo);
+    }
+    ISF_LAUNCH_CHECK();
+    return ISF_OK;
+  }
   const dim3 grid(ceil_div(num_queries, 256), num_heads, batch_size), block(256);
   const size_t lds = (size_t)num_keys * hd * 2 * sizeof(float);
   const float scale = 1.0f / sqrtf((float)hd);

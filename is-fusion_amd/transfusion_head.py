@@ -1,0 +1,211 @@
+"""TransFusionHeadV2.forward_single (mmdet3d/models/dense_heads/transfusion_head_v2.py:771-892):
+BEV feature map [B, 512, 180, 180] -> shared conv -> heat-map -> sigmoid + 3x3 NMS + top-200 proposals (the same fused
+kernel as the encoder's instance mining) -> one transformer decoder layer (200-query self-attention, 200 x 32400
+cross-attention over the BEV map with learned position embeddings, FFN) -> per-proposal regression / class heads.
+
+Parameter / sub-module names equal the reference's (96 state-dict keys; checked with ``load_state_dict(strict=True)``
+into the reference class in tests/golden/make_golden_head.py).  Inference forward only: losses, target assignment and box
+decoding (``loss``, ``get_targets``, ``get_bboxes``) are control plane around this path and are not built.
+
+HIP path: the two 3x3 convs on the f16x3 sparse-conv kernel over the dense grid, top-k through ``isf_instance_topk``,
+all Linear layers through ``isf_linear_forward`` (the key / value projection of the 32400 x B BEV tokens folds the
+learned key position embedding into a per-cell table), attention through ``isf_attention_forward`` (keys split into
+512-key chunks + merge).  The 2 -> 128 position MLPs, the 128 -> 10 heat-map conv and the Conv1d prediction heads on 200
+proposals stay stock torch ops (tiny, channel counts below the MFMA tile).
+"""
+import copy
+
+import torch
+from torch import nn
+
+from . import fusion_ops as ops
+from .dense_conv import PackedConvBN, SplitMap
+from .fusion_modules import PositionEmbeddingLearned, _SelfAttn
+from .spconv import from_split
+
+
+class _ConvModule1d(nn.Sequential):
+    """mmcv ConvModule(conv_cfg=Conv1d, norm_cfg=BN1d, bias='auto'): conv (no bias) / bn / activate"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("conv", nn.Conv1d(cin, cout, 1, bias=False))
+        self.add_module("bn", nn.BatchNorm1d(cout))
+        self.add_module("activate", nn.ReLU(inplace=True))
+
+
+class _ConvModule2d(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.add_module("conv", nn.Conv2d(cin, cout, 3, padding=1, bias=False))
+        self.add_module("bn", nn.BatchNorm2d(cout))
+        self.add_module("activate", nn.ReLU(inplace=True))
+
+
+class FFN(nn.Module):
+    """transfusion_head_v2.py:505-590: one Conv1d stack per output (`center`, `height`, ...)"""
+
+    def __init__(self, in_channels, heads, head_conv=64):
+        super().__init__()
+        self.heads = heads
+        for head, (classes, num_conv) in heads.items():
+            layers, c = [], in_channels
+            for _ in range(num_conv - 1):
+                layers.append(_ConvModule1d(c, head_conv))
+                c = head_conv
+            layers.append(nn.Conv1d(c, classes, 1))
+            setattr(self, head, nn.Sequential(*layers))
+
+    def forward(self, x):
+        return {head: getattr(self, head)(x) for head in self.heads}
+
+
+class TransformerDecoderLayer(nn.Module):
+    """transfusion_head_v2.py:42-120 parameter layout"""
+
+    def __init__(self, d_model, nhead, dim_feedforward):
+        super().__init__()
+        self.nhead = nhead
+        self.self_attn = _SelfAttn(d_model)
+        self.multihead_attn = _SelfAttn(d_model)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.self_posembed = PositionEmbeddingLearned(2, d_model)
+        self.cross_posembed = PositionEmbeddingLearned(2, d_model)
+
+
+class TransFusionHeadV2(nn.Module):
+
+    def __init__(self, num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+                 num_decoder_layers=1, num_heads=8, nms_kernel_size=3, ffn_channel=256, common_heads=None,
+                 num_heatmap_convs=2, test_cfg=None, dense_conv="hip", **kwargs):
+        super().__init__()
+        self.num_classes, self.num_proposals, self.auxiliary = num_classes, num_proposals, auxiliary
+        self.num_heads, self.num_decoder_layers, self.nms_kernel_size = num_heads, num_decoder_layers, nms_kernel_size
+        self.test_cfg = test_cfg or dict(dataset="nuScenes", grid_size=[1440, 1440, 40], out_size_factor=8)
+        self.dense_conv = dense_conv
+        common_heads = common_heads or dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))
+        self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1, bias=True)
+        self.heatmap_head = nn.Sequential(_ConvModule2d(hidden_channel, hidden_channel),
+                                          nn.Conv2d(hidden_channel, num_classes, 3, padding=1, bias=True))
+        self.class_encoding = nn.Conv1d(num_classes, hidden_channel, 1)
+        self.decoder = nn.ModuleList([TransformerDecoderLayer(hidden_channel, num_heads, ffn_channel)
+                                      for _ in range(num_decoder_layers)])
+        self.prediction_heads = nn.ModuleList()
+        for _ in range(num_decoder_layers):
+            heads = copy.deepcopy(common_heads)
+            heads.update(dict(heatmap=(num_classes, num_heatmap_convs)))
+            self.prediction_heads.append(FFN(hidden_channel, heads))
+        self.x_size = self.test_cfg["grid_size"][0] // self.test_cfg["out_size_factor"]
+        self.y_size = self.test_cfg["grid_size"][1] // self.test_cfg["out_size_factor"]
+
+    # ------------------------------------------------------------------------------------------------ pieces
+    def _bev_pos(self, device):
+        """create_2D_grid (:728-738): [1, X*Y, 2] cell centres, cell n = i*Y + j -> (i + .5, j + .5)"""
+        gx = torch.linspace(0, self.x_size - 1, self.x_size, device=device) + 0.5
+        gy = torch.linspace(0, self.y_size - 1, self.y_size, device=device) + 0.5
+        bx, by = torch.meshgrid(gx, gy, indexing="ij")
+        return torch.stack([bx, by], 0).view(1, 2, -1).permute(0, 2, 1)
+
+    def _packed(self, device):
+        c = self.__dict__.setdefault("_isf_packed", {})
+        if c.get("device") != device:
+            c.clear()
+            c["device"] = device
+            c["shared"] = PackedConvBN(self.shared_conv, None, relu=False)
+            c["hm0"] = PackedConvBN(self.heatmap_head[0].conv, self.heatmap_head[0].bn, relu=True)
+            bev_pos = self._bev_pos(device)
+            c["bev_pos"] = bev_pos
+            c["layers"] = []
+            E = self.shared_conv.out_channels
+            for l in self.decoder:
+                sa, ca = l.self_attn, l.multihead_attn
+                ws, bs = sa.in_proj_weight.detach().float(), sa.in_proj_bias.detach().float()
+                wc, bc = ca.in_proj_weight.detach().float(), ca.in_proj_bias.detach().float()
+                # key = value = feat + key_pos_embed (:104-106): (feat + pos) W + b = feat W + (pos W + b), the second
+                # term is input independent -> per-cell table added in the GEMM epilogue
+                kpe = ops._pos_embed(l.cross_posembed, bev_pos)[0]                    # [HW, E]
+                table = (kpe.double() @ wc[E:].double().t()).float().contiguous()     # [HW, 2E]
+                c["layers"].append(dict(
+                    s_qkv=ops.PackedLinear(ws, bs), s_out=ops.PackedLinear(sa.out_proj.weight, sa.out_proj.bias),
+                    c_q=ops.PackedLinear(wc[:E], bc[:E]), c_kv=ops.PackedLinear(wc[E:], bc[E:]), kv_table=table,
+                    c_out=ops.PackedLinear(ca.out_proj.weight, ca.out_proj.bias),
+                    l1=ops.PackedLinear(l.linear1.weight, l.linear1.bias),
+                    l2=ops.PackedLinear(l.linear2.weight, l.linear2.bias)))
+        return c
+
+    @torch.no_grad()
+    def forward_single(self, inputs, img_inputs=None, metas=None):
+        """inputs [B, in_channels, X, Y] -> [dict(center, height, dim, rot, vel, heatmap, query_heatmap_score,
+        dense_heatmap)] (one dict: num_decoder_layers results concatenated along the proposal axis when auxiliary)"""
+        assert not self.training, "isfusion_amd.TransFusionHeadV2 is the inference path (eval mode)"
+        B, _, X, Y = inputs.shape
+        HW = X * Y
+        c = self._packed(inputs.device)
+        E = self.shared_conv.out_channels
+        if self.dense_conv == "hip":
+            maps = [SplitMap.from_nchw(inputs, off, min(256, inputs.size(1) - off))
+                    for off in range(0, inputs.size(1), 256)]
+            feat = c["shared"](maps)                                              # SplitMap [B, E, X, Y]
+            hm_mid = c["hm0"](feat).to_nchw()
+            feat_tok = from_split(feat.data, (B * HW, E))                         # token-major fp32
+            lidar_feat = None
+        else:
+            lidar_feat = self.shared_conv(inputs)
+            hm_mid = self.heatmap_head[0](lidar_feat)
+            feat_tok = ops.to_tokens(lidar_feat)
+        dense_heatmap = self.heatmap_head[1](hm_mid)
+        pool1 = (8, 9) if self.test_cfg["dataset"] == "nuScenes" else (1, 2)
+        top_index, top_raw, masked = ops.instance_topk(dense_heatmap, self.num_proposals, self.nms_kernel_size, pool1,
+                                                       return_masked=True)
+        self.query_labels = top_class = torch.div(top_raw, HW, rounding_mode="floor")
+        bev_pos = c["bev_pos"].expand(B, -1, -1)
+        query_pos = bev_pos.gather(1, top_index[:, :, None].expand(-1, -1, 2))                      # [B, P, 2]
+        rows = (top_index + torch.arange(B, device=inputs.device)[:, None] * HW).reshape(-1)
+        query = feat_tok[rows]                                                                       # [B*P, E]
+        # class_encoding(one_hot) = column `class` of the 1x1 conv + bias
+        ce = self.class_encoding
+        query = query + (ce.weight[:, :, 0].t()[top_class.reshape(-1)] + ce.bias)
+        P = self.num_proposals
+        ret_dicts = []
+        for i, (l, p) in enumerate(zip(self.decoder, c["layers"])):
+            qpe = ops._pos_embed(l.self_posembed, query_pos).reshape(B * P, E)
+            # self attention: q = k = v = query + pos (:98-101)
+            x = query + qpe
+            qkv = ops.linear(x, p["s_qkv"])
+            att = ops.attention(qkv, qkv[:, E:], qkv[:, 2 * E:], B, P, P, E, l.nhead, ldkv=3 * E)
+            query = ops.linear(att, p["s_out"], residual=query, ln=l.norm1)
+            # cross attention over the BEV map (:104-108)
+            qc = ops.linear(query + qpe, p["c_q"])
+            idx = c.setdefault(("kv_index", B, HW), torch.arange(HW, device=inputs.device, dtype=torch.int32).repeat(B))
+            kv = ops.linear(feat_tok, p["c_kv"], table=p["kv_table"], index=idx)                     # [B*HW, 2E]
+            att = ops.attention(qc, kv, kv[:, E:], B, P, HW, E, l.nhead, ldkv=2 * E)
+            query = ops.linear(att, p["c_out"], residual=query, ln=l.norm2)
+            h = ops.linear(query, p["l1"], act=ops.ACT_RELU)
+            query = ops.linear(h, p["l2"], residual=query, ln=l.norm3)
+            qf = query.view(B, P, E).transpose(1, 2).contiguous()                                   # [B, E, P]
+            res = self.prediction_heads[i](qf)
+            res["center"] = res["center"] + query_pos.permute(0, 2, 1)
+            ret_dicts.append(res)
+            query_pos = res["center"].detach().clone().permute(0, 2, 1)
+        ret_dicts[0]["query_heatmap_score"] = masked.view(B, self.num_classes, HW).gather(
+            2, top_index[:, None, :].expand(-1, self.num_classes, -1))
+        ret_dicts[0]["dense_heatmap"] = dense_heatmap
+        if not self.auxiliary:
+            return [ret_dicts[-1]]
+        new_res = {}
+        for key in ret_dicts[0].keys():
+            if key not in ("dense_heatmap", "dense_heatmap_old", "query_heatmap_score"):
+                new_res[key] = torch.cat([r[key] for r in ret_dicts], dim=-1)
+            else:
+                new_res[key] = ret_dicts[0][key]
+        return [new_res]
+
+    def forward(self, feats, img_feats=None, metas=None):
+        """:894-908: one level"""
+        if isinstance(feats, torch.Tensor):
+            feats = [feats]
+        return tuple([self.forward_single(f, None, metas)] for f in feats)

@@ -312,3 +312,52 @@ def secondv2_stage(x, sd, prefix, stage, eps=1e-3):
                          sd[prefix + ".ds_layer.1.weight"], sd[prefix + ".ds_layer.1.bias"], False, 0.0, eps)
         return F.relu(y), feat
     return None, seq(x, prefix + ".blocks.1", n1)
+
+
+# ------------------------------------------------------------------------------------------------ 8f #1 (head)
+def transfusion_head_forward(inputs, sd, num_proposals=200, num_classes=10, nhead=8, nms_kernel=3,
+                             pool1_classes=(8, 9), heads=("center", "height", "dim", "rot", "vel", "heatmap")):
+    """TransFusionHeadV2.forward_single with one decoder layer, eval mode
+    (dense_heads/transfusion_head_v2.py:771-892, decoder layer :80-120, FFN :561-590)."""
+    B, _, X, Y = inputs.shape
+    HW = X * Y
+    feat = F.conv2d(inputs, sd["shared_conv.weight"], sd["shared_conv.bias"], 1, 1)
+    E = feat.shape[1]
+    flat = feat.view(B, E, HW)
+    g = torch.linspace(0, X - 1, X) + 0.5
+    g2 = torch.linspace(0, Y - 1, Y) + 0.5
+    bx, by = torch.meshgrid(g, g2, indexing="ij")
+    bev_pos = torch.stack([bx, by], 0).view(1, 2, -1).permute(0, 2, 1).repeat(B, 1, 1)
+    hm = conv_module(feat, sd, "heatmap_head.0")
+    dense_heatmap = F.conv2d(hm, sd["heatmap_head.1.weight"], sd["heatmap_head.1.bias"], 1, 1)
+    masked, top_idx, top_raw = instance_topk(dense_heatmap, num_proposals, nms_kernel, pool1_classes)
+    top_class = top_raw // HW
+    query_pos = bev_pos.gather(1, top_idx[:, :, None].expand(-1, -1, 2))
+    query = flat.gather(2, top_idx[:, None, :].expand(-1, E, -1))                         # [B, E, P]
+    one_hot = F.one_hot(top_class, num_classes=num_classes).permute(0, 2, 1).float()
+    query = query + F.conv1d(one_hot, sd["class_encoding.weight"], sd["class_encoding.bias"])
+    p = "decoder.0"
+    qpe = pos_embed_learned(query_pos, sd, p + ".self_posembed").permute(1, 0, 2)          # [P, B, E]
+    kpe = pos_embed_learned(bev_pos, sd, p + ".cross_posembed").permute(1, 0, 2)           # [HW, B, E]
+    q = query.permute(2, 0, 1)
+    k = flat.permute(2, 0, 1)
+    x = q + qpe
+    q = layer_norm(q + mha(x, x, x, sd, p + ".self_attn", nhead), sd, p + ".norm1")
+    kk = k + kpe
+    q = layer_norm(q + mha(q + qpe, kk, kk, sd, p + ".multihead_attn", nhead), sd, p + ".norm2")
+    f = F.linear(F.relu(F.linear(q, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                 sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    q = layer_norm(q + f, sd, p + ".norm3")
+    qf = q.permute(1, 2, 0)                                                                # [B, E, P]
+    out = {}
+    for h in heads:
+        hp = f"prediction_heads.0.{h}"
+        y = F.conv1d(qf, sd[hp + ".0.conv.weight"])
+        y = F.relu(F.batch_norm(y, sd[hp + ".0.bn.running_mean"], sd[hp + ".0.bn.running_var"], sd[hp + ".0.bn.weight"],
+                                sd[hp + ".0.bn.bias"], False, 0.0, 1e-5))
+        out[h] = F.conv1d(y, sd[hp + ".1.weight"], sd[hp + ".1.bias"])
+    out["center"] = out["center"] + query_pos.permute(0, 2, 1)
+    out["query_heatmap_score"] = masked.view(B, num_classes, HW).gather(2, top_idx[:, None, :].expand(-1, num_classes, -1))
+    out["dense_heatmap"] = dense_heatmap
+    out["top_idx"] = top_idx
+    return out

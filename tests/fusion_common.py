@@ -61,3 +61,23 @@ def check_sample(g, key, x, atol, rtol=0.0):
     assert (err <= tol).all(), f"{key}: max err {err.max():.3e} (tol {atol}), at value {val[err.argmax()]:.4f}"
     assert abs(flat.mean() - stat[0]) <= atol and abs(np.abs(flat).mean() - stat[1]) <= atol, key
     return float(err.max())
+
+
+# ------------------------------------------------------------------------------------------- detection head
+HEAD_SEED = 300
+HEAD_CONFIGS = {
+    "small": dict(seed=41, B=2, X=36, num_proposals=20),
+    "full": dict(seed=42, B=1, X=180, num_proposals=200),
+}
+
+
+def head_kwargs(cfg):
+    return dict(num_proposals=cfg["num_proposals"], auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+                num_decoder_layers=1, num_heads=8, nms_kernel_size=3, ffn_channel=256,
+                common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
+                test_cfg=dict(dataset="nuScenes", grid_size=[cfg["X"] * 8, cfg["X"] * 8, 40], out_size_factor=8))
+
+
+def head_input(cfg):
+    g = torch.Generator().manual_seed(cfg["seed"])
+    return torch.randn((cfg["B"], 512, cfg["X"], cfg["X"]), generator=g) * 0.5

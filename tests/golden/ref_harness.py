@@ -56,17 +56,22 @@ def _identity_decorator(*a, **k):
 
 
 class ConvModule(nn.Sequential):
-    """mmcv.cnn.ConvModule for the configuration the path uses: Conv2d(bias=False) + BN2d + ReLU, with the
-    sub-module names mmcv gives them (conv / bn / activate)."""
+    """mmcv.cnn.ConvModule for the configurations the path uses: Conv{1,2}d (bias = 'auto' -> no norm) + BN{1,2}d +
+    ReLU, with the sub-module names mmcv gives them (conv / bn / activate)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, conv_cfg=None, norm_cfg=None,
-                 act_cfg=dict(type="ReLU"), **kw):
+                 act_cfg=dict(type="ReLU"), bias="auto", **kw):
         super().__init__()
-        self.add_module("conv", nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding,
-                                          bias=norm_cfg is None))
+        ctype = (conv_cfg or {}).get("type", "Conv2d")
+        conv = {"Conv2d": nn.Conv2d, "Conv1d": nn.Conv1d, None: nn.Conv2d}[ctype]
+        if bias == "auto":
+            bias = norm_cfg is None
+        self.add_module("conv", conv(in_channels, out_channels, kernel_size, stride, padding, bias=bool(bias)))
         if norm_cfg is not None:
-            self.add_module("bn", nn.BatchNorm2d(out_channels, eps=norm_cfg.get("eps", 1e-5),
-                                                 momentum=norm_cfg.get("momentum", 0.1)))
+            ntype = norm_cfg.get("type", "BN")
+            norm = {"BN": nn.BatchNorm2d, "BN2d": nn.BatchNorm2d, "BN1d": nn.BatchNorm1d}[ntype]
+            self.add_module("bn", norm(out_channels, eps=norm_cfg.get("eps", 1e-5),
+                                       momentum=norm_cfg.get("momentum", 0.1)))
         if act_cfg is not None:
             self.add_module("activate", nn.ReLU(inplace=True))
 
@@ -74,8 +79,10 @@ class ConvModule(nn.Sequential):
 def build_conv_layer(cfg, *args, **kwargs):
     cfg = dict(cfg or dict(type="Conv2d"))
     t = cfg.pop("type")
-    assert t in ("Conv2d", None)
-    return nn.Conv2d(*args, **kwargs, **cfg)
+    conv = {"Conv2d": nn.Conv2d, "Conv1d": nn.Conv1d, None: nn.Conv2d}[t]
+    if "bias" in kwargs:
+        kwargs["bias"] = bool(kwargs["bias"])   # mmcv passes bias='auto' straight through: truthy
+    return conv(*args, **kwargs, **cfg)
 
 
 def build_norm_layer(cfg, num_features, postfix=""):
@@ -194,6 +201,27 @@ def install():
     m["fusion_encoder"] = _load("mmdet3d.models.middle_encoders.fusion_encoder",
                                 "mmdet3d/models/middle_encoders/fusion_encoder.py")
     m["ms_deform_core"] = core
+    # detection head: everything it imports beyond torch is loss / target / decoding machinery that
+    # forward_single never touches -> inert stubs
+    sys.modules["mmcv.cnn"].kaiming_init = lambda *a, **k: None
+    core_mod = sys.modules["mmdet3d.core"]
+    for n in ("circle_nms", "xywhr2xyxyr", "limit_period", "PseudoSampler", "Box3DMode", "LiDARInstance3DBoxes"):
+        setattr(core_mod, n, None)
+    _pkg("mmdet3d.core.bbox")
+    _mod("mmdet3d.core.bbox.structures", rotation_3d_in_axis=None)
+    regs["HEADS"] = _Registry("HEADS")
+    builder.HEADS = regs["HEADS"]
+    builder.build_loss = lambda cfg: None
+    sys.modules["mmdet3d.models"].builder = builder
+    _mod("mmdet3d.models.utils", clip_sigmoid=None)
+    _mod("mmdet3d.models.fusion_layers", apply_3d_transformation=None)
+    _pkg("mmdet3d.ops.iou3d")
+    _mod("mmdet3d.ops.iou3d.iou3d_utils", nms_gpu=None)
+    _mod("mmdet.core", build_bbox_coder=lambda cfg: None, multi_apply=None, build_assigner=lambda cfg: None,
+         build_sampler=lambda *a, **k: None, AssignResult=None)
+    _pkg("mmdet3d.models.dense_heads", os.path.join(base, "models", "dense_heads"))
+    m["transfusion_head"] = _load("mmdet3d.models.dense_heads.transfusion_head_v2",
+                                  "mmdet3d/models/dense_heads/transfusion_head_v2.py")
     _installed.update(m)
     return m
 

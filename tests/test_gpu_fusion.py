@@ -326,3 +326,37 @@ def test_fusion_encoder_batch4_matches_restatement(dev):
     assert (hm.cpu() - rhm).abs().max().item() < 1e-4
     assert torch.equal(enc.last_top_idx.cpu(), rtop)
     assert (got.cpu() - ref).abs().max().item() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- detection head (8f #1)
+@pytest.mark.parametrize("B,Lq,Lk,E", [(2, 200, 32400, 128), (1, 20, 1296, 128), (1, 7, 513, 256)])
+def test_attention_many_keys_matches_fp64(dev, B, Lq, Lk, E):
+    """keys split into 512-key chunks + merge (the head's 200 x 32400 cross attention)"""
+    from isfusion_amd import fusion_ops as ops
+    q, k, v = rnd((B * Lq, E), 33), rnd((B * Lk, E), 34), rnd((B * Lk, E), 35)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), B, Lq, Lk, E, 8).cpu()
+    hd = E // 8
+    qq, kk, vv = q.view(B, Lq, 8, hd), k.view(B, Lk, 8, hd), v.view(B, Lk, 8, hd)
+    a = torch.einsum("bihd,bjhd->bhij", qq.double(), kk.double()) * hd ** -0.5
+    ref = torch.einsum("bhij,bjhd->bihd", a.softmax(-1), vv.double()).reshape(B * Lq, E)
+    assert (out.double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name,dense", [("small", "hip"), ("full", "hip"), ("small", "stock")])
+def test_transfusion_head_matches_reference_golden(dev, golden, name, dense):
+    from fusion_common import HEAD_CONFIGS, HEAD_SEED, head_input, head_kwargs
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    from isfusion_amd.transfusion_head import TransFusionHeadV2
+    g = golden("head_ref.npz")
+    cfg = HEAD_CONFIGS[name]
+    head = TransFusionHeadV2(dense_conv=dense, **head_kwargs(cfg)).eval()
+    head.load_state_dict(seeded_state_dict(head, HEAD_SEED))
+    head = head.to(dev)
+    out = head.forward_single(head_input(cfg).to(dev))[0]
+    assert np.array_equal(head.query_labels.cpu().numpy(), g[name + ".labels"]), "proposal classes / order differ"
+    for k in ("center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score"):
+        got = out[k].cpu().numpy()
+        assert got.shape == g[f"{name}.{k}"].shape
+        assert np.abs(got - g[f"{name}.{k}"]).max() < 1e-3, k      # north_star tolerance (fp32, 1e-3)
+    dh = out["dense_heatmap"].reshape(-1).cpu().numpy()
+    assert np.abs(dh[g[name + ".dense_heatmap.idx"]] - g[name + ".dense_heatmap.val"]).max() < 1e-3

@@ -55,3 +55,26 @@ def test_instance_topk_edge_cases():
     flat, top, raw = orc.instance_topk(hm, 2)
     assert raw[0].tolist() == [3 * 64 + 36, 8 * 64] and top[0].tolist() == [36, 0]
     assert flat[0, 2 * 64] == 0
+
+
+# ------------------------------------------------------------------------------------------- detection head
+HEAD_KEYS = ("center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score")
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_head_restatement_matches_reference_outputs(golden, name):
+    """TransFusionHeadV2.forward_single (SURVEY 8f #1): restatement vs the reference's own outputs"""
+    from fusion_common import HEAD_CONFIGS, HEAD_SEED, head_input, head_kwargs
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    from isfusion_amd.transfusion_head import TransFusionHeadV2
+    from oracle import fusion_ops as orc
+    g = golden("head_ref.npz")
+    cfg = HEAD_CONFIGS[name]
+    sd = {k: v.float() for k, v in seeded_state_dict(TransFusionHeadV2(**head_kwargs(cfg)), HEAD_SEED).items()}
+    with torch.no_grad():
+        o = orc.transfusion_head_forward(head_input(cfg), sd, cfg["num_proposals"])
+    assert np.array_equal(o["top_idx"].numpy(), g[name + ".top_idx"])
+    for k in HEAD_KEYS:
+        assert np.abs(o[k].numpy() - g[f"{name}.{k}"]).max() < 2e-4, k
+    dh = o["dense_heatmap"].reshape(-1).numpy()
+    assert np.abs(dh[g[name + ".dense_heatmap.idx"]] - g[name + ".dense_heatmap.val"]).max() < 1e-4
