@@ -14,8 +14,9 @@ import torch
 from torch import nn
 
 from .fusion_encoder import ISFusionEncoder
-from .fusion_modules import SECONDV2
+from .fusion_modules import SECONDFPN, SECONDV2
 from .lidar_branch import ISFUSION_0075, LidarBranch
+from .transfusion_head import TransFusionHeadV2
 from .voxelize import Voxelization
 
 ISFUSION_0075_FUSION = dict(
@@ -27,13 +28,20 @@ ISFUSION_0075_FUSION = dict(
                         instance_num=200),
     pts_backbone=dict(in_channels=128, out_channels=[128, 256], layer_nums=[5, 5], layer_strides=[1, 2],
                       norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False)),
+    pts_neck=dict(in_channels=[128, 256], out_channels=[256, 256], upsample_strides=[1, 2],
+                  norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), upsample_cfg=dict(type="deconv", bias=False),
+                  use_conv_for_no_stride=True),
+    pts_bbox_head=dict(num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
+                       num_decoder_layers=1, num_heads=8, nms_kernel_size=3, ffn_channel=256,
+                       common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
+                       test_cfg=dict(dataset="nuScenes", grid_size=[1440, 1440, 40], out_size_factor=8)),
 )
 
 
 class ISFusionPtsPath(nn.Module):
 
     def __init__(self, voxel_size=None, pc_range=None, pts_voxel_encoder=None, pts_middle_encoder=None,
-                 fusion_encoder=None, pts_backbone=None, out_size_factor=None):
+                 fusion_encoder=None, pts_backbone=None, out_size_factor=None, pts_neck=None, pts_bbox_head=None):
         super().__init__()
         cfg = ISFUSION_0075
         self.voxel_size = list(voxel_size or cfg["voxel_size"])
@@ -50,6 +58,14 @@ class ISFusionPtsPath(nn.Module):
         bb = dict(pts_backbone or ISFUSION_0075_FUSION["pts_backbone"])
         bb.pop("type", None)
         self.pts_backbone = SECONDV2(**bb)
+        nk = dict(pts_neck or ISFUSION_0075_FUSION["pts_neck"])
+        nk.pop("type", None)
+        self.pts_neck = SECONDFPN(**nk)
+        hd = dict(pts_bbox_head or ISFUSION_0075_FUSION["pts_bbox_head"])
+        for k in ("type", "bbox_coder", "loss_cls", "loss_bbox", "loss_heatmap", "loss_iou", "dropout", "bn_momentum",
+                  "activation"):
+            hd.pop(k, None)   # losses / coder / training-only knobs: control plane
+        self.pts_bbox_head = TransFusionHeadV2(**hd)
         osf = out_size_factor or ISFUSION_0075_FUSION["out_size_factor"]
         # isfusion.py:45-51
         self.pillar_size = [self.voxel_size[0] * osf, self.voxel_size[1] * osf, self.pc_range[5] - self.pc_range[2]]
@@ -86,3 +102,10 @@ class ISFusionPtsPath(nn.Module):
         x = self._lidar(pts)
         feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)
         return (feats, ins_heatmap) if return_heatmap else feats
+
+    @torch.no_grad()
+    def forward_pts(self, pts, img_feats, img_metas, **kwargs):
+        """extract_pts_feat -> pts_neck -> pts_bbox_head (mvx_two_stage.py simple_test_pts without box decoding):
+        the raw head outputs [[dict(center, height, dim, rot, vel, heatmap, query_heatmap_score, dense_heatmap)]]."""
+        x = self.pts_neck(self.extract_pts_feat(pts, img_feats, img_metas, **kwargs))
+        return self.pts_bbox_head(x, img_feats, img_metas)

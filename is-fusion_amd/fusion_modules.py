@@ -217,3 +217,31 @@ def seeded_state_dict(module, seed):
         if k.endswith("sampling_offsets.bias"):  # keep sampling points a few cells around the reference point
             sd[k] = torch.randn(v.shape, generator=g) * 2.0
     return sd
+
+
+class SECONDFPN(nn.Module):
+    """necks/second_fpn.py:10-93 as the IS-Fusion config builds it (use_conv_for_no_stride=True): per level a
+    Conv2d(k = 1/stride) or ConvTranspose2d(k = stride) without bias + BN(eps 1e-3) + ReLU, concatenated, and the
+    final `permute(0, 1, 3, 2)`.  Stock PyTorch-ROCm ops (a 1x1 conv and a 2x2 transposed conv per frame)."""
+
+    def __init__(self, in_channels=(128, 256), out_channels=(256, 256), upsample_strides=(1, 2),
+                 norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), upsample_cfg=dict(type="deconv", bias=False),
+                 conv_cfg=dict(type="Conv2d", bias=False), use_conv_for_no_stride=True, **kw):
+        super().__init__()
+        self.in_channels, self.out_channels = list(in_channels), list(out_channels)
+        eps, mom = norm_cfg.get("eps", 1e-3), norm_cfg.get("momentum", 0.01)
+        blocks = []
+        for cin, cout, s in zip(in_channels, out_channels, upsample_strides):
+            if s > 1 or (s == 1 and not use_conv_for_no_stride):
+                up = nn.ConvTranspose2d(cin, cout, s, stride=s, bias=upsample_cfg.get("bias", False))
+            else:
+                k = int(round(1 / s))
+                up = nn.Conv2d(cin, cout, k, stride=k, bias=conv_cfg.get("bias", False))
+            blocks.append(nn.Sequential(up, nn.BatchNorm2d(cout, eps=eps, momentum=mom), nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(blocks)
+
+    def forward(self, x, **kwargs):
+        assert len(x) == len(self.in_channels)
+        ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
+        out = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        return [out.permute(0, 1, 3, 2).contiguous()]

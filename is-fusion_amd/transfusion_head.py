@@ -162,6 +162,7 @@ class TransFusionHeadV2(nn.Module):
         top_index, top_raw, masked = ops.instance_topk(dense_heatmap, self.num_proposals, self.nms_kernel_size, pool1,
                                                        return_masked=True)
         self.query_labels = top_class = torch.div(top_raw, HW, rounding_mode="floor")
+        self.last_top_index = top_index   # BEV cell of every proposal (for inspection)
         bev_pos = c["bev_pos"].expand(B, -1, -1)
         query_pos = bev_pos.gather(1, top_index[:, :, None].expand(-1, -1, 2))                      # [B, P, 2]
         rows = (top_index + torch.arange(B, device=inputs.device)[:, None] * HW).reshape(-1)
@@ -208,4 +209,5 @@ class TransFusionHeadV2(nn.Module):
         """:894-908: one level"""
         if isinstance(feats, torch.Tensor):
             feats = [feats]
-        return tuple([self.forward_single(f, None, metas)] for f in feats)
+        # multi_apply transposes the per-level lists: a 1-tuple holding the list of per-level result dicts
+        return ([self.forward_single(f, None, metas)[0] for f in feats],)

@@ -20,12 +20,15 @@ def main():
     ap.add_argument("--points", type=int, default=300000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--head", action="store_true", help="include pts_neck + TransFusionHeadV2.forward_single")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     net = ISFusionPtsPath().eval()
     net._lidar.randomize_weights_(0).randomize_bn_(1)
     net.fusion_encoder.load_state_dict(seeded_state_dict(net.fusion_encoder, 100))
     net.pts_backbone.load_state_dict(seeded_state_dict(net.pts_backbone, 200))
+    net.pts_neck.load_state_dict(seeded_state_dict(net.pts_neck, 250))
+    net.pts_bbox_head.load_state_dict(seeded_state_dict(net.pts_bbox_head, 300))
     net = net.to(dev)
     net._lidar.freeze()
     pts = [torch.from_numpy(p).to(dev) for p in synthetic.batch(2, a.batch, a.points)]
@@ -34,20 +37,24 @@ def main():
     kw = dict(lidar2img=torch.from_numpy(inp["lidar2img"]), img_aug_matrix=torch.from_numpy(inp["img_aug_matrix"]),
               lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
     metas = [dict(input_shape=inp["input_shape"]) for _ in range(a.batch)]
+    run = (lambda: net.forward_pts(pts, img_feats, metas, **kw)) if a.head else \
+        (lambda: net.extract_pts_feat(pts, img_feats, metas, **kw))
     for _ in range(a.warmup):
-        feats = net.extract_pts_feat(pts, img_feats, metas, **kw)
+        feats = run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.steps):
-        feats = net.extract_pts_feat(pts, img_feats, metas, **kw)
+        feats = run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.steps
     print(json.dumps({"workload": f"extract_pts_feat (LiDAR branch + pillar voxelize + ISFusionEncoder + SECONDV2), "
                                   f"{a.points}-pt sweeps, batch {a.batch}, random camera features [B*6,256,24,66]",
                       "ms_per_step": round(ms, 3), "frames_per_s": round(a.batch / ms * 1e3, 1),
-                      "outputs": [list(f.shape) for f in feats]}))
+                      "with_neck_and_head": bool(a.head),
+                      "outputs": ({k: list(v.shape) for k, v in feats[0][0].items()} if a.head
+                                  else [list(f.shape) for f in feats])}))
 
 
 if __name__ == "__main__":
