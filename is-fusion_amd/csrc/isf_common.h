@@ -84,6 +84,8 @@ int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStrea
 // coords of all set bits in rank order -> out [total,4]
 int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st);
 int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream sync
+int side_stream(hipStream_t* out);                         // per-device non-blocking helper stream
+int stream_wait_stream(hipStream_t waiter, hipStream_t producer);  // event from a recycled pool
 
 __device__ __forceinline__ int occ_lookup(const unsigned long long* __restrict__ bits,
                                           const uint32_t* __restrict__ prefix,

@@ -162,6 +162,13 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 int num_layers, float* spatial_features, int out_shape[4],
                                 isf_encoder_stats* stats, int time_layers, hipStream_t st) {
   ISF_REQUIRE(num_layers > 0 && num_layers <= 32, ISF_ERR_ARG, "sparse_encoder: %d layers (1..32)", num_layers);
+  // Geometry (occupancy indexes, output sets, neighbour tables: small integer kernels + the host syncs that size
+  // the next level) runs on a side stream and overlaps the convolutions of the previous level on `st`; a
+  // convolution waits for the event recorded behind its level's table.  `sg` first waits for everything the
+  // caller (the VFE) enqueued on `st`.
+  hipStream_t sg = nullptr;
+  ISF_TRY(side_stream(&sg));
+  ISF_TRY(stream_wait_stream(sg, st));
   LevelState L;
   for (int j = 0; j < 3; ++j) L.shape[j] = shape0[j];
   L.n = n0;
@@ -186,7 +193,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   }
   unsigned long long* pair_counts = nullptr;
   ISF_TRY(a.alloc_n(&pair_counts, 32));
-  ISF_HIP_TRY(hipMemsetAsync(pair_counts, 0, 32 * sizeof(unsigned long long), st));
+  ISF_HIP_TRY(hipMemsetAsync(pair_counts, 0, 32 * sizeof(unsigned long long), sg));
   std::vector<hipEvent_t> ev;
   if (time_layers && stats) {
     ev.resize((size_t)num_layers * 2);
@@ -206,43 +213,45 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
                        L.cache_ks[2] == ly.ksize[2];
       if (!hit) {
-        ISF_TRY(ensure_occ(a, L, B, st));
+        ISF_TRY(ensure_occ(a, L, B, sg));
         stride = isf_nbr_stride(L.n);
         ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
         ISF_TRY(launch_nbr(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
-                           stride, pair_counts + i, st));
+                           stride, pair_counts + i, sg));
         L.cache_nbr = nbr;
         L.cache_stride = stride;
         for (int j = 0; j < 3; ++j) L.cache_ks[j] = ly.ksize[j];
         L.cache_pairs = -(long long)i - 1;  // pairs live in pair_counts[i]; resolved after the final sync
+        ISF_TRY(stream_wait_stream(st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
         stride = L.cache_stride;
       }
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
     } else {
-      ISF_TRY(ensure_occ(a, L, B, st));
+      ISF_TRY(ensure_occ(a, L, B, sg));
       LevelState Nx;
       ISF_TRY(isf_conv_out_shape(L.shape, ly.ksize, ly.stride, ly.padding, Nx.shape));
       ISF_REQUIRE(Nx.shape[0] > 0 && Nx.shape[1] > 0 && Nx.shape[2] > 0, ISF_ERR_ARG,
                   "sparse_encoder: layer %d output shape empty", i);
-      ISF_TRY(occ_create(a, &Nx.occ, B, Nx.shape[0], Nx.shape[1], Nx.shape[2], st));
-      ISF_TRY(launch_mark_out(L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, Nx.occ, st));
-      ISF_TRY(occ_scan(a, Nx.occ, st));
-      ISF_TRY(read_int(Nx.occ.total, &Nx.n, st));  // host sync: sizes the next level's buffers / grids
+      ISF_TRY(occ_create(a, &Nx.occ, B, Nx.shape[0], Nx.shape[1], Nx.shape[2], sg));
+      ISF_TRY(launch_mark_out(L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, Nx.occ, sg));
+      ISF_TRY(occ_scan(a, Nx.occ, sg));
+      ISF_TRY(read_int(Nx.occ.total, &Nx.n, sg));  // host sync: sizes the next level's buffers / grids
       Nx.has_occ = true;
       int32_t* nc = nullptr;
       ISF_TRY(a.alloc_n(&nc, (size_t)std::max(Nx.n, 1) * 4));
-      if (Nx.n > 0) ISF_TRY(occ_compact_coords4(Nx.occ, nc, st));
+      if (Nx.n > 0) ISF_TRY(occ_compact_coords4(Nx.occ, nc, sg));
       Nx.coors = nc;
       stride = isf_nbr_stride(Nx.n);
       ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
       ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
-                         stride, pair_counts + i, st));
+                         stride, pair_counts + i, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_nbr = nullptr;
       n_out = Nx.n;
       L = Nx;
+      ISF_TRY(stream_wait_stream(st, sg));
     }
     void* y = nullptr;
     ISF_TRY(a.alloc(&y, (size_t)std::max(n_out, 1) * ly.c_out * 4));
@@ -275,7 +284,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     c_last = ly.c_out;
   }
   // dense BEV of the last level
-  ISF_TRY(ensure_occ(a, L, B, st));
+  ISF_TRY(ensure_occ(a, L, B, sg));
+  ISF_TRY(stream_wait_stream(st, sg));
   ISF_TRY(sparse_to_dense_bev_impl(a, x, use16, L.coors, L.n, c_last, B, L.shape[0], L.shape[1], L.shape[2],
                                    spatial_features, &L.occ, st));
   if (stats) stats->precision = use16 ? 1 : 0;

@@ -81,6 +81,53 @@ Arena& arena_for_current_device() {
   return g_arenas[dev];
 }
 
+// ---- side stream + event pool (geometry / rulebook work of the sparse encoder overlaps the convolutions)
+struct SideState {
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+  size_t next = 0;
+};
+static SideState g_side[16];
+
+static SideState& side_for_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  return g_side[dev];
+}
+
+int side_stream(hipStream_t* out) {
+  SideState& s = side_for_current_device();
+  if (!s.stream) ISF_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+  *out = s.stream;
+  return ISF_OK;
+}
+
+// events are recycled round-robin; 256 is far more than one forward records, so an event is never re-recorded
+// while a wait on its previous recording is still pending in the same call
+int pooled_event(hipEvent_t* out) {
+  SideState& s = side_for_current_device();
+  if (s.events.size() < 256) {
+    hipEvent_t e;
+    ISF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s.events.push_back(e);
+    *out = e;
+    return ISF_OK;
+  }
+  *out = s.events[s.next];
+  s.next = (s.next + 1) % s.events.size();
+  return ISF_OK;
+}
+
+// make stream `waiter` wait for everything enqueued on `producer` so far
+int stream_wait_stream(hipStream_t waiter, hipStream_t producer) {
+  hipEvent_t e;
+  ISF_TRY(pooled_event(&e));
+  ISF_HIP_TRY(hipEventRecord(e, producer));
+  ISF_HIP_TRY(hipStreamWaitEvent(waiter, e, 0));
+  return ISF_OK;
+}
+
 int read_int(const int* dev, int* host, hipStream_t st) {
   ISF_HIP_TRY(hipMemcpyAsync(host, dev, sizeof(int), hipMemcpyDeviceToHost, st));
   ISF_HIP_TRY(hipStreamSynchronize(st));
