@@ -86,6 +86,7 @@ int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st);
 int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream sync
 int side_stream(hipStream_t* out);                         // per-device non-blocking helper stream
 int stream_wait_stream(hipStream_t waiter, hipStream_t producer);  // event from a recycled pool
+int pooled_event(hipEvent_t* out);                         // recycled hipEventDisableTiming events
 
 __device__ __forceinline__ int occ_lookup(const unsigned long long* __restrict__ bits,
                                           const uint32_t* __restrict__ prefix,
@@ -119,7 +120,7 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
                      const float* shift1, int c1, const float* w2, const float* scale2,
                      const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
                      int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
-                     hipStream_t st);
+                     hipStream_t st, hipEvent_t* coords_ready = nullptr);
 // isf_rulebook.hip
 int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int32_t** perm_out,
                hipStream_t st);

@@ -160,15 +160,17 @@ static int ensure_occ(Arena& a, LevelState& L, int B, hipStream_t st) {
 int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0, int n0, int B,
                                 const int shape0[3], const OccIndex* occ0, const isf_conv_layer* layers,
                                 int num_layers, float* spatial_features, int out_shape[4],
-                                isf_encoder_stats* stats, int time_layers, hipStream_t st) {
+                                isf_encoder_stats* stats, int time_layers, hipStream_t st,
+                                hipEvent_t geometry_ready = nullptr) {
   ISF_REQUIRE(num_layers > 0 && num_layers <= 32, ISF_ERR_ARG, "sparse_encoder: %d layers (1..32)", num_layers);
   // Geometry (occupancy indexes, output sets, neighbour tables: small integer kernels + the host syncs that size
   // the next level) runs on a side stream and overlaps the convolutions of the previous level on `st`; a
   // convolution waits for the event recorded behind its level's table.  `sg` first waits for everything the
-  // caller (the VFE) enqueued on `st`.
+  // caller enqueued on `st` -- or only for `geometry_ready`, the point where the VFE's coordinates are final.
   hipStream_t sg = nullptr;
   ISF_TRY(side_stream(&sg));
-  ISF_TRY(stream_wait_stream(sg, st));
+  if (geometry_ready) ISF_HIP_TRY(hipStreamWaitEvent(sg, geometry_ready, 0));   // coords final: overlap the VFE tail too
+  else ISF_TRY(stream_wait_stream(sg, st));
   LevelState L;
   for (int j = 0; j < 3; ++j) L.shape[j] = shape0[j];
   L.n = n0;
@@ -408,16 +410,17 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
   ISF_TRY(a.alloc_n(&vc, (size_t)P * 4));
   int n0 = 0;
   OccIndex occ0;
+  hipEvent_t coords_ready = nullptr;
   ISF_TRY(dynamic_vfe_impl(a, points, coors4, P, Cin, batch_size, vfe_host->voxel_size, vfe_host->coors_range,
                            vfe_host->w1, vfe_host->scale1, vfe_host->shift1, vfe_host->c1, vfe_host->w2,
                            vfe_host->scale2, vfe_host->shift2, vfe_host->c2, vf, vc, nullptr, &n0, &occ0,
-                           sparse_shape_host[0], st));
+                           sparse_shape_host[0], st, &coords_ready));
   ISF_REQUIRE(n0 > 0, ISF_ERR_ARG, "lidar_branch_forward: no point falls inside the voxel grid");
   const bool occ_ok = occ0.D == sparse_shape_host[0] && occ0.H == sparse_shape_host[1] &&
                       occ0.W == sparse_shape_host[2];
   return sparse_encoder_forward_impl(a, vf, vc, n0, batch_size, sparse_shape_host, occ_ok ? &occ0 : nullptr,
                                      layers_host, num_layers, spatial_features, out_shape_host, stats_host,
-                                     time_layers, st);
+                                     time_layers, st, occ_ok ? coords_ready : nullptr);
 }
 
 }  // extern "C"

@@ -366,7 +366,8 @@ template <int CIN>
 static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, int B, const int grid[3],
                    VfeGeom g, const float* w1, const float* scale1, const float* shift1, const float* w2,
                    const float* scale2, const float* shift2, float* voxel_feats, int32_t* voxel_coors,
-                   int32_t* pt2vox_out, int* n_host, OccIndex* occ_out, int d_alloc, hipStream_t st) {
+                   int32_t* pt2vox_out, int* n_host, OccIndex* occ_out, int d_alloc, hipStream_t st,
+                   hipEvent_t* coords_ready) {
   const int F = CIN + 6;
   OccIndex occ;
   // d_alloc > grid z lets the sparse encoder (sparse_shape[0] = grid z + 1) reuse this index for level 0
@@ -406,6 +407,10 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   hipLaunchKernelGGL(vfe_count_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, coors4, P, occ.D, occ.H, occ.W,
                      occ.bits, occ.prefix, pt2vox, slot, cnt, voxel_coors);
   ISF_LAUNCH_CHECK();
+  if (coords_ready) {   // occupancy index + voxel coords are final here: the encoder's geometry can start now
+    ISF_TRY(pooled_event(coords_ready));
+    ISF_HIP_TRY(hipEventRecord(*coords_ready, st));
+  }
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
   hipLaunchKernelGGL(vfe_order_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, pt2vox, slot, P, start,
                      recs);
@@ -424,7 +429,7 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
                      const float* shift1, int c1, const float* w2, const float* scale2,
                      const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
                      int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
-                     hipStream_t st) {
+                     hipStream_t st, hipEvent_t* coords_ready) {
   ISF_REQUIRE(c1 == kC && c2 == kC, ISF_ERR_UNSUPPORTED,
               "dynamic_vfe: feat_channels (%d,%d) not built; this build has (64,64)", c1, c2);
   ISF_REQUIRE(Cin == 4 || Cin == 5, ISF_ERR_UNSUPPORTED, "dynamic_vfe: in_channels %d not built (4|5)", Cin);
@@ -437,9 +442,9 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
   g.ox = vs[0] / 2 + range[0]; g.oy = vs[1] / 2 + range[1]; g.oz = vs[2] / 2 + range[2];
   if (Cin == 5)
     return vfe_run<5>(a, points, coors4, P, B, grid, g, w1, scale1, shift1, w2, scale2, shift2,
-                      voxel_feats, voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st);
+                      voxel_feats, voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready);
   return vfe_run<4>(a, points, coors4, P, B, grid, g, w1, scale1, shift1, w2, scale2, shift2, voxel_feats,
-                    voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st);
+                    voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready);
 }
 
 }  // namespace isf
