@@ -47,11 +47,17 @@ def make_frames(rank, world, batch, num_points):
     return [synthetic.lidar_sweeps(1234 + 1000 * CFG_ID + f, num_points) for f in frames_for_rank(rank, world, batch)]
 
 
+def traffic_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    return files[-1] if files else ""
+
+
 def pmc_traffic(cin, cout):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_v5_traffic.json: FETCH_SIZE, corrected x2 for gfx950, + WRITE_SIZE; counters cannot be collected
+    (newest profiles/r*_traffic.json: FETCH_SIZE, corrected x2 for gfx950, + WRITE_SIZE; counters cannot be collected
     from inside the timed process).  None when no summary is committed for that kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_v5_traffic.json")
+    path = traffic_file()
     try:
         per = json.load(open(path))["per_launch"]
     except (OSError, ValueError, KeyError):
@@ -191,7 +197,7 @@ def main():
         else:
             roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(gbs / HBM_PEAK_GBS, 4))
-        roof.update(traffic=pmc_traffic(cin_dom, cout_dom), traffic_source="profiles/r01_v5_traffic.json (rocprofv3 --pmc "
+        roof.update(traffic=pmc_traffic(cin_dom, cout_dom), traffic_source="profiles/" + os.path.basename(traffic_file()) + " (rocprofv3 --pmc "
                     "FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)",
                     algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]), kernel=name, launches_per_step=dom["launches"],
                     avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
