@@ -178,33 +178,48 @@ __device__ __forceinline__ void vfe_layer1(const float (&f)[F], const float* __r
   for (int o = 0; o < kC; ++o) h[o] = fmaxf(fmaf(h[o], scale[o], shift[o]), 0.f);
 }
 
-// Segmented per-voxel max over the 64 sorted points of one wave; lane = channel.  `val(p)` yields this
-// lane's channel of point p (>= 0: post-ReLU).  A voxel whose whole segment [start[v], start[v+1]) lies
-// inside the wave's range is written with one 256-byte row store; a cut segment uses integer atomicMax on
-// the zero-initialised destination (identical result for non-negative floats).
+// Segmented per-voxel max over the 64 voxel-sorted points of one wave; lane = channel.  `val(p)` yields this lane's
+// channel of point p (>= 0: post-ReLU).  The wave's 64 voxel ids sit in one VGPR (`myvox`, lane p = point p) and are
+// broadcast with v_readlane (SGPR, no LDS round trip per point); the values are read from LDS 16 points at a time
+// (independent ds_reads in flight) before the serial run logic touches them.  A run that does not reach a wave
+// boundary -- or whose neighbour across the boundary belongs to another voxel (`vprev`, `vnext`: the voxel ids of
+// records j0-1 and j0+64) -- is written with one 256-byte row store; a run cut by the boundary uses integer
+// atomicMax on the zero-initialised destination (identical result for non-negative floats).
 template <typename ValFn>
-__device__ __forceinline__ void vfe_segmented_max(const int* __restrict__ vox, uint32_t j0, int lane,
-                                                  const uint32_t* __restrict__ start, float* __restrict__ dst,
+__device__ __forceinline__ void vfe_segmented_max(int myvox, int vprev, int vnext, int lane, float* __restrict__ dst,
                                                   ValFn val) {
-  int run = -1;
+  int run = -1, first = 0;
   float m = 0.f;
-  auto flush = [&]() {
+  auto flush = [&](int last) {   // run covers points [first, last]
     if (run < 0) return;
-    const bool whole = start[run] >= j0 && start[run + 1] <= j0 + 64;
+    const bool whole = (first > 0 || vprev != run) && (last < 63 || vnext != run);
     if (whole) dst[(size_t)run * kC + lane] = m;
     else if (m > 0.f) atomicMax(reinterpret_cast<int*>(dst) + (size_t)run * kC + lane, __float_as_int(m));
   };
-  for (int p = 0; p < 64; ++p) {
-    const int v = vox[p];
-    if (v < 0) continue;
-    if (v != run) {
-      flush();
-      run = v;
-      m = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; c += 16) {
+    float vals[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) vals[q] = val(c + q);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int v = __builtin_amdgcn_readlane(myvox, c + q);
+      if (v < 0) continue;   // past the last valid point (only at the very end of the sorted list)
+      if (v != run) {
+        flush(c + q - 1);
+        run = v;
+        first = c + q;
+        m = 0.f;
+      }
+      m = fmaxf(m, vals[q]);
     }
-    m = fmaxf(m, val(p));
   }
-  flush();
+  flush(63);
+}
+
+// voxel id stored in record j (wave-uniform scalar load), -1 outside [0, n)
+__device__ __forceinline__ int vfe_record_voxel(const float* __restrict__ recs, long long j, uint32_t n) {
+  return (j >= 0 && j < (long long)n) ? __float_as_int(recs[(size_t)j * kRec + kRec - 1]) : -1;
 }
 
 template <int CIN>
@@ -232,8 +247,10 @@ __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
   __syncthreads();
   const int wave = t >> 6, lane = t & 63;
   const float* wt = tile + wave * 64 * kLdsStride;
-  vfe_segmented_max(vox + wave * 64, blockIdx.x * kL1Threads + wave * 64, lane, start, vmax1,
-                    [&](int p) { return wt[p * kLdsStride + lane]; });
+  const long long wj0 = (long long)blockIdx.x * kL1Threads + wave * 64;
+  const uint32_t nv = (uint32_t)*n_valid;
+  vfe_segmented_max(vox[wave * 64 + lane], vfe_record_voxel(recs, wj0 - 1, nv), vfe_record_voxel(recs, wj0 + 64, nv),
+                    lane, vmax1, [&](int p) { return wt[p * kLdsStride + lane]; });
 }
 
 // ------------------------------------------------------------------------------------------ layer 2 (MFMA)
@@ -357,7 +374,8 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
       for (int t = 0; t < 4; ++t) ftile[(rg * 16 + 4 * kg + t) * kLdsStride + nt * 16 + col] = acc[rg][nt][t];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   const float sc = sc2[lane], sh = shift2[lane];
-  vfe_segmented_max(vox, j0, lane, start, out,
+  vfe_segmented_max(vox[lane], vfe_record_voxel(recs, (long long)j0 - 1, nv),
+                    vfe_record_voxel(recs, (long long)j0 + 64, nv), lane, out,
                     [&](int p) { return fmaxf(fmaf(ftile[p * kLdsStride + lane], sc, sh), 0.f); });
 }
 
