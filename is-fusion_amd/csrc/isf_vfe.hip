@@ -41,14 +41,45 @@ __device__ __forceinline__ void vfe_split8(const f32x8 v, uint4& hi, uint4& lo) 
 }
 
 // ------------------------------------------------------------------------------------------ weight prep
-// w1t[k][o] = w1[o][k]                                   (fp32, SGPR-streamed by layer 1)
 // w2p[kc][nt][hi|lo][lane][8] = split(w2[16nt + (lane&15)][32kc + 8(lane>>4) + jj] * 2^sw), kc = 0..3
 // sc2[o] = scale2[o] * 2^-sw
+// w1p[nt][hi|lo][lane][4] = split(w1[16nt + (lane&15)][4(lane>>4) + jj] * 2^sw1) (zero for k >= F): B fragments of
+// v_mfma_f32_16x16x16_f16;  sc1[o] = scale1[o] * 2^-sw1
 __global__ void vfe_prep_kernel(const float* __restrict__ w1, int F, const float* __restrict__ w2,
-                                const float* __restrict__ scale2, float* __restrict__ w1t,
+                                const float* __restrict__ scale1, const float* __restrict__ scale2,
+                                uint2* __restrict__ w1p, float* __restrict__ sc1,
                                 uint4* __restrict__ w2p, float* __restrict__ sc2) {
   __shared__ float amax_s;
+  __shared__ float amax1_s;
   const int t = threadIdx.x;  // 256 threads, one block
+  {
+    float m1 = 0.f;
+    for (int i = t; i < kC * F; i += 256) m1 = fmaxf(m1, fabsf(w1[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, d, 64));
+    if (t == 0) amax1_s = 0.f;
+    __syncthreads();
+    if ((t & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(&amax1_s), __float_as_uint(m1));
+    __syncthreads();
+    int e1 = 0;
+    if (amax1_s > 0.f) (void)frexpf(amax1_s, &e1);
+    const int sw1 = amax1_s > 0.f ? 13 - e1 : 0;
+    const float s1 = ldexpf(1.f, sw1), inv1 = ldexpf(1.f, -sw1);
+    if (t < kC) sc1[t] = scale1[t] * inv1;
+    for (int i = t; i < 4 * 64; i += 256) {  // (nt, lane)
+      const int lane = i & 63, nt = i >> 6;
+      _Float16 hi[4], lo[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int k = 4 * (lane >> 4) + jj;
+        const float x = k < F ? w1[(size_t)(16 * nt + (lane & 15)) * F + k] * s1 : 0.f;
+        hi[jj] = (_Float16)x;
+        lo[jj] = (_Float16)(x - (float)hi[jj]);
+      }
+      w1p[(nt * 2 + 0) * 64 + lane] = *reinterpret_cast<const uint2*>(hi);
+      w1p[(nt * 2 + 1) * 64 + lane] = *reinterpret_cast<const uint2*>(lo);
+    }
+  }
   float m = 0.f;
   for (int i = t; i < kC * 2 * kC; i += 256) m = fmaxf(m, fabsf(w2[i]));
 #pragma unroll
@@ -62,10 +93,6 @@ __global__ void vfe_prep_kernel(const float* __restrict__ w1, int F, const float
   if (amax > 0.f) (void)frexpf(amax, &e);
   const int sw = amax > 0.f ? 13 - e : 0;
   const float s = ldexpf(1.f, sw), inv = ldexpf(1.f, -sw);
-  for (int i = t; i < F * kC; i += 256) {
-    const int k = i / kC, o = i % kC;
-    w1t[i] = w1[(size_t)o * F + k];
-  }
   if (t < kC) sc2[t] = scale2[t] * inv;
   for (int i = t; i < 4 * 4 * 64; i += 256) {  // (kc, nt, lane)
     const int lane = i & 63, nt = (i >> 6) & 3, kc = i >> 8;
@@ -163,19 +190,75 @@ __device__ __forceinline__ void vfe_point_features(const float* __restrict__ p, 
   f[CIN + 5] = __fsub_rn(p[2], __fadd_rn(__fmul_rn((float)c.y, g.vz), g.oz));
 }
 
+// Layer 1 on the matrix cores: the wave's 64 points x F (<= 16) features times W1^T [16 x 64] as 4 row groups x
+// 4 column tiles of v_mfma_f32_16x16x16_f16 in the same hi/lo split arithmetic as everywhere else (fp32-class).
+// The per-lane features go through a 4 KiB wave-private LDS staging area ([point][16 hi | 16 lo] halves) to reach
+// the A-fragment layout; the result stays in the C/D layout: acc[rg][nt][t] = sum for point 16 rg + 4 (lane>>4) + t,
+// channel 16 nt + (lane & 15), before BatchNorm.  (The VALU version cost 704 FMAs per point fed by 44 scalar
+// weight loads per wave.)
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
 template <int F>
-__device__ __forceinline__ void vfe_layer1(const float (&f)[F], const float* __restrict__ w1t,
-                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                           float (&h)[kC]) {
+__device__ __forceinline__ void vfe_layer1_mfma(const float (&f)[F], bool valid, const uint2* __restrict__ w1p,
+                                                char* __restrict__ stage, int lane, f32x4 (&acc)[4][4]) {
+  static_assert(F <= 16, "layer-1 features must fit one K = 16 MFMA");
+  {
+    _Float16 hi[16], lo[16];
 #pragma unroll
-  for (int o = 0; o < kC; ++o) h[o] = 0.f;
-#pragma unroll
-  for (int k = 0; k < F; ++k) {
-#pragma unroll
-    for (int o = 0; o < kC; ++o) h[o] = fmaf(f[k], w1t[k * kC + o], h[o]);
+    for (int k = 0; k < 16; ++k) {
+      const float x = (k < F && valid) ? f[k < F ? k : 0] : 0.f;
+      hi[k] = (_Float16)x;
+      lo[k] = (_Float16)(x - (float)hi[k]);
+    }
+    uint4* sp = reinterpret_cast<uint4*>(stage + lane * 64);
+    sp[0] = *reinterpret_cast<const uint4*>(&hi[0]);
+    sp[1] = *reinterpret_cast<const uint4*>(&hi[8]);
+    sp[2] = *reinterpret_cast<const uint4*>(&lo[0]);
+    sp[3] = *reinterpret_cast<const uint4*>(&lo[8]);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const int col = lane & 15, kq = lane >> 4;
+  uint2 ah[4], al[4];
 #pragma unroll
-  for (int o = 0; o < kC; ++o) h[o] = fmaxf(fmaf(h[o], scale[o], shift[o]), 0.f);
+  for (int rg = 0; rg < 4; ++rg) {
+    const char* base = stage + (16 * rg + col) * 64 + kq * 8;
+    ah[rg] = *reinterpret_cast<const uint2*>(base);
+    al[rg] = *reinterpret_cast<const uint2*>(base + 32);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const uint2 bhu = w1p[(nt * 2 + 0) * 64 + lane];
+    const uint2 blu = w1p[(nt * 2 + 1) * 64 + lane];
+    const h4v bh = *reinterpret_cast<const h4v*>(&bhu);
+    const h4v bl = *reinterpret_cast<const h4v*>(&blu);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const h4v a_h = *reinterpret_cast<const h4v*>(&ah[rg]);
+      const h4v a_l = *reinterpret_cast<const h4v*>(&al[rg]);
+      f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+      c = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, bh, c, 0, 0, 0);
+      acc[rg][nt] = c;
+    }
+  }
+}
+
+// C/D-layout layer-1 sums -> relu(BN) -> fp32 tile [point][kLdsStride]
+__device__ __forceinline__ void vfe_layer1_store_tile(const f32x4 (&acc)[4][4], const float* __restrict__ sc1,
+                                                      const float* __restrict__ shift1, float* __restrict__ tile,
+                                                      int lane) {
+  const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const float sc = sc1[16 * nt + col], sh = shift1[16 * nt + col];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        tile[(16 * rg + 4 * kq + t) * kLdsStride + 16 * nt + col] = fmaxf(fmaf(acc[rg][nt][t], sc, sh), 0.f);
+  }
 }
 
 // Segmented per-voxel max over the 64 voxel-sorted points of one wave; lane = channel.  `val(p)` yields this lane's
@@ -225,32 +308,33 @@ __device__ __forceinline__ int vfe_record_voxel(const float* __restrict__ recs, 
 template <int CIN>
 __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
     const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
-    const uint32_t* __restrict__ start, const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
-    const float* __restrict__ scale1, const float* __restrict__ shift1, float* __restrict__ vmax1) {
-  __shared__ float tile[kL1Threads * kLdsStride];
-  __shared__ int vox[kL1Threads];
+    const float4* __restrict__ mean4, VfeGeom g, const uint2* __restrict__ w1p, const float* __restrict__ sc1,
+    const float* __restrict__ shift1, float* __restrict__ vmax1) {
+  __shared__ __attribute__((aligned(16))) float tile[kL1Threads * kLdsStride];
   const int t = threadIdx.x;
-  const uint32_t j = blockIdx.x * kL1Threads + t;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const long long wj0 = (long long)blockIdx.x * kL1Threads + wave * 64;
+  const uint32_t nv = (uint32_t)*n_valid;
+  if (wj0 >= (long long)nv) return;   // wave-uniform; the tile is wave-private, no block barrier below
+  const uint32_t j = (uint32_t)wj0 + lane;
   int v = -1;
-  if (j < (uint32_t)*n_valid) {
+  float f[CIN + 6];
+#pragma unroll
+  for (int k = 0; k < CIN + 6; ++k) f[k] = 0.f;
+  if (j < nv) {
     float rec[kRec];
     *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
     *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
     v = __float_as_int(rec[kRec - 1]);
-    float f[CIN + 6], h[kC];
     vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
-    vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
-#pragma unroll
-    for (int o = 0; o < kC; ++o) tile[t * kLdsStride + o] = h[o];
   }
-  vox[t] = v;
-  __syncthreads();
-  const int wave = t >> 6, lane = t & 63;
-  const float* wt = tile + wave * 64 * kLdsStride;
-  const long long wj0 = (long long)blockIdx.x * kL1Threads + wave * 64;
-  const uint32_t nv = (uint32_t)*n_valid;
-  vfe_segmented_max(vox[wave * 64 + lane], vfe_record_voxel(recs, wj0 - 1, nv), vfe_record_voxel(recs, wj0 + 64, nv),
-                    lane, vmax1, [&](int p) { return wt[p * kLdsStride + lane]; });
+  float* wt = tile + wave * 64 * kLdsStride;
+  f32x4 acc[4][4];
+  vfe_layer1_mfma<CIN + 6>(f, v >= 0, w1p, reinterpret_cast<char*>(wt), lane, acc);
+  vfe_layer1_store_tile(acc, sc1, shift1, wt, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  vfe_segmented_max(v, vfe_record_voxel(recs, wj0 - 1, nv), vfe_record_voxel(recs, wj0 + 64, nv), lane, vmax1,
+                    [&](int p) { return wt[p * kLdsStride + lane]; });
 }
 
 // ------------------------------------------------------------------------------------------ layer 2 (MFMA)
@@ -263,10 +347,9 @@ static constexpr int kL2WaveBytes = 64 * kLdsStride * 4;  // 16640 >= 16384
 template <int CIN>
 __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
     const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
-    const uint32_t* __restrict__ start, const float4* __restrict__ mean4, VfeGeom g, const float* __restrict__ w1t,
-    const float* __restrict__ scale1, const float* __restrict__ shift1, const float* __restrict__ vmax1,
-    const uint4* __restrict__ w2p, const float* __restrict__ sc2, const float* __restrict__ shift2,
-    float* __restrict__ out) {
+    const float4* __restrict__ mean4, VfeGeom g, const uint2* __restrict__ w1p, const float* __restrict__ sc1,
+    const float* __restrict__ shift1, const float* __restrict__ vmax1, const uint4* __restrict__ w2p,
+    const float* __restrict__ sc2, const float* __restrict__ shift2, float* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) char smem[kL2Waves * kL2WaveBytes];
   __shared__ int vox_s[kL2Waves * 64];
   const int lane = threadIdx.x & 63;
@@ -282,17 +365,26 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
   const uint32_t j = j0 + lane;
   int v = -1;
   float h[kC];
-  if (j < nv) {
-    float rec[kRec];
-    *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
-    *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
-    v = __float_as_int(rec[kRec - 1]);
+  {
     float f[CIN + 6];
-    vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
-    vfe_layer1<CIN + 6>(f, w1t, scale1, shift1, h);
-  } else {
 #pragma unroll
-    for (int o = 0; o < kC; ++o) h[o] = 0.f;
+    for (int k = 0; k < CIN + 6; ++k) f[k] = 0.f;
+    if (j < nv) {
+      float rec[kRec];
+      *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
+      *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
+      v = __float_as_int(rec[kRec - 1]);
+      vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
+    }
+    // layer 1 recomputed on the matrix cores (its output [P, 64] never goes to HBM), through the fp32 tile back
+    // to one-point-per-lane registers for the split-format A tile of layer 2
+    f32x4 acc1[4][4];
+    vfe_layer1_mfma<CIN + 6>(f, v >= 0, w1p, reinterpret_cast<char*>(ftile), lane, acc1);
+    vfe_layer1_store_tile(acc1, sc1, shift1, ftile, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int o = 0; o < kC; ++o) h[o] = ftile[lane * kLdsStride + o];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
   vox[lane] = v;
 
@@ -392,12 +484,14 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(occ_create(a, &occ, B, d_alloc > grid[2] ? d_alloc : grid[2], grid[1], grid[0], st, false));
   ISF_TRY(occ_mark_coords4_bytemap(occ, coors4, P, st));
   ISF_TRY(occ_scan(a, occ, st));
-  float *w1t, *sc2;
+  float *sc1, *sc2;
+  uint2* w1p;
   uint4* w2p;
-  ISF_TRY(a.alloc_n(&w1t, (size_t)F * kC));
+  ISF_TRY(a.alloc_n(&sc1, (size_t)kC));
   ISF_TRY(a.alloc_n(&sc2, (size_t)kC));
+  ISF_TRY(a.alloc_n(&w1p, (size_t)4 * 2 * 64));
   ISF_TRY(a.alloc_n(&w2p, (size_t)4 * 4 * 128));
-  hipLaunchKernelGGL(vfe_prep_kernel, dim3(1), dim3(256), 0, st, w1, F, w2, scale2, w1t, w2p, sc2);
+  hipLaunchKernelGGL(vfe_prep_kernel, dim3(1), dim3(256), 0, st, w1, F, w2, scale1, scale2, w1p, sc1, w2p, sc2);
   int N = 0;
   ISF_TRY(read_int(occ.total, &N, st));  // the one host sync of the VFE: sizes every per-voxel buffer
   *n_host = N;
@@ -435,9 +529,9 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(N, 256)), dim3(256), 0, st, recs, start, N, mean4);
   const int* n_valid = reinterpret_cast<const int*>(start + N);
   hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, recs,
-                     voxel_coors, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1);
+                     voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1);
   hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st, recs,
-                     voxel_coors, n_valid, start, mean4, g, w1t, scale1, shift1, vmax1, w2p, sc2, shift2, voxel_feats);
+                     voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1, w2p, sc2, shift2, voxel_feats);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
