@@ -174,3 +174,24 @@ def test_multiprocess_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_detector_level_state_dict_uses_reference_names():
+    """ISFusionPtsPath registers its sub-modules under the reference detector's attribute names (isfusion.py:20-51):
+    a released checkpoint's pts_* / fusion_encoder.* keys load unchanged (no wrapper prefixes, no duplicates)."""
+    from isfusion_amd.detector import ISFusionPtsPath
+    net = ISFusionPtsPath()
+    keys = list(net.state_dict().keys())
+    prefixes = {k.split(".")[0] for k in keys}
+    assert prefixes == {"pts_voxel_encoder", "pts_middle_encoder", "fusion_encoder", "pts_backbone", "pts_neck",
+                        "pts_bbox_head"}
+    assert len(keys) == len(set(keys))
+    for k in ("pts_voxel_encoder.vfe_layers.0.linear.weight", "pts_middle_encoder.conv_input.0.weight",
+              "fusion_encoder.grid2region_att.0.block_list.0.encoder_list.0.win_attn.self_attn.in_proj_weight",
+              "fusion_encoder.instance_att.layers.1.cross_attn.sampling_offsets.bias",
+              "pts_backbone.ds_layer.0.weight", "pts_neck.deblocks.1.0.weight",
+              "pts_bbox_head.decoder.0.multihead_attn.in_proj_weight",
+              "pts_bbox_head.prediction_heads.0.heatmap.1.bias"):
+        assert k in keys, k
+    # the transposed conv of the neck keeps torch's [Cin, Cout, k, k] layout
+    assert tuple(net.state_dict()["pts_neck.deblocks.1.0.weight"].shape) == (256, 256, 2, 2)
