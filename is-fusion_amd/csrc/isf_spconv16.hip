@@ -95,8 +95,8 @@ struct Conv16Smem {
 };
 
 // NW waves per workgroup (4 or 16): all of them share one weight stage per step, so the weight bytes a CU pulls
-// through its vector memory path per MFMA fall with NW -- the measured wall of this kernel is the ~10 TB/s of
-// aggregate L2 -> CU traffic (weights re-streamed per workgroup + gathered rows), not the MFMA pipe.
+// through its vector memory path per MFMA fall with NW (measured: a modest win for the 128-column layers of the
+// large levels only; what bounds the kernel is analysed in DESIGN.md section 5).
 template <int CIN, int NT, int RG, int NW>
 __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
