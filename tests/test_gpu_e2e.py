@@ -79,7 +79,8 @@ def test_extract_pts_feat_matches_oracle_composition(dev, oracle_mod):
         sdh = {k: v.float().cpu() for k, v in net.pts_bbox_head.state_dict().items()}
         ho = orc.transfusion_head_forward(x, sdh, 200)
     # the 512-channel neck output has magnitude O(1); the head sums 9*512 products per heat-map logit
-    assert (head_out["dense_heatmap"].cpu() - ho["dense_heatmap"]).abs().max().item() < 2e-3
+    assert (head_out["dense_heatmap"].cpu() - ho["dense_heatmap"]).abs().max().item() < \
+        2e-3 * max(1.0, ho["dense_heatmap"].abs().max().item())
     # Proposal selection: a LiDAR BEV map is empty over large areas, so many heat-map cells carry EXACTLY equal scores
     # and the reference's argsort breaks those ties arbitrarily (the HIP kernel: ascending flat index).  Compare what
     # is defined: the sorted top-200 scores, and per-proposal outputs for the proposals both sides selected.
