@@ -195,3 +195,41 @@ def test_detector_level_state_dict_uses_reference_names():
         assert k in keys, k
     # the transposed conv of the neck keeps torch's [Cin, Cout, k, k] layout
     assert tuple(net.state_dict()["pts_neck.deblocks.1.0.weight"].shape) == (256, 256, 2, 2)
+
+
+def test_fusion_modules_fail_loudly_without_gpu():
+    """no CPU fallback anywhere in the HSF / IGF / head path: CPU tensors raise instead of silently computing"""
+    import pytest
+    import torch
+    from isfusion_amd import _lib
+    from isfusion_amd import fusion_ops as ops
+    from isfusion_amd.dense_conv import PackedConvBN, SplitMap
+    from isfusion_amd.transfusion_head import TransFusionHeadV2
+    with pytest.raises(_lib.IsfError):
+        ops.PackedLinear(torch.zeros(16, 32))
+    with pytest.raises(_lib.IsfError):
+        SplitMap.from_nchw(torch.zeros(1, 32, 4, 4))
+    with pytest.raises(_lib.IsfError):
+        PackedConvBN(torch.nn.Conv2d(32, 32, 3, padding=1, bias=False), None)
+    with pytest.raises(_lib.IsfError):
+        ops.instance_topk(torch.zeros(1, 10, 8, 8), 4)
+    head = TransFusionHeadV2(test_cfg=dict(dataset="nuScenes", grid_size=[64, 64, 40], out_size_factor=8)).eval()
+    with pytest.raises(_lib.IsfError):
+        head.forward_single(torch.zeros(1, 512, 8, 8))
+    head.train()
+    with pytest.raises(AssertionError):
+        head.forward_single(torch.zeros(1, 512, 8, 8))
+
+
+def test_seeded_state_dict_keeps_signal_alive():
+    """normalisation scales are drawn around 1 for every norm layer (found by module type), so a parity check on the
+    last feature map of a conv stack exercises the whole data path"""
+    import torch
+    from isfusion_amd.fusion_modules import SECONDV2, seeded_state_dict
+    bb = SECONDV2(in_channels=128, out_channels=[128, 256], layer_nums=[5, 5], layer_strides=[1, 2])
+    sd = seeded_state_dict(bb, 200)
+    for name, m in bb.named_modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            w = sd[name + ".weight"]
+            assert float(w.min()) >= 0.75 and float(w.max()) <= 1.25, name
+    assert seeded_state_dict(bb, 200)["blocks.0.0.weight"].equal(sd["blocks.0.0.weight"])   # deterministic
