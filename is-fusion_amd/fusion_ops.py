@@ -4,7 +4,6 @@ libisf_hip.so.  No CPU fallback: every function raises when its tensors are not 
 Layout conventions: a dense BEV grid [B, C, S, S] becomes a token matrix [B*S*S, C] (row = (b*S + y)*S + x, the
 order fusion_encoder.py:1167-1173 builds); the transposes between the two are stock torch ops.
 """
-import math
 
 import torch
 

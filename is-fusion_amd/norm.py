@@ -9,7 +9,6 @@ import torch
 import torch.distributed as dist
 from torch import nn
 from torch.autograd import Function
-from torch.nn import functional as F
 
 
 class _AllReduceSum(Function):

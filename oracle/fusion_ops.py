@@ -10,7 +10,6 @@ State dicts use the reference's parameter names (e.g.
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -9,7 +9,6 @@ pytestmark = pytest.mark.gpu
 
 
 def test_extract_pts_feat_matches_oracle_composition(dev, oracle_mod):
-    import isfusion_amd as m
     from isfusion_amd import synthetic
     from isfusion_amd.detector import ISFusionPtsPath
     from isfusion_amd.fusion_modules import seeded_state_dict

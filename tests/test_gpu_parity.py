@@ -2,7 +2,6 @@
 oracle on the same seeded inputs, against the committed golden vectors, and -- at BASELINE config sizes --
 through size-independent properties.  Integer / index outputs must be bit-exact; floating point within the
 tolerance written next to each check (north_star: 1e-3 fp32 on BEV features)."""
-import ctypes
 
 import numpy as np
 import pytest
