@@ -332,6 +332,20 @@ int isf_msda_forward(const float* value, const float* sampling_offsets, const fl
                      const float* reference_points, int batch_size, int num_queries, int num_heads, int head_dim,
                      int num_points, int height, int width, float* out, isf_stream_t stream);
 
+/* 8f #1  box decoding (detection-head post-processing) ---------------------------------------------------
+ * replaces TransFusionHeadV2.get_bboxes with nms_type=None (dense_heads/transfusion_head_v2.py:1278-1312,1344-1418)
+ * including TransFusionBBoxCoder.decode(filter=True) (core/bbox/coders/transfusion_bbox_coder.py:39-124).
+ * heatmap / query_score [B, classes, ld] (the first num_proposals columns of each row are used; heatmap = logits),
+ * query_labels [B, P] int64, center [B,2,ld] (BEV cells), height [B,1,ld], dim [B,3,ld] (log metres), rot [B,2,ld]
+ * (sin, cos), vel [B,2,ld] or NULL.  coder = 12 HOST floats: out_size_factor*voxel_size (x, y), pc_range (x, y),
+ * post_center_range (6), score_threshold, apply_threshold (0/1; the reference tests `if self.score_threshold:`, so 0.0
+ * is not applied).  Outputs, compacted per sample in proposal order: boxes [B, P, 9 | 7 without vel]
+ * (x, y, z_bottom, dx, dy, dz, yaw, vx, vy), scores [B, P], labels [B, P] int32, counts [B] = boxes kept. */
+int isf_decode_boxes(const float* heatmap, const float* query_score, const int64_t* query_labels, const float* center,
+                     const float* height, const float* dim, const float* rot, const float* vel, int batch_size,
+                     int num_classes, int num_proposals, int ld, const float* coder, float* boxes, float* scores,
+                     int32_t* labels, int32_t* counts, isf_stream_t stream);
+
 /* A9 / A15  dense 3x3 BEV convolutions on the sparse-conv kernel ------------------------
  * replaces mmcv ConvModule / nn.Conv2d + BatchNorm2d + ReLU (fusion_encoder.py:862-960, backbones/second.py:126-165,
  * MIOpen Winograd + 2 elementwise kernels per layer).  A dense B x H x W grid is a sparse tensor with every cell

@@ -121,6 +121,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p]),
     "isf_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_void_p, c_void_p]),
+    "isf_decode_boxes": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float)]
+                         + [c_void_p] * 5),
     "isf_dense_grid_rulebook": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                         c_int * 2, c_void_p]),
     "isf_nchw_to_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -109,3 +109,20 @@ class ISFusionPtsPath(nn.Module):
         the raw head outputs [[dict(center, height, dim, rot, vel, heatmap, query_heatmap_score, dense_heatmap)]]."""
         x = self.pts_neck(self.extract_pts_feat(pts, img_feats, img_metas, **kwargs))
         return self.pts_bbox_head(x, img_feats, img_metas)
+
+    @torch.no_grad()
+    def simple_test_pts(self, x, x_img, img_metas, rescale=False):
+        """isfusion.py:274-283: head forward + get_bboxes + bbox3d2result (core/bbox/transforms.py:50-76) on the neck
+        output -> [dict(boxes_3d, scores_3d, labels_3d)] on the CPU, one per sample."""
+        outs = self.pts_bbox_head(x, x_img, img_metas)
+        out = []
+        for boxes, scores, labels in self.pts_bbox_head.get_bboxes(outs, img_metas, rescale=rescale):
+            out.append(dict(boxes_3d=boxes.to("cpu"), scores_3d=scores.cpu(), labels_3d=labels.cpu()))
+        return out
+
+    @torch.no_grad()
+    def simple_test(self, points, img_metas, img_feats, rescale=False, **kwargs):
+        """isfusion.py:285-305 for the point-cloud branch; `img_feats` are the camera neck outputs (the camera
+        backbone stays stock).  -> [dict(pts_bbox=...)] per sample."""
+        x = self.pts_neck(self.extract_pts_feat(points, img_feats, img_metas, **kwargs))
+        return [dict(pts_bbox=r) for r in self.simple_test_pts(x, img_feats, img_metas, rescale=rescale)]

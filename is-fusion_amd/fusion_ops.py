@@ -5,6 +5,8 @@ Layout conventions: a dense BEV grid [B, C, S, S] becomes a token matrix [B*S*S,
 order fusion_encoder.py:1167-1173 builds); the transposes between the two are stock torch ops.
 """
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -218,6 +220,32 @@ def instance_topk(heatmap, k=200, nms_kernel=3, pool1_classes=(8, 9), return_mas
     if return_masked:
         return top.long(), raw.long(), masked
     return top.long()
+
+
+def decode_boxes(heatmap, query_score, query_labels, center, height, dim, rot, vel, cell, origin, post_center_range,
+                 score_threshold):
+    """TransFusionHeadV2.get_bboxes with nms_type=None incl. TransFusionBBoxCoder.decode(filter=True)
+    (transfusion_head_v2.py:1286-1312, transfusion_bbox_coder.py:39-124) in one launch.  All inputs [B, *, P]
+    (heatmap = logits); -> boxes [B, P, 7|9], scores [B, P], labels [B, P] int32 compacted per sample in proposal
+    order, counts [B] int32 (device)."""
+    _lib.require_cuda(heatmap)
+    B, C, P = heatmap.shape
+    ts = [t.float().contiguous() for t in (heatmap, query_score, center, height, dim, rot)]
+    v = vel.float().contiguous() if vel is not None else None
+    lab = query_labels.long().contiguous()
+    dev = heatmap.device
+    boxes = torch.empty((B, P, 9 if v is not None else 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, P), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, P), dtype=torch.int32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    coder = (ctypes.c_float * 12)(cell[0], cell[1], origin[0], origin[1], *[float(r) for r in post_center_range],
+                                  float(score_threshold or 0.0), 1.0 if score_threshold else 0.0)
+    _lib.check(_lib.load().isf_decode_boxes(_lib.ptr(ts[0]), _lib.ptr(ts[1]), _lib.ptr(lab), _lib.ptr(ts[2]),
+                                            _lib.ptr(ts[3]), _lib.ptr(ts[4]), _lib.ptr(ts[5]),
+                                            _lib.ptr(v) if v is not None else None, B, C, P, P, coder, _lib.ptr(boxes),
+                                            _lib.ptr(scores), _lib.ptr(labels), _lib.ptr(counts), _lib.stream()),
+               "isf_decode_boxes")
+    return boxes, scores, labels, counts
 
 
 def gather_instances(x_scene, top_idx, bev_size):

@@ -81,12 +81,17 @@ class TransFusionHeadV2(nn.Module):
 
     def __init__(self, num_proposals=200, auxiliary=True, in_channels=512, hidden_channel=128, num_classes=10,
                  num_decoder_layers=1, num_heads=8, nms_kernel_size=3, ffn_channel=256, common_heads=None,
-                 num_heatmap_convs=2, test_cfg=None, dense_conv="hip", **kwargs):
+                 num_heatmap_convs=2, test_cfg=None, bbox_coder=None, dense_conv="hip", **kwargs):
         super().__init__()
         self.num_classes, self.num_proposals, self.auxiliary = num_classes, num_proposals, auxiliary
         self.num_heads, self.num_decoder_layers, self.nms_kernel_size = num_heads, num_decoder_layers, nms_kernel_size
         self.test_cfg = test_cfg or dict(dataset="nuScenes", grid_size=[1440, 1440, 40], out_size_factor=8)
         self.dense_conv = dense_conv
+        # TransFusionBBoxCoder arguments (configs/isfusion/isfusion_0075voxel.py:130-138); decoding runs in one kernel
+        self.bbox_coder = dict(pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075], out_size_factor=8,
+                               post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.0,
+                               code_size=10)
+        self.bbox_coder.update({k: v for k, v in (bbox_coder or {}).items() if k != "type"})
         common_heads = common_heads or dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2))
         self.shared_conv = nn.Conv2d(in_channels, hidden_channel, 3, padding=1, bias=True)
         self.heatmap_head = nn.Sequential(_ConvModule2d(hidden_channel, hidden_channel),
@@ -211,3 +216,28 @@ class TransFusionHeadV2(nn.Module):
             feats = [feats]
         # multi_apply transposes the per-level lists: a 1-tuple holding the list of per-level result dicts
         return ([self.forward_single(f, None, metas)[0] for f in feats],)
+
+    @torch.no_grad()
+    def get_bboxes(self, preds_dicts, metas=None, img=None, rescale=False, for_roi=False):
+        """:1278-1418 with test_cfg nms_type=None (the shipped nuScenes setting): proposal scores, box decoding and the
+        centre-range / score filter in one kernel (isf_decode_boxes).  -> one [boxes, scores, labels] per sample
+        (the reference asserts a single sample, :1407-1408); boxes are wrapped in metas[i]['box_type_3d'] when the meta
+        carries one."""
+        if self.test_cfg.get("nms_type") is not None:
+            raise NotImplementedError("get_bboxes: only nms_type=None (the shipped test_cfg) is built; circle / rotate "
+                                      "NMS is the TTA path (SURVEY.md section 8, out of scope)")
+        assert len(preds_dicts) == 1, "one feature level"
+        pd = preds_dicts[0][0]
+        P, bc = self.num_proposals, self.bbox_coder
+        last = {k: pd[k][..., -P:] for k in ("heatmap", "center", "height", "dim", "rot")}
+        vel = pd["vel"][..., -P:] if "vel" in pd else None
+        cell = [bc["out_size_factor"] * bc["voxel_size"][0], bc["out_size_factor"] * bc["voxel_size"][1]]
+        boxes, scores, labels, counts = ops.decode_boxes(
+            last["heatmap"], pd["query_heatmap_score"], self.query_labels, last["center"], last["height"], last["dim"],
+            last["rot"], vel, cell, bc["pc_range"], bc["post_center_range"], bc["score_threshold"])
+        res = []
+        for i, n in enumerate(counts.tolist()):
+            b = boxes[i, :n]
+            box_type = (metas[i] if metas and i < len(metas) else {}).get("box_type_3d")
+            res.append([box_type(b, box_dim=b.shape[-1]) if box_type is not None else b, scores[i, :n], labels[i, :n]])
+        return res

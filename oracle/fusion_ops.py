@@ -360,3 +360,29 @@ def transfusion_head_forward(inputs, sd, num_proposals=200, num_classes=10, nhea
     out["dense_heatmap"] = dense_heatmap
     out["top_idx"] = top_idx
     return out
+
+
+def decode_boxes(preds, query_labels, num_proposals, out_size_factor, voxel_size, pc_range, post_center_range,
+                 score_threshold=0.0, num_classes=10):
+    """TransFusionHeadV2.get_bboxes with nms_type=None (dense_heads/transfusion_head_v2.py:1286-1312,1344-1418) around
+    TransFusionBBoxCoder.decode(filter=True) (core/bbox/coders/transfusion_bbox_coder.py:39-124); the inputs are not
+    modified (the reference decodes centre / dim in place).  -> per sample (boxes [n, 7|9], scores [n], labels [n])."""
+    P = num_proposals
+    score = preds["heatmap"][..., -P:].sigmoid()
+    one_hot = F.one_hot(query_labels, num_classes=num_classes).permute(0, 2, 1)
+    score = score * preds["query_heatmap_score"] * one_hot
+    final_scores, final_preds = score.max(1)
+    center = preds["center"][..., -P:].clone()
+    center[:, 0] = center[:, 0] * out_size_factor * voxel_size[0] + pc_range[0]
+    center[:, 1] = center[:, 1] * out_size_factor * voxel_size[1] + pc_range[1]
+    dim = preds["dim"][..., -P:].exp()
+    height = preds["height"][..., -P:] - dim[:, 2:3] * 0.5
+    rot = preds["rot"][..., -P:]
+    yaw = torch.atan2(rot[:, 0:1], rot[:, 1:2])
+    parts = [center, height, dim, yaw] + ([preds["vel"][..., -P:]] if "vel" in preds else [])
+    boxes = torch.cat(parts, 1).permute(0, 2, 1)
+    rng = torch.tensor(post_center_range, dtype=boxes.dtype)
+    mask = (boxes[..., :3] >= rng[:3]).all(2) & (boxes[..., :3] <= rng[3:]).all(2)
+    if score_threshold:          # :108 -- a threshold of 0.0 is not applied
+        mask &= final_scores > score_threshold
+    return [(boxes[i, mask[i]], final_scores[i, mask[i]], final_preds[i, mask[i]]) for i in range(boxes.shape[0])]

@@ -69,6 +69,14 @@ HEAD_CONFIGS = {
     "small": dict(seed=41, B=2, X=36, num_proposals=20),
     "full": dict(seed=42, B=1, X=180, num_proposals=200),
 }
+# TransFusionBBoxCoder arguments for the get_bboxes goldens: the shipped ones (isfusion_0075voxel.py:130-138) and a
+# variant whose centre range / score threshold actually filter the seeded proposals
+HEAD_CODERS = {
+    "shipped": dict(pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075], out_size_factor=8,
+                    post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], score_threshold=0.0, code_size=10),
+    "tight": dict(pc_range=[-54.0, -54.0], voxel_size=[0.075, 0.075], out_size_factor=8,
+                  post_center_range=[-50.0, -52.0, -1.5, -35.0, 30.0, 0.8], score_threshold=0.33, code_size=10),
+}
 
 
 def head_kwargs(cfg):

@@ -219,6 +219,11 @@ def install():
     _mod("mmdet3d.ops.iou3d.iou3d_utils", nms_gpu=None)
     _mod("mmdet.core", build_bbox_coder=lambda cfg: None, multi_apply=None, build_assigner=lambda cfg: None,
          build_sampler=lambda *a, **k: None, AssignResult=None)
+    # box decoding (get_bboxes): the coder is plain torch; its base class / registry are inert stubs
+    regs["BBOX_CODERS"] = _Registry("BBOX_CODERS")
+    _pkg("mmdet.core.bbox", BaseBBoxCoder=object)
+    _mod("mmdet.core.bbox.builder", BBOX_CODERS=regs["BBOX_CODERS"])
+    m["bbox_coder"] = _load("isf_ref_transfusion_bbox_coder", "mmdet3d/core/bbox/coders/transfusion_bbox_coder.py")
     _pkg("mmdet3d.models.dense_heads", os.path.join(base, "models", "dense_heads"))
     m["transfusion_head"] = _load("mmdet3d.models.dense_heads.transfusion_head_v2",
                                   "mmdet3d/models/dense_heads/transfusion_head_v2.py")

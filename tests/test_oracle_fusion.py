@@ -78,3 +78,36 @@ def test_head_restatement_matches_reference_outputs(golden, name):
         assert np.abs(o[k].numpy() - g[f"{name}.{k}"]).max() < 2e-4, k
     dh = o["dense_heatmap"].reshape(-1).numpy()
     assert np.abs(dh[g[name + ".dense_heatmap.idx"]] - g[name + ".dense_heatmap.val"]).max() < 1e-4
+
+
+def _golden_head_outputs(g, name):
+    out = {k: torch.from_numpy(g[f"{name}.{k}"]) for k in HEAD_KEYS}
+    return out, torch.from_numpy(g[name + ".labels"])
+
+
+@pytest.mark.parametrize("coder", ["shipped", "tight"])
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_decode_boxes_restatement_matches_reference_get_bboxes(golden, name, coder):
+    """TransFusionHeadV2.get_bboxes (nms_type=None) + TransFusionBBoxCoder.decode: restatement vs the reference's own
+    boxes on the reference's head outputs; the 'tight' coder makes the centre-range / score filter bite"""
+    from fusion_common import HEAD_CODERS, HEAD_CONFIGS
+    from oracle import fusion_ops as orc
+    g = golden("head_ref.npz")
+    cfg, c = HEAD_CONFIGS[name], HEAD_CODERS[coder]
+    out, labels = _golden_head_outputs(g, name)
+    dec = orc.decode_boxes(out, labels, cfg["num_proposals"], c["out_size_factor"], c["voxel_size"], c["pc_range"],
+                           c["post_center_range"], c["score_threshold"])
+    assert len(dec) == cfg["B"]
+    kept = 0
+    for i, (boxes, scores, labs) in enumerate(dec):
+        ref = g[f"{name}.{coder}.{i}.boxes"]
+        assert boxes.shape == ref.shape and boxes.shape[1] == 9
+        assert np.array_equal(labs.numpy(), g[f"{name}.{coder}.{i}.box_labels"])
+        assert np.array_equal(scores.numpy(), g[f"{name}.{coder}.{i}.scores"])
+        if ref.size:
+            assert np.abs(boxes.numpy() - ref).max() < 1e-5
+        kept += ref.shape[0]
+    if coder == "tight":
+        assert 0 < kept < cfg["B"] * cfg["num_proposals"], "the filter must drop some and keep some"
+    # the inputs are left untouched (the reference decodes in place)
+    assert np.array_equal(out["center"].numpy(), g[name + ".center"])

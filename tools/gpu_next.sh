@@ -1,0 +1,7 @@
+#!/bin/bash
+# First GPU call of the next round: run the tests written after round 1's GPU budget was spent (marker gpu_next),
+# then the validated tier.   gpurun --timeout 900 -- 'bash tools/gpu_next.sh'
+set -u
+mkdir -p gpurun_out
+python -m pytest tests -q -m gpu_next 2>&1 | tail -25 | tee gpurun_out/gpu_next_tests.log
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/gpu_tests.log
