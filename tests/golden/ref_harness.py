@@ -231,6 +231,53 @@ def install():
     return m
 
 
+_pipelines = {}
+
+
+def install_pipelines():
+    """Load the reference's point-cloud input pipeline: datasets/pipelines/loading.py and
+    transforms_3d.py with core/points/*.  Everything they import beyond numpy / torch is registry, image or box
+    machinery the point transforms never touch -> inert stubs."""
+    if _pipelines:
+        return _pipelines
+    install()
+    base = os.path.join(REF, "mmdet3d")
+
+    class FileClient:
+        def __init__(self, backend="disk", **kw):
+            pass
+
+        def get(self, path):
+            with open(path, "rb") as f:
+                return f.read()
+
+    mmcv = sys.modules["mmcv"]
+    mmcv.FileClient = FileClient
+    mmcv.is_tuple_of = lambda seq, t: isinstance(seq, tuple) and all(isinstance(x, t) for x in seq)
+    reg = _Registry("PIPELINES")
+    _pkg("mmdet.datasets")
+    _mod("mmdet.datasets.builder", PIPELINES=reg)
+    _mod("mmdet.datasets.pipelines", LoadAnnotations=object, LoadImageFromFile=object, RandomFlip=object)
+    _pkg("mmdet3d.core.points", os.path.join(base, "core", "points"))
+    pts = _load("mmdet3d.core.points", "mmdet3d/core/points/__init__.py")
+    core = sys.modules["mmdet3d.core"]
+    core.points, core.VoxelGenerator = pts, None
+    bbox = sys.modules["mmdet3d.core.bbox"]
+    for n in ("CameraInstance3DBoxes", "DepthInstance3DBoxes", "LiDARInstance3DBoxes", "box_np_ops"):
+        setattr(bbox, n, None)
+    _pkg("mmdet3d.datasets", os.path.join(base, "datasets"))
+    _mod("mmdet3d.datasets.builder", OBJECTSAMPLERS=_Registry("OBJECTSAMPLERS"))
+    _pkg("mmdet3d.datasets.pipelines", os.path.join(base, "datasets", "pipelines"))
+    _mod("mmdet3d.datasets.pipelines.data_augment_utils", noise_per_object_v3_=None)
+    _mod("torchvision")
+    m = dict(points=pts)
+    m["loading"] = _load("mmdet3d.datasets.pipelines.loading", "mmdet3d/datasets/pipelines/loading.py")
+    m["transforms_3d"] = _load("mmdet3d.datasets.pipelines.transforms_3d",
+                               "mmdet3d/datasets/pipelines/transforms_3d.py")
+    _pipelines.update(m)
+    return m
+
+
 if __name__ == "__main__":
     mods = install()
     print({k: v.__name__ for k, v in mods.items()})

@@ -164,3 +164,24 @@ def test_dynamic_vfe_matches_torch_composition(oracle_mod):
     h2 = torch.relu(g @ torch.from_numpy(w2).T * torch.from_numpy(bn2[0]) + torch.from_numpy(bn2[1]))
     ref = torch.full((N, 64), -float("inf")).scatter_reduce(0, inv[:, None].expand(-1, 64), h2, "amax")
     assert np.allclose(vf, ref.numpy(), atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- input pre-pass (8f #3)
+@pytest.mark.parametrize("case", ["test", "remove_close", "train_aug"])
+@pytest.mark.parametrize("name", ["a", "b", "key_only"])
+def test_input_pipeline_restatement_matches_reference(golden, name, case):
+    """LoadPointsFromMultiSweeps + GlobalRotScaleTransV2 + RandomFlip3DV2 + PointsRangeFilter: the restatement equals
+    the reference's own output bit for bit (float64 sensor poses, float32 augmentation)"""
+    from input_common import INPUT_CONFIGS, PC_RANGE, sweep_inputs, train_aug
+    from oracle import input_ops
+    g = golden("input_ref.npz")
+    seed, key_n, sweep_ns = INPUT_CONFIGS[name]
+    key, sweeps, ts = sweep_inputs(seed, key_n, sweep_ns)
+    out = input_ops.load_frame(key, sweeps, ts, PC_RANGE, drop_close=(case == "remove_close"),
+                               aug=train_aug(77) if case == "train_aug" else None)
+    ref = g[f"{name}.{case}.points"]
+    assert out.dtype == np.float32 and out.shape == ref.shape
+    assert np.array_equal(out, ref)
+    # key-frame points come first with a zero time column; sweep points carry a positive lag
+    n_key = int((ref[:, 4] == 0).sum())
+    assert 0 < n_key <= key_n and (ref[:n_key, 4] == 0).all() and (ref[n_key:, 4] > 0).all()
