@@ -346,6 +346,41 @@ int isf_decode_boxes(const float* heatmap, const float* query_score, const int64
                      int num_classes, int num_proposals, int ld, const float* coder, float* boxes, float* scores,
                      int32_t* labels, int32_t* counts, isf_stream_t stream);
 
+/* 8f #3  input pre-pass: multi-sweep assembly + augmentation + range filter ---------------------------------
+ * replaces, per batch, the dataloader-side numpy / torch code of LoadPointsFromMultiSweeps.__call__
+ * (datasets/pipelines/loading.py:860-903), the point side of GlobalRotScaleTransV2 and RandomFlip3DV2
+ * (datasets/pipelines/transforms_3d.py:1887-1890, :1171-1183) and PointsRangeFilter (:2012-2025).
+ * raw = the sweep files of the batch as loaded (flat float32 [P, 5]: x, y, z, intensity, ring), uploaded untouched.
+ * One descriptor per file, grouped by ascending sample, key frame first within a sample (the order of the
+ * reference's concatenation).  Output: the kept points of the batch, compacted in input order, float32 [<= P, 5]
+ * (capacity P rows), and sample_offsets[batch+1] (rows; device, and host when sample_offsets_host != NULL).
+ * The call synchronizes `stream` once. */
+typedef struct {
+  int64_t first_point;     /* row of the file's first point in raw */
+  int32_t num_points;
+  int32_t sample;          /* batch index */
+  int32_t is_sweep;        /* 0: key frame (time column := 0)   1: previous sweep (pose applied, time := time_lag) */
+  int32_t remove_close;    /* sweeps only: drop points with |x| < r and |y| < r before the pose (loading.py:824-844) */
+  float close_radius;
+  float time_lag;          /* float32(key timestamp - sweep timestamp / 1e6) */
+  double rotation[9];      /* sensor2lidar_rotation, row-major; p @ R^T in float64 as numpy does (loading.py:883) */
+  double translation[3];   /* sensor2lidar_translation, float64 (loading.py:885) */
+} isf_sweep_t;
+
+typedef struct {
+  int32_t enabled;
+  float rot_mat_T[9];      /* points[:, :3] @ rot_mat_T, float32 (core/points/base_points.py:178) */
+  float translation[3];    /* then += translation (:206) */
+  float scale;             /* then *= scale (:270) */
+  int32_t flip_horizontal; /* then y := -y (core/points/lidar_points.py:31-32) */
+  int32_t flip_vertical;   /* and x := -x (:33-34) */
+} isf_point_aug_t;
+
+int isf_assemble_points(const float* raw, const isf_sweep_t* sweeps, int num_sweeps, int batch_size,
+                        const isf_point_aug_t* aug /* [batch] or NULL */,
+                        const float* point_range /* 6 host floats or NULL */, float* points_out,
+                        int32_t* sample_offsets, int32_t* sample_offsets_host, isf_stream_t stream);
+
 /* A9 / A15  dense 3x3 BEV convolutions on the sparse-conv kernel ------------------------
  * replaces mmcv ConvModule / nn.Conv2d + BatchNorm2d + ReLU (fusion_encoder.py:862-960, backbones/second.py:126-165,
  * MIOpen Winograd + 2 elementwise kernels per layer).  A dense B x H x W grid is a sparse tensor with every cell

@@ -51,6 +51,23 @@ class VfeParams(ctypes.Structure):
     ]
 
 
+class Sweep(ctypes.Structure):
+    """isf_sweep_t."""
+    _fields_ = [
+        ("first_point", ctypes.c_int64), ("num_points", ctypes.c_int32), ("sample", ctypes.c_int32),
+        ("is_sweep", ctypes.c_int32), ("remove_close", ctypes.c_int32), ("close_radius", ctypes.c_float),
+        ("time_lag", ctypes.c_float), ("rotation", ctypes.c_double * 9), ("translation", ctypes.c_double * 3),
+    ]
+
+
+class PointAug(ctypes.Structure):
+    """isf_point_aug_t."""
+    _fields_ = [
+        ("enabled", ctypes.c_int32), ("rot_mat_T", ctypes.c_float * 9), ("translation", ctypes.c_float * 3),
+        ("scale", ctypes.c_float), ("flip_horizontal", ctypes.c_int32), ("flip_vertical", ctypes.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/isf_hip.h declares
 _F3 = ctypes.c_float * 3
 _F6 = ctypes.c_float * 6
@@ -123,6 +140,9 @@ SIGNATURES = {
                                  c_int, c_int, c_void_p, c_void_p]),
     "isf_decode_boxes": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float)]
                          + [c_void_p] * 5),
+    "isf_assemble_points": (c_int, [c_void_p, ctypes.POINTER(Sweep), c_int, c_int, ctypes.POINTER(PointAug),
+                                    ctypes.POINTER(ctypes.c_float), c_void_p, c_void_p,
+                                    ctypes.POINTER(ctypes.c_int32), c_void_p]),
     "isf_dense_grid_rulebook": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                         c_int * 2, c_void_p]),
     "isf_nchw_to_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

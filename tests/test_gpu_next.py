@@ -60,3 +60,54 @@ def test_get_bboxes_box_type_and_simple_test(dev, golden):
         assert tuple(boxes.tensor.shape) == ref.shape
         assert np.abs(boxes.tensor.cpu().numpy() - ref).max() < 2e-3      # through the HIP head forward
         assert np.abs(scores.cpu().numpy() - g[f"small.shipped.{i}.scores"]).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- input pre-pass (8f #3)
+def _as_results(key, sweeps, ts):
+    return dict(pts_filename=key, timestamp=ts,
+                sweeps=[dict(data_path=s["points"], timestamp=s["timestamp"],
+                             sensor2lidar_rotation=s["sensor2lidar_rotation"],
+                             sensor2lidar_translation=s["sensor2lidar_translation"]) for s in sweeps])
+
+
+@pytest.mark.parametrize("case", ["test", "remove_close", "train_aug"])
+def test_input_prepass_matches_reference_pipeline(dev, golden, case):
+    """isf_assemble_points (whole batch, one call) vs the reference's per-sample CPU pipeline"""
+    from input_common import INPUT_CONFIGS, PC_RANGE, sweep_inputs, train_aug
+    from isfusion_amd.input_pipeline import MultiSweepPointLoader
+    g = golden("input_ref.npz")
+    names = ["a", "b", "key_only"]
+    batch = [_as_results(*sweep_inputs(*INPUT_CONFIGS[n])) for n in names]
+    loader = MultiSweepPointLoader(sweeps_num=10, remove_close=(case == "remove_close"), test_mode=True,
+                                   point_cloud_range=PC_RANGE, device=dev)
+    aug = [train_aug(77) for _ in names] if case == "train_aug" else None
+    out = loader(batch, aug=aug)
+    assert len(out) == len(names)
+    for n, pts in zip(names, out):
+        ref = g[f"{n}.{case}.points"]
+        assert tuple(pts.shape) == ref.shape, f"{n}: kept {pts.shape[0]} points, reference {ref.shape[0]}"
+        got = pts.cpu().numpy()
+        if case == "train_aug":
+            # the float32 [P,3]x[3,3] rotation's summation order / FMA use is the BLAS's choice: a few ulp of ~60
+            assert np.abs(got - ref).max() < 2e-5
+        else:
+            # float64 pose arithmetic rounded to float32: bit-exact up to fused-multiply-add double rounding
+            assert np.abs(got - ref).max() <= 4e-6
+            assert (got != ref).mean() < 1e-3
+        assert np.array_equal(got[:, 3], ref[:, 3])
+
+
+def test_input_prepass_feeds_the_lidar_branch(dev):
+    """pre-pass output == oracle pipeline output, handed to the voxelizer as the reference's collate would"""
+    from input_common import INPUT_CONFIGS, PC_RANGE, sweep_inputs
+    from isfusion_amd.input_pipeline import MultiSweepPointLoader
+    from oracle import input_ops
+    key, sweeps, ts = sweep_inputs(*INPUT_CONFIGS["a"])
+    loader = MultiSweepPointLoader(test_mode=True, point_cloud_range=PC_RANGE, device=dev)
+    pts = loader([_as_results(key, sweeps, ts)] * 2)
+    ref = input_ops.load_frame(key, sweeps, ts, PC_RANGE)
+    for p in pts:
+        assert tuple(p.shape) == ref.shape and np.abs(p.cpu().numpy() - ref).max() <= 4e-6
+    # empty sweep list and an empty file
+    empty = loader([dict(pts_filename=np.zeros((0, 5), np.float32), timestamp=ts, sweeps=[])])
+    assert empty[0].shape == (0, 5)

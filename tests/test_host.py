@@ -233,3 +233,21 @@ def test_seeded_state_dict_keeps_signal_alive():
             w = sd[name + ".weight"]
             assert float(w.min()) >= 0.75 and float(w.max()) <= 1.25, name
     assert seeded_state_dict(bb, 200)["blocks.0.0.weight"].equal(sd["blocks.0.0.weight"])   # deterministic
+
+
+def test_input_loader_refuses_cpu_and_replays_the_reference_rng():
+    """no CPU fallback; draw_train_aug consumes numpy's RNG in the reference's order (same draws as the golden)"""
+    import numpy as np
+    import pytest
+    from input_common import train_aug
+    from isfusion_amd import _lib
+    from isfusion_amd.input_pipeline import MultiSweepPointLoader, draw_train_aug
+    with pytest.raises(_lib.IsfError):
+        MultiSweepPointLoader(device="cpu")([dict(pts_filename=np.zeros((4, 5), np.float32), timestamp=0.0)])
+    np.random.seed(77)
+    mine, ref = draw_train_aug(), train_aug(77)
+    assert mine["scale"] == ref["scale"] and np.array_equal(mine["translation"], ref["translation"])
+    assert np.array_equal(mine["rot_mat_T"], ref["rot_mat_T"])
+    assert (mine["flip_horizontal"], mine["flip_vertical"]) == (ref["flip_horizontal"], ref["flip_vertical"])
+    ld = MultiSweepPointLoader(sweeps_num=3, test_mode=True)
+    assert list(ld._choose(2)) == [0, 1] and list(ld._choose(7)) == [0, 1, 2]
