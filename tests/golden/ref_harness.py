@@ -278,6 +278,26 @@ def install_pipelines():
     return m
 
 
+_voxel_encoders = {}
+
+
+def install_voxel_encoders():
+    """Load models/voxel_encoders/voxel_encoder.py (HardSimpleVFE: BASELINE configs[0]).  DynamicScatter has no CPU
+    implementation in the reference and stays an inert name: only HardSimpleVFE is exercised."""
+    if _voxel_encoders:
+        return _voxel_encoders
+    install()
+    base = os.path.join(REF, "mmdet3d")
+    sys.modules["mmdet3d.ops"].DynamicScatter = None
+    builder = sys.modules["mmdet3d.models.builder"]
+    builder.VOXEL_ENCODERS = _Registry("VOXEL_ENCODERS")
+    _pkg("mmdet3d.models.voxel_encoders", os.path.join(base, "models", "voxel_encoders"))
+    _load("mmdet3d.models.voxel_encoders.utils", "mmdet3d/models/voxel_encoders/utils.py")
+    _voxel_encoders["voxel_encoder"] = _load("mmdet3d.models.voxel_encoders.voxel_encoder",
+                                             "mmdet3d/models/voxel_encoders/voxel_encoder.py")
+    return _voxel_encoders
+
+
 if __name__ == "__main__":
     mods = install()
     print({k: v.__name__ for k, v in mods.items()})

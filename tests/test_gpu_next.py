@@ -111,3 +111,87 @@ def test_input_prepass_feeds_the_lidar_branch(dev):
     # empty sweep list and an empty file
     empty = loader([dict(pts_filename=np.zeros((0, 5), np.float32), timestamp=ts, sweeps=[])])
     assert empty[0].shape == (0, 5)
+
+
+# ------------------------------------------------------------------------------------------- BASELINE configs[0], [4]
+VS = [0.075, 0.075, 0.2]
+RG = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+
+
+def _T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_baseline_config0_hard_vfe_three_stage_encoder(dev, oracle_mod):
+    """BASELINE configs[0] (the reference's CPU-runnable case): one 20k-point cloud, 0.075 m hard voxelization,
+    HardSimpleVFE, 3-stage sparse encoder -> BEV, HIP vs the C oracle composition.  1e-3 on BEV features."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    pts = synthetic.lidar_sweeps(2020, 20000)
+    me = dict(in_channels=5, sparse_shape=[41, 1440, 1440], output_channels=32,
+              encoder_channels=((16,), (32,), (64,)), encoder_paddings=((1,), (1,), (1,)))
+    lb = m.LidarBranch(pts_middle_encoder=me).randomize_weights_(3).randomize_bn_(4).eval().to(dev)
+    enc = lb.pts_middle_encoder
+    v, c, n = m.voxelization(_T(pts, dev), VS, RG, 10, 60000)
+    ov, oc, on = oracle_mod.hard_voxelize(pts, VS, RG, 10, 60000)
+    assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(n.cpu().numpy(), on)
+    assert np.array_equal(v.cpu().numpy(), ov)
+    vf = m.HardSimpleVFE(num_features=5)(v, n, c)
+    ovf = oracle_mod.hard_simple_vfe(ov, on, 5)
+    assert np.abs(vf.cpu().numpy() - ovf).max() < 1e-5
+    c4 = torch.cat([torch.zeros((c.shape[0], 1), dtype=c.dtype, device=dev), c], 1)
+    bev = enc.forward_fused(vf, c4, 1)
+    obev, outs = oracle_mod.sparse_encoder_forward(enc.plan_to_numpy(), ovf,
+                                                   np.concatenate([np.zeros((len(oc), 1), np.int32), oc], 1), 1)
+    assert tuple(bev.shape) == obev.shape
+    assert np.abs(bev.cpu().numpy() - obev).max() < 1e-3
+    assert np.array_equal(bev.cpu().numpy() != 0, obev != 0) and np.abs(obev).max() > 0.1
+
+
+def test_baseline_config4_stress_005_voxels(dev, oracle_mod):
+    """BASELINE configs[4]: 0.05 m voxels (sparse shape [41, 2160, 2160]), 500k points per frame.  Oracle parity at a
+    size the scalar oracle finishes in seconds, then size-independent properties at full size."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    from isfusion_amd.norm import fold_bn
+    from isfusion_amd.voxelize import dynamic_voxelize_batched
+    vs = [0.05, 0.05, 0.2]
+    me = dict(m.ISFUSION_0075["pts_middle_encoder"])
+    me["sparse_shape"] = [41, 2160, 2160]
+    lb = m.LidarBranch(voxel_size=vs, pts_middle_encoder=me).randomize_weights_(0).randomize_bn_(1).eval()
+    # ---- small: vs oracle
+    B = 2
+    pl = [synthetic.lidar_sweeps(900 + i, 4000) for i in range(B)]
+    coors = np.concatenate([np.concatenate([np.full((p.shape[0], 1), b, np.int32),
+                                            oracle_mod.dynamic_voxelize(p, vs, RG)], 1) for b, p in enumerate(pl)])
+    vfe = lb.pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    ovf, ovc, _ = oracle_mod.dynamic_vfe(np.concatenate(pl), coors, vs, RG,
+                                         vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                         vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    obev, _ = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), ovf, ovc, B)
+    lb = lb.to(dev)
+    out = lb([_T(p, dev) for p in pl])
+    assert tuple(out.shape) == obev.shape == (B, 512, 270, 270)
+    assert np.abs(out.cpu().numpy() - obev).max() < 1e-3
+    # ---- full size: properties
+    P = 500000
+    big = [_T(synthetic.lidar_sweeps(7000 + i, P), dev) for i in range(B)]
+    o1 = lb(big, want_stats=True)
+    st = lb.last_stats
+    assert torch.isfinite(o1).all() and tuple(o1.shape) == (B, 512, 270, 270)
+    _, cc = dynamic_voxelize_batched(big, vs, RG)
+    assert st.num_in[0] == torch.unique(cc[(cc[:, 1:] >= 0).all(1)], dim=0).shape[0]
+    assert torch.equal(o1, lb(big)), "not deterministic"
+    assert torch.equal(lb([big[1]])[0], o1[1]), "frames are not independent"
+
+
+@pytest.mark.parametrize("name,seed,P,nf", [("nf4", 31, 3000, 4), ("nf5", 32, 2500, 5)])
+def test_hard_simple_vfe_matches_reference_golden(dev, golden, oracle_mod, name, seed, P, nf):
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    v, c, n = oracle_mod.hard_voxelize(synthetic.lidar_sweeps(seed, P), VS, RG, 10, 20000)
+    out = m.HardSimpleVFE(num_features=nf)(_T(v, dev), _T(n, dev), _T(c, dev))
+    ref = golden("vfe_ref.npz")[name]
+    assert tuple(out.shape) == ref.shape and np.abs(out.cpu().numpy() - ref).max() < 1e-5

@@ -185,3 +185,14 @@ def test_input_pipeline_restatement_matches_reference(golden, name, case):
     # key-frame points come first with a zero time column; sweep points carry a positive lag
     n_key = int((ref[:, 4] == 0).sum())
     assert 0 < n_key <= key_n and (ref[:n_key, 4] == 0).all() and (ref[n_key:, 4] > 0).all()
+
+
+@pytest.mark.parametrize("name,seed,P,nf", [("nf4", 31, 3000, 4), ("nf5", 32, 2500, 5)])
+def test_hard_simple_vfe_restatement_matches_reference(golden, oracle_mod, name, seed, P, nf):
+    """BASELINE configs[0]'s VFE: HardSimpleVFE (voxel_encoder.py:14-45) restatement vs the reference's output"""
+    from isfusion_amd import synthetic
+    v, c, n = oracle_mod.hard_voxelize(synthetic.lidar_sweeps(seed, P), [0.075, 0.075, 0.2],
+                                       [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0], 10, 20000)
+    ref = golden("vfe_ref.npz")[name]
+    out = oracle_mod.hard_simple_vfe(v, n, nf)
+    assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-6
