@@ -346,6 +346,25 @@ int isf_decode_boxes(const float* heatmap, const float* query_score, const int64
                      int num_classes, int num_proposals, int ld, const float* coder, float* boxes, float* scores,
                      int32_t* labels, int32_t* counts, isf_stream_t stream);
 
+/* 8f #2  sparse convolution backward ------------------------------------------------------------------------
+ * replaces sparse_conv_ext.indice_conv_backward_fp32(features, filters, out_bp, indice_pairs, indice_num, inverse,
+ *   subm) -> [input_bp, filters_bp]   (spconv_ops.h:363-456; SparseConvFunction.backward, functional.py:38-52).
+ * isf_transpose_rulebook: nbr_t [K, nbr_t_stride] with nbr_t[k][j] = o  <=>  nbr[k][o] = j (-1 elsewhere);
+ *   nbr_t_stride = isf_nbr_stride(num_in).  Built once per rulebook, shared by the convs that share it.
+ * isf_sparse_conv_backward_input: grad_in [num_in, Cin] = sum_k grad_out[nbr_t[k][j], :] @ W[k]^T, every row written
+ *   once (the forward kernel over the transposed table; no scatter-add, no atomics).
+ * isf_sparse_conv_backward_filter: grad_filters [K, Cin, Cout] = sum_o features[nbr[k][o], :]^T grad_out[o, :]
+ *   (fp32 MFMA, deterministic two-pass reduction over row chunks).  filters in the reference layout [K, Cin, Cout].
+ * All asynchronous. */
+int isf_transpose_rulebook(const int32_t* nbr, int nbr_stride, int num_out, int num_taps, int num_in,
+                           int32_t* nbr_t, int nbr_t_stride, isf_stream_t stream);
+int isf_sparse_conv_backward_input(const float* grad_out, int num_out, int c_out, const float* filters, int num_taps,
+                                   int c_in, const int32_t* nbr_t, int nbr_t_stride, int num_in, float* grad_in,
+                                   isf_stream_t stream);
+int isf_sparse_conv_backward_filter(const float* features, int num_in, int c_in, const float* grad_out, int num_out,
+                                    int c_out, const int32_t* nbr, int nbr_stride, int num_taps,
+                                    float* grad_filters, isf_stream_t stream);
+
 /* 8f #3  input pre-pass: multi-sweep assembly + augmentation + range filter ---------------------------------
  * replaces, per batch, the dataloader-side numpy / torch code of LoadPointsFromMultiSweeps.__call__
  * (datasets/pipelines/loading.py:860-903), the point side of GlobalRotScaleTransV2 and RandomFlip3DV2

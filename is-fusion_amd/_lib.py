@@ -143,6 +143,11 @@ SIGNATURES = {
     "isf_assemble_points": (c_int, [c_void_p, ctypes.POINTER(Sweep), c_int, c_int, ctypes.POINTER(PointAug),
                                     ctypes.POINTER(ctypes.c_float), c_void_p, c_void_p,
                                     ctypes.POINTER(ctypes.c_int32), c_void_p]),
+    "isf_transpose_rulebook": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "isf_sparse_conv_backward_input": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                               c_void_p, c_void_p]),
+    "isf_sparse_conv_backward_filter": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                                c_int, c_void_p, c_void_p]),
     "isf_dense_grid_rulebook": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                         c_int * 2, c_void_p]),
     "isf_nchw_to_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

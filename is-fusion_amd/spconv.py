@@ -176,6 +176,66 @@ def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=
     return out
 
 
+# Backward kernels (isf_spconv_bwd.hip) were written after round 1's GPU budget was spent: opt-in until
+# tests/test_gpu_next.py has passed on hardware, so that the default behaviour stays the validated one.
+TRAINING_KERNELS = False
+
+
+def transposed_nbr(rb):
+    """nbr_t [K, stride_t] of a Rulebook (isf_transpose_rulebook), cached on it: input row -> output row per tap."""
+    if getattr(rb, "nbr_t", None) is None:
+        lib = _lib.load()
+        K = rb.nbr.numel() // rb.stride
+        st = lib.isf_nbr_stride(max(rb.num_in, 1))
+        nbr_t = torch.empty((K, st), dtype=torch.int32, device=rb.nbr.device)
+        _lib.check(lib.isf_transpose_rulebook(_lib.ptr(rb.nbr), rb.stride, rb.num_out, K, rb.num_in, _lib.ptr(nbr_t),
+                                              st, _lib.stream()), "isf_transpose_rulebook")
+        rb.nbr_t, rb.stride_t = nbr_t, st
+    return rb.nbr_t, rb.stride_t
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """SparseConvFunction / SubMConvFunction of the reference (ops/spconv/functional.py:22-97): forward =
+    indice_conv, backward = indice_conv_backward -> (input_bp, filters_bp), on the HIP kernels.  `weight` is the
+    module parameter [kD, kH, kW, Cin, Cout]."""
+
+    @staticmethod
+    def forward(ctx, features, weight, rb):
+        _lib.require_cuda(features, weight)
+        K = int(np.prod(weight.shape[:-2]))
+        c_in, c_out = weight.shape[-2], weight.shape[-1]
+        w = weight.detach().float().contiguous()
+        out = torch.empty((rb.num_out, c_out), dtype=torch.float32, device=features.device)
+        _lib.check(_lib.load().isf_sparse_conv_forward(
+            _lib.ptr(features), rb.num_in, c_in, _lib.ptr(w), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+            None, None, None, 0, _lib.ptr(out), _lib.stream()), "isf_sparse_conv_forward")
+        ctx.save_for_backward(features, w)
+        ctx.rb, ctx.wshape = rb, tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, w = ctx.saved_tensors
+        rb = ctx.rb
+        K, c_in, c_out = int(np.prod(ctx.wshape[:-2])), ctx.wshape[-2], ctx.wshape[-1]
+        g = grad_out.contiguous().float()
+        lib = _lib.load()
+        grad_in = grad_w = None
+        if ctx.needs_input_grad[0]:
+            nbr_t, st = transposed_nbr(rb)
+            grad_in = torch.empty((rb.num_in, c_in), dtype=torch.float32, device=g.device)
+            _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(g), rb.num_out, c_out, _lib.ptr(w), K, c_in,
+                                                          _lib.ptr(nbr_t), st, rb.num_in, _lib.ptr(grad_in),
+                                                          _lib.stream()), "isf_sparse_conv_backward_input")
+        if ctx.needs_input_grad[1]:
+            grad_w = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
+            _lib.check(lib.isf_sparse_conv_backward_filter(_lib.ptr(features), rb.num_in, c_in, _lib.ptr(g),
+                                                           rb.num_out, c_out, _lib.ptr(rb.nbr), rb.stride, K,
+                                                           _lib.ptr(grad_w), _lib.stream()),
+                       "isf_sparse_conv_backward_filter")
+        return grad_in, grad_w, None
+
+
 class SparseModule(nn.Module):
     """marker base class (modules.py:38-41)."""
 
@@ -268,16 +328,27 @@ class SparseConvolution(SparseModule):
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
         feats = input.features
-        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError(
-                "isfusion_amd sparse conv: backward kernels are not built yet (SURVEY.md section 8f #2); "
-                "call under torch.no_grad() / module.eval() with requires_grad_(False)")
         rb = self.rulebook_for(input)
+        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
+            if not TRAINING_KERNELS:
+                raise NotImplementedError(
+                    "isfusion_amd sparse conv: the backward kernels (SURVEY.md section 8f #2) are built but not yet "
+                    "validated on hardware; set isfusion_amd.spconv.TRAINING_KERNELS = True to use them, or call "
+                    "under torch.no_grad() / module.eval() with requires_grad_(False)")
+            # training: the reference's SparseConvFunction / SubMConvFunction (functional.py:22-97) -- conv without
+            # epilogue through autograd, the bias added by a stock broadcast (conv.py:209-210)
+            out_f = SparseConvFunction.apply(feats.contiguous().float(), self.weight, rb)
+            if self.bias is not None:
+                out_f = out_f + self.bias
+            return self._wrap(input, out_f, rb)
         K = int(np.prod(self.kernel_size))
         shift = self.bias.detach().float() if self.bias is not None else None
         scale = torch.ones_like(shift) if shift is not None else None
         out_f = sparse_conv_forward(feats.contiguous().float(), self.packed_weight(), K, self.in_channels,
                                     self.out_channels, rb, scale, shift)
+        return self._wrap(input, out_f, rb)
+
+    def _wrap(self, input, out_f, rb):
         out = SparseConvTensor(out_f, rb.out_indices, rb.out_shape, input.batch_size)
         out.indice_dict = input.indice_dict
         if self.subm:

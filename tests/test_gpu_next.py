@@ -195,3 +195,70 @@ def test_hard_simple_vfe_matches_reference_golden(dev, golden, oracle_mod, name,
     out = m.HardSimpleVFE(num_features=nf)(_T(v, dev), _T(n, dev), _T(c, dev))
     ref = golden("vfe_ref.npz")[name]
     assert tuple(out.shape) == ref.shape and np.abs(out.cpu().numpy() - ref).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- conv backward (8f #2)
+@pytest.mark.parametrize("case", ["subm_k3", "conv_s2p1", "conv_s2p011", "conv_311", "subm_5to16"])
+def test_sparse_conv_backward_vs_oracle_golden_geometries(dev, golden, oracle_mod, case):
+    """SparseConvFunction.backward (isf_sparse_conv_backward_input / _filter) vs the C restatement of
+    indice_conv_backward (itself pinned to conv3d autograd) on the golden rulebook geometries"""
+    import isfusion_amd as m
+    from isfusion_amd import spconv
+    g = golden("spconv_dense_ref.npz")
+    cfg = g[case + "_cfg"]
+    B, shape, ks, st, pd, subm = int(cfg[0]), [int(v) for v in cfg[1:4]], [int(v) for v in cfg[4:7]], \
+        [int(v) for v in cfg[7:10]], [int(v) for v in cfg[10:13]], bool(cfg[13])
+    idx, feats, w = g[case + "_idx"], g[case + "_feats"], g[case + "_w"]
+    # the library orders rows (b,z,y,x): feed sorted rows so that gradients line up with the oracle's
+    order = np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))
+    idx, feats = idx[order], feats[order]
+    out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, ks, st, pd, subm=subm)
+    cls = m.SubMConv3d if subm else m.SparseConv3d
+    conv = cls(w.shape[-2], w.shape[-1], ks, stride=st, padding=pd, bias=True).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(_T(w, dev))
+    x = _T(feats, dev).requires_grad_()
+    spconv.TRAINING_KERNELS = True
+    try:
+        out = conv(m.SparseConvTensor(x, _T(idx, dev), shape, B))
+        # rows of the strided output are sorted (b,z,y,x); the oracle numbers them first-come
+        oi = out.indices.cpu().numpy()
+        key = {tuple(r): i for i, r in enumerate(out_idx.tolist())}
+        perm = np.array([key[tuple(r)] for r in oi.tolist()])
+        gout = np.random.default_rng(5).normal(size=(out_idx.shape[0], w.shape[-1])).astype(np.float32)
+        out.features.backward(_T(gout[perm], dev))
+    finally:
+        spconv.TRAINING_KERNELS = False
+    y = oracle_mod.indice_conv(feats, w, pairs, num, out_idx.shape[0])
+    assert np.abs(out.features.detach().cpu().numpy() - (y[perm] + conv.bias.detach().cpu().numpy())).max() < 2e-4
+    dx, dw = oracle_mod.indice_conv_backward(feats, w, gout, pairs, num)
+    assert np.abs(x.grad.cpu().numpy() - dx).max() < 2e-4
+    assert np.abs(conv.weight.grad.cpu().numpy() - dw).max() < 2e-4 * max(1.0, np.abs(dw).max())
+    assert np.abs(conv.bias.grad.cpu().numpy() - gout.sum(0)).max() < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 64), (128, 256), (256, 256)])
+def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout):
+    """every (Cin, Cout) block shape of the dW kernel and the transposed-filter dX path; several row chunks"""
+    from isfusion_amd import spconv
+    rng = np.random.default_rng(cin * 1000 + cout)
+    B, shape = 2, [9, 24, 24]
+    n = 1500
+    cells = rng.choice(B * shape[0] * shape[1] * shape[2], n, replace=False)
+    cells.sort()
+    idx = np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32)
+    feats = rng.normal(size=(n, cin)).astype(np.float32)
+    w = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], subm=True)
+    gout = rng.normal(size=(n, cout)).astype(np.float32)
+    dx, dw = oracle_mod.indice_conv_backward(feats, w, gout, pairs, num)
+    rb = spconv.build_rulebook(_T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    x, wt = _T(feats, dev).requires_grad_(), _T(w, dev).requires_grad_()
+    out = spconv.SparseConvFunction.apply(x, wt, rb)
+    out.backward(_T(gout, dev))
+    assert np.abs(x.grad.cpu().numpy() - dx).max() < 1e-3 * max(1.0, np.abs(dx).max())
+    assert np.abs(wt.grad.cpu().numpy() - dw).max() < 1e-3 * max(1.0, np.abs(dw).max())
+    # deterministic: a second backward gives the same bits
+    x2, w2 = _T(feats, dev).requires_grad_(), _T(w, dev).requires_grad_()
+    spconv.SparseConvFunction.apply(x2, w2, rb).backward(_T(gout, dev))
+    assert torch.equal(x.grad, x2.grad) and torch.equal(wt.grad, w2.grad)

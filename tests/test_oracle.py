@@ -196,3 +196,30 @@ def test_hard_simple_vfe_restatement_matches_reference(golden, oracle_mod, name,
     ref = golden("vfe_ref.npz")[name]
     out = oracle_mod.hard_simple_vfe(v, n, nf)
     assert out.shape == ref.shape and np.abs(out - ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", ["subm_k3", "conv_s2p1", "conv_s2p011", "conv_311", "subm_5to16"])
+def test_sparse_conv_backward_matches_dense_conv3d_autograd(oracle_mod, golden, case):
+    """indice_conv_backward restatement (spconv_ops.h:363-456) vs torch autograd through the dense-conv3d identity
+    the forward goldens rest on: y = conv3d(dense(x), W)[output sites]; dL/dx, dL/dW for a random dL/dy."""
+    import torch.nn.functional as F
+    g = golden("spconv_dense_ref.npz")
+    cfg = g[case + "_cfg"]
+    B, shape, ks, st, pd, subm = int(cfg[0]), [int(v) for v in cfg[1:4]], [int(v) for v in cfg[4:7]], \
+        [int(v) for v in cfg[7:10]], [int(v) for v in cfg[10:13]], bool(cfg[13])
+    idx, feats, w = g[case + "_idx"], g[case + "_feats"], g[case + "_w"]
+    out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, ks, st, pd, subm=subm)
+    gout = np.random.default_rng(5).normal(size=(out_idx.shape[0], w.shape[-1])).astype(np.float32)
+    dx, dw = oracle_mod.indice_conv_backward(feats, w, gout, pairs, num)
+    # dense identity in float64
+    x = torch.from_numpy(feats).double().requires_grad_()
+    wt = torch.from_numpy(w).double().requires_grad_()
+    ii = torch.from_numpy(idx).long()
+    dense = torch.zeros((B, *shape, feats.shape[1]), dtype=torch.float64)
+    dense = dense.index_put((ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), x).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(dense, wt.permute(4, 3, 0, 1, 2), stride=st, padding=pd)
+    oo = torch.from_numpy(out_idx).long()
+    ys = y[oo[:, 0], :, oo[:, 1], oo[:, 2], oo[:, 3]]
+    ys.backward(torch.from_numpy(gout).double())
+    assert np.abs(dx - x.grad.numpy()).max() < 1e-4
+    assert np.abs(dw - wt.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(wt.grad.numpy()).max())
