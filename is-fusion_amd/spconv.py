@@ -49,20 +49,34 @@ class SparseConvTensor:
     def dense(self, channels_first=True):
         """[B, C, D, H, W] (structure.py:49-59) through isf_sparse_to_dense_bev."""
         _lib.require_cuda(self.features)
-        D, H, W = self.spatial_shape
-        C = self.features.size(1)
-        out = torch.empty((self.batch_size, C * D, H, W), dtype=torch.float32, device=self.features.device)
-        lib = _lib.load()
-        _lib.check(lib.isf_sparse_to_dense_bev(_lib.ptr(self.features.contiguous().float()),
-                                               _lib.ptr(self.indices.contiguous()), self.features.size(0), C,
-                                               self.batch_size, D, H, W, _lib.ptr(out), _lib.stream()),
-                   "isf_sparse_to_dense_bev")
-        out = out.view(self.batch_size, C, D, H, W)
+        out = _SparseToDense.apply(self.features, self.indices, tuple(self.spatial_shape), self.batch_size)
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
     @property
     def sparity(self):
         return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+
+
+class _SparseToDense(torch.autograd.Function):
+    """dense() with a gradient: forward = isf_sparse_to_dense_bev, backward = the rows of the dense gradient at the
+    active sites (what autograd derives for the reference's scatter_nd, structure.py:8-25)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, spatial_shape, batch_size):
+        D, H, W = spatial_shape
+        C = features.size(1)
+        out = torch.empty((batch_size, C * D, H, W), dtype=torch.float32, device=features.device)
+        _lib.check(_lib.load().isf_sparse_to_dense_bev(_lib.ptr(features.detach().contiguous().float()),
+                                                       _lib.ptr(indices.contiguous()), features.size(0), C,
+                                                       batch_size, D, H, W, _lib.ptr(out), _lib.stream()),
+                   "isf_sparse_to_dense_bev")
+        ctx.save_for_backward(indices)
+        return out.view(batch_size, C, D, H, W)
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx = ctx.saved_tensors[0].long()
+        return grad[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].contiguous(), None, None, None
 
 
 class Rulebook:

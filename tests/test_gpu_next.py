@@ -262,3 +262,54 @@ def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout):
     x2, w2 = _T(feats, dev).requires_grad_(), _T(w, dev).requires_grad_()
     spconv.SparseConvFunction.apply(x2, w2, rb).backward(_T(gout, dev))
     assert torch.equal(x.grad, x2.grad) and torch.equal(wt.grad, w2.grad)
+
+
+def test_sparse_encoder_training_step_matches_torch_dense_autograd(dev):
+    """SparseEncoder in train() mode (module-by-module: HIP conv Function + stock BatchNorm1d / ReLU, as the reference
+    composes them) -- loss.backward() vs the same network written with dense torch conv3d on the zero-filled grid
+    restricted to the active sites (valid for SubM stacks: here conv_input + one SubM stage)."""
+    import isfusion_amd as m
+    from isfusion_amd import spconv
+    rng = np.random.default_rng(8)
+    B, shape, n, cin = 2, [8, 16, 16], 600, 16
+    cells = np.sort(rng.choice(B * shape[0] * shape[1] * shape[2], n, replace=False))
+    idx = np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32)
+    feats = rng.normal(size=(n, cin)).astype(np.float32)
+    convs = [m.SubMConv3d(cin, 32, 3, padding=1, bias=False, indice_key="subm1").to(dev),
+             m.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="subm1").to(dev)]
+    bns = [torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01).to(dev) for _ in convs]
+    x = _T(feats, dev).requires_grad_()
+    spconv.TRAINING_KERNELS = True
+    try:
+        t = m.SparseConvTensor(x, _T(idx, dev), shape, B)
+        for conv, bn in zip(convs, bns):
+            t = conv(t)
+            t.features = torch.relu(bn(t.features))
+        dense = t.dense()
+        loss = (dense ** 2).mean()
+        loss.backward()
+    finally:
+        spconv.TRAINING_KERNELS = False
+    # dense torch reference on the same parameters
+    ii = _T(idx, dev).long()
+    xr = _T(feats, dev).requires_grad_()
+    mask = torch.zeros((B, 1, *shape), device=dev)
+    mask[ii[:, 0], 0, ii[:, 1], ii[:, 2], ii[:, 3]] = 1
+    cur = torch.zeros((B, *shape, cin), device=dev).index_put((ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), xr)
+    cur = cur.permute(0, 4, 1, 2, 3)
+    grads_ref = []
+    for conv, bn in zip(convs, bns):
+        w = conv.weight.detach().clone().requires_grad_()
+        grads_ref.append(w)
+        y = torch.nn.functional.conv3d(cur, w.permute(4, 3, 0, 1, 2), padding=1)
+        rows = y[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]]                        # active sites only (SubM)
+        mu, var = rows.mean(0), rows.var(0, unbiased=False)
+        rows = torch.relu((rows - mu) / torch.sqrt(var + 1e-3) * bn.weight.detach() + bn.bias.detach())
+        cur = torch.zeros((B, *shape, rows.shape[1]), device=dev).index_put(
+            (ii[:, 0], ii[:, 1], ii[:, 2], ii[:, 3]), rows).permute(0, 4, 1, 2, 3)
+    loss_ref = (cur ** 2).mean()
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+    assert (x.grad - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
+    for conv, w in zip(convs, grads_ref):
+        assert (conv.weight.grad - w.grad).abs().max().item() < 1e-4 * max(1.0, w.grad.abs().max().item())
