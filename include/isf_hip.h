@@ -400,6 +400,17 @@ int isf_assemble_points(const float* raw, const isf_sweep_t* sweeps, int num_swe
                         const float* point_range /* 6 host floats or NULL */, float* points_out,
                         int32_t* sample_offsets, int32_t* sample_offsets_host, isf_stream_t stream);
 
+/* 8f #2  multi-scale deformable attention backward (one level) --------------------------------------------------
+ * replaces MultiScaleDeformableAttnFunction.backward -> ms_deform_attn_backward (ops/src/cuda/ms_deform_attn_cuda.cu,
+ * ms_deform_im2col_cuda.cuh:301-920) plus the backward of the softmax / location arithmetic isf_msda_forward folds in.
+ * Same tensors as the forward plus grad_out [B*Q, heads*hd]; outputs grad_value [B, H*W, heads*hd] (zeroed here,
+ * fp32 atomics), grad_offsets [B*Q, heads*P*2], grad_logits [B*Q, heads*P].  No gradient for reference_points
+ * (the IS-Fusion path feeds constants).  Asynchronous. */
+int isf_msda_backward(const float* value, const float* sampling_offsets, const float* attention_logits,
+                      const float* reference_points, const float* grad_out, int batch_size, int num_queries,
+                      int num_heads, int head_dim, int num_points, int height, int width, float* grad_value,
+                      float* grad_offsets, float* grad_logits, isf_stream_t stream);
+
 /* A9 / A15  dense 3x3 BEV convolutions on the sparse-conv kernel ------------------------
  * replaces mmcv ConvModule / nn.Conv2d + BatchNorm2d + ReLU (fusion_encoder.py:862-960, backbones/second.py:126-165,
  * MIOpen Winograd + 2 elementwise kernels per layer).  A dense B x H x W grid is a sparse tensor with every cell

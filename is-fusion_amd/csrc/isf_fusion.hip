@@ -277,6 +277,103 @@ __global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ val
   out[tid] = acc;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// 8f #2  multi-scale deformable attention backward, single level (ms_deform_im2col_cuda.cuh:301-920 in the reference:
+// ms_deformable_col2im_* with their shared-memory / block reductions), through the softmax over the sampling points
+// and the location arithmetic the forward folds in.  A 16-lane group owns one (b, q, head): the lanes are the D = 16
+// channels, so the tap geometry is computed once per group and the channel reductions for d(attention) and d(location)
+// are four xor-shuffles inside the group.  grad_value is accumulated with hardware fp32 atomics (the reference does
+// the same, atomicAdd at :128-150), everything else is written once.
+template <int D, int P>
+__global__ __launch_bounds__(256) void msda_backward_kernel(
+    const float* __restrict__ value, const float* __restrict__ offsets, const float* __restrict__ logits,
+    const float* __restrict__ ref, const float* __restrict__ grad_out, int B, int Q, int heads, int H, int W,
+    float* __restrict__ grad_value, float* __restrict__ grad_offsets, float* __restrict__ grad_logits) {
+  static_assert(D == 16 && P == 16, "one 16-lane group per head: lanes = channels, and lane p stores point p");
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * Q * heads * D;
+  const bool live = tid < total;          // dead lanes of the last group keep shuffling with zeros
+  const long long t = live ? tid : total - 1;
+  const int dch = (int)(t % D);
+  const int h = (int)((t / D) % heads);
+  const long long bq = t / ((long long)D * heads);
+  const int b = (int)(bq / Q);
+  const float* lg = logits + bq * heads * P + h * P;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < P; ++p) mx = fmaxf(mx, lg[p]);
+  float a[P], sum = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) { a[p] = expf(lg[p] - mx); sum += a[p]; }
+  const float rx = ref[bq * 2], ry = ref[bq * 2 + 1];
+  const float* off = offsets + bq * heads * P * 2 + h * P * 2;
+  const size_t vstride = (size_t)heads * D;
+  const size_t vbase = (size_t)b * H * W * vstride + (size_t)h * D + dch;
+  const float go = live ? grad_out[t] : 0.f;
+  float ga[P];                     // d loss / d a[p], reduced over the channels
+  float my_gx = 0.f, my_gy = 0.f;  // lane p keeps d loss / d offset of point p
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    a[p] /= sum;
+    const float lx = rx + off[2 * p] / (float)W, ly = ry + off[2 * p + 1] / (float)H;
+    const float w_im = lx * (float)W - 0.5f, h_im = ly * (float)H - 0.5f;
+    float s = 0.f, dsw = 0.f, dsh = 0.f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+      const float fh = floorf(h_im), fw = floorf(w_im);
+      const int h0 = (int)fh, w0 = (int)fw;
+      const float lh = h_im - fh, lw = w_im - fw;
+      const float gv = a[p] * go;
+      float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+      if (h0 >= 0 && w0 >= 0) {
+        const size_t at = vbase + ((size_t)h0 * W + w0) * vstride;
+        v00 = value[at];
+        if (live) atomicAdd(grad_value + at, (1.f - lh) * (1.f - lw) * gv);
+      }
+      if (h0 >= 0 && w0 + 1 <= W - 1) {
+        const size_t at = vbase + ((size_t)h0 * W + w0 + 1) * vstride;
+        v01 = value[at];
+        if (live) atomicAdd(grad_value + at, (1.f - lh) * lw * gv);
+      }
+      if (h0 + 1 <= H - 1 && w0 >= 0) {
+        const size_t at = vbase + ((size_t)(h0 + 1) * W + w0) * vstride;
+        v10 = value[at];
+        if (live) atomicAdd(grad_value + at, lh * (1.f - lw) * gv);
+      }
+      if (h0 + 1 <= H - 1 && w0 + 1 <= W - 1) {
+        const size_t at = vbase + ((size_t)(h0 + 1) * W + w0 + 1) * vstride;
+        v11 = value[at];
+        if (live) atomicAdd(grad_value + at, lh * lw * gv);
+      }
+      s = (1.f - lh) * (1.f - lw) * v00 + (1.f - lh) * lw * v01 + lh * (1.f - lw) * v10 + lh * lw * v11;
+      dsw = (1.f - lh) * (v01 - v00) + lh * (v11 - v10);      // d s / d w_im
+      dsh = (1.f - lw) * (v10 - v00) + lw * (v11 - v01);      // d s / d h_im
+    }
+    float r0 = go * s, r1 = a[p] * go * dsw, r2 = a[p] * go * dsh;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+      r0 += __shfl_xor(r0, m, 16);
+      r1 += __shfl_xor(r1, m, 16);
+      r2 += __shfl_xor(r2, m, 16);
+    }
+    ga[p] = r0;
+    // w_im = (rx + off_x / W) * W - 0.5  =>  d w_im / d off_x = 1 (likewise y)
+    if (p == dch) { my_gx = r1; my_gy = r2; }
+  }
+  // softmax backward: d logit[p] = a[p] * (ga[p] - sum_j a[j] ga[j])
+  float dot = 0.f, mine_a = 0.f, mine_ga = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    dot += a[p] * ga[p];
+    if (p == dch) { mine_a = a[p]; mine_ga = ga[p]; }
+  }
+  if (live) {
+    grad_logits[bq * heads * P + h * P + dch] = mine_a * (mine_ga - dot);
+    float* go_off = grad_offsets + bq * heads * P * 2 + h * P * 2 + 2 * dch;
+    go_off[0] = my_gx;
+    go_off[1] = my_gy;
+  }
+}
+
 }  // namespace isf
 
 extern "C" {
@@ -353,6 +450,29 @@ int isf_msda_forward(const float* value, const float* sampling_offsets, const fl
   hipLaunchKernelGGL((msda_kernel<16, 16>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), value,
                      sampling_offsets, attention_logits, reference_points, batch_size, num_queries, num_heads, height,
                      width, out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_msda_backward(const float* value, const float* sampling_offsets, const float* attention_logits,
+                      const float* reference_points, const float* grad_out, int batch_size, int num_queries,
+                      int num_heads, int head_dim, int num_points, int height, int width, float* grad_value,
+                      float* grad_offsets, float* grad_logits, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && num_queries >= 0 && height > 0 && width > 0, ISF_ERR_ARG, "msda_backward: bad sizes");
+  ISF_REQUIRE(grad_value, ISF_ERR_ARG, "msda_backward: null grad_value");
+  hipStream_t st = as_stream(stream);
+  ISF_HIP_TRY(hipMemsetAsync(grad_value, 0,
+                             sizeof(float) * (size_t)batch_size * height * width * num_heads * head_dim, st));
+  if (batch_size == 0 || num_queries == 0) return ISF_OK;
+  ISF_REQUIRE(value && sampling_offsets && attention_logits && reference_points && grad_out && grad_offsets &&
+                  grad_logits, ISF_ERR_ARG, "msda_backward: null pointer");
+  ISF_REQUIRE(head_dim == 16 && num_points == 16, ISF_ERR_UNSUPPORTED,
+              "msda_backward: built for head_dim 16, 16 points, one level (got %d, %d)", head_dim, num_points);
+  const long long total = (long long)batch_size * num_queries * num_heads * head_dim;
+  hipLaunchKernelGGL((msda_backward_kernel<16, 16>), dim3(ceil_div(total, 256)), dim3(256), 0, st, value,
+                     sampling_offsets, attention_logits, reference_points, grad_out, batch_size, num_queries, num_heads,
+                     height, width, grad_value, grad_offsets, grad_logits);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

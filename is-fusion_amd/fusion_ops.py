@@ -274,6 +274,31 @@ def msda(value, offsets, logits, ref, B, Q, nhead, hd, npts, H, W):
     return out
 
 
+class MSDAFunction(torch.autograd.Function):
+    """MultiScaleDeformableAttnFunction of the reference (multi_scale_deformable_attn_function.py; one level), taking
+    the raw sampling offsets and attention logits: forward = isf_msda_forward, backward = isf_msda_backward
+    -> gradients for value, offsets and logits (SURVEY.md 8f #2; not yet validated on hardware)."""
+
+    @staticmethod
+    def forward(ctx, value, offsets, logits, ref, B, Q, nhead, hd, npts, H, W):
+        _lib.require_cuda(value, offsets, logits, ref)
+        args = [t.detach().float().contiguous() for t in (value, offsets, logits, ref)]
+        ctx.save_for_backward(*args)
+        ctx.dims = (B, Q, nhead, hd, npts, H, W)
+        return msda(*args, B, Q, nhead, hd, npts, H, W)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, offsets, logits, ref = ctx.saved_tensors
+        B, Q, nhead, hd, npts, H, W = ctx.dims
+        g = grad_out.contiguous().float()
+        gv, goff, glog = torch.empty_like(value), torch.empty_like(offsets), torch.empty_like(logits)
+        _lib.check(_lib.load().isf_msda_backward(_lib.ptr(value), _lib.ptr(offsets), _lib.ptr(logits), _lib.ptr(ref),
+                                                 _lib.ptr(g), B, Q, nhead, hd, npts, H, W, _lib.ptr(gv), _lib.ptr(goff),
+                                                 _lib.ptr(glog), _lib.stream()), "isf_msda_backward")
+        return (gv, goff, glog) + (None,) * 8
+
+
 def _pos_embed(mod, xy):
     """PositionEmbeddingLearned (fusion_encoder.py:173-189): stock Conv1d/BN1d stack on [B, N, 2] -> [B, N, E]"""
     return mod.position_embedding_head(xy.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()

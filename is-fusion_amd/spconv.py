@@ -342,13 +342,14 @@ class SparseConvolution(SparseModule):
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
         feats = input.features
+        training = torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad)
+        if training and not TRAINING_KERNELS:
+            raise NotImplementedError(
+                "isfusion_amd sparse conv: the backward kernels (SURVEY.md section 8f #2) are built but not yet "
+                "validated on hardware; set isfusion_amd.spconv.TRAINING_KERNELS = True to use them, or call "
+                "under torch.no_grad() / module.eval() with requires_grad_(False)")
         rb = self.rulebook_for(input)
-        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
-            if not TRAINING_KERNELS:
-                raise NotImplementedError(
-                    "isfusion_amd sparse conv: the backward kernels (SURVEY.md section 8f #2) are built but not yet "
-                    "validated on hardware; set isfusion_amd.spconv.TRAINING_KERNELS = True to use them, or call "
-                    "under torch.no_grad() / module.eval() with requires_grad_(False)")
+        if training:
             # training: the reference's SparseConvFunction / SubMConvFunction (functional.py:22-97) -- conv without
             # epilogue through autograd, the bias added by a stock broadcast (conv.py:209-210)
             out_f = SparseConvFunction.apply(feats.contiguous().float(), self.weight, rb)

@@ -89,3 +89,21 @@ def head_kwargs(cfg):
 def head_input(cfg):
     g = torch.Generator().manual_seed(cfg["seed"])
     return torch.randn((cfg["B"], 512, cfg["X"], cfg["X"]), generator=g) * 0.5
+
+
+# ------------------------------------------------------------------------------------------- MSDA gradients (8f #2)
+def msda_grad_inputs(B, Q, H, heads=8, hd=16, P=16, raw=False):
+    """value [B, H*H, heads, hd], sampling locations [B, Q, heads, 1, P, 2] (some outside [0, 1]), attention weights
+    [B, Q, heads, 1, P] (softmax of seeded logits), grad_out [B, Q, heads*hd] -- float32, seeded."""
+    g = torch.Generator().manual_seed(1000 + 31 * B + 7 * Q + H)
+    value = torch.randn((B, H * H, heads, hd), generator=g)
+    ref = torch.rand((B, Q, 1, 1, 1, 2), generator=g) * 1.2 - 0.1
+    off = torch.randn((B, Q, heads, 1, P, 2), generator=g) * 2.0
+    loc = ref + off / H
+    logits = torch.randn((B, Q, heads, P), generator=g)
+    aw = logits.softmax(-1).view(B, Q, heads, 1, P)
+    gout = torch.randn((B, Q, heads * hd), generator=g)
+    if raw:     # the kernel's parameterisation: reference points, pixel offsets, pre-softmax logits
+        return value, loc, aw, gout, ref.reshape(B * Q, 2), off.reshape(B * Q, heads * P * 2), \
+            logits.reshape(B * Q, heads * P)
+    return value, loc, aw, gout

@@ -313,3 +313,28 @@ def test_sparse_encoder_training_step_matches_torch_dense_autograd(dev):
     assert (x.grad - xr.grad).abs().max().item() < 1e-4 * max(1.0, xr.grad.abs().max().item())
     for conv, w in zip(convs, grads_ref):
         assert (conv.weight.grad - w.grad).abs().max().item() < 1e-4 * max(1.0, w.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------- MSDA backward (8f #2)
+@pytest.mark.parametrize("name,B,Q,H", [("small", 1, 20, 12), ("edge", 2, 16, 7)])
+def test_msda_backward_matches_reference_autograd_golden(dev, golden, name, B, Q, H):
+    """isf_msda_backward (through MSDAFunction) vs autograd through the reference's pure-torch MSDA"""
+    from fusion_common import msda_grad_inputs
+    from isfusion_amd import fusion_ops as ops
+    g = golden("msda_grad_ref.npz")
+    value, loc, aw, gout, ref, off, logits = msda_grad_inputs(B, Q, H, raw=True)
+    v = value.reshape(B, H * H, 128).to(dev).requires_grad_()
+    o, lg = off.to(dev).requires_grad_(), logits.to(dev).requires_grad_()
+    out = ops.MSDAFunction.apply(v, o, lg, ref.to(dev), B, Q, 8, 16, 16, H, H)
+    assert np.abs(out.detach().cpu().numpy() - g[name + ".out"].reshape(B * Q, 128)).max() < 5e-5
+    out.backward(gout.reshape(B * Q, 128).to(dev))
+    gv = g[name + ".grad_value"].reshape(B, H * H, 128)
+    assert np.abs(v.grad.cpu().numpy() - gv).max() < 1e-4 * max(1.0, np.abs(gv).max())
+    # loc = ref + off / (W, H)  =>  d/d off = d/d loc / (W, H)
+    goff = g[name + ".grad_loc"].reshape(B * Q, 8 * 16 * 2) / H
+    assert np.abs(o.grad.cpu().numpy() - goff).max() < 1e-4 * max(1.0, np.abs(goff).max())
+    # attention weights = softmax(logits)
+    gw = torch.from_numpy(g[name + ".grad_weight"]).reshape(B * Q, 8, 16)
+    a = aw.reshape(B * Q, 8, 16)
+    glog = (a * (gw - (a * gw).sum(-1, keepdim=True))).reshape(B * Q, 128).numpy()
+    assert np.abs(lg.grad.cpu().numpy() - glog).max() < 1e-4 * max(1.0, np.abs(glog).max())

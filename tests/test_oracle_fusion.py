@@ -111,3 +111,20 @@ def test_decode_boxes_restatement_matches_reference_get_bboxes(golden, name, cod
         assert 0 < kept < cfg["B"] * cfg["num_proposals"], "the filter must drop some and keep some"
     # the inputs are left untouched (the reference decodes in place)
     assert np.array_equal(out["center"].numpy(), g[name + ".center"])
+
+
+@pytest.mark.parametrize("name,B,Q,H", [("small", 1, 20, 12), ("edge", 2, 16, 7)])
+def test_msda_backward_restatement_matches_reference_autograd(golden, name, B, Q, H):
+    """gradients of the multi-scale deformable attention: autograd through the restatement (CUDA
+    kernel's bilinear rule) vs autograd through the reference's pure-torch implementation (float64 goldens)"""
+    from fusion_common import msda_grad_inputs
+    from oracle import fusion_ops as orc
+    g = golden("msda_grad_ref.npz")
+    value, loc, aw, gout = msda_grad_inputs(B, Q, H)
+    v, l, a = value.clone().requires_grad_(), loc.clone().requires_grad_(), aw.clone().requires_grad_()
+    out = orc.msda_core(v, torch.tensor([[H, H]]), l, a).reshape(B, Q, -1)
+    out.backward(gout)
+    assert np.abs(out.detach().numpy() - g[name + ".out"]).max() < 1e-5
+    for got, key in ((v.grad, "grad_value"), (l.grad, "grad_loc"), (a.grad, "grad_weight")):
+        ref = g[f"{name}.{key}"]
+        assert np.abs(got.numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), key
