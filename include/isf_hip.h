@@ -411,6 +411,19 @@ int isf_msda_backward(const float* value, const float* sampling_offsets, const f
                       int num_heads, int head_dim, int num_points, int height, int width, float* grad_value,
                       float* grad_offsets, float* grad_logits, isf_stream_t stream);
 
+/* 8f #2  attention backward ------------------------------------------------------------------------------------
+ * replaces autograd through nn.MultiheadAttention's softmax(q k^T / sqrt(hd)) v core (sst_basic_block_v2.py:41-75,
+ * fusion_encoder.py:371-470) for the layouts of isf_attention_forward / isf_window_attention_forward.  The Lq x Lk
+ * probabilities are recomputed (row statistics logsumexp and dO.O), never stored; every gradient row is written
+ * once, no atomics.  `out` = the forward result.  head dim 16 (window: 16 or 32).  Asynchronous. */
+int isf_attention_backward(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                           const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
+                           int embed_dims, int num_heads, float* grad_q, int ldgq, float* grad_k, float* grad_v,
+                           int ldgkv, isf_stream_t stream);
+int isf_window_attention_backward(const float* qkv, const float* grad_out, int batch_size, int grid_size,
+                                  int embed_dims, int num_heads, int window, int shift, float* grad_qkv,
+                                  isf_stream_t stream);
+
 /* A9 / A15  dense 3x3 BEV convolutions on the sparse-conv kernel ------------------------
  * replaces mmcv ConvModule / nn.Conv2d + BatchNorm2d + ReLU (fusion_encoder.py:862-960, backbones/second.py:126-165,
  * MIOpen Winograd + 2 elementwise kernels per layer).  A dense B x H x W grid is a sparse tensor with every cell

@@ -149,6 +149,11 @@ SIGNATURES = {
     "isf_sparse_conv_backward_filter": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                 c_int, c_void_p, c_void_p]),
     "isf_msda_backward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p] * 4),
+    "isf_attention_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                       c_void_p]),
+    "isf_window_attention_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                              c_void_p]),
     "isf_dense_grid_rulebook": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                         c_int * 2, c_void_p]),
     "isf_nchw_to_split": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -1,0 +1,334 @@
+// isf_attention_bwd.hip -- SURVEY 8f #2: backward of the softmax-attention cores (isf_attention.hip).
+//
+// Reference: autograd through nn.MultiheadAttention / multi_head_attention_forward (sst_basic_block_v2.py:41-75,
+// fusion_encoder.py:371-470): bmm, softmax, bmm backward kernels with the [B*heads, Lq, Lk] probability matrix
+// materialised in HBM (32400 x 200 x 8 heads x B floats for the instance-to-scene attention).
+//
+// Here nothing of size Lq x Lk touches HBM: probabilities are recomputed from q, k and the row statistics
+//   L_i = logsumexp_j(s_ij),   D_i = dO_i . O_i          (s = q k^T / sqrt(hd)),
+// and every gradient row is produced by exactly one wave in a fixed order (no atomics, deterministic):
+//   rows    wave per (b, head, query i), lanes over keys:   L_i, D_i, dQ_i = scale * sum_j p_ij (dO_i.v_j - D_i) k_j
+//   cols    wave per (b, head, key j),   lanes over queries: dV_j = sum_i p_ij dO_i,
+//                                                            dK_j = scale * sum_i p_ij (dO_i.v_j - D_i) q_i
+//   window  the 36-token windows of the dense grid: one wave per (window, head) does both roles out of LDS.
+// fp32 VALU like the forward cores (head dim 16: these are dot products of 16 floats).
+#include "isf_common.h"
+
+namespace isf {
+
+template <int HD>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float r[HD]) {
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p + c);
+    r[c] = t.x; r[c + 1] = t.y; r[c + 2] = t.z; r[c + 3] = t.w;
+  }
+}
+
+template <int HD>
+__device__ __forceinline__ float dot_row(const float a[HD], const float b[HD]) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) s = fmaf(a[c], b[c], s);
+  return s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- rows
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_rows_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
+    const float* __restrict__ out, const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale,
+    float* __restrict__ gq, int ldgq, float* __restrict__ stat /* [B, heads, Lq, 2] = (L, D) */) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+  if (i >= Lq) return;                                     // wave-uniform
+  float qi[HD], go[HD], oi[HD];
+  load_row<HD>(q + ((size_t)b * Lq + i) * ldq + head * HD, qi);
+  load_row<HD>(gout + ((size_t)b * Lq + i) * ldo + head * HD, go);
+  load_row<HD>(out + ((size_t)b * Lq + i) * ldo + head * HD, oi);
+  const float D = dot_row<HD>(go, oi);
+  const float* kb = k + (size_t)b * Lk * ldkv + head * HD;
+  const float* vb = v + (size_t)b * Lk * ldkv + head * HD;
+  // pass 1: L = logsumexp
+  float m = -INFINITY, sum = 0.f;
+  for (int j = lane; j < Lk; j += 64) {
+    float kj[HD];
+    load_row<HD>(kb + (size_t)j * ldkv, kj);
+    const float s = scale * dot_row<HD>(qi, kj);
+    const float nm = fmaxf(m, s);
+    sum = sum * __expf(m - nm) + __expf(s - nm);
+    m = nm;
+  }
+  const float M = wave_max(m);
+  sum = wave_sum(m == -INFINITY ? 0.f : sum * __expf(m - M));
+  const float L = M + __logf(sum);
+  // pass 2: dQ
+  float acc[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+  for (int j = lane; j < Lk; j += 64) {
+    float kj[HD], vj[HD];
+    load_row<HD>(kb + (size_t)j * ldkv, kj);
+    load_row<HD>(vb + (size_t)j * ldkv, vj);
+    const float p = __expf(scale * dot_row<HD>(qi, kj) - L);
+    const float ds = p * (dot_row<HD>(go, vj) - D);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, kj[c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c) acc[c] = wave_sum(acc[c]) * scale;
+  if (lane == 0) {
+    float* g = gq + ((size_t)b * Lq + i) * ldgq + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) *reinterpret_cast<float4*>(g + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    float* st = stat + (((size_t)b * heads + head) * Lq + i) * 2;
+    st[0] = L;
+    st[1] = D;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- cols
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
+    const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale, const float* __restrict__ stat,
+    float* __restrict__ gk, float* __restrict__ gv, int ldgkv) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+  if (j >= Lk) return;                                     // wave-uniform
+  float kj[HD], vj[HD], dk[HD], dv[HD];
+  load_row<HD>(k + ((size_t)b * Lk + j) * ldkv + head * HD, kj);
+  load_row<HD>(v + ((size_t)b * Lk + j) * ldkv + head * HD, vj);
+#pragma unroll
+  for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
+  const float* qb = q + (size_t)b * Lq * ldq + head * HD;
+  const float* gb = gout + (size_t)b * Lq * ldo + head * HD;
+  const float* st = stat + ((size_t)b * heads + head) * Lq * 2;
+  for (int i = lane; i < Lq; i += 64) {
+    float qi[HD], go[HD];
+    load_row<HD>(qb + (size_t)i * ldq, qi);
+    load_row<HD>(gb + (size_t)i * ldo, go);
+    const float2 ld = *reinterpret_cast<const float2*>(st + (size_t)i * 2);
+    const float p = __expf(scale * dot_row<HD>(qi, kj) - ld.x);
+    const float ds = p * (dot_row<HD>(go, vj) - ld.y);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      dv[c] = fmaf(p, go[c], dv[c]);
+      dk[c] = fmaf(ds, qi[c], dk[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < HD; ++c) {
+    dv[c] = wave_sum(dv[c]);
+    dk[c] = wave_sum(dk[c]) * scale;
+  }
+  if (lane == 0) {
+    float* g1 = gk + ((size_t)b * Lk + j) * ldgkv + head * HD;
+    float* g2 = gv + ((size_t)b * Lk + j) * ldgkv + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      *reinterpret_cast<float4*>(g1 + c) = make_float4(dk[c], dk[c + 1], dk[c + 2], dk[c + 3]);
+      *reinterpret_cast<float4*>(g2 + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- window
+// same geometry as window_attention_kernel; HPB heads per workgroup (one wave each)
+template <int HD, int WIN, int HPB>
+__global__ __launch_bounds__(64 * HPB) void window_attention_bwd_kernel(const float* __restrict__ qkv,
+                                                                       const float* __restrict__ gout, int S, int d,
+                                                                       int y_off, float scale, int head_groups,
+                                                                       float* __restrict__ gqkv) {
+  constexpr int T = WIN * WIN;
+  static_assert(T <= 64, "window must fit one wave");
+  __shared__ __attribute__((aligned(16))) float sm[HPB][4][T][HD];   // q | k | v | dO of the wave's head
+  __shared__ float st[HPB][2][T];                                    // L, D per query
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z / head_groups, head = (blockIdx.z % head_groups) * HPB + w;
+  const int y0 = (int)blockIdx.y * WIN - y_off, x0 = (int)blockIdx.x * WIN - y_off;
+  const int y = y0 + lane / WIN, x = x0 + lane % WIN;
+  const bool valid = lane < T && y >= 0 && y < S && x >= 0 && x < S;
+  const size_t row = ((size_t)b * S + (valid ? y : 0)) * S + (valid ? x : 0);
+  float qi[HD], ki[HD], vi[HD], go[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) qi[c] = ki[c] = vi[c] = go[c] = 0.f;
+  if (valid) {
+    const float* base = qkv + row * (size_t)(3 * d) + head * HD;
+    load_row<HD>(base, qi);
+    load_row<HD>(base + d, ki);
+    load_row<HD>(base + 2 * d, vi);
+    load_row<HD>(gout + row * (size_t)d + head * HD, go);
+  }
+  if (lane < T) {
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      sm[w][0][lane][c] = qi[c];
+      sm[w][1][lane][c] = ki[c];
+      sm[w][2][lane][c] = vi[c];
+      sm[w][3][lane][c] = go[c];
+    }
+  }
+  __syncthreads();
+  float dq[HD], dk[HD], dv[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) dq[c] = dk[c] = dv[c] = 0.f;
+  // ---- query role: L_i, D_i, dQ_i
+  float L = 0.f, D = 0.f;
+  if (valid) {
+    float m = -INFINITY;
+    float s[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const int yy = y0 + j / WIN, xx = x0 + j % WIN;
+      const bool ok = yy >= 0 && yy < S && xx >= 0 && xx < S;   // wave-uniform
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) a = fmaf(qi[c], sm[w][1][j][c], a);
+      s[j] = ok ? a * scale : -INFINITY;
+      m = fmaxf(m, s[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < T; ++j) sum += __expf(s[j] - m);
+    L = m + __logf(sum);
+    // D_i = sum_j p_ij dO_i . v_j
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dp = fmaf(go[c], sm[w][2][j][c], dp);
+      D = fmaf(__expf(s[j] - L), dp, D);
+    }
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      float dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dp = fmaf(go[c], sm[w][2][j][c], dp);
+      const float ds = __expf(s[j] - L) * (dp - D);   // masked keys: exp(-inf) = 0
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, sm[w][1][j][c], dq[c]);
+    }
+  }
+  if (lane < T) {
+    st[w][0][lane] = L;
+    st[w][1][lane] = D;
+  }
+  __syncthreads();
+  // ---- key role: dK_j, dV_j
+  if (valid) {
+#pragma unroll 4
+    for (int i = 0; i < T; ++i) {
+      const int yy = y0 + i / WIN, xx = x0 + i % WIN;
+      if (!(yy >= 0 && yy < S && xx >= 0 && xx < S)) continue;   // wave-uniform
+      float a = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        a = fmaf(sm[w][0][i][c], ki[c], a);
+        dp = fmaf(sm[w][3][i][c], vi[c], dp);
+      }
+      const float p = __expf(a * scale - st[w][0][i]);
+      const float ds = p * (dp - st[w][1][i]);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        dv[c] = fmaf(p, sm[w][3][i][c], dv[c]);
+        dk[c] = fmaf(ds, sm[w][0][i][c], dk[c]);
+      }
+    }
+    float* g = gqkv + row * (size_t)(3 * d) + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      *reinterpret_cast<float4*>(g + c) =
+          make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale);
+      *reinterpret_cast<float4*>(g + d + c) =
+          make_float4(dk[c] * scale, dk[c + 1] * scale, dk[c + 2] * scale, dk[c + 3] * scale);
+      *reinterpret_cast<float4*>(g + 2 * d + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+    }
+  }
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_attention_backward(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                           const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
+                           int embed_dims, int num_heads, float* grad_q, int ldgq, float* grad_k, float* grad_v,
+                           int ldgkv, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && num_queries >= 0 && num_keys > 0 && num_heads > 0, ISF_ERR_ARG,
+              "attention_backward: bad sizes");
+  if (batch_size == 0) return ISF_OK;
+  ISF_REQUIRE(embed_dims == 16 * num_heads, ISF_ERR_UNSUPPORTED, "attention_backward: head dim %d (built for 16)",
+              num_heads ? embed_dims / num_heads : 0);
+  ISF_REQUIRE(q && k && v && out && grad_out && grad_q && grad_k && grad_v, ISF_ERR_ARG,
+              "attention_backward: null pointer");
+  ISF_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldgq % 4 == 0 && ldgkv % 4 == 0, ISF_ERR_ARG,
+              "attention_backward: leading dimensions must be multiples of 4 floats");
+  hipStream_t st = as_stream(stream);
+  if (num_queries == 0) {
+    // no query: the key / value gradients are zero
+    ISF_HIP_TRY(hipMemset2DAsync(grad_k, sizeof(float) * ldgkv, 0, sizeof(float) * embed_dims,
+                                 (size_t)batch_size * num_keys, st));
+    ISF_HIP_TRY(hipMemset2DAsync(grad_v, sizeof(float) * ldgkv, 0, sizeof(float) * embed_dims,
+                                 (size_t)batch_size * num_keys, st));
+    return ISF_OK;
+  }
+  Arena& a = arena_for_current_device();
+  ISF_TRY(a.reset());
+  float* stat = nullptr;
+  ISF_TRY(a.alloc_n(&stat, (size_t)batch_size * num_heads * num_queries * 2));
+  const float scale = 1.f / sqrtf(16.f);
+  hipLaunchKernelGGL((attention_bwd_rows_kernel<16>), dim3(ceil_div(num_queries, 4), num_heads, batch_size), dim3(256),
+                     0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
+  ISF_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4), num_heads, batch_size), dim3(256), 0,
+                     st, q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, grad_k, grad_v, ldgkv);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_window_attention_backward(const float* qkv, const float* grad_out, int batch_size, int grid_size,
+                                  int embed_dims, int num_heads, int window, int shift, float* grad_qkv,
+                                  isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(batch_size >= 0 && grid_size > 0, ISF_ERR_ARG, "window_attention_backward: bad sizes");
+  if (batch_size == 0) return ISF_OK;
+  ISF_REQUIRE(qkv && grad_out && grad_qkv, ISF_ERR_ARG, "window_attention_backward: null pointer");
+  const int hd = num_heads > 0 ? embed_dims / num_heads : 0;
+  ISF_REQUIRE(window == 6 && (hd == 16 || hd == 32) && hd * num_heads == embed_dims && num_heads % 4 == 0,
+              ISF_ERR_UNSUPPORTED,
+              "window_attention_backward: built for 6x6 windows, head dim 16 / 32, heads %% 4 == 0 (got window %d, "
+              "dims %d, heads %d)", window, embed_dims, num_heads);
+  // window origins exactly as the forward: shift 0 -> aligned at 0; shift 1 -> offset by window / 2
+  const int y_off = shift ? window / 2 : 0;
+  const int nwin = ceil_div(grid_size + y_off, window);
+  const float scale = 1.f / sqrtf((float)hd);
+  if (hd == 16) {
+    const int groups = num_heads / 4;
+    hipLaunchKernelGGL((window_attention_bwd_kernel<16, 6, 4>), dim3(nwin, nwin, batch_size * groups), dim3(256), 0,
+                       as_stream(stream), qkv, grad_out, grid_size, embed_dims, y_off, scale, groups, grad_qkv);
+  } else {
+    const int groups = num_heads / 2;
+    hipLaunchKernelGGL((window_attention_bwd_kernel<32, 6, 2>), dim3(nwin, nwin, batch_size * groups), dim3(128), 0,
+                       as_stream(stream), qkv, grad_out, grid_size, embed_dims, y_off, scale, groups, grad_qkv);
+  }
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // extern "C"

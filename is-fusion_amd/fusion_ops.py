@@ -299,6 +299,58 @@ class MSDAFunction(torch.autograd.Function):
         return (gv, goff, glog) + (None,) * 8
 
 
+class AttentionFunction(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v of nn.MultiheadAttention (fusion_encoder.py:371-470) with a gradient: forward =
+    isf_attention_forward, backward = isf_attention_backward (not yet validated on hardware).
+    q [B*Lq, E], k / v [B*Lk, E] row-major."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, Lq, Lk, E, nhead):
+        _lib.require_cuda(q, k, v)
+        q, k, v = [t.detach().float().contiguous() for t in (q, k, v)]
+        out = attention(q, k, v, B, Lq, Lk, E, nhead)
+        ctx.save_for_backward(q, k, v, out)
+        ctx.dims = (B, Lq, Lk, E, nhead)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, out = ctx.saved_tensors
+        B, Lq, Lk, E, nhead = ctx.dims
+        g = grad_out.contiguous().float()
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        _lib.check(_lib.load().isf_attention_backward(
+            _lib.ptr(q), q.stride(0), _lib.ptr(k), _lib.ptr(v), k.stride(0), _lib.ptr(out), _lib.ptr(g), g.stride(0),
+            B, Lq, Lk, E, nhead, _lib.ptr(gq), gq.stride(0), _lib.ptr(gk), _lib.ptr(gv), gk.stride(0), _lib.stream()),
+            "isf_attention_backward")
+        return (gq, gk, gv) + (None,) * 5
+
+
+class WindowAttentionFunction(torch.autograd.Function):
+    """the window attention core of SST's BasicShiftBlockV2 on a dense grid (sst_basic_block_v2.py:41-75) with a
+    gradient: forward = isf_window_attention_forward, backward = isf_window_attention_backward.
+    qkv [B*S*S, 3d] -> [B*S*S, d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, S, d, nhead, win, shift):
+        _lib.require_cuda(qkv)
+        qkv = qkv.detach().float().contiguous()
+        ctx.save_for_backward(qkv)
+        ctx.dims = (B, S, d, nhead, win, shift)
+        return window_attention(qkv, B, S, d, nhead, win, shift)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (qkv,) = ctx.saved_tensors
+        B, S, d, nhead, win, shift = ctx.dims
+        g = grad_out.contiguous().float()
+        gqkv = torch.empty_like(qkv)
+        _lib.check(_lib.load().isf_window_attention_backward(_lib.ptr(qkv), _lib.ptr(g), B, S, d, nhead, win, shift,
+                                                             _lib.ptr(gqkv), _lib.stream()),
+                   "isf_window_attention_backward")
+        return (gqkv,) + (None,) * 6
+
+
 def _pos_embed(mod, xy):
     """PositionEmbeddingLearned (fusion_encoder.py:173-189): stock Conv1d/BN1d stack on [B, N, 2] -> [B, N, E]"""
     return mod.position_embedding_head(xy.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()

@@ -338,3 +338,73 @@ def test_msda_backward_matches_reference_autograd_golden(dev, golden, name, B, Q
     a = aw.reshape(B * Q, 8, 16)
     glog = (a * (gw - (a * gw).sum(-1, keepdim=True))).reshape(B * Q, 128).numpy()
     assert np.abs(lg.grad.cpu().numpy() - glog).max() < 1e-4 * max(1.0, np.abs(glog).max())
+
+
+# ------------------------------------------------------------------------------------------- attention backward (8f #2)
+def _torch_mha_core(q, k, v, B, Lq, Lk, heads):
+    """softmax(q k^T / sqrt(hd)) v per head in float64 (what nn.MultiheadAttention computes after its projections)"""
+    E = q.shape[1]
+    hd = E // heads
+    qh = q.view(B, Lq, heads, hd).transpose(1, 2)
+    kh = k.view(B, Lk, heads, hd).transpose(1, 2)
+    vh = v.view(B, Lk, heads, hd).transpose(1, 2)
+    p = (qh @ kh.transpose(-1, -2) / hd ** 0.5).softmax(-1)
+    return (p @ vh).transpose(1, 2).reshape(B * Lq, E)
+
+
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 50, 37), (1, 300, 200), (1, 70, 1500)])
+def test_attention_backward_matches_torch_autograd(dev, B, Lq, Lk):
+    """isf_attention_backward (rows + cols kernels) vs torch autograd of the same formula in float64: few keys, the
+    32400 x 200-shaped case (more queries than keys) and the many-keys (split-key forward) case"""
+    from isfusion_amd import fusion_ops as ops
+    g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
+    q, k, v = [torch.randn((B * n, 128), generator=g) for n in (Lq, Lk, Lk)]
+    gout = torch.randn((B * Lq, 128), generator=g)
+    qd, kd, vd = [t.double().requires_grad_() for t in (q, k, v)]
+    ref = _torch_mha_core(qd, kd, vd, B, Lq, Lk, 8)
+    ref.backward(gout.double())
+    qg, kg, vg = [t.to(dev).requires_grad_() for t in (q, k, v)]
+    out = ops.AttentionFunction.apply(qg, kg, vg, B, Lq, Lk, 128, 8)
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4
+    out.backward(gout.to(dev))
+    for got, want, name in ((qg, qd, "dq"), (kg, kd, "dk"), (vg, vd, "dv")):
+        err = (got.grad.cpu().double() - want.grad).abs().max().item()
+        assert err < 2e-4 * max(1.0, want.grad.abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize("S,d,shift", [(12, 128, 0), (12, 128, 1), (16, 128, 1), (9, 256, 1), (12, 256, 0)])
+def test_window_attention_backward_matches_torch_autograd(dev, S, d, shift):
+    """isf_window_attention_backward vs torch autograd over the explicit window partition (partial edge windows when
+    the grid is shifted or not a multiple of 6)"""
+    from isfusion_amd import fusion_ops as ops
+    B, heads, win = 2, 8, 6
+    hd = d // heads
+    g = torch.Generator().manual_seed(S * 10 + d + shift)
+    qkv = torch.randn((B * S * S, 3 * d), generator=g)
+    gout = torch.randn((B * S * S, d), generator=g)
+    x = qkv.double().requires_grad_()
+    xr = x.view(B, S, S, 3, heads, hd)
+    off = win // 2 if shift else 0
+    out_ref = torch.zeros((B, S, S, heads, hd), dtype=torch.float64)
+    for wy in range((S + off + win - 1) // win):
+        for wx in range((S + off + win - 1) // win):
+            ys = [y for y in range(wy * win - off, wy * win - off + win) if 0 <= y < S]
+            xs = [c for c in range(wx * win - off, wx * win - off + win) if 0 <= c < S]
+            if not ys or not xs:
+                continue
+            blk = xr[:, ys][:, :, xs]                                       # [B, ny, nx, 3, heads, hd]
+            t = blk.reshape(B, len(ys) * len(xs), 3, heads, hd)
+            qh, kh, vh = [t[:, :, i].transpose(1, 2) for i in range(3)]    # [B, heads, T, hd]
+            o = (qh @ kh.transpose(-1, -2) / hd ** 0.5).softmax(-1) @ vh
+            o = o.transpose(1, 2).reshape(B, len(ys), len(xs), heads, hd)
+            idx_y = torch.tensor(ys).view(-1, 1).expand(len(ys), len(xs))
+            idx_x = torch.tensor(xs).view(1, -1).expand(len(ys), len(xs))
+            out_ref[:, idx_y, idx_x] = o
+    out_ref = out_ref.reshape(B * S * S, d)
+    out_ref.backward(gout.double())
+    xg = qkv.to(dev).requires_grad_()
+    out = ops.WindowAttentionFunction.apply(xg, B, S, d, heads, win, shift)
+    assert (out.detach().cpu().double() - out_ref.detach()).abs().max().item() < 1e-4
+    out.backward(gout.to(dev))
+    err = (xg.grad.cpu().double() - x.grad).abs().max().item()
+    assert err < 2e-4 * max(1.0, x.grad.abs().max().item()), err
