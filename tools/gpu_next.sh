@@ -5,3 +5,7 @@ set -u
 mkdir -p gpurun_out
 python -m pytest tests -q -m gpu_next 2>&1 | tail -25 | tee gpurun_out/gpu_next_tests.log
 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/gpu_tests.log
+# hardware question behind the deeper conv prefetch ring: are LDS-DMA and register loads of one
+# wave retired strictly in issue order under counted s_waitcnt?
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/vmcnt_probe.hip -o gpurun_out/vmcnt_probe \
+  && timeout 120 gpurun_out/vmcnt_probe | tee gpurun_out/vmcnt_probe.json
