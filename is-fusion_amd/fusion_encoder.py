@@ -59,6 +59,7 @@ class ISFusionEncoder(nn.Module):
         """ConvModule `name` packed for the f16x3 kernel (cached per device)"""
         mod = getattr(self, name)
         cache = self.__dict__.setdefault("_isf_packed", {})
+        ops.watch_parameters(self)
         dev = mod.conv.weight.device
         if cache.get(name, (None,))[0] != dev:
             cache[name] = (dev, PackedConvBN(mod.conv, mod.bn, relu=True))

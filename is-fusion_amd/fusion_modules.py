@@ -157,7 +157,9 @@ class SECONDV2(nn.Module):
 
     def _packed(self, name, seq):
         from .dense_conv import pack_sequential
+        from .fusion_ops import watch_parameters
         cache = self.__dict__.setdefault("_isf_packed", {})
+        watch_parameters(self)
         dev = next(seq.parameters()).device
         if cache.get(name, (None,))[0] != dev:
             cache[name] = (dev, pack_sequential(seq))

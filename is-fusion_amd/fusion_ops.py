@@ -73,11 +73,28 @@ def linear(x, pl, *, table=None, index=None, act=ACT_NONE, residual=None, ln=Non
     return y
 
 
+def drop_caches(module, *_):
+    """Forget every packed-weight / table cache below `module` (they are derived from the parameters)."""
+    for sub in module.modules():
+        sub.__dict__.pop("_isf_cache", None)
+        sub.__dict__.pop("_isf_packed", None)
+
+
+def watch_parameters(module):
+    """Packed weights are cached per device; a load_state_dict() into the module (or into any ancestor: the post
+    hooks run for every module of the recursion, children first) must invalidate them -- otherwise a checkpoint
+    loaded after the first forward would be ignored silently."""
+    if not module.__dict__.get("_isf_watched", False):
+        module.register_load_state_dict_post_hook(drop_caches)
+        module.__dict__["_isf_watched"] = True
+
+
 def _cache(module, device):
-    c = getattr(module, "_isf_cache", None)
+    c = module.__dict__.get("_isf_cache")
     if c is None or c.get("device") != device:
         c = {"device": device}
-        module._isf_cache = c
+        module.__dict__["_isf_cache"] = c
+        watch_parameters(module)
     return c
 
 

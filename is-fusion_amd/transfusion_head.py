@@ -117,6 +117,7 @@ class TransFusionHeadV2(nn.Module):
 
     def _packed(self, device):
         c = self.__dict__.setdefault("_isf_packed", {})
+        ops.watch_parameters(self)
         if c.get("device") != device:
             c.clear()
             c["device"] = device

@@ -251,3 +251,24 @@ def test_input_loader_refuses_cpu_and_replays_the_reference_rng():
     assert (mine["flip_horizontal"], mine["flip_vertical"]) == (ref["flip_horizontal"], ref["flip_vertical"])
     ld = MultiSweepPointLoader(sweeps_num=3, test_mode=True)
     assert list(ld._choose(2)) == [0, 1] and list(ld._choose(7)) == [0, 1, 2]
+
+
+def test_load_state_dict_invalidates_packed_weight_caches():
+    """packed weights / tables are cached per module; loading a checkpoint (into the module or an ancestor) after the
+    first forward must drop them, or the new weights would be ignored silently"""
+    import torch
+    from isfusion_amd import fusion_ops as ops
+    from fusion_common import CONFIGS, encoder_kwargs
+    from isfusion_amd.fusion_encoder import ISFusionEncoder
+    enc = ISFusionEncoder(**encoder_kwargs(CONFIGS["small"]))
+    sub = enc.grid2region_att[0]
+    dev = torch.device("cpu")
+    ops._cache(sub, dev)["linear0"] = "stale"               # what a first forward leaves behind
+    enc.__dict__.setdefault("_isf_packed", {})["conv_fusion"] = (dev, "stale")
+    ops.watch_parameters(enc)
+    assert ops._cache(sub, dev).get("linear0") == "stale"   # the cache survives ordinary calls
+    enc.load_state_dict(enc.state_dict())                   # ancestor load: children hooks fire too
+    assert "_isf_cache" not in sub.__dict__ and "_isf_packed" not in enc.__dict__
+    ops._cache(sub, dev)["linear0"] = "stale"
+    sub.load_state_dict(sub.state_dict())                   # direct load into the owner
+    assert "_isf_cache" not in sub.__dict__
