@@ -62,9 +62,8 @@ class ISFusionPtsPath(nn.Module):
         nk.pop("type", None)
         self.pts_neck = SECONDFPN(**nk)
         hd = dict(pts_bbox_head or ISFUSION_0075_FUSION["pts_bbox_head"])
-        for k in ("type", "bbox_coder", "loss_cls", "loss_bbox", "loss_heatmap", "loss_iou", "dropout", "bn_momentum",
-                  "activation"):
-            hd.pop(k, None)   # losses / coder / training-only knobs: control plane
+        for k in ("type", "loss_cls", "loss_bbox", "loss_heatmap", "loss_iou", "dropout", "bn_momentum", "activation"):
+            hd.pop(k, None)   # losses / training-only knobs: control plane
         self.pts_bbox_head = TransFusionHeadV2(**hd)
         osf = out_size_factor or ISFUSION_0075_FUSION["out_size_factor"]
         # isfusion.py:45-51

@@ -272,3 +272,39 @@ def test_load_state_dict_invalidates_packed_weight_caches():
     ops._cache(sub, dev)["linear0"] = "stale"
     sub.load_state_dict(sub.state_dict())                   # direct load into the owner
     assert "_isf_cache" not in sub.__dict__
+
+
+def test_registry_surface_and_build_from_the_unmodified_reference_config():
+    """SURVEY 8b level 1: the reference's type names resolve to this build's classes; the point-cloud path builds from
+    configs/isfusion/isfusion_0075voxel.py as it stands (authoring container only: the file is not copied)"""
+    import os
+    import pytest
+    from isfusion_amd import registry
+    from isfusion_amd.detector import ISFusionPtsPath
+
+    class FakeRegistry:
+        def __init__(self):
+            self.mods = {}
+
+        def register_module(self, name=None, force=False, module=None):
+            assert force and name not in self.mods
+            self.mods[name] = module
+
+    regs = {n: FakeRegistry() for n in ("MODELS", "BACKBONES", "NORM_LAYERS")}
+    done = registry.register_into(regs)
+    assert "MODELS.ISFusionEncoder" in done and "BACKBONES.SECONDV2" in done and "NORM_LAYERS.naiveSyncBN1d" in done
+    assert not any(d.startswith("CONV_LAYERS") for d in done)          # registry not offered -> skipped
+    assert regs["MODELS"].mods["SparseEncoder"] is registry.lookup("SparseEncoder")
+    vfe = registry.build(dict(type="HardSimpleVFE", num_features=5))
+    assert type(vfe).__name__ == "HardSimpleVFE" and vfe.num_features == 5
+    with pytest.raises(KeyError):
+        registry.lookup("CenterHead")
+    cfg = "/root/reference/configs/isfusion/isfusion_0075voxel.py"
+    if not os.path.exists(cfg):
+        pytest.skip("reference tree not present (GPU box)")
+    net = registry.build_pts_path(cfg)
+    ref = ISFusionPtsPath()
+    a = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert a == {k: tuple(v.shape) for k, v in ref.state_dict().items()} and len(a) > 400
+    assert net.pts_bbox_head.test_cfg["nms_type"] is None and net.pts_bbox_head.bbox_coder["code_size"] == 10
+    assert net.fusion_encoder.num_points_in_pillar == 12 and net.pillar_size == [0.6, 0.6, 8]
