@@ -271,3 +271,83 @@ def test_window_attention_backward_formulas_with_partial_windows():
     assert (dq[idx] * scale - qa.grad).abs().max() < 1e-12
     assert (dk[idx] * scale - ka.grad).abs().max() < 1e-12
     assert (dv[idx] - va.grad).abs().max() < 1e-12
+
+
+def test_assemble_points_block_partition_and_compaction(golden):
+    """isf_assemble_points (isf_input.hip): per-file block prefix, per-block binary search for the owning file, keep
+    flags, exclusive scan of block counts, packed write, per-sample offsets -- emulated block by block vs the
+    reference pipeline's goldens (a batch of three samples, one without sweeps, plus an empty file)"""
+    from input_common import INPUT_CONFIGS, PC_RANGE, sweep_inputs
+    g = golden("input_ref.npz")
+    BLK = 256
+    names = ["a", "key_only", "b"]
+    files, raw = [], []                                   # descriptors in the loader's order
+    row = 0
+
+    def add(arr, sample, is_sweep, lag=0.0, rot=None, trans=None):
+        nonlocal row
+        files.append(dict(first=row, n=arr.shape[0], sample=sample, is_sweep=is_sweep, lag=np.float32(lag),
+                          rot=np.eye(3) if rot is None else rot, trans=np.zeros(3) if trans is None else trans))
+        raw.append(arr)
+        row += arr.shape[0]
+
+    for b, n in enumerate(names):
+        key, sweeps, ts = sweep_inputs(*INPUT_CONFIGS[n])
+        add(key, b, False)
+        if n == "a":
+            add(np.zeros((0, 5), np.float32), b, True)    # an empty file in the middle
+        for sw in sweeps:
+            add(sw["points"], b, True, ts - sw["timestamp"] / 1e6, sw["sensor2lidar_rotation"],
+                sw["sensor2lidar_translation"])
+    raw = np.concatenate(raw)
+    B = len(names)
+    # host side of isf_assemble_points
+    blocks, prev, first_block = 0, 0, [0] * (B + 1)
+    for f in files:
+        for bb in range(prev + 1, f["sample"] + 1):
+            first_block[bb] = blocks
+        prev = f["sample"]
+        f["block_begin"] = blocks
+        blocks += (f["n"] + BLK - 1) // BLK
+    for bb in range(prev + 1, B + 1):
+        first_block[bb] = blocks
+    live = len(files)
+    while live > 0 and files[live - 1]["n"] == 0:
+        live -= 1
+    rng = np.float32(PC_RANGE)
+
+    def block(blk):
+        lo, hi = 0, live - 1                              # last file with block_begin <= blk
+        while lo < hi:
+            mid = (lo + hi + 1) >> 1
+            if files[mid]["block_begin"] <= blk:
+                lo = mid
+            else:
+                hi = mid - 1
+        f = files[lo]
+        start = (blk - f["block_begin"]) * BLK
+        n = min(BLK, f["n"] - start)
+        assert n > 0, "a block must own points"
+        p = raw[f["first"] + start: f["first"] + start + n].copy()
+        if f["is_sweep"]:
+            xyz = (p[:, :3].astype(np.float64) @ f["rot"].T).astype(np.float32)
+            p[:, :3] = (xyz.astype(np.float64) + f["trans"]).astype(np.float32)
+            p[:, 4] = f["lag"]
+        else:
+            p[:, 4] = 0
+        keep = ((p[:, 0] > rng[0]) & (p[:, 1] > rng[1]) & (p[:, 2] > rng[2]) &
+                (p[:, 0] < rng[3]) & (p[:, 1] < rng[4]) & (p[:, 2] < rng[5]))
+        return p, keep
+
+    counts = np.array([block(blk)[1].sum() for blk in range(blocks)])
+    offsets = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    out = np.zeros((raw.shape[0], 5), np.float32)
+    for blk in range(blocks):
+        p, keep = block(blk)
+        rank = np.cumsum(keep) - keep                     # ballot + popcount prefix, wave counts added in order
+        out[offsets[blk] + rank[keep]] = p[keep]
+    sample_offsets = [int(offsets[fb]) if fb < blocks else int(offsets[-1] + counts[-1]) for fb in first_block]
+    for b, n in enumerate(names):
+        ref = g[f"{n}.test.points"]
+        got = out[sample_offsets[b]:sample_offsets[b + 1]]
+        assert got.shape == ref.shape and np.array_equal(got, ref), n
