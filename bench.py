@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--cpu-points", type=int, default=20000, help="points of the CPU-baseline sample frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
+    ap.add_argument("--f16", action="store_true",
+                    help="DIAGNOSTIC ONLY: single-pass f16 conv kernels (fp16-autocast accuracy, BASELINE configs[4] "
+                         "dtype); reduced precision, never the headline line")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +133,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
 
     from isfusion_amd import _lib
-    _lib.check(_lib.load().isf_set_conv_precision(1 if args.fp32 else 0))
+    _lib.check(_lib.load().isf_set_conv_precision(2 if args.f16 else 1 if args.fp32 else 0))
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
     frames = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
     torch.cuda.synchronize()
@@ -185,6 +188,8 @@ def main():
         # the matrix-pipe roofline is the f16 peak against 3x the algorithmic flops
         split = st.precision == 1
         mult, peak = (3.0, MFMA_F16_PEAK_TFLOPS) if split else (1.0, MFMA_F32_PEAK_TFLOPS)
+        if args.f16:
+            mult = 1.0   # one f16 MFMA pass per product
         t_roof_mfma = mult * dom["flops"] / (peak * 1e12)
         t_roof_hbm = dom["bytes"] / (HBM_PEAK_GBS * 1e9)
         if t_roof_mfma >= t_roof_hbm:
@@ -215,7 +220,8 @@ def main():
             "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (f16x3 split-precision MFMA, fp32 accumulate)" if st.precision == 1 else "f32",
+            "dtype": "f16 operands, fp32 accumulate (DIAGNOSTIC: reduced precision, not the headline)" if args.f16
+            else "f32 (f16x3 split-precision MFMA, fp32 accumulate)" if st.precision == 1 else "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: isfusion_0075voxel LiDAR-only branch (dynamic voxelize + "
                                    "DynamicVFE + 21-layer SparseEncoder -> BEV [B,512,180,180]), synthetic "

@@ -190,7 +190,10 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * contiguous); isf_f32_to_split / isf_split_to_f32 convert ([N, C] row-major fp32, N*C a multiple of 32).
  * |activation| must be < 65504.  Cin, Cout in {32,64,128,256}.
  * isf_set_conv_precision(0) (default): isf_sparse_encoder_forward / isf_lidar_branch_forward use this path
- * when every layer carries packed16; isf_set_conv_precision(1) forces the fp32 MFMA kernels. */
+ * when every layer carries packed16; isf_set_conv_precision(1) forces the fp32 MFMA kernels;
+ * isf_set_conv_precision(2) (opt-in, never the default): single-pass f16 -- the same kernels fetch and multiply only
+ * the hi halves (f16 operands, fp32 accumulate: the accuracy of the reference's indice_conv_half under fp16 autocast,
+ * BASELINE configs[4]); results are still exchanged in the split format. */
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
 int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
                            isf_stream_t stream);

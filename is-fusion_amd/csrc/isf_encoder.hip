@@ -133,7 +133,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* _
 }
 
 // ----------------------------------------------------------------------------------------- encoder
-int g_conv_precision = 0;  // 0 = auto (f16x3 split MFMA where packed), 1 = force fp32 MFMA
+int g_conv_precision = 0;  // 0 = auto (f16x3 split MFMA where packed), 1 = force fp32 MFMA, 2 = single-pass f16 (opt-in)
 
 struct LevelState {
   int shape[3];
@@ -311,7 +311,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
 extern "C" {
 
 int isf_set_conv_precision(int mode) {
-  if (mode != 0 && mode != 1) return ISF_ERR_ARG;
+  if (mode != 0 && mode != 1 && mode != 2) return ISF_ERR_ARG;
   isf::g_conv_precision = mode;
   return ISF_OK;
 }

@@ -35,6 +35,8 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int kMaxTaps = 27;
 
+extern int g_conv_precision;   // isf_encoder.hip: 0 f16x3 split (default), 1 fp32 MFMA, 2 single-pass f16 (opt-in)
+
 // LDS-DMA of 16 B per lane: LDS[lds_base + lane*16] = *gsrc.  Issued through inline asm on purpose: when hipcc
 // sees a global_load_lds it drains vmcnt(0) before every later ds_read (it cannot prove the buffers differ),
 // which would serialise the next step's weight/activation prefetch behind the current step's MFMAs.  Hidden
@@ -97,7 +99,11 @@ struct Conv16Smem {
 // NW waves per workgroup (4 or 16): all of them share one weight stage per step, so the weight bytes a CU pulls
 // through its vector memory path per MFMA fall with NW (measured: a modest win for the 128-column layers of the
 // large levels only; what bounds the kernel is analysed in DESIGN.md section 5).
-template <int CIN, int NT, int RG, int NW>
+// HALF = single-pass mode (isf_set_conv_precision(2)): only the hi halves of activations and weights are fetched and
+// multiplied -- plain f16 operands with fp32 accumulation, the accuracy of the reference under fp16 autocast
+// (indice_conv_half), one MFMA per product instead of three.  Same buffers, same layouts; outputs are still written
+// split.  Never the default: the headline configuration is fp32-class.
+template <int CIN, int NT, int RG, int NW, bool HALF = false>
 __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
           for (int kc = 0; kc < KCH; ++kc) {
             const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4) * 2 + kg;   // chunk base + k-group
             a_nxt[rg][kc][0] = p[0];   // 4 contiguous hi pieces per row and instruction
-            a_nxt[rg][kc][1] = p[4];   // 4 contiguous lo pieces
+            if (!HALF) a_nxt[rg][kc][1] = p[4];   // 4 contiguous lo pieces
           }
         }
       }
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
 #pragma unroll
       for (int i = 0; i < (NT * 128 + NTHR - 1) / NTHR; ++i) {
         const int base = i * NTHR + wave * 64;   // wave-uniform: this wave's 64 consecutive 16-byte pieces
-        if (base < NT * 128) glds16(src + base + lane, dst + (unsigned)base * 16u);
+        // pieces come in 64-lane groups, hi (even group) then lo (odd group) per column tile
+        if (base < NT * 128 && !(HALF && ((base >> 6) & 1))) glds16(src + base + lane, dst + (unsigned)base * 16u);
       }
     }
   };
@@ -281,14 +288,15 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         bool need[RG];
   #pragma unroll
         for (int rg = 0; rg < RG; ++rg) need[rg] = (rgm[rg] >> tap) & 1u;   // scalar (wave-uniform)
-        uint4 bhu_n = b[0], blu_n = b[64];   // the next B fragments are read from LDS while these multiply
+        uint4 bhu_n = b[0], blu_n = make_uint4(0, 0, 0, 0);   // the next B fragments are read from LDS while these multiply
+        if (!HALF) blu_n = b[64];
   #pragma unroll
         for (int i = 0; i < KCH * NT; ++i) {   // i = kc * NT + nt
           const int kc = i / NT, nt = i % NT;
           const uint4 bhu = bhu_n, blu = blu_n;
           if (i + 1 < KCH * NT) {
             bhu_n = b[((i + 1) * 2 + 0) * 64];
-            blu_n = b[((i + 1) * 2 + 1) * 64];
+            if (!HALF) blu_n = b[((i + 1) * 2 + 1) * 64];
           }
           const h8 bh = *reinterpret_cast<const h8*>(&bhu);
           const h8 bl = *reinterpret_cast<const h8*>(&blu);
@@ -297,8 +305,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
             if (need[rg]) {
               const h8 ah = *reinterpret_cast<const h8*>(&a_cur[rg][kc][0]);
               const h8 al = *reinterpret_cast<const h8*>(&a_cur[rg][kc][1]);
-              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
-              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+              if (!HALF) {
+                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
+                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+              }
               acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
             }
           }
@@ -456,12 +466,12 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
          (c_out == 32 || c_out == 64 || c_out == 128 || c_out == 256);
 }
 
-template <int CIN, int NT, int RG, int NW>
+template <int CIN, int NT, int RG, int NW, bool HALF = false>
 static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                     int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                     int relu, uint4* ys, hipStream_t st) {
   using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
-  auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW>;
+  auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, HALF>;
   static bool attr_set = false;
   if (!attr_set && S::bytes > 48 * 1024) {
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -488,6 +498,9 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
+  if (g_conv_precision == 2)   // single-pass f16 (opt-in): the default workgroup shape only
+    return launch16<CIN, NT, 2, 4, true>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu,
+                                         ys, st);
   bool wide_wg = NT == 8 && CIN >= 64 && (long long)ceil_div(n_out, 512) * ncb >= 200;
   if (g_conv16_nw == 4) wide_wg = false;
   if (g_conv16_nw == 16) wide_wg = NT <= 8;
@@ -509,7 +522,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 64:  return launch16_rows<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
-      if (g_conv16_wide)
+      if (g_conv16_wide && g_conv_precision != 2)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }

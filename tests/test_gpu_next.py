@@ -408,3 +408,39 @@ def test_window_attention_backward_matches_torch_autograd(dev, S, d, shift):
     out.backward(gout.to(dev))
     err = (xg.grad.cpu().double() - x.grad).abs().max().item()
     assert err < 2e-4 * max(1.0, x.grad.abs().max().item()), err
+
+
+# ------------------------------------------------------------------------------------------- single-pass f16 mode
+def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mod):
+    """isf_set_conv_precision(2): the conv kernels multiply only the hi halves (f16 operands, fp32 accumulate) -- the
+    accuracy class of the reference's indice_conv_half; the default (0) must be restored and stay fp32-class"""
+    import isfusion_amd as m
+    from isfusion_amd import _lib, synthetic
+    from isfusion_amd.norm import fold_bn
+    B = 2
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval()
+    pl = [synthetic.lidar_sweeps(300 + i, 4000) for i in range(B)]
+    coors = np.concatenate([np.concatenate([np.full((p.shape[0], 1), b, np.int32),
+                                            oracle_mod.dynamic_voxelize(p, VS, RG)], 1) for b, p in enumerate(pl)])
+    vfe = lb.pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    ovf, ovc, _ = oracle_mod.dynamic_vfe(np.concatenate(pl), coors, VS, RG,
+                                         vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                         vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    obev, _ = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), ovf, ovc, B)
+    lb = lb.to(dev)
+    pts = [_T(p, dev) for p in pl]
+    lib = _lib.load()
+    try:
+        _lib.check(lib.isf_set_conv_precision(2))
+        half = lb(pts).cpu().numpy()
+    finally:
+        _lib.check(lib.isf_set_conv_precision(0))
+    full = lb(pts).cpu().numpy()
+    scale = np.abs(obev).max()
+    err_half, err_full = np.abs(half - obev).max(), np.abs(full - obev).max()
+    assert err_full < 1e-3                                   # default path untouched
+    assert err_half < 3e-2 * scale, (err_half, scale)        # 21 layers of f16 rounding (2^-11 relative per operand)
+    assert err_half > 10 * err_full                          # the mode really ran (it is NOT fp32-class)
+    assert np.array_equal(half != 0, obev != 0)

@@ -9,3 +9,8 @@ python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/gpu_tests.lo
 # wave retired strictly in issue order under counted s_waitcnt?
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/vmcnt_probe.hip -o gpurun_out/vmcnt_probe \
   && timeout 120 gpurun_out/vmcnt_probe | tee gpurun_out/vmcnt_probe.json
+# diagnostic: the same conv kernels with one MFMA pass instead of three (reduced precision, NOT the headline) -- shows
+# how much of the conv time is the matrix pipe and how much is everything else
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --f16 > gpurun_out/bench_f16_diag.json 2> gpurun_out/bench_f16_diag.err
+tail -c 600 gpurun_out/bench_default.json; tail -c 600 gpurun_out/bench_f16_diag.json
