@@ -247,8 +247,55 @@ class SECONDFPN(nn.Module):
             blocks.append(nn.Sequential(up, nn.BatchNorm2d(cout, eps=eps, momentum=mom), nn.ReLU(inplace=True)))
         self.deblocks = nn.ModuleList(blocks)
 
+    # "stock": the torch modules above (MIOpen).  "hip" (opt-in until it has run on hardware): both
+    # levels are GEMMs over BEV tokens -- the 1x1 conv is a linear layer, the k = s transposed conv is ONE linear layer
+    # with s*s*Cout outputs whose columns are dealt to the s x s sub-cells -- on the fused f16x3 linear kernel with
+    # BatchNorm folded into weight / bias and ReLU in its epilogue.
+    dense_conv = "stock"
+
+    def _folded(self, i):
+        """(weight [taps*Cout, Cin], bias [taps*Cout], stride) of level i with eval BatchNorm folded in"""
+        up, bn = self.deblocks[i][0], self.deblocks[i][1]
+        scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+        shift = (bn.bias - bn.running_mean * scale).detach().float()
+        w = up.weight.detach().float()
+        if isinstance(up, nn.ConvTranspose2d):
+            s = up.stride[0]
+            assert up.kernel_size == (s, s) and up.stride == (s, s) and up.bias is None
+            wt = w.permute(2, 3, 1, 0).reshape(s * s * w.shape[1], w.shape[0])     # row = (dy*s + dx)*Cout + co
+            return wt * scale.repeat(s * s)[:, None], shift.repeat(s * s), s
+        assert up.kernel_size == (1, 1) and up.stride == (1, 1) and up.bias is None
+        return w[:, :, 0, 0] * scale[:, None], shift, 1
+
+    def forward_tokens(self, x, linear_relu):
+        """the "hip" data path with the GEMM injected: linear_relu(x [B, Cin, H, W], weight, bias) -> relu(tokens W^T +
+        b) as [B*H*W, N] rows ((b, y, x) order).  (tests/test_host.py runs it with a torch GEMM against the modules.)"""
+        ups = []
+        for i in range(len(self.deblocks)):
+            w, b, s = self._folded(i)
+            B, _, H, W = x[i].shape
+            y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout]
+            cout = y.shape[1] // (s * s)
+            y = y.view(B, H, W, s, s, cout).permute(0, 5, 1, 3, 2, 4).reshape(B, cout, H * s, W * s)
+            ups.append(y)
+        out = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        return [out.permute(0, 1, 3, 2).contiguous()]
+
     def forward(self, x, **kwargs):
         assert len(x) == len(self.in_channels)
+        if self.dense_conv == "hip" and not self.training:
+            from . import fusion_ops as ops
+            cache = self.__dict__.setdefault("_isf_packed", {})
+            ops.watch_parameters(self)
+
+            def linear_relu(t, w, b):
+                key = (w.shape[0], w.shape[1], t.device)
+                if key not in cache:
+                    cache[key] = ops.PackedLinear(w.to(t.device), b.to(t.device))
+                return ops.linear(t.float(), cache[key], act=ops.ACT_RELU)
+
+            with torch.no_grad():
+                return self.forward_tokens(x, linear_relu)
         ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
         out = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         return [out.permute(0, 1, 3, 2).contiguous()]

@@ -444,3 +444,20 @@ def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mo
     assert err_half < 3e-2 * scale, (err_half, scale)        # 21 layers of f16 rounding (2^-11 relative per operand)
     assert err_half > 10 * err_full                          # the mode really ran (it is NOT fp32-class)
     assert np.array_equal(half != 0, obev != 0)
+
+
+# ------------------------------------------------------------------------------------------- neck on the linear kernel
+def test_neck_on_linear_kernel_matches_stock_modules(dev):
+    """SECONDFPN(dense_conv="hip") (SURVEY 8f #4): 1x1 conv and 2x2 transposed conv as fused f16x3 GEMMs vs MIOpen"""
+    from isfusion_amd.fusion_modules import SECONDFPN, seeded_state_dict
+    neck = SECONDFPN().eval()
+    neck.load_state_dict(seeded_state_dict(neck, 250))
+    neck = neck.to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = [torch.randn((2, 128, 180, 180), generator=g).to(dev), torch.randn((2, 256, 90, 90), generator=g).to(dev)]
+    with torch.no_grad():
+        want = neck(x)[0]
+        neck.dense_conv = "hip"
+        got = neck(x)[0]
+    assert got.shape == want.shape == (2, 512, 180, 180)
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())

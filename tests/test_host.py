@@ -308,3 +308,24 @@ def test_registry_surface_and_build_from_the_unmodified_reference_config():
     assert a == {k: tuple(v.shape) for k, v in ref.state_dict().items()} and len(a) > 400
     assert net.pts_bbox_head.test_cfg["nms_type"] is None and net.pts_bbox_head.bbox_coder["code_size"] == 10
     assert net.fusion_encoder.num_points_in_pillar == 12 and net.pillar_size == [0.6, 0.6, 8]
+
+
+def test_neck_gemm_formulation_equals_the_conv_modules():
+    """SECONDFPN "hip" path: BN-folded 1x1 conv and 2x2 stride-2 transposed conv as token GEMMs +
+    sub-cell interleave -- with a torch GEMM standing in for the HIP linear kernel, against the stock modules"""
+    import torch
+    from isfusion_amd.fusion_modules import SECONDFPN, seeded_state_dict
+    neck = SECONDFPN().eval()
+    neck.load_state_dict(seeded_state_dict(neck, 250))
+    g = torch.Generator().manual_seed(0)
+    x = [torch.randn((2, 128, 12, 12), generator=g), torch.randn((2, 256, 6, 6), generator=g)]
+
+    def linear_relu(t, w, b):
+        tok = t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+        return torch.relu(tok @ w.t() + b)
+
+    with torch.no_grad():
+        want = neck(x)[0]
+        got = neck.forward_tokens(x, linear_relu)[0]
+    assert got.shape == want.shape == (2, 512, 12, 12)
+    assert (got - want).abs().max().item() < 1e-4
