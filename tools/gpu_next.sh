@@ -1,16 +1,25 @@
 #!/bin/bash
-# First GPU call of the next round: run the tests written after round 1's GPU budget was spent (marker gpu_next),
-# then the validated tier.   gpurun --timeout 900 -- 'bash tools/gpu_next.sh'
+# First GPU call of the next round (about 8 GPU-minutes):   gpurun --timeout 1200 -- 'bash tools/gpu_next.sh'
+#  1. the tests written after round 1's GPU budget was spent (marker gpu_next) -- every failure is listed, no -x
+#  2. two questions that decide the conv restructuring: the vmcnt ordering probe and the
+#     single-pass (one MFMA per product) diagnostic bench next to the default bench
+#  3. the validated tier, to make sure nothing regressed
 set -u
 mkdir -p gpurun_out
-python -m pytest tests -q -m gpu_next 2>&1 | tail -25 | tee gpurun_out/gpu_next_tests.log
-python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/gpu_tests.log
-# hardware question behind the deeper conv prefetch ring: are LDS-DMA and register loads of one
-# wave retired strictly in issue order under counted s_waitcnt?
+timeout 600 python -m pytest tests -q -m gpu_next -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/gpu_next_tests.log
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/vmcnt_probe.hip -o gpurun_out/vmcnt_probe \
   && timeout 120 gpurun_out/vmcnt_probe | tee gpurun_out/vmcnt_probe.json
-# diagnostic: the same conv kernels with one MFMA pass instead of three (reduced precision, NOT the headline) -- shows
-# how much of the conv time is the matrix pipe and how much is everything else
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --f16 > gpurun_out/bench_f16_diag.json 2> gpurun_out/bench_f16_diag.err
-tail -c 600 gpurun_out/bench_default.json; tail -c 600 gpurun_out/bench_f16_diag.json
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --f16 > gpurun_out/bench_f16_diag.json 2> gpurun_out/bench_f16_diag.err
+python - <<'PY'
+import json
+for name in ("bench_default", "bench_f16_diag"):
+    try:
+        d = json.loads(open(f"gpurun_out/{name}.json").read().strip().splitlines()[-1])
+        r = d["roofline"]
+        print(name, d["value"], d["unit"], "ms/step", d["ms_per_step"], "conv ms", r["conv_ms_per_step"],
+              {k: v["ms"] for k, v in r["per_kernel"].items()})
+    except Exception as e:   # noqa: BLE001
+        print(name, "unreadable:", e)
+PY
+timeout 600 python -m pytest tests -x -q -m gpu -p no:cacheprovider 2>&1 | tail -5 | tee gpurun_out/gpu_tests.log
