@@ -443,7 +443,9 @@ def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mo
     assert err_full < 1e-3                                   # default path untouched
     assert err_half < 3e-2 * scale, (err_half, scale)        # 21 layers of f16 rounding (2^-11 relative per operand)
     assert err_half > 10 * err_full                          # the mode really ran (it is NOT fp32-class)
-    assert np.array_equal(half != 0, obev != 0)
+    # (CPU emulation of the mode -- f16-rounded operands through the oracle -- gives 2.7e-3 on this case, 6e-4 of
+    #  the feature scale; ReLU outputs next to zero may flip, so the supports are only almost equal)
+    assert ((half != 0) != (obev != 0)).mean() < 1e-3
 
 
 # ------------------------------------------------------------------------------------------- neck on the linear kernel
