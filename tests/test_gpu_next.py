@@ -88,8 +88,9 @@ def test_input_prepass_matches_reference_pipeline(dev, golden, case):
         assert tuple(pts.shape) == ref.shape, f"{n}: kept {pts.shape[0]} points, reference {ref.shape[0]}"
         got = pts.cpu().numpy()
         if case == "train_aug":
-            # the float32 [P,3]x[3,3] rotation's summation order / FMA use is the BLAS's choice: a few ulp of ~60
-            assert np.abs(got - ref).max() < 2e-5
+            # the float32 [P,3]x[3,3] rotation's summation order / FMA use is the BLAS's choice: a few ulp (7.6e-6 at
+            # |coord| up to 79) carried through translate and scale; no point is closer than 3.7e-4 to a range bound
+            assert np.abs(got - ref).max() < 6e-5
         else:
             # float64 pose arithmetic rounded to float32: bit-exact up to fused-multiply-add double rounding
             assert np.abs(got - ref).max() <= 4e-6
