@@ -109,7 +109,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
-    ap.add_argument("--cpu-points", type=int, default=20000, help="points of the CPU-baseline sample frame")
+    ap.add_argument("--cpu-points", type=int, default=100000,
+                    help="points of the CPU-baseline sample frame (100 k points = about 10 s of scalar CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
     ap.add_argument("--f16", action="store_true",
