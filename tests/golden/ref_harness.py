@@ -298,6 +298,97 @@ def install_voxel_encoders():
     return _voxel_encoders
 
 
+_sparse_encoder = {}
+
+
+def install_sparse_encoder():
+    """Load the reference's OWN Python layers of the LiDAR backbone -- the vendored spconv-1 Python package
+    (ops/bevfusion-ops/spconv: conv.py, modules.py, structure.py, functional.py, ops.py), ops/sparse_block.py and
+    models/middle_encoders/sparse_encoder.py -- on top of a stand-in for exactly ONE thing: the compiled module
+    `sparse_conv_ext` (the native-op boundary this build replaces), whose two entry points the path uses are served
+    by the CPU oracle (oracle.get_indice_pairs / oracle.indice_conv).  What this pins is everything ABOVE that
+    boundary: SparseConvolution.forward (indice_key sharing, output-shape rule, SubM padding), SparseSequential,
+    SparseBasicBlock, make_sparse_convmodule and SparseEncoder's stage wiring, plus the state-dict key names.
+    mmdet's ResNet BasicBlock (absent third-party) is restated from its documented constructor: conv1 / norm1 /
+    conv2 / norm2 / relu built through build_conv_layer / build_norm_layer."""
+    if _sparse_encoder:
+        return _sparse_encoder
+    install()
+    import numpy as np
+    import oracle
+    oracle.build()
+    base = os.path.join(REF, "mmdet3d")
+    conv_layers = _Registry("CONV_LAYERS")
+    sys.modules["mmcv.cnn"].CONV_LAYERS = conv_layers
+
+    def build_conv(cfg, *args, **kwargs):
+        cfg = dict(cfg or dict(type="Conv2d"))
+        t = cfg.pop("type")
+        if t in conv_layers.module_dict:
+            return conv_layers.module_dict[t](*args, **kwargs, **cfg)
+        return build_conv_layer(dict(type=t, **cfg), *args, **kwargs)
+
+    sys.modules["mmcv.cnn"].build_conv_layer = build_conv
+
+    # ---- the compiled module, served by the oracle
+    def get_indice_pairs_3d(indices, batch_size, out_shape, spatial_shape, ksize, stride, padding, dilation,
+                            out_padding, subm, transpose):
+        assert not transpose and list(dilation) == [1, 1, 1] and list(out_padding) == [0, 0, 0]
+        out_idx, pairs, num = oracle.get_indice_pairs(indices.numpy().astype(np.int32), int(batch_size),
+                                                      list(spatial_shape), list(ksize), list(stride), list(padding),
+                                                      subm=bool(subm))
+        return torch.from_numpy(out_idx), torch.from_numpy(pairs), torch.from_numpy(num)
+
+    def indice_conv_fp32(features, filters, indice_pairs, indice_num, num_act_out, inverse, subm):
+        assert not inverse
+        y = oracle.indice_conv(features.detach().numpy(), filters.detach().numpy(), indice_pairs.numpy(),
+                               indice_num.numpy(), int(num_act_out))
+        return torch.from_numpy(y)
+
+    pkg = "isf_ref_spconv"
+    _pkg(pkg, os.path.join(base, "ops", "bevfusion-ops", "spconv"))
+    _mod(pkg + ".sparse_conv_ext", get_indice_pairs_3d=get_indice_pairs_3d, indice_conv_fp32=indice_conv_fp32)
+    sp = {n: _load(f"{pkg}.{n}", f"mmdet3d/ops/bevfusion-ops/spconv/{n}.py")
+          for n in ("structure", "modules", "ops", "functional", "conv")}
+    mops = sys.modules["mmcv.ops"]
+    mops.SparseConvTensor = sp["structure"].SparseConvTensor
+    mops.SparseSequential = sp["modules"].SparseSequential
+    mops.SparseModule = sp["modules"].SparseModule
+
+    class BasicBlock(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch", with_cp=False,
+                     conv_cfg=None, norm_cfg=dict(type="BN"), dcn=None, plugins=None, init_cfg=None):
+            super().__init__()
+            self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+            self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+            self.conv1 = build_conv(conv_cfg, inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation,
+                                    bias=False)
+            self.add_module(self.norm1_name, norm1)
+            self.conv2 = build_conv(conv_cfg, planes, planes, 3, padding=1, bias=False)
+            self.add_module(self.norm2_name, norm2)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample, self.stride, self.dilation, self.with_cp = downsample, stride, dilation, with_cp
+
+        @property
+        def norm1(self):
+            return getattr(self, self.norm1_name)
+
+        @property
+        def norm2(self):
+            return getattr(self, self.norm2_name)
+
+    _pkg("mmdet.models.backbones")
+    _mod("mmdet.models.backbones.resnet", BasicBlock=BasicBlock, Bottleneck=BasicBlock)
+    block = _load("mmdet3d.ops.sparse_block", "mmdet3d/ops/sparse_block.py")
+    ops_pkg = sys.modules["mmdet3d.ops"]
+    ops_pkg.SparseBasicBlock, ops_pkg.make_sparse_convmodule = block.SparseBasicBlock, block.make_sparse_convmodule
+    enc = _load("mmdet3d.models.middle_encoders.sparse_encoder", "mmdet3d/models/middle_encoders/sparse_encoder.py")
+    _sparse_encoder.update(spconv=sp, sparse_block=block, sparse_encoder=enc)
+    return _sparse_encoder
+
+
 if __name__ == "__main__":
     mods = install()
     print({k: v.__name__ for k, v in mods.items()})

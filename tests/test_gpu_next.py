@@ -464,3 +464,24 @@ def test_neck_on_linear_kernel_matches_stock_modules(dev):
         got = neck(x)[0]
     assert got.shape == want.shape == (2, 512, 180, 180)
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------- encoder wiring golden
+@pytest.mark.parametrize("name", ["isfusion", "conv_module"])
+def test_sparse_encoder_matches_reference_module_tree_golden(dev, golden, name):
+    """HIP SparseEncoder (fused engine and module-by-module path) vs the reference's own module tree output"""
+    import isfusion_amd as m
+    from encoder_common import ENCODER_CASES, encoder_input
+    g = golden("encoder_ref.npz")
+    case = ENCODER_CASES[name]
+    lb = m.LidarBranch(pts_middle_encoder=dict(case["cfg"]))
+    lb = lb.randomize_weights_(case["seed"]).randomize_bn_(case["seed"] + 1).eval().to(dev)
+    feats, coors, B = encoder_input(case)
+    enc = lb.pts_middle_encoder
+    out = enc.forward_fused(_T(feats, dev), _T(coors, dev), B)
+    assert list(out.shape) == g[name + ".shape"].tolist()
+    assert np.abs(out.cpu().numpy().reshape(-1)[g[name + ".idx"]] - g[name + ".val"]).max() < 1e-3
+    with torch.no_grad():
+        out2, enc_feats = enc.forward_modules(_T(feats, dev), _T(coors, dev), B)
+    assert np.abs(out2.cpu().numpy().reshape(-1)[g[name + ".idx"]] - g[name + ".val"]).max() < 1e-3
+    assert [int(t.features.shape[0]) for t in enc_feats] == g[name + ".stage_voxels"].tolist()

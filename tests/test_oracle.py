@@ -223,3 +223,22 @@ def test_sparse_conv_backward_matches_dense_conv3d_autograd(oracle_mod, golden, 
     ys.backward(torch.from_numpy(gout).double())
     assert np.abs(dx - x.grad.numpy()).max() < 1e-4
     assert np.abs(dw - wt.grad.numpy()).max() < 2e-4 * max(1.0, np.abs(wt.grad.numpy()).max())
+
+
+# ------------------------------------------------------------------------------------------- encoder wiring (A5-A7)
+@pytest.mark.parametrize("name", ["isfusion", "conv_module"])
+def test_encoder_plan_matches_reference_module_tree(golden, oracle_mod, name):
+    """the exported layer plan (stage wiring, paddings, residuals, BN fold, dense layout) run by the oracle equals the
+    REFERENCE's SparseEncoder / SparseBasicBlock / spconv Python layer running over the same two native ops
+    (tests/golden/make_golden_encoder.py; the state dict was loaded into the reference module with strict=True)"""
+    import isfusion_amd as m
+    from encoder_common import ENCODER_CASES, encoder_input
+    g = golden("encoder_ref.npz")
+    case = ENCODER_CASES[name]
+    cfg = dict(case["cfg"])
+    lb = m.LidarBranch(pts_middle_encoder=cfg).randomize_weights_(case["seed"]).randomize_bn_(case["seed"] + 1).eval()
+    feats, coors, B = encoder_input(case)
+    bev, outs = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), feats, coors, B)
+    assert list(bev.shape) == g[name + ".shape"].tolist()
+    assert np.abs(bev.reshape(-1)[g[name + ".idx"]] - g[name + ".val"]).max() < 1e-4
+    assert int(np.count_nonzero(bev)) == int(g[name + ".nonzero"][0])
