@@ -389,6 +389,49 @@ def install_sparse_encoder():
     return _sparse_encoder
 
 
+_dynamic_vfe = {}
+
+
+def install_dynamic_vfe():
+    """Load the reference's DynamicVFE (models/voxel_encoders/voxel_encoder.py:287-547, utils.py) and its Python
+    DynamicScatter wrapper (ops/voxel/scatter_points.py) on top of a stand-in for ONE compiled entry point:
+    voxel_layer.dynamic_point_to_voxel_forward (GPU-only in the reference, voxelization.h:118), served by the CPU
+    oracle's restatement (itself pinned by the brute-force reference of the reference's own test).  Pins the feature
+    decoration (cluster centre, voxel centre, map_voxel_center_to_point), the layer stack and the key names."""
+    if _dynamic_vfe:
+        return _dynamic_vfe
+    install()
+    import numpy as np
+    import oracle
+    oracle.build()
+    base = os.path.join(REF, "mmdet3d")
+
+    def dynamic_point_to_voxel_forward(feats, coors, reduce_type):
+        f, c, cmap, cnt = oracle.dynamic_scatter(feats.detach().numpy(), coors.numpy().astype(np.int32), reduce_type)
+        return [torch.from_numpy(f), torch.from_numpy(c).to(coors.dtype), torch.from_numpy(cmap), torch.from_numpy(cnt)]
+
+    def dynamic_point_to_voxel_backward(*a, **k):
+        raise NotImplementedError("inference golden")
+
+    pkg = "isf_ref_voxel"
+    _pkg(pkg, os.path.join(base, "ops", "voxel"))
+    _mod(pkg + ".voxel_layer", dynamic_point_to_voxel_forward=dynamic_point_to_voxel_forward,
+         dynamic_point_to_voxel_backward=dynamic_point_to_voxel_backward)
+    scatter = _load(pkg + ".scatter_points", "mmdet3d/ops/voxel/scatter_points.py")
+    sys.modules["mmdet3d.ops"].DynamicScatter = scatter.DynamicScatter
+    builder = sys.modules["mmdet3d.models.builder"]
+    builder.VOXEL_ENCODERS = _Registry("VOXEL_ENCODERS")
+    builder.build_fusion_layer = lambda cfg: None
+    for stale in ("mmdet3d.models.voxel_encoders.utils", "mmdet3d.models.voxel_encoders.voxel_encoder"):
+        sys.modules.pop(stale, None)          # (re)load against the DynamicScatter above
+    _pkg("mmdet3d.models.voxel_encoders", os.path.join(base, "models", "voxel_encoders"))
+    _load("mmdet3d.models.voxel_encoders.utils", "mmdet3d/models/voxel_encoders/utils.py")
+    _dynamic_vfe["voxel_encoder"] = _load("mmdet3d.models.voxel_encoders.voxel_encoder",
+                                          "mmdet3d/models/voxel_encoders/voxel_encoder.py")
+    _dynamic_vfe["scatter_points"] = scatter
+    return _dynamic_vfe
+
+
 if __name__ == "__main__":
     mods = install()
     print({k: v.__name__ for k, v in mods.items()})

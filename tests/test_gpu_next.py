@@ -485,3 +485,21 @@ def test_sparse_encoder_matches_reference_module_tree_golden(dev, golden, name):
         out2, enc_feats = enc.forward_modules(_T(feats, dev), _T(coors, dev), B)
     assert np.abs(out2.cpu().numpy().reshape(-1)[g[name + ".idx"]] - g[name + ".val"]).max() < 1e-3
     assert [int(t.features.shape[0]) for t in enc_feats] == g[name + ".stage_voxels"].tolist()
+
+
+@pytest.mark.parametrize("name,seed,B,P", [("b2", 41, 2, 3000), ("b1", 43, 1, 5000)])
+def test_dynamic_vfe_matches_reference_module_golden(dev, golden, oracle_mod, name, seed, B, P):
+    """HIP DynamicVFE (fused C call) vs the reference's DynamicVFE module output"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    g = golden("dynvfe_ref.npz")
+    pl = []
+    for i in range(B):
+        p = synthetic.lidar_sweeps(seed + i, P)
+        pl.append(p[(oracle_mod.dynamic_voxelize(p, VS, RG) >= 0).all(1)])
+    coors = np.concatenate([np.concatenate([np.full((p.shape[0], 1), b, np.int32),
+                                            oracle_mod.dynamic_voxelize(p, VS, RG)], 1) for b, p in enumerate(pl)])
+    vfe = m.LidarBranch().randomize_weights_(seed).randomize_bn_(seed + 1).eval().pts_voxel_encoder.to(dev)
+    vf, vc = vfe(_T(np.concatenate(pl), dev), _T(coors, dev))
+    assert np.array_equal(vc.cpu().numpy(), g[name + ".voxel_coors"])
+    assert np.abs(vf.cpu().numpy()[::4] - g[name + ".voxel_feats_every4"]).max() < 1e-4

@@ -242,3 +242,29 @@ def test_encoder_plan_matches_reference_module_tree(golden, oracle_mod, name):
     assert list(bev.shape) == g[name + ".shape"].tolist()
     assert np.abs(bev.reshape(-1)[g[name + ".idx"]] - g[name + ".val"]).max() < 1e-4
     assert int(np.count_nonzero(bev)) == int(g[name + ".nonzero"][0])
+
+
+@pytest.mark.parametrize("name,seed,B,P", [("b2", 41, 2, 3000), ("b1", 43, 1, 5000)])
+def test_dynamic_vfe_restatement_matches_reference_module(golden, oracle_mod, name, seed, B, P):
+    """DynamicVFE (A4): the fused restatement vs the REFERENCE's DynamicVFE module + Python DynamicScatter wrapper
+    running over the oracle's scatter op (tests/golden/make_golden_dynvfe.py; strict state-dict load)"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    from isfusion_amd.norm import fold_bn
+    VS, RG = [0.075, 0.075, 0.2], [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+    g = golden("dynvfe_ref.npz")
+    pl = []
+    for i in range(B):
+        p = synthetic.lidar_sweeps(seed + i, P)
+        pl.append(p[(oracle_mod.dynamic_voxelize(p, VS, RG) >= 0).all(1)])
+    coors = np.concatenate([np.concatenate([np.full((p.shape[0], 1), b, np.int32),
+                                            oracle_mod.dynamic_voxelize(p, VS, RG)], 1) for b, p in enumerate(pl)])
+    vfe = m.LidarBranch().randomize_weights_(seed).randomize_bn_(seed + 1).eval().pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    vf, vc, _ = oracle_mod.dynamic_vfe(np.concatenate(pl), coors, VS, RG,
+                                       vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                       vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    assert np.array_equal(vc, g[name + ".voxel_coors"])
+    assert np.abs(vf[::4] - g[name + ".voxel_feats_every4"]).max() < 1e-4
+    assert np.abs(vf.astype(np.float64).sum(0) - g[name + ".feat_sums"]).max() < 1e-2
