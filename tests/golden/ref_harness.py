@@ -432,6 +432,93 @@ def install_dynamic_vfe():
     return _dynamic_vfe
 
 
+_detector = {}
+
+
+class _AttrDict(dict):
+    """mmcv ConfigDict stand-in: cfg.pts style attribute access"""
+    __getattr__ = dict.get
+
+
+def install_detector():
+    """Load the reference's detector code -- models/detectors/isfusion.py (ISFusionDetector) over mvx_two_stage.py and
+    base.py -- with every point-cloud sub-module being the reference's OWN class (DynamicVFE, SparseEncoder,
+    ISFusionEncoder, SECONDV2, SECONDFPN; the Python Voxelization wrapper of ops/voxel/voxelize.py), on top of the
+    stand-ins for the compiled ops only (voxel_layer.{dynamic,hard}_voxelize, dynamic_point_to_voxel_forward,
+    sparse_conv_ext.*: all served by the CPU oracle, which is pinned op by op elsewhere).  mmdet's BaseDetector is an
+    nn.Module with init_cfg.  Pins the GLUE of extract_pts_feat: batching / padding of coordinates, pillar layer
+    parameters, kwargs hand-over, concatenation order, neck."""
+    if _detector:
+        return _detector
+    m = dict(install())
+    m.update(install_sparse_encoder())
+    m.update(install_dynamic_vfe())
+    import numpy as np
+    import oracle
+    base = os.path.join(REF, "mmdet3d")
+    builder = sys.modules["mmdet3d.models.builder"]
+
+    # ---- ops/voxel/voxelize.py over the oracle's voxelization (itself bit-exact against the reference C++)
+    def dynamic_voxelize(points, coors, voxel_size, coors_range, ndim=3):
+        coors.copy_(torch.from_numpy(oracle.dynamic_voxelize(points.numpy(), list(voxel_size), list(coors_range))))
+
+    def hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size, coors_range, max_points, max_voxels,
+                      ndim=3, deterministic=True):
+        v, c, n = oracle.hard_voxelize(points.numpy(), list(voxel_size), list(coors_range), int(max_points),
+                                       int(max_voxels))
+        k = v.shape[0]
+        voxels[:k] = torch.from_numpy(v)
+        coors[:k] = torch.from_numpy(c)
+        num_points_per_voxel[:k] = torch.from_numpy(n)
+        return k
+
+    vl = sys.modules["isf_ref_voxel.voxel_layer"]
+    vl.dynamic_voxelize, vl.hard_voxelize = dynamic_voxelize, hard_voxelize
+    voxelize = _load("isf_ref_voxel.voxelize", "mmdet3d/ops/voxel/voxelize.py")
+    sys.modules["mmdet3d.ops"].Voxelization = voxelize.Voxelization
+
+    # ---- registries / builders the detector constructor calls
+    necks, dets = _Registry("NECKS"), _Registry("DETECTORS")
+    mm = sys.modules["mmdet.models"]
+    mm.NECKS, mm.DETECTORS = necks, dets
+    sys.modules["mmcv.cnn"].build_upsample_layer = lambda cfg, *a, **k: (
+        nn.ConvTranspose2d(*a, **{kk: vv for kk, vv in k.items()}, bias=cfg.get("bias", False)))
+    sys.modules["mmcv.runner"].auto_fp16 = _identity_decorator
+    _pkg("mmdet3d.models.necks", os.path.join(base, "models", "necks"))
+    m["second_fpn"] = _load("mmdet3d.models.necks.second_fpn", "mmdet3d/models/necks/second_fpn.py")
+    venc = builder.VOXEL_ENCODERS
+
+    def build_any(cfg):      # mmdet3d's MIDDLE_ENCODERS / FUSION_LAYERS / ... are one MODELS registry
+        for reg in (builder.MIDDLE_ENCODERS, builder.FUSION_LAYERS):
+            if cfg["type"] in reg.module_dict:
+                return reg.build(cfg)
+        raise KeyError(cfg["type"])
+
+    builder.build_middle_encoder = build_any
+    builder.build_voxel_encoder = lambda cfg: venc.build(cfg)
+    builder.build_neck = lambda cfg: necks.build(cfg)
+    builder.build_head = lambda cfg: None
+    builder.build_fusion_layer = lambda cfg: None
+
+    class BaseDetector(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    _pkg("mmcv.parallel", DataContainer=object)
+    _pkg("mmdet.models.detectors", BaseDetector=BaseDetector)
+    core = sys.modules["mmdet3d.core"]
+    for n in ("Box3DMode", "Coord3DMode", "bbox3d2result", "merge_aug_bboxes_3d", "show_result"):
+        setattr(core, n, None)
+    sys.modules["mmdet.core"].multi_apply = None
+    _pkg("mmdet3d.models.detectors", os.path.join(base, "models", "detectors"))
+    _load("mmdet3d.models.detectors.base", "mmdet3d/models/detectors/base.py")
+    _load("mmdet3d.models.detectors.mvx_two_stage", "mmdet3d/models/detectors/mvx_two_stage.py")
+    m["isfusion"] = _load("mmdet3d.models.detectors.isfusion", "mmdet3d/models/detectors/isfusion.py")
+    m["AttrDict"] = _AttrDict
+    _detector.update(m)
+    return m
+
+
 if __name__ == "__main__":
     mods = install()
     print({k: v.__name__ for k, v in mods.items()})

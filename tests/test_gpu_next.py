@@ -503,3 +503,20 @@ def test_dynamic_vfe_matches_reference_module_golden(dev, golden, oracle_mod, na
     vf, vc = vfe(_T(np.concatenate(pl), dev), _T(coors, dev))
     assert np.array_equal(vc.cpu().numpy(), g[name + ".voxel_coors"])
     assert np.abs(vf.cpu().numpy()[::4] - g[name + ".voxel_feats_every4"]).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- detector-level golden
+def test_extract_pts_feat_and_neck_match_reference_detector_golden(dev, golden, oracle_mod):
+    """ISFusionPtsPath.extract_pts_feat + pts_neck (raw sweeps + camera features -> [B,512,180,180]) vs the
+    REFERENCE's ISFusionDetector.extract_pts_feat executed on the CPU (detector_ref.npz); 1e-3 (north_star)"""
+    from detector_common import build_path, detector_inputs
+    g = golden("detector_ref.npz")
+    net = build_path().to(dev)
+    pts, inp, kw, metas = detector_inputs()
+    img_feats = tuple(torch.from_numpy(a).to(dev) for a in inp["img_feats"])
+    feats = net.extract_pts_feat([_T(p, dev) for p in pts], img_feats, metas, **kw)
+    with torch.no_grad():
+        out = net.pts_neck(feats)[0]
+    assert list(out.shape) == g["shape"].tolist()
+    flat = out.cpu().numpy().reshape(-1)
+    assert np.abs(flat[g["idx"]] - g["val"]).max() < 1e-3

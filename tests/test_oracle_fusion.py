@@ -128,3 +128,20 @@ def test_msda_backward_restatement_matches_reference_autograd(golden, name, B, Q
     for got, key in ((v.grad, "grad_value"), (l.grad, "grad_loc"), (a.grad, "grad_weight")):
         ref = g[f"{name}.{key}"]
         assert np.abs(got.numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), key
+
+
+def test_extract_pts_feat_oracle_composition_matches_reference_detector(golden, oracle_mod):
+    """the composition of the CPU oracles (what the GPU end-to-end test compares against) vs the REFERENCE's own
+    ISFusionDetector.extract_pts_feat run on the CPU: reference detector code + reference sub-modules over the oracle's
+    compiled-op restatements (tests/golden/make_golden_detector.py) -- pins the glue between the pinned pieces"""
+    from detector_common import build_path, detector_inputs, oracle_extract_pts_feat
+    g = golden("detector_ref.npz")
+    net = build_path()
+    pts, inp, kw, _ = detector_inputs()
+    f0, f1, _, _ = oracle_extract_pts_feat(net, pts, inp, kw)
+    with torch.no_grad():
+        out = net.pts_neck([f0, f1])[0]
+    assert list(out.shape) == g["shape"].tolist()
+    flat = out.numpy().reshape(-1)
+    assert np.abs(flat[g["idx"]] - g["val"]).max() < 1e-4
+    assert abs(np.abs(flat).mean() - g["mean_abs"][0]) < 1e-5
