@@ -409,6 +409,10 @@ void orc_indice_conv(const float* feats, int N_in, int Cin, const float* filt, i
   memset(out, 0, (size_t)N_out * Cout * sizeof(float));
   for (int k = 0; k < K; ++k) {
     const float* W = filt + (size_t)k * Cin * Cout;
+    /* within one tap every output row occurs at most once (out = (in + pad - k) / stride), so the pairs of a tap
+     * can be processed by different threads; taps stay sequential => the per-row summation order, and therefore
+     * every bit of the result, is the same with 1 or N threads */
+#pragma omp parallel for schedule(static)
     for (int s = 0; s < indice_num[k]; ++s) {
       int i = pairs[((size_t)k * 2 + 0) * N_in + s];
       int o = pairs[((size_t)k * 2 + 1) * N_in + s];
@@ -474,3 +478,11 @@ void orc_dense_bev(const float* feats, const int32_t* indices, int N, int C, int
       out[((((size_t)c[0] * C + ch) * D + c[1]) * H + c[2]) * W + c[3]] = feats[(size_t)i * C + ch];
   }
 }
+
+/* threads the OpenMP loops above use (1 when built without -fopenmp) */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_num_threads(void) { return 1; }
+#endif

@@ -35,7 +35,13 @@ def lib():
         _lib.orc_dynamic_scatter.restype = ctypes.c_int
         _lib.orc_dynamic_vfe.restype = ctypes.c_int
         _lib.orc_get_indice_pairs.restype = ctypes.c_int
+        _lib.orc_num_threads.restype = ctypes.c_int
     return _lib
+
+
+def num_threads():
+    """threads the conv loop of the oracle uses (OpenMP over the pairs of one tap; every other stage is scalar)"""
+    return int(lib().orc_num_threads())
 
 
 def _f(a):

@@ -268,3 +268,31 @@ def test_dynamic_vfe_restatement_matches_reference_module(golden, oracle_mod, na
     assert np.array_equal(vc, g[name + ".voxel_coors"])
     assert np.abs(vf[::4] - g[name + ".voxel_feats_every4"]).max() < 1e-4
     assert np.abs(vf.astype(np.float64).sum(0) - g[name + ".feat_sums"]).max() < 1e-2
+
+
+def test_oracle_conv_is_bit_identical_across_thread_counts(oracle_mod):
+    """the OpenMP loop of the oracle's conv (pairs of one tap in parallel, taps sequential) must not change a bit"""
+    import os
+    import subprocess
+    import sys
+    code = """
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np, oracle
+rng = np.random.default_rng(0)
+cells = np.sort(rng.choice(2 * 9 * 40 * 40, 4000, replace=False))
+idx = np.stack(np.unravel_index(cells, (2, 9, 40, 40)), 1).astype(np.int32)
+x = rng.normal(size=(4000, 32)).astype(np.float32)
+w = rng.normal(size=(3, 3, 3, 32, 64)).astype(np.float32)
+o, p, n = oracle.get_indice_pairs(idx, 2, [9, 40, 40], [3, 3, 3], [2, 2, 2], [1, 1, 1])
+y = oracle.indice_conv(x, w, p, n, o.shape[0])
+print(oracle.num_threads(), hashlib.sha256(y.tobytes()).hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for t in ("1", "4"):
+        env = dict(os.environ, OMP_NUM_THREADS=t)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+        n, h = r.stdout.split()
+        out[t] = h
+        assert int(n) in (1, int(t))          # 1 when the oracle was built without OpenMP
+    assert out["1"] == out["4"]
