@@ -103,12 +103,16 @@ struct Conv16Smem {
 // multiplied -- plain f16 operands with fp32 accumulation, the accuracy of the reference under fp16 autocast
 // (indice_conv_half), one MFMA per product instead of three.  Same buffers, same layouts; outputs are still written
 // split.  Never the default: the headline configuration is fp32-class.
-template <int CIN, int NT, int RG, int NW, bool HALF = false>
+// MODE bits 2 / 4 / 8 are TIMING DIAGNOSTICS (ISF_CONV16_DIAG, results are garbage): 2 = no activation gathers
+// (A = 0), 4 = no weight DMA, 8 = no main loop (prologue + epilogue only) -- the knock-out decomposition of DESIGN.md
+// section 5 as a permanent tool (tools/conv_knockout.sh).  MODE 0 and 1 compile to exactly what they did without them.
+template <int CIN, int NT, int RG, int NW, int MODE = 0>
 __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, int row_tiles) {
+  constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
   using S = Conv16Smem<NT, RG, KCH, NW>;
   constexpr int NTHR = 64 * NW;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   for (int w = 0; w < NW; ++w) wg_mask |= (unsigned)misc[w];
   wg_mask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int ntaps = __popc(wg_mask);
-  const int nsteps = ntaps * NCG;
+  const int nsteps = NOLOOP ? 0 : ntaps * NCG;
 
   f32x4 acc[RG][NT];
 #pragma unroll
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
           a_nxt[rg][kc][0] = make_uint4(0, 0, 0, 0);
           a_nxt[rg][kc][1] = make_uint4(0, 0, 0, 0);
         }
-        if (idx >= 0) {
+        if (idx >= 0 && !NOGATHER) {
 #pragma unroll
           for (int kc = 0; kc < KCH; ++kc) {
             const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4) * 2 + kg;   // chunk base + k-group
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
       for (int i = 0; i < (NT * 128 + NTHR - 1) / NTHR; ++i) {
         const int base = i * NTHR + wave * 64;   // wave-uniform: this wave's 64 consecutive 16-byte pieces
         // pieces come in 64-lane groups, hi (even group) then lo (odd group) per column tile
-        if (base < NT * 128 && !(HALF && ((base >> 6) & 1))) glds16(src + base + lane, dst + (unsigned)base * 16u);
+        if (base < NT * 128 && !(HALF && ((base >> 6) & 1)) && !NODMA) glds16(src + base + lane, dst + (unsigned)base * 16u);
       }
     }
   };
@@ -456,6 +460,10 @@ static const int g_conv16_nw = [] {
   const char* e = getenv("ISF_CONV16_NW");
   return e ? atoi(e) : 0;
 }();
+static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_kernel
+  const char* e = getenv("ISF_CONV16_DIAG");
+  return e ? atoi(e) : 0;
+}();
 static const int g_conv16_rg = [] {
   const char* e = getenv("ISF_CONV16_RG");
   return e ? atoi(e) : 0;
@@ -466,12 +474,12 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
          (c_out == 32 || c_out == 64 || c_out == 128 || c_out == 256);
 }
 
-template <int CIN, int NT, int RG, int NW, bool HALF = false>
+template <int CIN, int NT, int RG, int NW, int MODE = 0>
 static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                     int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                     int relu, uint4* ys, hipStream_t st) {
   using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
-  auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, HALF>;
+  auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, MODE>;
   static bool attr_set = false;
   if (!attr_set && S::bytes > 48 * 1024) {
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -498,9 +506,23 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
-  if (g_conv_precision == 2)   // single-pass f16 (opt-in): the default workgroup shape only
-    return launch16<CIN, NT, 2, 4, true>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu,
-                                         ys, st);
+  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag;
+  if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
+#define ISF_MODE16(M)                                                                                                 \
+  case M:                                                                                                             \
+    return launch16<CIN, NT, 2, 4, M>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, \
+                                      st)
+    switch (mode) {
+      ISF_MODE16(1);
+      ISF_MODE16(2);
+      ISF_MODE16(4);
+      ISF_MODE16(6);
+      ISF_MODE16(8);
+      default:
+        ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2 / ISF_CONV16_DIAG in {2,4,6,8})", mode);
+    }
+#undef ISF_MODE16
+  }
   bool wide_wg = NT == 8 && CIN >= 64 && (long long)ceil_div(n_out, 512) * ncb >= 200;
   if (g_conv16_nw == 4) wide_wg = false;
   if (g_conv16_nw == 16) wide_wg = NT <= 8;
@@ -522,7 +544,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 64:  return launch16_rows<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
-      if (g_conv16_wide && g_conv_precision != 2)
+      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Knock-out decomposition of the sparse-conv time as a repeatable measurement:
+#   gpurun --timeout 900 -- 'bash tools/conv_knockout.sh'
+# ISF_CONV16_DIAG: 2 = no activation gathers, 4 = no weight DMA, 6 = neither, 8 = no main loop.  The outputs of the
+# diagnostic kernels are garbage; only `conv_ms_per_step` is read.  All variants use the default workgroup shape
+# (ISF_CONV16_NW=4), so the reference line is measured with that shape too.
+set -u
+mkdir -p gpurun_out
+run() {  # name, env...
+  local name=$1; shift
+  env ISF_CONV16_NW=4 "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline \
+      > gpurun_out/knock_$name.json 2> gpurun_out/knock_$name.err
+}
+run full
+run nogather ISF_CONV16_DIAG=2
+run nodma ISF_CONV16_DIAG=4
+run neither ISF_CONV16_DIAG=6
+run noloop ISF_CONV16_DIAG=8
+python - <<'PY'
+import json
+rows = []
+for name in ("full", "nogather", "nodma", "neither", "noloop"):
+    try:
+        d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
+        rows.append((name, d["roofline"]["conv_ms_per_step"], d["ms_per_step"]))
+    except Exception as e:   # noqa: BLE001
+        rows.append((name, None, str(e)))
+for r in rows:
+    print("%-10s conv ms/step %-8s step ms %s" % r)
+open("gpurun_out/conv_knockout.json", "w").write(json.dumps(rows))
+PY
