@@ -167,7 +167,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(out).all()
+    diag = os.environ.get("ISF_CONV16_DIAG", "0") not in ("", "0")   # timing diagnostics: results are garbage
+    assert diag or torch.isfinite(out).all()
 
     if rank == 0:
         st = lb.last_stats
@@ -222,7 +223,8 @@ def main():
             "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 operands, fp32 accumulate (DIAGNOSTIC: reduced precision, not the headline)" if args.f16
+            "dtype": "DIAGNOSTIC (ISF_CONV16_DIAG knock-out kernels: results are garbage, timing only)" if diag
+            else "f16 operands, fp32 accumulate (DIAGNOSTIC: reduced precision, not the headline)" if args.f16
             else "f32 (f16x3 split-precision MFMA, fp32 accumulate)" if st.precision == 1 else "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: isfusion_0075voxel LiDAR-only branch (dynamic voxelize + "
