@@ -113,6 +113,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, int row_tiles) {
   constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
+  // MODE bit 16 (ISF_CONV16_PRIO=1, experiment): raise the wave's issue priority while it is in its MFMA block, so that
+  // a wave that has its operands is not starved by waves still issuing loads / address arithmetic on the same SIMD
+  constexpr bool PRIO = (MODE & 16) != 0;
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
   using S = Conv16Smem<NT, RG, KCH, NW>;
   constexpr int NTHR = 64 * NW;
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         stage_B(cur.tap, cur.ch, (s + 1) & 1);
       }
       if ((wmask >> tap) & 1u) {
+        if (PRIO) __builtin_amdgcn_s_setprio(2);
         const uint4* b = bbuf + (s & 1) * (KCH * NT * 128) + lane;
         bool need[RG];
   #pragma unroll
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
             }
           }
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
       }
     }
   }
@@ -464,6 +469,10 @@ static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_
   const char* e = getenv("ISF_CONV16_DIAG");
   return e ? atoi(e) : 0;
 }();
+static const bool g_conv16_prio = [] {   // experiment: s_setprio around the MFMA block (default shape only)
+  const char* e = getenv("ISF_CONV16_PRIO");
+  return e ? (e[0] != '0') : false;
+}();
 static const int g_conv16_rg = [] {
   const char* e = getenv("ISF_CONV16_RG");
   return e ? atoi(e) : 0;
@@ -506,7 +515,7 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
-  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag;
+  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0);
   if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
 #define ISF_MODE16(M)                                                                                                 \
   case M:                                                                                                             \
@@ -518,8 +527,9 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
       ISF_MODE16(4);
       ISF_MODE16(6);
       ISF_MODE16(8);
+      ISF_MODE16(16);
       default:
-        ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2 / ISF_CONV16_DIAG in {2,4,6,8})", mode);
+        ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2, ISF_CONV16_DIAG in {2,4,6,8} and ISF_CONV16_PRIO are not combinable)", mode);
     }
 #undef ISF_MODE16
   }
@@ -544,7 +554,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 64:  return launch16_rows<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
-      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0)
+      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }
