@@ -116,6 +116,12 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // MODE bit 16 (ISF_CONV16_PRIO=1, experiment): raise the wave's issue priority while it is in its MFMA block, so that
   // a wave that has its operands is not starved by waves still issuing loads / address arithmetic on the same SIMD
   constexpr bool PRIO = (MODE & 16) != 0;
+  // MODE bit 32 (ISF_CONV16_TEPI=1, experiment): operands swapped in the MFMAs (weights as A, activations as B), so
+  // the accumulators hold Y^T: lane (r = lane&15, g = lane>>4) owns FOUR CONSECUTIVE CHANNELS 16nt + 4g .. +3 of output
+  // row r.  The epilogue then needs no LDS transpose, no fences and no cross-lane traffic: every lane folds BN, adds
+  // its 8-byte halves of the residual, and stores its 4 hi and 4 lo halves (8 B each; the four lanes of a row cover
+  // one 32-byte run).  Same products, same summation order as the default.
+  constexpr bool TEPI = (MODE & 32) != 0;
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
   using S = Conv16Smem<NT, RG, KCH, NW>;
   constexpr int NTHR = 64 * NW;
@@ -313,11 +319,19 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
             if (need[rg]) {
               const h8 ah = *reinterpret_cast<const h8*>(&a_cur[rg][kc][0]);
               const h8 al = *reinterpret_cast<const h8*>(&a_cur[rg][kc][1]);
-              if (!HALF) {
-                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
-                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+              if (TEPI) {
+                if (!HALF) {
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc[rg][nt], 0, 0, 0);
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc[rg][nt], 0, 0, 0);
+                }
+                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[rg][nt], 0, 0, 0);
+              } else {
+                if (!HALF) {
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+                }
+                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
               }
-              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
             }
           }
         }
@@ -334,6 +348,50 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   constexpr int RS = 16 * EPN + 4;
   float* tile_l = reinterpret_cast<float*>(smem) + wave * 16 * RS;
   const float winv = *w_inv_scale;
+  if (TEPI) {
+    // split format addressed in 8-byte halves of the 16-byte pieces: piece index p -> uint2 index 2p (+1 for the
+    // upper 4 channels of the unit)
+    const uint2* res2 = reinterpret_cast<const uint2*>(residual);
+    uint2* ys2 = reinterpret_cast<uint2*>(ys);
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+      const int grow = row0 + wave * WR + rg * 16 + col;
+      if (grow >= n_out) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int gc = cb * BN + nt * 16 + 4 * kg;                       // this lane's 4 channels
+        const size_t piece = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
+        const size_t h2 = piece * 2 + ((gc >> 2) & 1), l2 = (piece + 4) * 2 + ((gc >> 2) & 1);
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float sc = scale ? scale[gc + t] * winv : winv;
+          const float sh = shift ? shift[gc + t] : 0.f;
+          v[t] = fmaf(acc[rg][nt][t], sc, sh);
+        }
+        if (residual) {
+          const uint2 rh = res2[h2], rl = res2[l2];
+          const _Float16* ph = reinterpret_cast<const _Float16*>(&rh);
+          const _Float16* pl = reinterpret_cast<const _Float16*>(&rl);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] += (float)ph[t] + (float)pl[t];
+        }
+        uint2 oh, ol;
+        _Float16* qh = reinterpret_cast<_Float16*>(&oh);
+        _Float16* ql = reinterpret_cast<_Float16*>(&ol);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float x = relu ? fmaxf(v[t], 0.f) : v[t];
+          const _Float16 hi = (_Float16)x;
+          qh[t] = hi;
+          ql[t] = (_Float16)(x - (float)hi);
+        }
+        ys2[h2] = oh;
+        ys2[l2] = ol;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
 #pragma unroll
@@ -469,6 +527,10 @@ static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_
   const char* e = getenv("ISF_CONV16_DIAG");
   return e ? atoi(e) : 0;
 }();
+static const bool g_conv16_tepi = [] {   // experiment: transposed accumulators, LDS-free epilogue (default shape only)
+  const char* e = getenv("ISF_CONV16_TEPI");
+  return e ? (e[0] != '0') : false;
+}();
 static const bool g_conv16_prio = [] {   // experiment: s_setprio around the MFMA block (default shape only)
   const char* e = getenv("ISF_CONV16_PRIO");
   return e ? (e[0] != '0') : false;
@@ -515,7 +577,7 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
-  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0);
+  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0) | (g_conv16_tepi ? 32 : 0);
   if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
 #define ISF_MODE16(M)                                                                                                 \
   case M:                                                                                                             \
@@ -528,6 +590,8 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
       ISF_MODE16(6);
       ISF_MODE16(8);
       ISF_MODE16(16);
+      ISF_MODE16(32);
+      ISF_MODE16(48);
       default:
         ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2, ISF_CONV16_DIAG in {2,4,6,8} and ISF_CONV16_PRIO are not combinable)", mode);
     }
@@ -554,7 +618,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 64:  return launch16_rows<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
-      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio)
+      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio && !g_conv16_tepi)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }

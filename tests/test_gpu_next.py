@@ -520,3 +520,26 @@ def test_extract_pts_feat_and_neck_match_reference_detector_golden(dev, golden, 
     assert list(out.shape) == g["shape"].tolist()
     flat = out.cpu().numpy().reshape(-1)
     assert np.abs(flat[g["idx"]] - g["val"]).max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------- conv kernel variants
+@pytest.mark.parametrize("variant", ["ISF_CONV16_TEPI", "ISF_CONV16_PRIO"])
+def test_conv_kernel_variant_reproduces_default_bits(dev, variant, tmp_path):
+    """opt-in variants of the sparse-conv kernel (same products, same summation order) must give the default kernels'
+    BEV features bit for bit; the switches are read at library load, hence one subprocess per variant.  Both sides use
+    the 4-wave workgroup shape (the variants exist for that shape only)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for name, extra in (("default", {}), (variant, {variant: "1"})):
+        env = dict(os.environ, ISF_CONV16_NW="4", **extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_variant_check.py"), "20000",
+                            str(tmp_path / (name + ".npy"))], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[name] = r.stdout.split()
+    assert digests["default"][2] == "True" and float(digests["default"][1]) > 0.5
+    if digests["default"][0] != digests[variant][0]:
+        a, b = np.load(tmp_path / "default.npy"), np.load(tmp_path / (variant + ".npy"))
+        raise AssertionError(f"{variant}: max |diff| {np.abs(a - b).max():.3e} (expected bit-identical)")

@@ -351,3 +351,51 @@ def test_assemble_points_block_partition_and_compaction(golden):
         ref = g[f"{n}.test.points"]
         got = out[sample_offsets[b]:sample_offsets[b + 1]]
         assert got.shape == ref.shape and np.array_equal(got, ref), n
+
+
+def test_conv_transposed_epilogue_lane_mapping():
+    """spconv_f16x3_kernel MODE 32 (ISF_CONV16_TEPI): with the MFMA operands swapped (weights as A, activations as B)
+    lane (r = lane & 15, g = lane >> 4) holds 4 consecutive channels 16nt + 4g.. of output row r, and its two 8-byte
+    stores land on the right halves of the split-format pieces (isf_common.h: split_hi_index, lo = hi + 4)"""
+    rng = np.random.default_rng(4)
+    cout, NT = 64, 4
+    X = rng.normal(size=(16, 32))                      # 16 output rows x one 32-channel chunk (already gathered)
+    W = rng.normal(size=(32, cout))
+    Y = X @ W
+
+    def mfma_16x16x32(a_frag, b_frag):
+        """a_frag[l][j] = A[m = l & 15][k = 8 (l >> 4) + j], b_frag[l][j] = B[k = 8 (l >> 4) + j][n = l & 15];
+        returns acc[l][t] = D[m = 4 (l >> 4) + t][n = l & 15]"""
+        A = np.zeros((16, 32))
+        Bm = np.zeros((32, 16))
+        for l in range(64):
+            for j in range(8):
+                A[l & 15, 8 * (l >> 4) + j] = a_frag[l][j]
+                Bm[8 * (l >> 4) + j, l & 15] = b_frag[l][j]
+        D = A @ Bm
+        return np.array([[D[4 * (l >> 4) + t, l & 15] for t in range(4)] for l in range(64)])
+
+    x_frag = np.array([[X[l & 15, 8 * (l >> 4) + j] for j in range(8)] for l in range(64)])   # the A fragment loads
+    c_units = cout // 8
+    n_rows = 16
+    buf = np.full((n_rows * c_units * 2, 8), np.nan)   # 16-byte pieces as 8 f16 slots; chunk = 4 hi + 4 lo pieces
+
+    def split_hi_index(row, c_units, u):
+        return (row * c_units + (u & ~3)) * 2 + (u & 3)
+
+    for nt in range(NT):
+        w_frag = np.array([[W[8 * (l >> 4) + j, 16 * nt + (l & 15)] for j in range(8)] for l in range(64)])
+        acc = mfma_16x16x32(w_frag, x_frag)             # operands swapped
+        for l in range(64):
+            r, g = l & 15, l >> 4
+            gc = 16 * nt + 4 * g
+            piece = split_hi_index(r, c_units, gc >> 3)
+            half = (gc >> 2) & 1
+            for t in range(4):
+                buf[piece, 4 * half + t] = acc[l][t]            # "hi" piece (values stand for their hi halves)
+                buf[piece + 4, 4 * half + t] = -acc[l][t]       # "lo" piece, marked by the sign
+    assert not np.isnan(buf).any(), "some half of the split buffer is never written"
+    for r in range(16):
+        for u in range(c_units):
+            p = split_hi_index(r, c_units, u)
+            assert np.allclose(buf[p], Y[r, 8 * u: 8 * u + 8]) and np.allclose(buf[p + 4], -Y[r, 8 * u: 8 * u + 8])

@@ -17,11 +17,13 @@ run nodma ISF_CONV16_DIAG=4
 run neither ISF_CONV16_DIAG=6
 run noloop ISF_CONV16_DIAG=8
 run prio ISF_CONV16_PRIO=1          # experiment (valid results): s_setprio around the MFMA block
+run tepi ISF_CONV16_TEPI=1          # experiment (valid results): transposed accumulators, LDS-free epilogue
+run tepi_prio ISF_CONV16_TEPI=1 ISF_CONV16_PRIO=1
 run rg4 ISF_CONV16_RG=4             # existing variant: 64-row waves
 python - <<'PY'
 import json
 rows = []
-for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "rg4"):
+for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "rg4"):
     try:
         d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
         rows.append((name, d["roofline"]["conv_ms_per_step"], d["ms_per_step"]))
