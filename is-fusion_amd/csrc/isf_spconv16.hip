@@ -83,6 +83,18 @@ struct Conv16Step {
   static constexpr int KCH = (CIN <= 64 && NT <= 4) ? CIN / 32 : 1;      // 32-channel chunks per step
 };
 
+// MODE bit 64 (ISF_CONV16_TPS=1, experiment): several TAPS per step for the narrow layers whose step already holds all
+// chunks of a tap (CIN <= 64, <= 64 output columns).  Measured (profiles/r01_v8_bench.json): conv<32,32> takes 85 us
+// per launch for 2800 workgroups on 768 slots, i.e. ~23 us per 128-row tile whose MFMA work is < 2 us -- every step
+// (12-24 MFMAs, ~300 cycles) waits a full memory round trip for gathers issued one step earlier.  Four or two taps
+// per step issue that many gathers / weight DMAs back to back and expose the latency once.
+template <int CIN, int NT, int MODE>
+constexpr int conv16_tps() {
+  // register budget (two A sets of TPS * RG * KCH * 2 uint4 next to the accumulators, 168 VGPRs for 3 waves / SIMD):
+  // 4 taps only for 32 -> 32; 2 taps for 32 -> 64 and 64 -> 32; 64 -> 64 would spill and stays at one tap
+  return ((MODE & 64) != 0 && Conv16Step<CIN, NT>::KCH == CIN / 32 && CIN * NT <= 128) ? (CIN * NT <= 64 ? 4 : 2) : 1;
+}
+
 template <int NT, int RG, int KCH, int NW>
 struct Conv16Smem {
   static constexpr int TM = 16 * RG * NW;                                // rows per workgroup
@@ -123,7 +135,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // one 32-byte run).  Same products, same summation order as the default.
   constexpr bool TEPI = (MODE & 32) != 0;
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
-  using S = Conv16Smem<NT, RG, KCH, NW>;
+  constexpr int TPS = conv16_tps<CIN, NT, MODE>();   // taps per step (1 unless MODE bit 64)
+  using S = Conv16Smem<NT, RG, KCH * TPS, NW>;       // the weight ring holds TPS taps per stage
   constexpr int NTHR = 64 * NW;
   constexpr int TM = S::TM;
   constexpr int WR = 16 * RG;         // rows per wave
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     }
   };
 
-  {
+  if constexpr (TPS == 1) {
     Cursor cur{0u, -1, -1};
     if (nsteps > 0) {
       advance(cur);
@@ -337,6 +350,122 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
       }
+    }
+  } else {
+    // ---- multi-tap steps: a step covers the next TPS taps of wg_mask (increasing tap order, so every accumulator
+    // sees its products in the same order as with one tap per step)
+    unsigned rem = wg_mask;
+    int nxt_t[TPS];
+    uint4 a_n[TPS][RG][KCH][2];
+    auto next_group = [&]() {
+#pragma unroll
+      for (int tp = 0; tp < TPS; ++tp) {
+        nxt_t[tp] = -1;
+        if (rem) {
+          nxt_t[tp] = __ffs(rem) - 1;
+          rem &= rem - 1;
+        }
+      }
+    };
+    auto load_group = [&](int buf) {
+#pragma unroll
+      for (int tp = 0; tp < TPS; ++tp) {
+        const int tap = nxt_t[tp];
+        if (tap < 0) continue;   // wave-uniform (wg_mask is)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          if ((rgm[rg] >> tap) & 1u) {
+            const int idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+              a_n[tp][rg][kc][0] = make_uint4(0, 0, 0, 0);
+              a_n[tp][rg][kc][1] = make_uint4(0, 0, 0, 0);
+            }
+            if (idx >= 0 && !NOGATHER) {
+#pragma unroll
+              for (int kc = 0; kc < KCH; ++kc) {
+                const uint4* p = xs + ((size_t)idx * CH8 + kc * 4) * 2 + kg;
+                a_n[tp][rg][kc][0] = p[0];
+                if (!HALF) a_n[tp][rg][kc][1] = p[4];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+          const uint4* src = wpk + (((size_t)tap * NCH + kc) * ntiles_total + cb * NT) * 128;
+          const unsigned dst = bbuf_addr + (unsigned)(((buf * TPS + tp) * KCH + kc) * (NT * 128)) * 16u;
+#pragma unroll
+          for (int i = 0; i < (NT * 128 + NTHR - 1) / NTHR; ++i) {
+            const int base = i * NTHR + wave * 64;
+            if (base < NT * 128 && !(HALF && ((base >> 6) & 1)) && !NODMA)
+              glds16(src + base + lane, dst + (unsigned)base * 16u);
+          }
+        }
+      }
+    };
+    const int ngroups = NOLOOP ? 0 : (ntaps + TPS - 1) / TPS;
+    if (ngroups > 0) {
+      next_group();
+      load_group(0);
+    }
+    for (int g = 0; g < ngroups; ++g) {
+      int cur_t[TPS];
+      uint4 a_c[TPS][RG][KCH][2];
+#pragma unroll
+      for (int tp = 0; tp < TPS; ++tp) {
+        cur_t[tp] = nxt_t[tp];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+          for (int kc = 0; kc < KCH; ++kc) {
+            a_c[tp][rg][kc][0] = a_n[tp][rg][kc][0];
+            a_c[tp][rg][kc][1] = a_n[tp][rg][kc][1];
+          }
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();   // stage g complete for every wave; everyone is done reading stage (g+1)&1
+      if (g + 1 < ngroups) {
+        next_group();
+        load_group((g + 1) & 1);
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int tp = 0; tp < TPS; ++tp) {
+        const int tap = cur_t[tp];
+        if (tap < 0 || !((wmask >> tap) & 1u)) continue;   // wave-uniform
+        const uint4* b = bbuf + ((g & 1) * TPS + tp) * (KCH * NT * 128) + lane;
+#pragma unroll
+        for (int i = 0; i < KCH * NT; ++i) {   // i = kc * NT + nt
+          const int kc = i / NT, nt = i % NT;
+          const uint4 bhu = b[(i * 2 + 0) * 64];
+          uint4 blu = make_uint4(0, 0, 0, 0);
+          if (!HALF) blu = b[(i * 2 + 1) * 64];
+          const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+          const h8 bl = *reinterpret_cast<const h8*>(&blu);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg) {
+            if ((rgm[rg] >> tap) & 1u) {
+              const h8 ah = *reinterpret_cast<const h8*>(&a_c[tp][rg][kc][0]);
+              const h8 al = *reinterpret_cast<const h8*>(&a_c[tp][rg][kc][1]);
+              if (TEPI) {
+                if (!HALF) {
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc[rg][nt], 0, 0, 0);
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc[rg][nt], 0, 0, 0);
+                }
+                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[rg][nt], 0, 0, 0);
+              } else {
+                if (!HALF) {
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
+                  acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+                }
+                acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -527,6 +656,10 @@ static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_
   const char* e = getenv("ISF_CONV16_DIAG");
   return e ? atoi(e) : 0;
 }();
+static const bool g_conv16_tps = [] {   // experiment: several taps per step for the narrow layers (default shape only)
+  const char* e = getenv("ISF_CONV16_TPS");
+  return e ? (e[0] != '0') : false;
+}();
 static const bool g_conv16_tepi = [] {   // experiment: transposed accumulators, LDS-free epilogue (default shape only)
   const char* e = getenv("ISF_CONV16_TEPI");
   return e ? (e[0] != '0') : false;
@@ -549,7 +682,7 @@ template <int CIN, int NT, int RG, int NW, int MODE = 0>
 static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                     int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                     int relu, uint4* ys, hipStream_t st) {
-  using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
+  using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH * conv16_tps<CIN, NT, MODE>(), NW>;
   auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, MODE>;
   static bool attr_set = false;
   if (!attr_set && S::bytes > 48 * 1024) {
@@ -577,7 +710,8 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
-  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0) | (g_conv16_tepi ? 32 : 0);
+  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0) | (g_conv16_tepi ? 32 : 0) |
+                   (g_conv16_tps ? 64 : 0);
   if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
 #define ISF_MODE16(M)                                                                                                 \
   case M:                                                                                                             \
@@ -592,6 +726,8 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
       ISF_MODE16(16);
       ISF_MODE16(32);
       ISF_MODE16(48);
+      ISF_MODE16(64);
+      ISF_MODE16(96);
       default:
         ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2, ISF_CONV16_DIAG in {2,4,6,8} and ISF_CONV16_PRIO are not combinable)", mode);
     }
@@ -618,7 +754,8 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 64:  return launch16_rows<CIN, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
-      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio && !g_conv16_tepi)
+      if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio && !g_conv16_tepi &&
+          !g_conv16_tps)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }

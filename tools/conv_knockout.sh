@@ -19,14 +19,17 @@ run noloop ISF_CONV16_DIAG=8
 run prio ISF_CONV16_PRIO=1          # experiment (valid results): s_setprio around the MFMA block
 run tepi ISF_CONV16_TEPI=1          # experiment (valid results): transposed accumulators, LDS-free epilogue
 run tepi_prio ISF_CONV16_TEPI=1 ISF_CONV16_PRIO=1
+run tps ISF_CONV16_TPS=1            # experiment (valid results): 4 / 2 taps per step for the narrow layers
+run tps_tepi ISF_CONV16_TPS=1 ISF_CONV16_TEPI=1
 run rg4 ISF_CONV16_RG=4             # existing variant: 64-row waves
 python - <<'PY'
 import json
 rows = []
-for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "rg4"):
+for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "rg4"):
     try:
         d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
         rows.append((name, d["roofline"]["conv_ms_per_step"], d["ms_per_step"]))
+        print(name, {k.replace("spconv_mfma", ""): v["ms"] for k, v in d["roofline"]["per_kernel"].items()})
     except Exception as e:   # noqa: BLE001
         rows.append((name, None, str(e)))
 for r in rows:
