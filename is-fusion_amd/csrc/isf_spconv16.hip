@@ -704,7 +704,7 @@ static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K,
 // 4x wider than 4 waves do.  Measured (B=4 x 300 k points): a win only for the 128-column layers of the large
 // levels (128 -> 128: 1.13 -> 1.03 ms per 4 launches, 64 -> 128: 0.173 -> 0.147 ms); the narrow layers lose
 // (fewer independent workgroups to hide the gather latency) and the small deep levels do not have enough tiles
-// for 256 CUs.  ISF_CONV16_NW=4|16 and ISF_CONV16_RG=2|4 override (tuning).
+// for 256 CUs.  ISF_CONV16_NW=4|16 and ISF_CONV16_RG=1|2|4 override (tuning; RG=1 applies to <= 64-column layers only).
 template <int CIN, int NT>
 static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
@@ -739,6 +739,9 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
   if (wide_wg)
     return launch16<CIN, (NT <= 8 ? NT : 2), 2, 16>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
                                                      residual, relu, ys, st);
+  if (g_conv16_rg == 1 && NT <= 4)   // experiment: 64-row workgroups for the narrow layers (twice the waves in flight)
+    return launch16<CIN, (NT <= 4 ? NT : 2), 1, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual,
+                                                  relu, ys, st);
   if (g_conv16_rg == 4 && NT * 4 <= 32)
     return launch16<CIN, (NT * 4 <= 32 ? NT : 2), 4, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
                                                         residual, relu, ys, st);
