@@ -285,7 +285,94 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     }
   };
 
-  if constexpr (TPS == 1) {
+  // MODE bit 128 (ISF_CONV16_WIND=1, experiment) for the <= 64-column layers: WAVE-INDEPENDENT main loop.  Their
+  // weights are tiny (<= 8 KiB per tap and chunk, L2 / L1 resident), so each wave reads its B fragments straight
+  // from global memory into registers instead of sharing them through the LDS ring: no DMA in inline asm, hence no
+  // hand-placed vmcnt(0), no barrier per step and no lock-step between the waves -- every load is visible to the
+  // compiler, which emits counted waits for a software pipeline of (tap, chunk) items two deep; a wave walks ITS OWN
+  // tap mask.  Same products, same summation order (tap ascending, chunk ascending) as the default.
+  constexpr bool WIND = (MODE & 128) != 0 && NT <= 4 && KCH == NCH;
+  if constexpr (WIND) {
+    struct Item {
+      uint4 a[RG][2];   // [row group][hi, lo]
+      uint4 b[NT][2];   // [column tile][hi, lo]
+    };
+    auto load_item = [&](Item& it, int tap, int kc) {
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        it.a[rg][0] = make_uint4(0, 0, 0, 0);
+        it.a[rg][1] = make_uint4(0, 0, 0, 0);
+        if ((rgm[rg] >> tap) & 1u) {
+          const int idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
+          if (idx >= 0) {
+            const uint4* p = xs + ((size_t)idx * CH8 + kc * 4) * 2 + kg;
+            it.a[rg][0] = p[0];
+            it.a[rg][1] = p[4];
+          }
+        }
+      }
+      const uint4* src = wpk + (((size_t)tap * NCH + kc) * ntiles_total + cb * NT) * 128 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        it.b[nt][0] = src[nt * 128];
+        it.b[nt][1] = src[nt * 128 + 64];
+      }
+    };
+    auto mma_item = [&](const Item& it, int tap) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const h8 bh = *reinterpret_cast<const h8*>(&it.b[nt][0]);
+        const h8 bl = *reinterpret_cast<const h8*>(&it.b[nt][1]);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          if ((rgm[rg] >> tap) & 1u) {
+            const h8 ah = *reinterpret_cast<const h8*>(&it.a[rg][0]);
+            const h8 al = *reinterpret_cast<const h8*>(&it.a[rg][1]);
+            if (TEPI) {
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al, acc[rg][nt], 0, 0, 0);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah, acc[rg][nt], 0, 0, 0);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah, acc[rg][nt], 0, 0, 0);
+            } else {
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+              acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    // item cursor: taps of this wave's mask ascending, chunks ascending inside a tap (all wave-uniform scalars)
+    unsigned rem = wmask;
+    int cur_tap = -1, cur_kc = NCH;
+    auto next = [&](int& tap, int& kc) -> bool {
+      if (cur_kc + 1 < NCH) {
+        ++cur_kc;
+      } else {
+        if (rem == 0) return false;
+        cur_tap = __ffs(rem) - 1;
+        rem &= rem - 1;
+        cur_kc = 0;
+      }
+      tap = cur_tap;
+      kc = cur_kc;
+      return true;
+    };
+    Item i0, i1;
+    int t0 = 0, k0 = 0, t1 = 0, k1 = 0;
+    bool v0 = !NOLOOP && next(t0, k0);
+    if (v0) load_item(i0, t0, k0);
+    bool v1 = v0 && next(t1, k1);
+    if (v1) load_item(i1, t1, k1);
+    while (v0) {
+      mma_item(i0, t0);
+      v0 = v1 && next(t0, k0);   // items are consumed in order: slot 0 refills only while slot 1 still holds one
+      if (v0) load_item(i0, t0, k0);
+      if (!v1) break;
+      mma_item(i1, t1);
+      v1 = v0 && next(t1, k1);
+      if (v1) load_item(i1, t1, k1);
+    }
+  } else if constexpr (TPS == 1) {
     Cursor cur{0u, -1, -1};
     if (nsteps > 0) {
       advance(cur);
@@ -656,6 +743,10 @@ static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_
   const char* e = getenv("ISF_CONV16_DIAG");
   return e ? atoi(e) : 0;
 }();
+static const bool g_conv16_wind = [] {   // experiment: wave-independent main loop for the <= 64-column layers
+  const char* e = getenv("ISF_CONV16_WIND");
+  return e ? (e[0] != '0') : false;
+}();
 static const bool g_conv16_tps = [] {   // experiment: several taps per step for the narrow layers (default shape only)
   const char* e = getenv("ISF_CONV16_TPS");
   return e ? (e[0] != '0') : false;
@@ -711,7 +802,7 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
   const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0) | (g_conv16_tepi ? 32 : 0) |
-                   (g_conv16_tps ? 64 : 0);
+                   (g_conv16_tps ? 64 : 0) | (g_conv16_wind ? 128 : 0);
   if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
 #define ISF_MODE16(M)                                                                                                 \
   case M:                                                                                                             \
@@ -728,6 +819,8 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
       ISF_MODE16(48);
       ISF_MODE16(64);
       ISF_MODE16(96);
+      ISF_MODE16(128);
+      ISF_MODE16(160);
       default:
         ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2, ISF_CONV16_DIAG in {2,4,6,8} and ISF_CONV16_PRIO are not combinable)", mode);
     }
@@ -758,7 +851,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
       if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio && !g_conv16_tepi &&
-          !g_conv16_tps)
+          !g_conv16_tps && !g_conv16_wind)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }

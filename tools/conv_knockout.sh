@@ -21,12 +21,14 @@ run tepi ISF_CONV16_TEPI=1          # experiment (valid results): transposed acc
 run tepi_prio ISF_CONV16_TEPI=1 ISF_CONV16_PRIO=1
 run tps ISF_CONV16_TPS=1            # experiment (valid results): 4 / 2 taps per step for the narrow layers
 run tps_tepi ISF_CONV16_TPS=1 ISF_CONV16_TEPI=1
+run wind ISF_CONV16_WIND=1          # experiment (valid results): wave-independent loop for the narrow layers
+run wind_tepi ISF_CONV16_WIND=1 ISF_CONV16_TEPI=1
 run rg4 ISF_CONV16_RG=4             # existing variant: 64-row waves
 run rg1 ISF_CONV16_RG=1             # experiment: 64-row workgroups for the <= 64-column layers
 python - <<'PY'
 import json
 rows = []
-for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "rg4", "rg1"):
+for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "wind", "wind_tepi", "rg4", "rg1"):
     try:
         d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
         rows.append((name, d["roofline"]["conv_ms_per_step"], d["ms_per_step"]))
