@@ -399,3 +399,42 @@ def test_conv_transposed_epilogue_lane_mapping():
         for u in range(c_units):
             p = split_hi_index(r, c_units, u)
             assert np.allclose(buf[p], Y[r, 8 * u: 8 * u + 8]) and np.allclose(buf[p + 4], -Y[r, 8 * u: 8 * u + 8])
+
+
+def test_conv_wave_independent_pipeline_visits_items_in_order():
+    """spconv_f16x3_kernel MODE 128 (ISF_CONV16_WIND): the two-slot software pipeline over (tap, chunk) items must
+    process every item of the wave's tap mask exactly once, taps ascending, chunks ascending -- the summation order
+    of the default kernel.  Control flow restated statement by statement."""
+    rng = np.random.default_rng(9)
+    for NCH in (1, 2):
+        for _ in range(200):
+            wmask = int(rng.integers(0, 1 << 27)) if rng.random() > 0.1 else int(rng.integers(0, 4))
+            state = dict(rem=wmask, cur_tap=-1, cur_kc=NCH)
+
+            def nxt():
+                if state["cur_kc"] + 1 < NCH:
+                    state["cur_kc"] += 1
+                else:
+                    if state["rem"] == 0:
+                        return None
+                    state["cur_tap"] = (state["rem"] & -state["rem"]).bit_length() - 1     # __ffs(rem) - 1
+                    state["rem"] &= state["rem"] - 1
+                    state["cur_kc"] = 0
+                return (state["cur_tap"], state["cur_kc"])
+
+            done = []
+            i0 = nxt()
+            v0 = i0 is not None
+            i1 = nxt() if v0 else None
+            v1 = v0 and i1 is not None
+            while v0:
+                done.append(i0)                      # mma_item(i0)
+                i0 = nxt() if v1 else None
+                v0 = v1 and i0 is not None
+                if not v1:
+                    break
+                done.append(i1)                      # mma_item(i1)
+                i1 = nxt() if v0 else None
+                v1 = v0 and i1 is not None
+            want = [(t, k) for t in range(27) if (wmask >> t) & 1 for k in range(NCH)]
+            assert done == want, (wmask, NCH)
