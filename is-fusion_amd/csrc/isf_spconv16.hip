@@ -795,7 +795,7 @@ static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K,
 // 4x wider than 4 waves do.  Measured (B=4 x 300 k points): a win only for the 128-column layers of the large
 // levels (128 -> 128: 1.13 -> 1.03 ms per 4 launches, 64 -> 128: 0.173 -> 0.147 ms); the narrow layers lose
 // (fewer independent workgroups to hide the gather latency) and the small deep levels do not have enough tiles
-// for 256 CUs.  ISF_CONV16_NW=4|16 and ISF_CONV16_RG=1|2|4 override (tuning; RG=1 applies to <= 64-column layers only).
+// for 256 CUs.  ISF_CONV16_NW=4|8|16 and ISF_CONV16_RG=1|2|4 override (tuning; RG=1 applies to <= 64-column layers only).
 template <int CIN, int NT>
 static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
@@ -829,6 +829,9 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
   bool wide_wg = NT == 8 && CIN >= 64 && (long long)ceil_div(n_out, 512) * ncb >= 200;
   if (g_conv16_nw == 4) wide_wg = false;
   if (g_conv16_nw == 16) wide_wg = NT <= 8;
+  if (g_conv16_nw == 8 && NT == 8)   // experiment: 8-wave (256-row) workgroups, two per CU, for the 128-column layers
+    return launch16<CIN, (NT == 8 ? NT : 2), 2, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual,
+                                                  relu, ys, st);
   if (wide_wg)
     return launch16<CIN, (NT <= 8 ? NT : 2), 2, 16>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
                                                      residual, relu, ys, st);

@@ -25,10 +25,17 @@ run wind ISF_CONV16_WIND=1          # experiment (valid results): wave-independe
 run wind_tepi ISF_CONV16_WIND=1 ISF_CONV16_TEPI=1
 run rg4 ISF_CONV16_RG=4             # existing variant: 64-row waves
 run rg1 ISF_CONV16_RG=1             # experiment: 64-row workgroups for the <= 64-column layers
+# workgroup-shape variants: these are NOT forced to 4 waves (the reference for them is the production heuristic)
+runfree() { local name=$1; shift; env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline \
+      > gpurun_out/knock_$name.json 2> gpurun_out/knock_$name.err; }
+runfree heuristic
+runfree nw8 ISF_CONV16_NW=8         # experiment: 8-wave (256-row) workgroups for the 128-column layers
+runfree nw16 ISF_CONV16_NW=16
 python - <<'PY'
 import json
 rows = []
-for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "wind", "wind_tepi", "rg4", "rg1"):
+for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "wind", "wind_tepi", "rg4", "rg1", "heuristic", "nw8",
+             "nw16"):
     try:
         d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
         rows.append((name, d["roofline"]["conv_ms_per_step"], d["ms_per_step"]))
