@@ -801,8 +801,9 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
                          int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
                          int relu, uint4* ys, hipStream_t st) {
   const int ncb = cout / (16 * NT);
+  // the narrow-layer experiments (TPS, WIND) leave the other layers on the production heuristic below
   const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0) | (g_conv16_tepi ? 32 : 0) |
-                   (g_conv16_tps ? 64 : 0) | (g_conv16_wind ? 128 : 0);
+                   (NT <= 4 ? (g_conv16_tps ? 64 : 0) | (g_conv16_wind ? 128 : 0) : 0);
   if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
 #define ISF_MODE16(M)                                                                                                 \
   case M:                                                                                                             \
