@@ -4,6 +4,7 @@
 #  2. two questions that decide the conv restructuring: the vmcnt ordering probe and the
 #     single-pass (one MFMA per product) diagnostic bench next to the default bench
 #  3. the validated tier, to make sure nothing regressed
+# Second call: `bash tools/conv_knockout.sh` (about 7 GPU-minutes): knock-out decomposition + every queued conv variant.
 set -u
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests -q -m gpu_next -p no:cacheprovider 2>&1 | tail -60 | tee gpurun_out/gpu_next_tests.log
