@@ -15,9 +15,13 @@ collective (scaling "weak"); timing = barrier + synchronize on both sides, max o
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   "roofline":     dominant kernel (sparse-conv template instantiation with the largest share of GPU time),
-                  achieved = algorithmic flops (2*pairs*Cin*Cout) / mean hipEvent kernel time, vs the fp32 MFMA
-                  peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- plus the per-kernel table;
-  "cpu_baseline": the CPU oracle (scalar C port of the reference algorithm) on a bounded sample.
+                  achieved = algorithmic flops (2*pairs*Cin*Cout) / mean hipEvent kernel time, vs what the matrix
+                  pipe delivers per algorithmic flop (dense f16 peak / 3 passes of the split arithmetic, or the fp32
+                  MFMA peak with --fp32; MI355X_MICROARCH.md) -- plus the per-kernel table;
+  "cpu_baseline": the CPU oracle (C port of the reference algorithm, conv loop on all host threads) on one frame.
+
+Diagnostics (never the headline; the line is labelled): --f16 (single-pass f16 kernels, reduced precision) and the
+ISF_CONV16_DIAG knock-out kernels (garbage results, timing only; tools/conv_knockout.sh).
 """
 import argparse
 import json
