@@ -297,25 +297,26 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
       uint4 a[RG][2];   // [row group][hi, lo]
       uint4 b[NT][2];   // [column tile][hi, lo]
     };
+    // Every item issues the SAME number of loads in the same order -- weights first, gathers last, rows without a
+    // neighbour read the all-zero line -- so the compiler's wait before an item's first MFMA is vmcnt(loads of one
+    // item): exactly the next item's loads, gathers included, stay in flight.  (Conditional gathers would make it
+    // assume none were issued and wait them out.)
     auto load_item = [&](Item& it, int tap, int kc) {
-#pragma unroll
-      for (int rg = 0; rg < RG; ++rg) {
-        it.a[rg][0] = make_uint4(0, 0, 0, 0);
-        it.a[rg][1] = make_uint4(0, 0, 0, 0);
-        if ((rgm[rg] >> tap) & 1u) {
-          const int idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
-          if (idx >= 0) {
-            const uint4* p = xs + ((size_t)idx * CH8 + kc * 4) * 2 + kg;
-            it.a[rg][0] = p[0];
-            it.a[rg][1] = p[4];
-          }
-        }
-      }
       const uint4* src = wpk + (((size_t)tap * NCH + kc) * ntiles_total + cb * NT) * 128 + lane;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         it.b[nt][0] = src[nt * 128];
         it.b[nt][1] = src[nt * 128 + 64];
+      }
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        int idx = -1;
+        if ((rgm[rg] >> tap) & 1u) idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
+        const uint4* row = xs + ((size_t)(idx >= 0 ? idx : 0) * CH8 + kc * 4) * 2 + kg;
+        const uint4* hi = idx >= 0 ? row : g_zero_line + kg;
+        const uint4* lo = idx >= 0 ? row + 4 : g_zero_line + kg;
+        it.a[rg][0] = *hi;
+        it.a[rg][1] = *lo;
       }
     };
     auto mma_item = [&](const Item& it, int tap) {
@@ -357,20 +358,25 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
       kc = cur_kc;
       return true;
     };
+    // Two slots.  The loads of the NEXT item are issued, unconditionally and in straight-line code, right before the
+    // MFMAs of the current one (past the last item a slot re-reads item (tap 0, chunk 0): valid addresses, never
+    // multiplied), so the compiler's wait before those MFMAs is exactly vmcnt(loads of one item) -- conditional or
+    // loop-carried refills make its bookkeeping assume the worst and drain the prefetch.
     Item i0, i1;
     int t0 = 0, k0 = 0, t1 = 0, k1 = 0;
     bool v0 = !NOLOOP && next(t0, k0);
-    if (v0) load_item(i0, t0, k0);
-    bool v1 = v0 && next(t1, k1);
-    if (v1) load_item(i1, t1, k1);
+    if (!v0) t0 = k0 = 0;
+    load_item(i0, t0, k0);
     while (v0) {
+      bool v1 = next(t1, k1);
+      if (!v1) t1 = k1 = 0;
+      load_item(i1, t1, k1);
       mma_item(i0, t0);
-      v0 = v1 && next(t0, k0);   // items are consumed in order: slot 0 refills only while slot 1 still holds one
-      if (v0) load_item(i0, t0, k0);
       if (!v1) break;
+      v0 = next(t0, k0);
+      if (!v0) t0 = k0 = 0;
+      load_item(i0, t0, k0);
       mma_item(i1, t1);
-      v1 = v0 && next(t1, k1);
-      if (v1) load_item(i1, t1, k1);
     }
   } else if constexpr (TPS == 1) {
     Cursor cur{0u, -1, -1};

@@ -425,16 +425,14 @@ def test_conv_wave_independent_pipeline_visits_items_in_order():
             done = []
             i0 = nxt()
             v0 = i0 is not None
-            i1 = nxt() if v0 else None
-            v1 = v0 and i1 is not None
             while v0:
+                i1 = nxt()                           # load_item(i1) -- issued before the MFMAs of i0
+                v1 = i1 is not None
                 done.append(i0)                      # mma_item(i0)
-                i0 = nxt() if v1 else None
-                v0 = v1 and i0 is not None
                 if not v1:
                     break
+                i0 = nxt()                           # load_item(i0)
+                v0 = i0 is not None
                 done.append(i1)                      # mma_item(i1)
-                i1 = nxt() if v0 else None
-                v1 = v0 and i1 is not None
             want = [(t, k) for t in range(27) if (wmask >> t) & 1 for k in range(NCH)]
             assert done == want, (wmask, NCH)
