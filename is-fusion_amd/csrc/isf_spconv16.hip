@@ -362,21 +362,47 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     // MFMAs of the current one (past the last item a slot re-reads item (tap 0, chunk 0): valid addresses, never
     // multiplied), so the compiler's wait before those MFMAs is exactly vmcnt(loads of one item) -- conditional or
     // loop-carried refills make its bookkeeping assume the worst and drain the prefetch.
+    // (An item of a 32-column layer is 8 loads and 12 MFMAs: three slots there -- two items in flight per wave.)
+    constexpr int WD = NT <= 2 ? 3 : 2;
     Item i0, i1;
     int t0 = 0, k0 = 0, t1 = 0, k1 = 0;
     bool v0 = !NOLOOP && next(t0, k0);
     if (!v0) t0 = k0 = 0;
     load_item(i0, t0, k0);
-    while (v0) {
-      bool v1 = next(t1, k1);
+    if constexpr (WD == 2) {
+      while (v0) {
+        bool v1 = next(t1, k1);
+        if (!v1) t1 = k1 = 0;
+        load_item(i1, t1, k1);
+        mma_item(i0, t0);
+        if (!v1) break;
+        v0 = next(t0, k0);
+        if (!v0) t0 = k0 = 0;
+        load_item(i0, t0, k0);
+        mma_item(i1, t1);
+      }
+    } else {
+      Item i2;
+      int t2 = 0, k2 = 0;
+      bool v1 = v0 && next(t1, k1);
       if (!v1) t1 = k1 = 0;
       load_item(i1, t1, k1);
-      mma_item(i0, t0);
-      if (!v1) break;
-      v0 = next(t0, k0);
-      if (!v0) t0 = k0 = 0;
-      load_item(i0, t0, k0);
-      mma_item(i1, t1);
+      while (v0) {
+        bool v2 = next(t2, k2);
+        if (!v2) t2 = k2 = 0;
+        load_item(i2, t2, k2);
+        mma_item(i0, t0);
+        if (!v1) break;
+        v0 = next(t0, k0);
+        if (!v0) t0 = k0 = 0;
+        load_item(i0, t0, k0);
+        mma_item(i1, t1);
+        if (!v2) break;
+        v1 = next(t1, k1);
+        if (!v1) t1 = k1 = 0;
+        load_item(i1, t1, k1);
+        mma_item(i2, t2);
+      }
     }
   } else if constexpr (TPS == 1) {
     Cursor cur{0u, -1, -1};

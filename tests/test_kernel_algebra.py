@@ -425,7 +425,7 @@ def test_conv_wave_independent_pipeline_visits_items_in_order():
             done = []
             i0 = nxt()
             v0 = i0 is not None
-            while v0:
+            while v0:                                # two slots (column tiles > 2)
                 i1 = nxt()                           # load_item(i1) -- issued before the MFMAs of i0
                 v1 = i1 is not None
                 done.append(i0)                      # mma_item(i0)
@@ -434,5 +434,28 @@ def test_conv_wave_independent_pipeline_visits_items_in_order():
                 i0 = nxt()                           # load_item(i0)
                 v0 = i0 is not None
                 done.append(i1)                      # mma_item(i1)
+            want = [(t, k) for t in range(27) if (wmask >> t) & 1 for k in range(NCH)]
+            assert done == want, (wmask, NCH)
+            # three slots (32-column layers)
+            state.update(rem=wmask, cur_tap=-1, cur_kc=NCH)
+            done = []
+            i0 = nxt()
+            v0 = i0 is not None
+            i1 = nxt() if v0 else None
+            v1 = v0 and i1 is not None
+            while v0:
+                i2 = nxt()
+                v2 = i2 is not None
+                done.append(i0)
+                if not v1:
+                    break
+                i0 = nxt()
+                v0 = i0 is not None
+                done.append(i1)
+                if not v2:
+                    break
+                i1 = nxt()
+                v1 = i1 is not None
+                done.append(i2)
             want = [(t, k) for t in range(27) if (wmask >> t) & 1 for k in range(NCH)]
             assert done == want, (wmask, NCH)
