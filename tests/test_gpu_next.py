@@ -543,3 +543,20 @@ def test_conv_kernel_variant_reproduces_default_bits(dev, variant, tmp_path):
     if digests["default"][0] != digests[variant][0]:
         a, b = np.load(tmp_path / "default.npy"), np.load(tmp_path / (variant + ".npy"))
         raise AssertionError(f"{variant}: max |diff| {np.abs(a - b).max():.3e} (expected bit-identical)")
+
+
+def test_p2g_pipelined_variant_reproduces_default_bits(dev):
+    """ISF_P2G_PIPE=1 (two (slot, camera) pairs per step, eight unconditional corner loads in flight) must give the
+    default Point-to-Grid kernel's canvas bit for bit"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, extra in (("default", {}), ("pipe", {"ISF_P2G_PIPE": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "p2g_variant_check.py"), "6000"],
+                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = r.stdout.split()
+    assert float(res["default"][1]) > 0.1
+    assert res["default"][0] == res["pipe"][0], f"canvas differs (ms: {res['default'][2]} vs {res['pipe'][2]})"

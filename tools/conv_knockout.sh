@@ -48,3 +48,6 @@ for r in rows:
     print("%-10s conv ms/step %-8s step ms %s" % r)
 open("gpurun_out/conv_knockout.json", "w").write(json.dumps(rows))
 PY
+# Point-to-Grid: default vs the pipelined variant (digest, max, ms per call)
+python tools/p2g_variant_check.py 15000 | tee gpurun_out/p2g_default.txt
+ISF_P2G_PIPE=1 python tools/p2g_variant_check.py 15000 | tee gpurun_out/p2g_pipe.txt
