@@ -775,6 +775,10 @@ static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_
   const char* e = getenv("ISF_CONV16_DIAG");
   return e ? atoi(e) : 0;
 }();
+static const bool g_conv16_deep = [] {   // experiment: 8 waves x 16 rows for the 128-column layers of the small levels
+  const char* e = getenv("ISF_CONV16_DEEP");
+  return e ? (e[0] != '0') : false;
+}();
 static const bool g_conv16_wind = [] {   // experiment: wave-independent main loop for the <= 64-column layers
   const char* e = getenv("ISF_CONV16_WIND");
   return e ? (e[0] != '0') : false;
@@ -868,6 +872,9 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
   if (wide_wg)
     return launch16<CIN, (NT <= 8 ? NT : 2), 2, 16>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
                                                      residual, relu, ys, st);
+  if (g_conv16_deep && NT == 8)   // experiment: the same 128-row tile on 8 waves x 16 rows (twice the waves per SIMD)
+    return launch16<CIN, (NT == 8 ? NT : 2), 1, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual,
+                                                  relu, ys, st);
   if (g_conv16_rg == 1 && NT <= 4)   // experiment: 64-row workgroups for the narrow layers (twice the waves in flight)
     return launch16<CIN, (NT <= 4 ? NT : 2), 1, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual,
                                                   relu, ys, st);

@@ -31,13 +31,14 @@ runfree() { local name=$1; shift; env "$@" timeout 300 python bench.py --steps 1
 runfree heuristic
 runfree nw8 ISF_CONV16_NW=8         # experiment: 8-wave (256-row) workgroups for the 128-column layers
 runfree nw16 ISF_CONV16_NW=16
+runfree deep ISF_CONV16_DEEP=1      # experiment: 128-row tiles on 8 waves x 16 rows for the 128-column layers of the small levels
 runfree wind_free ISF_CONV16_WIND=1   # narrow layers wave-independent, the others on the production heuristic
 runfree tps_free ISF_CONV16_TPS=1
 python - <<'PY'
 import json
 rows = []
 for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "wind", "wind_tepi", "rg4", "rg1", "heuristic", "nw8",
-             "nw16", "wind_free", "tps_free"):
+             "nw16", "deep", "wind_free", "tps_free"):
     try:
         d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
         rows.append((name, d["roofline"]["conv_ms_per_step"], d["ms_per_step"]))
