@@ -134,6 +134,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // its 8-byte halves of the residual, and stores its 4 hi and 4 lo halves (8 B each; the four lanes of a row cover
   // one 32-byte run).  Same products, same summation order as the default.
   constexpr bool TEPI = (MODE & 32) != 0;
+  // MODE bit 256 (ISF_CONV16_VEPI=1, experiment): the default epilogue fetches the 8 BN scales / shifts of an item
+  // with two 32-byte loads issued together.  In the generated code of the scalar form every channel is a
+  // `global_load_dword ; s_waitcnt vmcnt(0)` pair -- 16 dependent round trips per (row, unit) item, 8 items per wave
+  // and tile -- which alone accounts for several microseconds of every tile's lifetime.
+  constexpr bool VEPI = (MODE & 256) != 0;
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
   constexpr int TPS = conv16_tps<CIN, NT, MODE>();   // taps per step (1 unless MODE bit 64)
   using S = Conv16Smem<NT, RG, KCH * TPS, NW>;       // the weight ring holds TPS taps per stage
@@ -610,12 +615,15 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         const int gc = cb * BN + nt * 16 + 4 * kg;                       // this lane's 4 channels
         const size_t piece = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
         const size_t h2 = piece * 2 + ((gc >> 2) & 1), l2 = (piece + 4) * 2 + ((gc >> 2) & 1);
+        // one 16-byte load each for the four scales / shifts (the scalar form compiles to a load-wait pair per channel)
+        f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f}, sh4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (scale) sc4 = *reinterpret_cast<const f32x4*>(scale + gc);
+        if (shift) sh4 = *reinterpret_cast<const f32x4*>(shift + gc);
         float v[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float sc = scale ? scale[gc + t] * winv : winv;
-          const float sh = shift ? shift[gc + t] : 0.f;
-          v[t] = fmaf(acc[rg][nt][t], sc, sh);
+          const float sc = scale ? sc4[t] * winv : winv;
+          v[t] = fmaf(acc[rg][nt][t], sc, sh4[t]);
         }
         if (residual) {
           const uint2 rh = res2[h2], rl = res2[l2];
@@ -678,11 +686,21 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = tp[j];
           const int gc = cb * BN + ps * (16 * EPN) + u * 8;
+          if (VEPI) {
+            f32x8 sc8, sh8;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float sc = scale ? scale[gc + j] * winv : winv;
-            const float sh = shift ? shift[gc + j] : 0.f;
-            v[j] = fmaf(v[j], sc, sh);
+            for (int j = 0; j < 8; ++j) { sc8[j] = 1.f; sh8[j] = 0.f; }
+            if (scale) sc8 = *reinterpret_cast<const f32x8*>(scale + gc);
+            if (shift) sh8 = *reinterpret_cast<const f32x8*>(shift + gc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], scale ? sc8[j] * winv : winv, sh8[j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float sc = scale ? scale[gc + j] * winv : winv;
+              const float sh = shift ? shift[gc + j] : 0.f;
+              v[j] = fmaf(v[j], sc, sh);
+            }
           }
           const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
           if (residual) v += join8(res_hi[it], res_lo[it]);
@@ -775,6 +793,10 @@ static const int g_conv16_diag = [] {   // timing diagnostics, see spconv_f16x3_
   const char* e = getenv("ISF_CONV16_DIAG");
   return e ? atoi(e) : 0;
 }();
+static const bool g_conv16_vepi = [] {   // experiment: vector loads of the BN scale / shift in the epilogue
+  const char* e = getenv("ISF_CONV16_VEPI");
+  return e ? (e[0] != '0') : false;
+}();
 static const bool g_conv16_deep = [] {   // experiment: 8 waves x 16 rows for the 128-column layers of the small levels
   const char* e = getenv("ISF_CONV16_DEEP");
   return e ? (e[0] != '0') : false;
@@ -839,7 +861,7 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
   const int ncb = cout / (16 * NT);
   // the narrow-layer experiments (TPS, WIND) leave the other layers on the production heuristic below
   const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv16_diag | (g_conv16_prio ? 16 : 0) | (g_conv16_tepi ? 32 : 0) |
-                   (NT <= 4 ? (g_conv16_tps ? 64 : 0) | (g_conv16_wind ? 128 : 0) : 0);
+                   (NT <= 4 ? (g_conv16_tps ? 64 : 0) | (g_conv16_wind ? 128 : 0) : 0) | (g_conv16_vepi ? 256 : 0);
   if (mode != 0) {   // single-pass f16 (opt-in) and the timing diagnostics: the default workgroup shape only
 #define ISF_MODE16(M)                                                                                                 \
   case M:                                                                                                             \
@@ -858,6 +880,8 @@ static int launch16_rows(const uint4* xs, const uint4* wpk, const float* winv, i
       ISF_MODE16(96);
       ISF_MODE16(128);
       ISF_MODE16(160);
+      ISF_MODE16(256);
+      ISF_MODE16(384);
       default:
         ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (precision 2, ISF_CONV16_DIAG in {2,4,6,8} and ISF_CONV16_PRIO are not combinable)", mode);
     }
@@ -894,7 +918,7 @@ static int dispatch16(const uint4* xs, const uint4* wpk, const float* winv, int 
     case 128: return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
     case 256:
       if (g_conv16_wide && g_conv_precision != 2 && g_conv16_diag == 0 && !g_conv16_prio && !g_conv16_tepi &&
-          !g_conv16_tps && !g_conv16_wind)
+          !g_conv16_tps && !g_conv16_wind && !g_conv16_vepi)
         return launch16<CIN, 16, 2, 4>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
       return launch16_rows<CIN, 8>(xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
   }

@@ -523,7 +523,7 @@ def test_extract_pts_feat_and_neck_match_reference_detector_golden(dev, golden, 
 
 
 # ------------------------------------------------------------------------------------------- conv kernel variants
-@pytest.mark.parametrize("variant", ["ISF_CONV16_TEPI", "ISF_CONV16_PRIO", "ISF_CONV16_TPS", "ISF_CONV16_WIND", "ISF_CONV16_DEEP"])
+@pytest.mark.parametrize("variant", ["ISF_CONV16_TEPI", "ISF_CONV16_PRIO", "ISF_CONV16_TPS", "ISF_CONV16_WIND", "ISF_CONV16_DEEP", "ISF_CONV16_VEPI"])
 def test_conv_kernel_variant_reproduces_default_bits(dev, variant, tmp_path):
     """opt-in variants of the sparse-conv kernel (same products, same summation order) must give the default kernels'
     BEV features bit for bit; the switches are read at library load, hence one subprocess per variant.  Both sides use

@@ -23,6 +23,8 @@ run tps ISF_CONV16_TPS=1            # experiment (valid results): 4 / 2 taps per
 run tps_tepi ISF_CONV16_TPS=1 ISF_CONV16_TEPI=1
 run wind ISF_CONV16_WIND=1          # experiment (valid results): wave-independent loop for the narrow layers
 run wind_tepi ISF_CONV16_WIND=1 ISF_CONV16_TEPI=1
+run vepi ISF_CONV16_VEPI=1          # experiment (valid results): vector loads of the BN scale / shift in the epilogue
+run vepi_wind ISF_CONV16_VEPI=1 ISF_CONV16_WIND=1
 run rg4 ISF_CONV16_RG=4             # existing variant: 64-row waves
 run rg1 ISF_CONV16_RG=1             # experiment: 64-row workgroups for the <= 64-column layers
 # workgroup-shape variants: these are NOT forced to 4 waves (the reference for them is the production heuristic)
@@ -37,7 +39,7 @@ runfree tps_free ISF_CONV16_TPS=1
 python - <<'PY'
 import json
 rows = []
-for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "wind", "wind_tepi", "rg4", "rg1", "heuristic", "nw8",
+for name in ("full", "nogather", "nodma", "neither", "noloop", "prio", "tepi", "tepi_prio", "tps", "tps_tepi", "wind", "wind_tepi", "vepi", "vepi_wind", "rg4", "rg1", "heuristic", "nw8",
              "nw16", "deep", "wind_free", "tps_free"):
     try:
         d = json.loads(open(f"gpurun_out/knock_{name}.json").read().strip().splitlines()[-1])
