@@ -11,6 +11,8 @@
 //   epilogue    + bias, + per-row table add (T[idx[r]]: the window position-embedding contribution pos.Wq),
 //               activation (ReLU / exact GELU), + residual, LayerNorm over the row (needs the whole row in
 //               one chunk: N <= 256), written once.
+#include <stdlib.h>
+
 #include "isf_common.h"
 
 namespace isf {
@@ -45,8 +47,14 @@ struct LinearEpilogue {
 // step -- CT tiles x 2 KB, contiguous in the packed layout -- are staged once per workgroup through a
 // double-buffered LDS ring (global -> registers during the MFMAs of the previous step -> ds_write), so the L2
 // sees each weight byte once per 64 RG rows instead of once per 16.
+// VE (ISF_LINEAR_VEPI=1, experiment): batched epilogue loads.  In the generated code of the default epilogue every
+// bias / table / residual / gamma / beta element is its own `global_load_dword ; s_waitcnt vmcnt(0)` pair (the loads
+// sit behind per-element null / bounds branches): 300-450 full waits per kernel, tens of dependent round trips per
+// row group.  With VE the loads of a whole group of column tiles are issued unconditionally from clamped, always
+// valid addresses (a null operand reads x[0]; the value is discarded by a select, never multiplied) and consumed
+// afterwards; the arithmetic and its order are unchanged.
 template <int KC /* K/32 */, int CT /* column tiles per chunk */, int RG /* row groups per wave */,
-          bool CF /* some operand is channels-first */>
+          bool CF /* some operand is channels-first */, bool VE = false>
 __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16x3_kernel(const float* __restrict__ x, int M, int ldx,
                                                            const uint4* __restrict__ wp,
                                                            const float* __restrict__ w_inv_scale, int N,
@@ -159,6 +167,61 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
       float v[CT][4];
+      if constexpr (VE) {
+        constexpr int NB = CT < 4 ? CT : 4;                 // column tiles whose operands are fetched together
+        const int rq = r0 + 16 * g + 4 * kg;
+        const bool has_b = ep.bias != nullptr, has_t = ep.table != nullptr, has_r = ep.residual != nullptr;
+        const bool res_cf = CF && ep.res_hw;
+        const float* bp = has_b ? ep.bias : x;
+        const float* tp = has_t ? ep.table : x;
+        const float* rp = has_r ? ep.residual : x;
+        int rr[4], ti[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rr[t] = min(rq + t, M - 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ti[t] = has_t ? ep.idx[rr[t]] : 0;
+#pragma unroll
+        for (int nt0 = 0; nt0 < CT; nt0 += NB) {
+          float bb_[NB], tb[NB][4], rs[NB][4];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int nt = nt0 + j;
+            const bool cok = c0 + nt < ntiles;
+            const int n = cok ? (c0 + nt) * 16 + col : 0;
+            bb_[j] = bp[has_b ? n : 0];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) tb[j][t] = tp[has_t ? (size_t)ti[t] * N + n : 0];
+            if (res_cf) {
+              const int r0c = min(rq, M - 4 > 0 ? M - 4 : 0);      // hw % 4 == 0: rq + 3 < M whenever rq < M
+              const int bq = r0c / ep.res_hw, pos = r0c - bq * ep.res_hw;
+              const float4 q = *reinterpret_cast<const float4*>(rp + ((size_t)bq * N + n) * ep.res_hw + pos);
+              rs[j][0] = q.x; rs[j][1] = q.y; rs[j][2] = q.z; rs[j][3] = q.w;
+            } else {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) rs[j][t] = rp[has_r ? (size_t)rr[t] * N + n : 0];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int nt = nt0 + j;
+            const bool cok = c0 + nt < ntiles;
+            const float b = (has_b && cok) ? bb_[j] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              float z = acc[g][nt][t] * winv + b;
+              if (cok && rq + t < M) {
+                if (has_t) z += tb[j][t];
+                if (ep.act == 1) z = fmaxf(z, 0.f);
+                else if (ep.act == 2) z = 0.5f * z * (1.f + erff(z * 0.70710678118654752440f));
+                if (has_r) z += rs[j][t];
+              } else {
+                z = 0.f;
+              }
+              v[nt][t] = z;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int nt = 0; nt < CT; ++nt) {
         const int n = (c0 + nt) * 16 + col;
@@ -188,7 +251,37 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
           v[nt][t] = z;
         }
       }
-      if (ep.ln_gamma) {  // whole row in this chunk (host guarantees ntiles <= CT)
+      }
+      if (VE && ep.ln_gamma) {   // gamma / beta of every column tile fetched once, then the same arithmetic
+        float gm[CT], bt[CT];
+#pragma unroll
+        for (int nt = 0; nt < CT; ++nt) {
+          const int n = (c0 + nt < ntiles) ? (c0 + nt) * 16 + col : 0;
+          gm[nt] = ep.ln_gamma[n];
+          bt[nt] = ep.ln_beta[n];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float s = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < CT; ++nt) s += v[nt][t];
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) s += __shfl_xor(s, d, 64);
+          const float mean = s / (float)N;
+          float q = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < CT; ++nt) {
+            const float dlt = (c0 + nt < ntiles) ? v[nt][t] - mean : 0.f;
+            q += dlt * dlt;
+          }
+#pragma unroll
+          for (int d = 1; d < 16; d <<= 1) q += __shfl_xor(q, d, 64);
+          const float rstd = rsqrtf(q / (float)N + ep.ln_eps);
+#pragma unroll
+          for (int nt = 0; nt < CT; ++nt)
+            if (c0 + nt < ntiles) v[nt][t] = (v[nt][t] - mean) * rstd * gm[nt] + bt[nt];
+        }
+      } else if (ep.ln_gamma) {  // whole row in this chunk (host guarantees ntiles <= CT)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           float s = 0.f;
@@ -282,7 +375,7 @@ static int launch_linear(const float* x, int M, int ldx, const void* packed, int
   const int ntiles = N / 16;
   const bool wide_ln = ep.ln_gamma && ntiles > 8;   // LayerNorm needs the whole row in one column chunk
   const bool cf = ep.x_hw || ep.res_hw || ep.y_hw;
-  static bool attr_set = false;
+  static bool attr_set = false, attr_set_ve = false;
   if (!attr_set) {   // channels-first input stages a [K][rows + 4] fp32 tile in dynamic LDS on top of the weight ring
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<KC, 16, 1, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, KC * 32 * 68 * 4));
@@ -291,9 +384,27 @@ static int launch_linear(const float* x, int M, int ldx, const void* packed, int
     attr_set = true;
   }
   const size_t lds1 = ep.x_hw ? (size_t)KC * 32 * 68 * 4 : 0;
-#define ISF_LIN(CT_, RG_, CF_, ROWS_, LDS_)                                                                        \
-  hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, RG_, CF_>), dim3(ceil_div(M, ROWS_)), block, LDS_, st, x, M, ldx, \
-                     wp, winv, N, ep, y, ldy)
+  static const bool vepi = [] {   // experiment: batched epilogue loads (see linear_f16x3_kernel)
+    const char* e = getenv("ISF_LINEAR_VEPI");
+    return e ? (e[0] != '0') : false;
+  }();
+  if (vepi && !attr_set_ve) {
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<KC, 16, 1, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, KC * 32 * 68 * 4));
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<KC, 8, 1, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, KC * 32 * 68 * 4));
+    attr_set_ve = true;
+  }
+  // (the batched epilogue exists for one row group per wave only: with two it spills)
+#define ISF_LIN(CT_, RG_, CF_, ROWS_, LDS_)                                                                             \
+  do {                                                                                                                  \
+    if (vepi)                                                                                                           \
+      hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, 1, CF_, true>), dim3(ceil_div(M, 64)), block, LDS_, st, x, M, ldx, \
+                         wp, winv, N, ep, y, ldy);                                                                      \
+    else                                                                                                                \
+      hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, RG_, CF_>), dim3(ceil_div(M, ROWS_)), block, LDS_, st, x, M, ldx,  \
+                         wp, winv, N, ep, y, ldy);                                                                      \
+  } while (0)
   if (wide_ln) {
     if (cf) ISF_LIN(16, 1, true, 64, lds1); else ISF_LIN(16, 1, false, 64, 0);
   } else if (M <= 4096 || KC == 8) {   // few rows: more, smaller workgroups; K = 256: A fragments fill the registers

@@ -560,3 +560,25 @@ def test_p2g_pipelined_variant_reproduces_default_bits(dev):
         res[name] = r.stdout.split()
     assert float(res["default"][1]) > 0.1
     assert res["default"][0] == res["pipe"][0], f"canvas differs (ms: {res['default'][2]} vs {res['pipe'][2]})"
+
+
+def test_linear_batched_epilogue_variant_matches_default(dev, tmp_path):
+    """ISF_LINEAR_VEPI=1 (epilogue operands of several column tiles fetched together from always-valid addresses) vs
+    the default fused linear kernel on every epilogue / layout combination: same arithmetic, same order"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, extra in (("default", {}), ("vepi", {"ISF_LINEAR_VEPI": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "linear_variant_check.py"),
+                            str(tmp_path / (name + ".npz"))], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        print(name, r.stdout.strip())
+    a, b = np.load(tmp_path / "default.npz"), np.load(tmp_path / "vepi.npz")
+    assert sorted(a.files) == sorted(b.files) and len(a.files) > 30
+    for k in a.files:
+        assert np.isfinite(a[k]).all()
+        # the 64-row workgroups of the variant see the same products in the same order; only fused-multiply-add
+        # contraction of the epilogue expressions may differ
+        assert np.abs(a[k] - b[k]).max() <= 2e-6 * max(1.0, np.abs(a[k]).max()), k

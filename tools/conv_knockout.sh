@@ -54,3 +54,7 @@ PY
 # Point-to-Grid: default vs the pipelined variant (digest, max, ms per call)
 python tools/p2g_variant_check.py 15000 | tee gpurun_out/p2g_default.txt
 ISF_P2G_PIPE=1 python tools/p2g_variant_check.py 15000 | tee gpurun_out/p2g_pipe.txt
+# fused linear kernel: default vs batched epilogue loads (timings at the encoder's shapes)
+python tools/linear_variant_check.py gpurun_out/linear_default.npz | tee gpurun_out/linear_default.txt
+ISF_LINEAR_VEPI=1 python tools/linear_variant_check.py gpurun_out/linear_vepi.npz | tee gpurun_out/linear_vepi.txt
+rm -f gpurun_out/linear_default.npz gpurun_out/linear_vepi.npz
