@@ -1,6 +1,7 @@
 #!/bin/bash
-# Knock-out decomposition of the sparse-conv time as a repeatable measurement:
-#   gpurun --timeout 900 -- 'bash tools/conv_knockout.sh'
+# Knock-out decomposition of the sparse-conv time and a sweep over every queued kernel variant
+# (DESIGN.md section 10), as one repeatable measurement:
+#   gpurun --timeout 1500 -- 'bash tools/conv_knockout.sh'      (22 bench runs + 4 micro-checks: about 10 GPU-minutes)
 # ISF_CONV16_DIAG: 2 = no activation gathers, 4 = no weight DMA, 6 = neither, 8 = no main loop.  The outputs of the
 # diagnostic kernels are garbage; only `conv_ms_per_step` is read.  All variants use the default workgroup shape
 # (ISF_CONV16_NW=4), so the reference line is measured with that shape too.
