@@ -47,8 +47,24 @@ def frames_for_rank(rank, world, batch):
 
 
 def make_frames(rank, world, batch, num_points):
+    """Seeded synthetic sweeps of this rank.  ISF_BENCH_FRAME_CACHE=<dir> (tuning sweeps only: tools/conv_knockout.sh
+    runs bench.py two dozen times) keeps the generated frames on disk; the frames are the same either way."""
+    import numpy as np
     from isfusion_amd import synthetic
-    return [synthetic.lidar_sweeps(1234 + 1000 * CFG_ID + f, num_points) for f in frames_for_rank(rank, world, batch)]
+    cache = os.environ.get("ISF_BENCH_FRAME_CACHE", "")
+    frames = []
+    for f in frames_for_rank(rank, world, batch):
+        seed = 1234 + 1000 * CFG_ID + f
+        path = os.path.join(cache, f"frame_{seed}_{num_points}.npy") if cache else ""
+        if path and os.path.exists(path):
+            frames.append(np.load(path))
+            continue
+        pts = synthetic.lidar_sweeps(seed, num_points)
+        if path:
+            os.makedirs(cache, exist_ok=True)
+            np.save(path, pts)
+        frames.append(pts)
+    return frames
 
 
 def traffic_file():

@@ -7,6 +7,7 @@
 # (ISF_CONV16_NW=4), so the reference line is measured with that shape too.
 set -u
 mkdir -p gpurun_out
+export ISF_BENCH_FRAME_CACHE=/tmp/isf_bench_frames     # the 4 x 300 k-point frames take 11 s of CPU to generate
 run() {  # name, env...
   local name=$1; shift
   env ISF_CONV16_NW=4 "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline \
