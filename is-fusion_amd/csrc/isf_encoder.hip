@@ -113,14 +113,14 @@ int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int3
   return ISF_OK;
 }
 
-__global__ void check_rank_order_kernel(const int32_t* __restrict__ coors4, int n, int D, int H, int W,
+__global__ void check_rank_order_kernel(const int32_t* __restrict__ coors4, int n, int B, int D, int H, int W,
                                         const unsigned long long* __restrict__ bits,
                                         const uint32_t* __restrict__ prefix, int* __restrict__ flag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coors4)[i];
   int r = -1;
-  if (c.x >= 0 && c.y >= 0 && c.z >= 0 && c.w >= 0 && c.y < D && c.z < H && c.w < W)
+  if (c.x >= 0 && c.y >= 0 && c.z >= 0 && c.w >= 0 && c.x < B && c.y < D && c.z < H && c.w < W)
     r = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
   if (r != i) *flag = 1;
 }
@@ -350,7 +350,7 @@ int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors
   ISF_TRY(a.alloc_n(&flag, 64));
   ISF_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), st));
   hipLaunchKernelGGL(check_rank_order_kernel, dim3(ceil_div(num_voxels, 256)), dim3(256), 0, st, coors,
-                     num_voxels, occ0.D, occ0.H, occ0.W, occ0.bits, occ0.prefix, flag);
+                     num_voxels, occ0.B, occ0.D, occ0.H, occ0.W, occ0.bits, occ0.prefix, flag);
   ISF_LAUNCH_CHECK();
   int h[2] = {0, 0};
   ISF_HIP_TRY(hipMemcpyAsync(&h[0], flag, sizeof(int), hipMemcpyDeviceToHost, st));

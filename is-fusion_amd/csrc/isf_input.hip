@@ -138,15 +138,13 @@ __global__ __launch_bounds__(kInBlock) void assemble_kernel(const float* __restr
   for (int i = tid; i < total * kDim; i += kInBlock) dst[i] = tile[i];
 }
 
-__global__ void sample_offsets_kernel(const uint32_t* __restrict__ block_counts,
-                                      const uint32_t* __restrict__ block_offsets, int num_blocks,
+__global__ void sample_offsets_kernel(const uint32_t* __restrict__ block_offsets, int num_blocks,
                                       const int* __restrict__ sample_first_block, int batch_size,
                                       int32_t* __restrict__ sample_offsets) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > batch_size) return;
   const int blk = sample_first_block[b];
-  sample_offsets[b] = blk < num_blocks ? (int32_t)block_offsets[blk]
-                                       : (int32_t)(block_offsets[num_blocks - 1] + block_counts[num_blocks - 1]);
+  sample_offsets[b] = (int32_t)block_offsets[min(blk, num_blocks)];   // block_offsets[num_blocks] = total
 }
 
 }  // namespace isf
@@ -209,7 +207,7 @@ int isf_assemble_points(const float* raw, const isf_sweep_t* sweeps, int num_swe
   ISF_TRY(a.alloc_n(&d_sweeps, (size_t)live));
   ISF_TRY(a.alloc_n(&d_first, (size_t)batch_size + 1));
   ISF_TRY(a.alloc_n(&d_counts, (size_t)num_blocks));
-  ISF_TRY(a.alloc_n(&d_offsets, (size_t)num_blocks));
+  ISF_TRY(a.alloc_n(&d_offsets, (size_t)num_blocks + 1));   // the scan writes n + 1 entries (out[n] = total)
   ISF_HIP_TRY(hipMemcpyAsync(d_sweeps, dev.data(), sizeof(SweepDev) * live, hipMemcpyHostToDevice, st));
   ISF_HIP_TRY(hipMemcpyAsync(d_first, first_block.data(), sizeof(int) * (batch_size + 1), hipMemcpyHostToDevice, st));
   std::vector<AugDev> haug;
@@ -238,8 +236,8 @@ int isf_assemble_points(const float* raw, const isf_sweep_t* sweeps, int num_swe
   hipLaunchKernelGGL((assemble_kernel<true>), dim3(num_blocks), dim3(kInBlock), 0, st, raw, d_sweeps, live, d_aug, rng,
                      d_counts, d_offsets, points_out);
   ISF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sample_offsets_kernel, dim3(ceil_div(batch_size + 1, 64)), dim3(64), 0, st, d_counts, d_offsets,
-                     num_blocks, d_first, batch_size, sample_offsets);
+  hipLaunchKernelGGL(sample_offsets_kernel, dim3(ceil_div(batch_size + 1, 64)), dim3(64), 0, st, d_offsets, num_blocks,
+                     d_first, batch_size, sample_offsets);
   ISF_LAUNCH_CHECK();
   // ONE stream sync per batch: the caller needs the per-sample counts to hand the points on (the reference's
   // pipeline is host code throughout), and the pageable descriptor vectors above must outlive their uploads

@@ -15,14 +15,18 @@ namespace isf {
 struct RbGeom {
   int ks[3], st[3], pd[3];
   int in_shape[3], out_shape[3];
+  int batch;   // rows whose batch index is outside [0, batch) have no neighbours
 };
 
-__global__ void rb_perm_kernel(const int32_t* __restrict__ coors4, int n, int D, int H, int W,
+__global__ void rb_perm_kernel(const int32_t* __restrict__ coors4, int n, int B, int D, int H, int W,
                                const unsigned long long* __restrict__ bits,
                                const uint32_t* __restrict__ prefix, int32_t* __restrict__ perm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coors4)[i];
+  // rows outside the grid (dynamic voxelize emits -1 for invalid points; callers may pass anything) own no cell:
+  // the same guard as occ_mark_coords4, so the unsigned cell index can never leave the bitmap
+  if (c.x < 0 || c.y < 0 || c.z < 0 || c.w < 0 || c.x >= B || c.y >= D || c.z >= H || c.w >= W) return;
   const int r = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
   if (r >= 0) perm[r] = i;
 }
@@ -46,7 +50,8 @@ __global__ __launch_bounds__(256) void rb_nbr_kernel(const int32_t* __restrict__
     const int iz = c.y * g.st[0] - g.pd[0] + kz;
     const int iy = c.z * g.st[1] - g.pd[1] + ky;
     const int ix = c.w * g.st[2] - g.pd[2] + kx;
-    if (iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && ix >= 0 && ix < g.in_shape[2]) {
+    if (c.x >= 0 && c.x < g.batch && iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && ix >= 0 &&
+        ix < g.in_shape[2]) {
       r = occ_lookup(in_bits, in_prefix,
                      (((unsigned long long)c.x * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2] + ix);
       if (r >= 0 && perm) r = perm[r];
@@ -88,6 +93,9 @@ __global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restr
   const int k = blockIdx.y;
   const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
   const int4 c = reinterpret_cast<const int4*>(in_coors4)[i];
+  if (c.x < 0 || c.x >= g.batch || c.y < 0 || c.z < 0 || c.w < 0 || c.y >= g.in_shape[0] || c.z >= g.in_shape[1] ||
+      c.w >= g.in_shape[2])
+    return;
   const int tz = c.y + g.pd[0] - kz, ty = c.z + g.pd[1] - ky, tx = c.w + g.pd[2] - kx;
   if (tz < 0 || ty < 0 || tx < 0 || tz % g.st[0] || ty % g.st[1] || tx % g.st[2]) return;
   const int oz = tz / g.st[0], oy = ty / g.st[1], ox = tx / g.st[2];
@@ -100,8 +108,9 @@ __global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restr
 }
 
 static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[3], const int pd[3],
-                           bool subm) {
+                           bool subm, int batch) {
   RbGeom g;
+  g.batch = batch;
   for (int j = 0; j < 3; ++j) {
     g.ks[j] = ks[j];
     g.st[j] = subm ? 1 : st[j];
@@ -115,7 +124,7 @@ static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[
 int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
                const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
                int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_) {
-  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, subm);
+  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, subm, in_occ.B);
   const int K = ks[0] * ks[1] * ks[2], nbx = ceil_div(nbr_stride, 256);
   uint32_t* block_pairs = nullptr;
   if (pair_count) ISF_TRY(a.alloc_n(&block_pairs, (size_t)K * nbx));
@@ -130,7 +139,7 @@ int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shap
 int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], const int ks[3],
                     const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_) {
   if (n_in <= 0) return ISF_OK;
-  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, false);
+  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, false, out_occ.B);
   hipLaunchKernelGGL(rb_mark_out_kernel, dim3(ceil_div(n_in, 256), ks[0] * ks[1] * ks[2]), dim3(256), 0, st_,
                      in_coors4, n_in, g, out_occ.bits);
   ISF_LAUNCH_CHECK();
@@ -142,8 +151,8 @@ int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int3
   int32_t* perm = nullptr;
   ISF_TRY(a.alloc_n(&perm, (size_t)(n > 0 ? n : 1)));
   if (n > 0) {
-    hipLaunchKernelGGL(rb_perm_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, coors4, n, occ.D, occ.H,
-                       occ.W, occ.bits, occ.prefix, perm);
+    hipLaunchKernelGGL(rb_perm_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, coors4, n, occ.B, occ.D,
+                       occ.H, occ.W, occ.bits, occ.prefix, perm);
     ISF_LAUNCH_CHECK();
   }
   *perm_out = perm;

@@ -114,6 +114,26 @@ def test_input_prepass_feeds_the_lidar_branch(dev):
     assert empty[0].shape == (0, 5)
 
 
+@pytest.mark.parametrize("with_aug", [False, True])
+def test_input_prepass_block_count_multiple_of_64(dev, with_aug):
+    """the block-offset scan writes n + 1 entries: with a total block count that is a multiple of 64 the extra word
+    used to land in the next arena allocation (the augmentation table / the scan's own partial sums).  30 + 17 + 17
+    workgroups of 256 points = 64 blocks; several samples so that per-sample offsets are exercised too."""
+    from input_common import PC_RANGE, sweep_inputs, train_aug
+    from isfusion_amd.input_pipeline import MultiSweepPointLoader
+    from oracle import input_ops
+    frames = [sweep_inputs(21, 256 * 30, (256 * 17, 256 * 17)), sweep_inputs(22, 256 * 40, (256 * 24,)),
+              sweep_inputs(23, 256 * 64, ())]
+    loader = MultiSweepPointLoader(test_mode=True, point_cloud_range=PC_RANGE, device=dev)
+    for group in ([0], [0, 1], [1, 2], [0, 1, 2]):           # 64, 128, 128, 192 blocks
+        aug = [train_aug(90 + i) if (with_aug and i != 1) else None for i in group] if with_aug else None
+        out = loader([_as_results(*frames[i]) for i in group], aug=aug)
+        for j, i in enumerate(group):
+            ref = input_ops.load_frame(*frames[i], PC_RANGE, aug=aug[j] if aug else None)
+            assert tuple(out[j].shape) == ref.shape, (group, i, out[j].shape, ref.shape)
+            assert np.abs(out[j].cpu().numpy() - ref).max() < (6e-5 if with_aug else 4e-6)
+
+
 # ------------------------------------------------------------------------------------------- BASELINE configs[0], [4]
 VS = [0.075, 0.075, 0.2]
 RG = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
