@@ -21,7 +21,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   "cpu_baseline": the CPU oracle (C port of the reference algorithm, conv loop on all host threads) on one frame.
 
 Diagnostics (never the headline; the line is labelled): --f16 (single-pass f16 kernels, reduced precision) and the
-ISF_CONV16_DIAG knock-out kernels (garbage results, timing only; tools/conv_knockout.sh).
+--conv-diag knock-out kernels (garbage results, timing only; tools/conv_knockout.sh).
 """
 import argparse
 import json
@@ -134,6 +134,9 @@ def main():
                          "core, about 10 s on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
+    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8],
+                    help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_set_conv_diagnostic; "
+                         "results are garbage, the line is labelled)")
     ap.add_argument("--f16", action="store_true",
                     help="DIAGNOSTIC ONLY: single-pass f16 conv kernels (fp16-autocast accuracy, BASELINE configs[4] "
                          "dtype); reduced precision, never the headline line")
@@ -156,6 +159,7 @@ def main():
 
     from isfusion_amd import _lib
     _lib.check(_lib.load().isf_set_conv_precision(2 if args.f16 else 1 if args.fp32 else 0))
+    _lib.check(_lib.load().isf_set_conv_diagnostic(args.conv_diag))
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
     frames = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
     torch.cuda.synchronize()
@@ -187,7 +191,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    diag = os.environ.get("ISF_CONV16_DIAG", "0") not in ("", "0")   # timing diagnostics: results are garbage
+    diag = args.conv_diag != 0   # timing diagnostics: results are garbage
     assert diag or torch.isfinite(out).all()
 
     if rank == 0:
@@ -243,7 +247,7 @@ def main():
             "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "DIAGNOSTIC (ISF_CONV16_DIAG knock-out kernels: results are garbage, timing only)" if diag
+            "dtype": "DIAGNOSTIC (--conv-diag knock-out kernels: results are garbage, timing only)" if diag
             else "f16 operands, fp32 accumulate (DIAGNOSTIC: reduced precision, not the headline)" if args.f16
             else "f32 (f16x3 split-precision MFMA, fp32 accumulate)" if st.precision == 1 else "f32",
             "data": "synthetic",

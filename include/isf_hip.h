@@ -204,6 +204,10 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
                                   const float* scale, const float* shift, const void* residual_split, int relu,
                                   void* out_split, isf_stream_t stream);
 int isf_set_conv_precision(int mode);
+/* TIMING DIAGNOSTICS of the sparse-conv kernel (tools/conv_knockout.sh; never set in production): 0 = off (default),
+ * 2 = no activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop.  The convolution RESULTS ARE
+ * GARBAGE while a mode is set; only kernel times are meaningful. */
+int isf_set_conv_diagnostic(int mode);
 
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
  * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros

@@ -114,6 +114,7 @@ SIGNATURES = {
     "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "isf_set_conv_precision": (c_int, [c_int]),
+    "isf_set_conv_diagnostic": (c_int, [c_int]),
     "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p]),
     "isf_sparse_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, _I3,

@@ -88,92 +88,6 @@ __global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pill
   for (int c = 0; c < CPL; ++c) o[(size_t)c * bev * bev] = acc[c];
 }
 
-// Experiment (ISF_P2G_PIPE=1, 256-channel maps): the in-view (slot, camera) pairs are visited TWO at a time and their
-// eight bilinear corner rows are loaded unconditionally (coordinates clamped, weight 0 for corners outside the map or
-// for the missing second pair) before any of them is accumulated.  The default kernel's per-corner `continue` makes
-// every pair a separate dependent round trip (4 loads, wait, 16 FMAs); here 8 KB per wave are in flight per step.
-// fma(0, f, acc) == acc for finite f, and the accumulation order (pairs ascending, corners 0..3) is unchanged, so the
-// result is bit-identical.
-__global__ __launch_bounds__(256) void p2g_pipe_kernel(const float* __restrict__ pillars, int pillar_ld, int T,
-                                                       const int32_t* __restrict__ coors, int M,
-                                                       const float* __restrict__ img /* [B*cam, H, W, 256] */,
-                                                       int num_cam, int H, int W, const float* __restrict__ cam,
-                                                       float in_h, float in_w, int bev, float* __restrict__ out) {
-  constexpr int C = 256;
-  const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= M) return;
-  const int b = coors[4 * p], y = coors[4 * p + 2], x = coors[4 * p + 3];
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int c0 = lane * 4;
-  const int pairs = T * num_cam;
-  for (int base0 = 0; base0 < pairs; base0 += 64) {
-    const int pr = base0 + lane;
-    bool ok = false;
-    float ix = 0.f, iy = 0.f;
-    int k = 0;
-    if (pr < pairs) {
-      const int t = pr / num_cam;
-      k = pr - t * num_cam;
-      const float* pt = pillars + ((size_t)p * T + t) * pillar_ld;
-      const float px = pt[0], py = pt[1], pz = pt[2];
-      const float* m = cam + (size_t)(b * num_cam + k) * 20;
-      float cx = m[0] * px + m[1] * py + m[2] * pz + m[9];
-      float cy = m[3] * px + m[4] * py + m[5] * pz + m[10];
-      float cz = m[6] * px + m[7] * py + m[8] * pz + m[11];
-      cz = fminf(fmaxf(cz, 1e-5f), 1e5f);
-      cx /= cz;
-      cy /= cz;
-      const float u = m[12] * cx + m[13] * cy + m[14] * cz + m[18];
-      const float v = m[15] * cx + m[16] * cy + m[17] * cz + m[19];
-      const float gx = (u / in_w - 0.5f) * 2.f, gy = (v / in_h - 0.5f) * 2.f;
-      ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
-      iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
-      ok = ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H;
-    }
-    unsigned long long live = __ballot(ok);
-    while (live) {
-      const int la = __ffsll((long long)live) - 1;
-      live &= live - 1;
-      const bool has_b = live != 0;
-      const int lb = has_b ? __ffsll((long long)live) - 1 : la;
-      if (has_b) live &= live - 1;
-      float4 f[2][4];
-      float wgt[2][4];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int src_lane = q ? lb : la;
-        const float sx = __shfl(ix, src_lane, 64), sy = __shfl(iy, src_lane, 64);
-        const int sk = __shfl(k, src_lane, 64);
-        const float fx = floorf(sx), fy = floorf(sy);
-        const int x0 = (int)fx, y0 = (int)fy;
-        const float lx = sx - fx, ly = sy - fy;
-        const float* base = img + (size_t)(b * num_cam + sk) * H * W * C + c0;
-#pragma unroll
-        for (int tap = 0; tap < 4; ++tap) {
-          const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
-          const bool in = xx >= 0 && xx < W && yy >= 0 && yy < H && (q == 0 || has_b);
-          wgt[q][tap] = in ? ((tap & 1) ? lx : 1.f - lx) * ((tap >> 1) ? ly : 1.f - ly) : 0.f;
-          const int cxx = min(max(xx, 0), W - 1), cyy = min(max(yy, 0), H - 1);
-          f[q][tap] = *reinterpret_cast<const float4*>(base + ((size_t)cyy * W + cxx) * C);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int tap = 0; tap < 4; ++tap) {
-          acc[0] = fmaf(wgt[q][tap], f[q][tap].x, acc[0]);
-          acc[1] = fmaf(wgt[q][tap], f[q][tap].y, acc[1]);
-          acc[2] = fmaf(wgt[q][tap], f[q][tap].z, acc[2]);
-          acc[3] = fmaf(wgt[q][tap], f[q][tap].w, acc[3]);
-        }
-    }
-  }
-  float* o = out + ((size_t)b * C + c0) * bev * bev + (size_t)y * bev + x;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) o[(size_t)c * bev * bev] = acc[c];
-}
-
 // ----------------------------------------------------------------------------------------------------------------
 // A12  sigmoid -> 3x3 local-maximum suppression (1x1 for the listed classes) -> top-k over all classes
 // (fusion_encoder.py:1100-1131).  The reference materialises the suppressed map and argsorts all K*H*W
@@ -480,16 +394,6 @@ int isf_p2g_forward(const float* pillars, int pillar_ld, int slots, const int32_
   ISF_REQUIRE(channels % 64 == 0 && channels <= 512 && pillar_ld >= 3, ISF_ERR_UNSUPPORTED,
               "p2g: channels %d (need %%64 == 0, <= 512)", channels);
   const dim3 grid(ceil_div(num_pillars, 4)), block(256);
-  static const bool pipe = [] {
-    const char* e = getenv("ISF_P2G_PIPE");
-    return e ? (e[0] != '0') : false;
-  }();
-  if (pipe && channels == 256) {
-    hipLaunchKernelGGL(p2g_pipe_kernel, grid, block, 0, st, pillars, pillar_ld, slots, pillar_coors, num_pillars, img_nhwc,
-                       num_cam, feat_h, feat_w, cam_params, (float)input_h, (float)input_w, bev_size, out);
-    ISF_LAUNCH_CHECK();
-    return ISF_OK;
-  }
 #define ISF_P2G(CPL)                                                                                              \
   hipLaunchKernelGGL((p2g_kernel<CPL>), grid, block, 0, st, pillars, pillar_ld, slots, pillar_coors, num_pillars, \
                      img_nhwc, num_cam, feat_h, feat_w, channels, cam_params, (float)input_h, (float)input_w,      \

@@ -47,7 +47,9 @@ struct LinearEpilogue {
 // step -- CT tiles x 2 KB, contiguous in the packed layout -- are staged once per workgroup through a
 // double-buffered LDS ring (global -> registers during the MFMAs of the previous step -> ds_write), so the L2
 // sees each weight byte once per 64 RG rows instead of once per 16.
-// VE (ISF_LINEAR_VEPI=1, experiment): batched epilogue loads.  In the generated code of the default epilogue every
+// VE: batched epilogue loads, used when the epilogue has a position table or a residual / LayerNorm (measured on an
+// MI355X, 129600 rows: 128 -> 384 + table 154 -> 128 us, 128 -> 128 + residual + LN 85 -> 54 us; the plain and GELU
+// epilogues are 5-18 % faster WITHOUT it and stay on the default form; profiles/r02_call1_knockout_variants.txt).  In the generated code of the default epilogue every
 // bias / table / residual / gamma / beta element is its own `global_load_dword ; s_waitcnt vmcnt(0)` pair (the loads
 // sit behind per-element null / bounds branches): 300-450 full waits per kernel, tens of dependent round trips per
 // row group.  With VE the loads of a whole group of column tiles are issued unconditionally from clamped, always
@@ -384,10 +386,7 @@ static int launch_linear(const float* x, int M, int ldx, const void* packed, int
     attr_set = true;
   }
   const size_t lds1 = ep.x_hw ? (size_t)KC * 32 * 68 * 4 : 0;
-  static const bool vepi = [] {   // experiment: batched epilogue loads (see linear_f16x3_kernel)
-    const char* e = getenv("ISF_LINEAR_VEPI");
-    return e ? (e[0] != '0') : false;
-  }();
+  const bool vepi = ep.table || ep.residual || ep.ln_gamma;   // batched epilogue loads (see linear_f16x3_kernel)
   if (vepi && !attr_set_ve) {
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_f16x3_kernel<KC, 16, 1, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, KC * 32 * 68 * 4));

@@ -1,0 +1,178 @@
+// isf_spconv16.h -- device helpers shared by the f16x3 sparse-conv kernels (isf_spconv16.hip: one-step-prefetch kernel,
+// isf_spconv_ring.hip: multi-stage ring kernel): fragment types, LDS-DMA, the split format, and the common epilogue.
+#pragma once
+#include "isf_common.h"
+
+namespace isf {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int kMaxTaps = 27;
+
+// LDS-DMA of 16 B per lane: LDS[lds_base + lane*16] = *gsrc.  Issued through inline asm on purpose: when hipcc
+// sees a global_load_lds it drains vmcnt(0) before every later ds_read (it cannot prove the buffers differ),
+// which would serialise the next step's weight/activation prefetch behind the current step's MFMAs.  Hidden
+// here, the DMA stays in flight during the compute; the loops wait for it explicitly (s_waitcnt vmcnt(N) +
+// barrier) right before the buffer is read.  M0 carries the wave-uniform LDS base and is restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_bytes /* wave-uniform */) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base_bytes)
+      : "memory");
+}
+
+// 4 B per lane: LDS[lds_base + lane*4] = *gsrc (neighbour indices of a wave's rows)
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_base_bytes /* wave-uniform */) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base_bytes)
+      : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+__device__ __forceinline__ void split8(const f32x8 v, uint4& hi, uint4& lo) {
+  const h8 h = __builtin_convertvector(v, h8);
+  const f32x8 r = v - __builtin_convertvector(h, f32x8);
+  const h8 l = __builtin_convertvector(r, h8);
+  hi = *reinterpret_cast<const uint4*>(&h);
+  lo = *reinterpret_cast<const uint4*>(&l);
+}
+
+__device__ __forceinline__ f32x8 join8(const uint4 hi, const uint4 lo) {
+  const h8 h = *reinterpret_cast<const h8*>(&hi);
+  const h8 l = *reinterpret_cast<const h8*>(&lo);
+  return __builtin_convertvector(h, f32x8) + __builtin_convertvector(l, f32x8);
+}
+
+// XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2) in
+// linear-id order.  XCD x works through ONE CONTIGUOUS range of row tiles (rows are (b,z,y,x)-sorted, so the
+// y / z neighbours a tile gathers are rows of tiles the same XCD touches a little earlier or later: its L2
+// holds that sliding window instead of every XCD fetching every row), and with two column blocks only ever
+// on column block x & 1, so that the weights it streams are half of the layer's.
+// -> false when this workgroup has no tile.
+__device__ __forceinline__ bool conv16_tile_of_block(int ncb, int row_tiles, int& cb, int& tile) {
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  if (ncb == 2) {
+    cb = xcd & 1;
+    tile = (xcd >> 1) * ((row_tiles + 3) >> 2) + j;
+    if (j >= ((row_tiles + 3) >> 2)) return false;
+  } else {
+    cb = 0;
+    tile = xcd * ((row_tiles + 7) >> 3) + j;
+    if (j >= ((row_tiles + 7) >> 3)) return false;
+  }
+  return tile < row_tiles;
+}
+static inline int conv16_grid_blocks(int ncb, int row_tiles) {
+  return 8 * (ncb == 2 ? ceil_div(row_tiles, 4) : ceil_div(row_tiles, 8));
+}
+
+// Epilogue shared by both kernels: per 16-row group, accumulator (col = lane&15, row = 4*(lane>>4)+t) -> LDS row-major
+// (wave-private transpose tile) -> one lane per (row, 8-channel unit): BN fold (incl. the weight scale), residual,
+// ReLU, split, store.  The 8 BN scales / shifts of an item are fetched with two 32-byte loads issued together (the
+// scalar form compiled to a load-wait pair per channel: 128 dependent round trips per wave and tile; measured
+// 4.49 -> 4.09 ms per step over the 21 convs, profiles/r02_call1_knockout_variants.txt).
+// tile_l: this wave's 16 x (16*EPN+4) fp32 LDS tile.  All rows of the wave: row0w .. row0w + 16*RG.
+template <int NT, int RG>
+struct Conv16Epi {
+  static constexpr int EPN = NT > 4 ? 4 : NT;            // column tiles per pass (keeps the transpose tile small)
+  static constexpr int RS = 16 * EPN + 4;
+  static constexpr int wave_bytes = 16 * RS * 4;
+};
+
+template <int NT, int RG>
+__device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], float* tile_l, int lane, int row0w,
+                                                int col0 /* first output channel of this workgroup */, int cout,
+                                                float winv, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, const uint4* __restrict__ residual,
+                                                uint4* __restrict__ ys, int n_out, int relu) {
+  using E = Conv16Epi<NT, RG>;
+  constexpr int EPN = E::EPN, RS = E::RS;
+  const int col = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+#pragma unroll
+    for (int ps = 0; ps < NT / EPN; ++ps) {
+      constexpr int UNITS = (16 * EPN) / 8;           // 8-channel units per row in this pass
+      constexpr int ITEMS = (16 * UNITS + 63) / 64;   // (row, unit) items per lane
+      // the residual rows of this pass are requested before the LDS transpose, so their latency hides behind it
+      uint4 res_hi[ITEMS], res_lo[ITEMS];
+      if (residual) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+          const int i = lane + 64 * it;
+          const int grow = row0w + rg * 16 + i / UNITS;
+          res_hi[it] = make_uint4(0, 0, 0, 0);
+          res_lo[it] = make_uint4(0, 0, 0, 0);
+          if (i < 16 * UNITS && grow < n_out) {
+            const size_t o = split_hi_index((size_t)grow, cout >> 3, (col0 + ps * (16 * EPN)) / 8 + i % UNITS);
+            res_hi[it] = residual[o];
+            res_lo[it] = residual[o + 4];
+          }
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < EPN; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tile_l[(4 * kg + t) * RS + nt * 16 + col] = acc[rg][ps * EPN + nt][t];
+      // wave-private tile: a wave-level fence is enough (LDS ops of one wave complete in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      for (int it = 0; it < ITEMS; ++it) {
+        const int i = lane + 64 * it;
+        const int r = i / UNITS, u = i % UNITS;
+        const int grow = row0w + rg * 16 + r;
+        if (i < 16 * UNITS && grow < n_out) {
+          const float* tp = tile_l + r * RS + u * 8;
+          f32x8 v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = tp[j];
+          const int gc = col0 + ps * (16 * EPN) + u * 8;
+          f32x8 sc8, sh8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { sc8[j] = 1.f; sh8[j] = 0.f; }
+          if (scale) sc8 = *reinterpret_cast<const f32x8*>(scale + gc);
+          if (shift) sh8 = *reinterpret_cast<const f32x8*>(shift + gc);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], scale ? sc8[j] * winv : winv, sh8[j]);
+          const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
+          if (residual) v += join8(res_hi[it], res_lo[it]);
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          uint4 hi, lo;
+          split8(v, hi, lo);
+          ys[o] = hi;
+          ys[o + 4] = lo;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+  }
+}
+
+// isf_spconv_ring.hip: the multi-stage ring kernel (gmask = per-16-row-group tap masks, see rb_group_masks)
+bool sparse_conv_ring_supported(int c_in, int c_out);
+int sparse_conv_forward_ring_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
+                                  int nbr_stride, int n_out, const uint32_t* gmask, const float* scale,
+                                  const float* shift, const void* residual, int relu, void* ys, int half,
+                                  hipStream_t st);
+
+}  // namespace isf

@@ -13,7 +13,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_next: GPU tests not yet run on hardware (see tests/test_gpu_next.py)")
 
 
 @pytest.fixture(scope="session")

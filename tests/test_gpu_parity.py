@@ -395,6 +395,40 @@ def test_encoder_training_mode_is_loud(dev):
 
 
 # ------------------------------------------------------------------------------------------- full size
+def test_full_size_numeric_parity_cfg2_frame(dev, oracle_mod):
+    """BASELINE configs[1] at FULL size, numerically: one 300k-point bench frame through the whole LiDAR branch, HIP vs
+    the C oracle (its conv loop runs on all host threads: seconds).  A failure class the small cases cannot see lives
+    here (tiles in every wave slot, the big-level workgroup shapes, prefetch rings at depth).  1e-3 on BEV features
+    (north_star), identical non-zero mask, per-layer voxel counts and pair counts exact; the frame is also run inside a
+    batch of 4 (the benchmark's shape) and must reproduce its single-frame bits."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    from isfusion_amd.norm import fold_bn
+    P = 300000
+    pts = synthetic.lidar_sweeps(1234 + 2000, P)            # bench.py frame 0
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval()
+    vfe = lb.pts_voxel_encoder
+    coors = np.concatenate([np.zeros((P, 1), np.int32), oracle_mod.dynamic_voxelize(pts, VS, RG)], 1)
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    ovf, ovc, _ = oracle_mod.dynamic_vfe(pts, coors, VS, RG, vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                         vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    obev, outs = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), ovf, ovc, 1)
+    lb = lb.to(dev)
+    out = lb([T(pts, dev)], want_stats=True)
+    st = lb.last_stats
+    got = out.cpu().numpy()
+    assert got.shape == obev.shape == (1, 512, 180, 180)
+    assert st.num_in[0] == len(ovc)
+    assert np.array_equal(got != 0, obev != 0), "non-zero BEV mask differs from the oracle"
+    err = np.abs(got - obev).max()
+    assert err < 1e-3, err
+    assert np.abs(obev).max() > 0.5
+    others = [T(synthetic.lidar_sweeps(1234 + 2000 + i, P), dev) for i in (1, 2, 3)]
+    out4 = lb([others[0], T(pts, dev), others[1], others[2]])
+    assert torch.equal(out4[1], out[0]), "the frame's bits depend on its batch"
+
+
 def test_full_size_properties_cfg2(dev):
     """BASELINE configs[1]: B=4 x 300k points.  No oracle at this size: size-independent properties."""
     import isfusion_amd as m

@@ -351,111 +351,3 @@ def test_assemble_points_block_partition_and_compaction(golden):
         ref = g[f"{n}.test.points"]
         got = out[sample_offsets[b]:sample_offsets[b + 1]]
         assert got.shape == ref.shape and np.array_equal(got, ref), n
-
-
-def test_conv_transposed_epilogue_lane_mapping():
-    """spconv_f16x3_kernel MODE 32 (ISF_CONV16_TEPI): with the MFMA operands swapped (weights as A, activations as B)
-    lane (r = lane & 15, g = lane >> 4) holds 4 consecutive channels 16nt + 4g.. of output row r, and its two 8-byte
-    stores land on the right halves of the split-format pieces (isf_common.h: split_hi_index, lo = hi + 4)"""
-    rng = np.random.default_rng(4)
-    cout, NT = 64, 4
-    X = rng.normal(size=(16, 32))                      # 16 output rows x one 32-channel chunk (already gathered)
-    W = rng.normal(size=(32, cout))
-    Y = X @ W
-
-    def mfma_16x16x32(a_frag, b_frag):
-        """a_frag[l][j] = A[m = l & 15][k = 8 (l >> 4) + j], b_frag[l][j] = B[k = 8 (l >> 4) + j][n = l & 15];
-        returns acc[l][t] = D[m = 4 (l >> 4) + t][n = l & 15]"""
-        A = np.zeros((16, 32))
-        Bm = np.zeros((32, 16))
-        for l in range(64):
-            for j in range(8):
-                A[l & 15, 8 * (l >> 4) + j] = a_frag[l][j]
-                Bm[8 * (l >> 4) + j, l & 15] = b_frag[l][j]
-        D = A @ Bm
-        return np.array([[D[4 * (l >> 4) + t, l & 15] for t in range(4)] for l in range(64)])
-
-    x_frag = np.array([[X[l & 15, 8 * (l >> 4) + j] for j in range(8)] for l in range(64)])   # the A fragment loads
-    c_units = cout // 8
-    n_rows = 16
-    buf = np.full((n_rows * c_units * 2, 8), np.nan)   # 16-byte pieces as 8 f16 slots; chunk = 4 hi + 4 lo pieces
-
-    def split_hi_index(row, c_units, u):
-        return (row * c_units + (u & ~3)) * 2 + (u & 3)
-
-    for nt in range(NT):
-        w_frag = np.array([[W[8 * (l >> 4) + j, 16 * nt + (l & 15)] for j in range(8)] for l in range(64)])
-        acc = mfma_16x16x32(w_frag, x_frag)             # operands swapped
-        for l in range(64):
-            r, g = l & 15, l >> 4
-            gc = 16 * nt + 4 * g
-            piece = split_hi_index(r, c_units, gc >> 3)
-            half = (gc >> 2) & 1
-            for t in range(4):
-                buf[piece, 4 * half + t] = acc[l][t]            # "hi" piece (values stand for their hi halves)
-                buf[piece + 4, 4 * half + t] = -acc[l][t]       # "lo" piece, marked by the sign
-    assert not np.isnan(buf).any(), "some half of the split buffer is never written"
-    for r in range(16):
-        for u in range(c_units):
-            p = split_hi_index(r, c_units, u)
-            assert np.allclose(buf[p], Y[r, 8 * u: 8 * u + 8]) and np.allclose(buf[p + 4], -Y[r, 8 * u: 8 * u + 8])
-
-
-def test_conv_wave_independent_pipeline_visits_items_in_order():
-    """spconv_f16x3_kernel MODE 128 (ISF_CONV16_WIND): the two-slot software pipeline over (tap, chunk) items must
-    process every item of the wave's tap mask exactly once, taps ascending, chunks ascending -- the summation order
-    of the default kernel.  Control flow restated statement by statement."""
-    rng = np.random.default_rng(9)
-    for NCH in (1, 2):
-        for _ in range(200):
-            wmask = int(rng.integers(0, 1 << 27)) if rng.random() > 0.1 else int(rng.integers(0, 4))
-            state = dict(rem=wmask, cur_tap=-1, cur_kc=NCH)
-
-            def nxt():
-                if state["cur_kc"] + 1 < NCH:
-                    state["cur_kc"] += 1
-                else:
-                    if state["rem"] == 0:
-                        return None
-                    state["cur_tap"] = (state["rem"] & -state["rem"]).bit_length() - 1     # __ffs(rem) - 1
-                    state["rem"] &= state["rem"] - 1
-                    state["cur_kc"] = 0
-                return (state["cur_tap"], state["cur_kc"])
-
-            done = []
-            i0 = nxt()
-            v0 = i0 is not None
-            while v0:                                # two slots (column tiles > 2)
-                i1 = nxt()                           # load_item(i1) -- issued before the MFMAs of i0
-                v1 = i1 is not None
-                done.append(i0)                      # mma_item(i0)
-                if not v1:
-                    break
-                i0 = nxt()                           # load_item(i0)
-                v0 = i0 is not None
-                done.append(i1)                      # mma_item(i1)
-            want = [(t, k) for t in range(27) if (wmask >> t) & 1 for k in range(NCH)]
-            assert done == want, (wmask, NCH)
-            # three slots (32-column layers)
-            state.update(rem=wmask, cur_tap=-1, cur_kc=NCH)
-            done = []
-            i0 = nxt()
-            v0 = i0 is not None
-            i1 = nxt() if v0 else None
-            v1 = v0 and i1 is not None
-            while v0:
-                i2 = nxt()
-                v2 = i2 is not None
-                done.append(i0)
-                if not v1:
-                    break
-                i0 = nxt()
-                v0 = i0 is not None
-                done.append(i1)
-                if not v2:
-                    break
-                i1 = nxt()
-                v1 = i1 is not None
-                done.append(i2)
-            want = [(t, k) for t in range(27) if (wmask >> t) & 1 for k in range(NCH)]
-            assert done == want, (wmask, NCH)
