@@ -199,15 +199,24 @@ int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_o
                            isf_stream_t stream);
 int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream);
 int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream);
+/* group_masks [nbr_stride / 16] (isf_rulebook_group_masks: bit k of entry g = some row of [16 g, 16 g + 16) has a
+ * neighbour through tap k; a property of the rulebook, built once and shared by every conv that uses it) lets the
+ * kernel skip staging the neighbour tile; NULL = derived inside the call when needed. */
+int isf_rulebook_group_masks(const int32_t* nbr, int nbr_stride, int num_taps, uint32_t* group_masks,
+                             isf_stream_t stream);
 int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
-                                  const float* scale, const float* shift, const void* residual_split, int relu,
-                                  void* out_split, isf_stream_t stream);
+                                  const uint32_t* group_masks /* or NULL */, const float* scale, const float* shift,
+                                  const void* residual_split, int relu, void* out_split, isf_stream_t stream);
 int isf_set_conv_precision(int mode);
 /* TIMING DIAGNOSTICS of the sparse-conv kernel (tools/conv_knockout.sh; never set in production): 0 = off (default),
  * 2 = no activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop.  The convolution RESULTS ARE
  * GARBAGE while a mode is set; only kernel times are meaningful. */
 int isf_set_conv_diagnostic(int mode);
+/* TUNING (tools/conv_sweep.py): enable = 0 runs the one-step-prefetch kernel everywhere, 1 the multi-stage ring
+ * kernel (isf_spconv_ring.hip: bit-identical results) wherever the rulebook's group masks are at hand; num_waves /
+ * row_groups / prefetch override the workgroup shape and prefetch distance the launcher would choose (0 = its choice). */
+int isf_tune_conv_ring(int enable, int num_waves, int row_groups, int prefetch);
 
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
  * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros

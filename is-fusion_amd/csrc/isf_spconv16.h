@@ -11,6 +11,13 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int kMaxTaps = 27;
 
+// narrow layers (CIN <= 64, <= 64 output columns) run all their 32-channel chunks in one step: half / the same
+// number of barriers for twice the MFMAs per barrier
+template <int CIN, int NT>
+struct Conv16Step {
+  static constexpr int KCH = (CIN <= 64 && NT <= 4) ? CIN / 32 : 1;      // 32-channel chunks per step
+};
+
 // LDS-DMA of 16 B per lane: LDS[lds_base + lane*16] = *gsrc.  Issued through inline asm on purpose: when hipcc
 // sees a global_load_lds it drains vmcnt(0) before every later ds_read (it cannot prove the buffers differ),
 // which would serialise the next step's weight/activation prefetch behind the current step's MFMAs.  Hidden
