@@ -137,7 +137,6 @@ def main():
     ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8],
                     help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_set_conv_diagnostic; "
                          "results are garbage, the line is labelled)")
-    ap.add_argument("--ring", default="", help="TUNING: run the ring conv kernel, optionally as NW,RG,PA (0 = launcher's choice)")
     ap.add_argument("--f16", action="store_true",
                     help="DIAGNOSTIC ONLY: single-pass f16 conv kernels (fp16-autocast accuracy, BASELINE configs[4] "
                          "dtype); reduced precision, never the headline line")
@@ -161,8 +160,6 @@ def main():
     from isfusion_amd import _lib
     _lib.check(_lib.load().isf_set_conv_precision(2 if args.f16 else 1 if args.fp32 else 0))
     _lib.check(_lib.load().isf_set_conv_diagnostic(args.conv_diag))
-    if args.ring:
-        _lib.check(_lib.load().isf_tune_conv_ring(1, *[int(v) for v in (args.ring + ",0,0,0").split(",")[:3]]))
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
     frames = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
     torch.cuda.synchronize()

@@ -199,24 +199,15 @@ int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_o
                            isf_stream_t stream);
 int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream);
 int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream);
-/* group_masks [nbr_stride / 16] (isf_rulebook_group_masks: bit k of entry g = some row of [16 g, 16 g + 16) has a
- * neighbour through tap k; a property of the rulebook, built once and shared by every conv that uses it) lets the
- * kernel skip staging the neighbour tile; NULL = derived inside the call when needed. */
-int isf_rulebook_group_masks(const int32_t* nbr, int nbr_stride, int num_taps, uint32_t* group_masks,
-                             isf_stream_t stream);
 int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
-                                  const uint32_t* group_masks /* or NULL */, const float* scale, const float* shift,
-                                  const void* residual_split, int relu, void* out_split, isf_stream_t stream);
+                                  const float* scale, const float* shift, const void* residual_split, int relu,
+                                  void* out_split, isf_stream_t stream);
 int isf_set_conv_precision(int mode);
 /* TIMING DIAGNOSTICS of the sparse-conv kernel (tools/conv_knockout.sh; never set in production): 0 = off (default),
  * 2 = no activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop.  The convolution RESULTS ARE
  * GARBAGE while a mode is set; only kernel times are meaningful. */
 int isf_set_conv_diagnostic(int mode);
-/* TUNING (tools/conv_sweep.py): enable = 0 runs the one-step-prefetch kernel everywhere, 1 the multi-stage ring
- * kernel (isf_spconv_ring.hip: bit-identical results) wherever the rulebook's group masks are at hand; num_waves /
- * row_groups / prefetch override the workgroup shape and prefetch distance the launcher would choose (0 = its choice). */
-int isf_tune_conv_ring(int enable, int num_waves, int row_groups, int prefetch);
 
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
  * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros
@@ -339,7 +330,29 @@ int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int
                       unsigned pool1_class_mask, int32_t* top_index, int32_t* top_index_raw, float* masked_heatmap,
                       isf_stream_t stream);
 
-/* A13  multi-scale deformable attention (one level) -----------------------------------------------------
+/* A13  multi-scale deformable attention with the op signature of mmcv -----------------------------------------
+ * replaces ext_module.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+ *   sampling_locations, attention_weights, im2col_step)
+ *   (mmdet3d/models/middle_encoders/multi_scale_deformable_attn_function.py:118-124; kernel
+ *   ms_deform_im2col_cuda.cuh:237-299); im2col_step only blocks the reference's batch loop and has no counterpart.
+ * value [B, num_keys, heads, hd]; spatial_shapes [L, 2] int64 (h, w); level_start_index [L] int64;
+ * sampling_loc [B, Q, heads, L, P, 2] (x, y) in [0, 1]; attn_weight [B, Q, heads, L, P] (post-softmax);
+ * out [B, Q, heads*hd].  Any head_dim / level / point count. */
+int isf_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* sampling_loc, const float* attn_weight, int batch_size, int num_keys,
+                               int num_heads, int head_dim, int num_queries, int num_levels, int num_points,
+                               float* out, isf_stream_t stream);
+
+/* A10  in-group (in-window) indices -------------------------------------------------------------------------
+ * replaces TorchEx ingroup_indices.forward(group_inds, out_inds)
+ *   (mmdet3d/ops/TorchEx/torchex/src/ingroup_inds/ingroup_inds.cpp:24-54, ingroup_inds_kernel.cu:17-31; called by
+ *   get_inner_win_inds_cuda, ops/sst/sst_ops.py:197-211): out_inds[i] = a distinct number in [0, count(group of i))
+ *   for every element.  The reference hands the numbers out with atomicAdd (any order); here out_inds[i] is the
+ *   number of EARLIER elements of the same group -- one of the reference's possible results, and deterministic.
+ * group_inds / out_inds [num] int64 (torch.long, as the reference op takes them). */
+int isf_ingroup_indices(const int64_t* group_inds, int num, int64_t* out_inds, isf_stream_t stream);
+
+/* A13  fused single-level form used by the InsContextAtt path -------------------------------------------------
  * replaces MultiScaleDeformableAttnFunction.forward (mmdet3d/ops/.../ms_deform_attn, called at
  * fusion_encoder.py:597) plus the softmax / location arithmetic of :585-596.
  * value [B, H*W, heads*hd]; sampling_offsets [B*Q, heads*P*2]; attention_logits [B*Q, heads*P] (pre-softmax);

@@ -112,11 +112,12 @@ SIGNATURES = {
     "isf_f32_to_split": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_split_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "isf_rulebook_group_masks": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "isf_set_conv_precision": (c_int, [c_int]),
+    "isf_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_ingroup_indices": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "isf_set_conv_diagnostic": (c_int, [c_int]),
-    "isf_tune_conv_ring": (c_int, [c_int, c_int, c_int, c_int]),
     "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p]),
     "isf_sparse_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, _I3,

@@ -129,8 +129,6 @@ int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shap
                int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_);
 int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], const int ks[3],
                     const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_);
-// gmask [nbr_stride / 16]: per-16-row-group tap masks of a neighbour table (see rb_group_masks_kernel)
-int launch_group_masks(const int32_t* nbr, int nbr_stride, int K, uint32_t* gmask, hipStream_t st);
 // isf_spconv.hip
 bool sparse_conv_mfma_supported(int c_in, int c_out);
 int pack_filters_impl(const float* w, int K, int cin, int cout, float* packed, hipStream_t st);
@@ -145,8 +143,8 @@ int sparse_conv_forward_generic_impl(const float* x, int c_in, const float* w, i
 // isf_spconv16.hip
 bool sparse_conv_f16x3_supported(int c_in, int c_out);
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
-                                   const int32_t* nbr, int nbr_stride, int n_out, const uint32_t* gmask /* or null */,
-                                   const float* scale, const float* shift, const void* residual, int relu, void* ys,
+                                   const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
+                                   const float* shift, const void* residual, int relu, void* ys,
                                    hipStream_t st);
 int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st);
 int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st);

@@ -144,7 +144,6 @@ struct LevelState {
   // SubM rulebook cache for this level (all SubM convs of one level share the active set)
   int cache_ks[3];
   int32_t* cache_nbr;
-  uint32_t* cache_gmask;   // per-16-row-group tap masks of cache_nbr (ring conv kernel)
   int cache_stride;
   long long cache_pairs;
 };
@@ -179,7 +178,6 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.has_occ = false;
   if (occ0) { L.occ = *occ0; L.has_occ = true; }
   L.cache_nbr = nullptr;
-  L.cache_gmask = nullptr;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
   bool use16 = g_conv_precision != 1;
   for (int i = 0; i < num_layers; ++i)
@@ -210,7 +208,6 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     ISF_REQUIRE(K >= 1 && K <= 27, ISF_ERR_UNSUPPORTED, "sparse_encoder: layer %d has %d taps", i, K);
     ISF_REQUIRE(ly.c_in == c_last, ISF_ERR_ARG, "sparse_encoder: layer %d expects %d channels, got %d", i, ly.c_in, c_last);
     int32_t* nbr = nullptr;
-    uint32_t* gmask = nullptr;
     int stride = 0;
     int n_out = L.n;
     int n_in = L.n;
@@ -223,17 +220,13 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
         ISF_TRY(launch_nbr(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
                            stride, pair_counts + i, sg));
-        ISF_TRY(a.alloc_n(&gmask, (size_t)stride / 16 + 1));
-        ISF_TRY(launch_group_masks(nbr, stride, K, gmask, sg));
         L.cache_nbr = nbr;
-        L.cache_gmask = gmask;
         L.cache_stride = stride;
         for (int j = 0; j < 3; ++j) L.cache_ks[j] = ly.ksize[j];
         L.cache_pairs = -(long long)i - 1;  // pairs live in pair_counts[i]; resolved after the final sync
         ISF_TRY(stream_wait_stream(st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
-        gmask = L.cache_gmask;
         stride = L.cache_stride;
       }
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
@@ -256,8 +249,6 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
       ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
                          stride, pair_counts + i, sg));
-      ISF_TRY(a.alloc_n(&gmask, (size_t)stride / 16 + 1));
-      ISF_TRY(launch_group_masks(nbr, stride, K, gmask, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_nbr = nullptr;
       n_out = Nx.n;
@@ -275,7 +266,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     }
     if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i], st));
     if (use16)
-      ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, gmask, ly.scale,
+      ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y, st));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
       ISF_TRY(sparse_conv_forward_packed_impl(reinterpret_cast<const float*>(x), n_in, ly.c_in, ly.packed, K,

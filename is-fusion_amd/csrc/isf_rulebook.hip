@@ -107,34 +107,6 @@ __global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restr
   if (!(*p & bit)) atomicOr(p, bit);
 }
 
-// Per-16-row-group tap masks of a neighbour table: bit k of gmask[g] = some row of [16 g, 16 g + 16) has a neighbour
-// through tap k.  The ring conv kernel (isf_spconv_ring.hip) reads its tile's masks from here instead of staging the
-// whole neighbour tile in LDS and balloting over it; built once per rulebook (all SubM convs of a level share it).
-// One lane per row, one wave per 4 groups; the K loads of a lane are coalesced across the wave.  nbr_stride % 128 == 0.
-__global__ __launch_bounds__(256) void rb_group_masks_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K,
-                                                             uint32_t* __restrict__ gmask) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  unsigned m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-  for (int k = 0; k < K; ++k) {
-    const int v = row < nbr_stride ? nbr[(size_t)k * nbr_stride + row] : -1;
-    const unsigned long long b = __ballot(v >= 0);
-    m0 |= ((b & 0xffffull) ? 1u : 0u) << k;
-    m1 |= (((b >> 16) & 0xffffull) ? 1u : 0u) << k;
-    m2 |= (((b >> 32) & 0xffffull) ? 1u : 0u) << k;
-    m3 |= (((b >> 48) & 0xffffull) ? 1u : 0u) << k;
-  }
-  const int g = (row - lane) / 16;
-  if (lane < 4 && (g + lane) * 16 < nbr_stride) gmask[g + lane] = lane == 0 ? m0 : lane == 1 ? m1 : lane == 2 ? m2 : m3;
-}
-
-int launch_group_masks(const int32_t* nbr, int nbr_stride, int K, uint32_t* gmask, hipStream_t st) {
-  if (nbr_stride <= 0) return ISF_OK;
-  hipLaunchKernelGGL(rb_group_masks_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st, nbr, nbr_stride, K, gmask);
-  ISF_LAUNCH_CHECK();
-  return ISF_OK;
-}
-
 static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[3], const int pd[3],
                            bool subm, int batch) {
   RbGeom g;

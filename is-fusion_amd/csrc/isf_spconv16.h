@@ -1,5 +1,5 @@
-// isf_spconv16.h -- device helpers shared by the f16x3 sparse-conv kernels (isf_spconv16.hip: one-step-prefetch kernel,
-// isf_spconv_ring.hip: multi-stage ring kernel): fragment types, LDS-DMA, the split format, and the common epilogue.
+// isf_spconv16.h -- device helpers of the f16x3 sparse-conv kernel (isf_spconv16.hip): fragment types, LDS-DMA, the
+// split format, the XCD-aware tile mapping and the epilogue.
 #pragma once
 #include "isf_common.h"
 
@@ -30,20 +30,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_bytes
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_base_bytes)
-      : "memory");
-}
-
-// 4 B per lane: LDS[lds_base + lane*4] = *gsrc (neighbour indices of a wave's rows)
-__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_base_bytes /* wave-uniform */) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dword %1, off\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base_bytes)
@@ -174,12 +160,5 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
     }
   }
 }
-
-// isf_spconv_ring.hip: the multi-stage ring kernel (gmask = per-16-row-group tap masks, see rb_group_masks)
-bool sparse_conv_ring_supported(int c_in, int c_out);
-int sparse_conv_forward_ring_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
-                                  int nbr_stride, int n_out, const uint32_t* gmask, const float* scale,
-                                  const float* shift, const void* residual, int relu, void* ys, int half,
-                                  hipStream_t st);
 
 }  // namespace isf

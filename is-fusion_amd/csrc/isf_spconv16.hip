@@ -31,7 +31,6 @@ namespace isf {
 
 extern int g_conv_precision;   // isf_encoder.hip: 0 f16x3 split (default), 1 fp32 MFMA, 2 single-pass f16 (opt-in)
 int g_conv_diag = 0;           // isf_set_conv_diagnostic: knock-out timing modes of the kernel below (results are garbage)
-int g_conv_ring = 0;           // isf_tune_conv_ring: 1 = the ring kernel runs wherever a rulebook carries group masks
 
 template <int NT, int RG, int KCH, int NW>
 struct Conv16Smem {
@@ -387,15 +386,10 @@ static int dispatch16(int mode, const uint4* xs, const uint4* wpk, const float* 
 
 // packed16 = K*Cin*Cout*4 bytes of fragments followed by a 64-byte header
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
-                                   const int32_t* nbr, int nbr_stride, int n_out, const uint32_t* gmask,
-                                   const float* scale, const float* shift, const void* residual, int relu, void* ys,
+                                   const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
+                                   const float* shift, const void* residual, int relu, void* ys,
                                    hipStream_t st) {
   if (n_out <= 0) return ISF_OK;
-  // the multi-stage ring kernel (isf_spconv_ring.hip) needs the rulebook's group masks; the timing diagnostics exist
-  // in the one-step-prefetch kernel below only
-  if (g_conv_ring && gmask && g_conv_diag == 0 && sparse_conv_ring_supported(c_in, c_out))
-    return sparse_conv_forward_ring_impl(xs, c_in, packed16, K, c_out, nbr, nbr_stride, n_out, gmask, scale, shift,
-                                         residual, relu, ys, g_conv_precision == 2, st);
   ISF_REQUIRE(K >= 1 && K <= kMaxTaps, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d taps (max 27)", K);
   ISF_REQUIRE(sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "sparse_conv16: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
@@ -483,34 +477,18 @@ int isf_set_conv_diagnostic(int mode) {
   return ISF_OK;
 }
 
-int isf_rulebook_group_masks(const int32_t* nbr, int nbr_stride, int num_taps, uint32_t* group_masks,
-                             isf_stream_t stream) {
-  ISF_REQUIRE(nbr && group_masks && nbr_stride > 0 && nbr_stride % 128 == 0 && num_taps >= 1 && num_taps <= 27,
-              ISF_ERR_ARG, "rulebook_group_masks: bad arguments");
-  return isf::launch_group_masks(nbr, nbr_stride, num_taps, group_masks, isf::as_stream(stream));
-}
-
 int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
-                                  const uint32_t* group_masks, const float* scale, const float* shift,
-                                  const void* residual_split, int relu, void* out_split, isf_stream_t stream) {
+                                  const float* scale, const float* shift, const void* residual_split, int relu,
+                                  void* out_split, isf_stream_t stream) {
   ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0, ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: bad arguments");
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  hipStream_t st = isf::as_stream(stream);
-  const uint32_t* gmask = group_masks;
-  if (isf::g_conv_ring && !gmask) {   // the rulebook arrives without its group masks: build them (one pass over the table)
-    uint32_t* gm = nullptr;
-    isf::Arena& a = isf::arena_for_current_device();
-    ISF_TRY(a.reset());
-    ISF_TRY(a.alloc_n(&gm, (size_t)nbr_stride / 16 + 1));
-    ISF_TRY(isf::launch_group_masks(nbr, nbr_stride, num_taps, gm, st));
-    gmask = gm;
-  }
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
-                                             num_out, gmask, scale, shift, residual_split, relu, out_split, st);
+                                             num_out, scale, shift, residual_split, relu, out_split,
+                                             isf::as_stream(stream));
 }
 
 }  // extern "C"

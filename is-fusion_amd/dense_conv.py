@@ -62,10 +62,7 @@ def grid_rulebook(device, B, H, W, stride=1, transpose=False):
         nbr = torch.empty((9, nstride), dtype=torch.int32, device=device)
         _lib.check(lib.isf_dense_grid_rulebook(B, H, W, 3, 3, stride, 1, int(transpose), _lib.ptr(nbr), nstride, ohw,
                                                _lib.stream()), "isf_dense_grid_rulebook")
-        gmask = torch.empty((nstride // 16 + 1,), dtype=torch.int32, device=device)
-        _lib.check(lib.isf_rulebook_group_masks(_lib.ptr(nbr), nstride, 9, _lib.ptr(gmask), _lib.stream()),
-                   "isf_rulebook_group_masks")
-        _grids[key] = (nbr, nstride, ohw[0], ohw[1], gmask)
+        _grids[key] = (nbr, nstride, ohw[0], ohw[1])
     return _grids[key]
 
 
@@ -110,7 +107,7 @@ class PackedConvBN:
         maps = inputs if isinstance(inputs, (list, tuple)) else [inputs]
         assert len(maps) == len(self.groups), "one SplitMap per 256-channel group"
         m0 = maps[0]
-        nbr, nstride, oh, ow, gmask = grid_rulebook(m0.data.device, m0.B, m0.H, m0.W, self.stride, False)
+        nbr, nstride, oh, ow = grid_rulebook(m0.data.device, m0.B, m0.H, m0.W, self.stride, False)
         n_out = m0.B * oh * ow
         lib = _lib.load()
         acc = None
@@ -120,7 +117,7 @@ class PackedConvBN:
             out = torch.empty(n_out * self.c_out * 4, dtype=torch.uint8, device=m.data.device)
             _lib.check(lib.isf_sparse_conv_forward_f16x3(
                 _lib.ptr(m.data), m.num_tokens, c, _lib.ptr(pkt if transpose else pk), 9, self.c_out, _lib.ptr(nbr),
-                nstride, n_out, _lib.ptr(gmask), _lib.ptr(self.scale), _lib.ptr(self.shift if last else self.zero_shift),
+                nstride, n_out, _lib.ptr(self.scale), _lib.ptr(self.shift if last else self.zero_shift),
                 _lib.ptr(acc) if acc is not None else None, int(self.relu and last), _lib.ptr(out), _lib.stream()),
                 "isf_sparse_conv_forward_f16x3")
             acc = out

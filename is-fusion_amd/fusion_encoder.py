@@ -58,12 +58,10 @@ class ISFusionEncoder(nn.Module):
     def _conv(self, name):
         """ConvModule `name` packed for the f16x3 kernel (cached per device)"""
         mod = getattr(self, name)
-        cache = self.__dict__.setdefault("_isf_packed", {})
-        ops.watch_parameters(self)
-        dev = mod.conv.weight.device
-        if cache.get(name, (None,))[0] != dev:
-            cache[name] = (dev, PackedConvBN(mod.conv, mod.bn, relu=True))
-        return cache[name][1]
+        c = ops._cache(mod, mod.conv.weight.device)     # dropped when the conv / BN tensors change
+        if "packed" not in c:
+            c["packed"] = PackedConvBN(mod.conv, mod.bn, relu=True)
+        return c["packed"]
 
     def img_fv_to_bev(self, mlvl_feats, bs, **kwargs):
         """A8 Point-to-Grid: one kernel over (pillar, slot, camera) instead of B*6 grid_sample calls."""

@@ -1,8 +1,10 @@
-"""Parameter containers of the HSF / IGF modules with the REFERENCE's sub-module and parameter names, so that
-``state_dict()`` keys equal those of mmdet3d/models/middle_encoders/fusion_encoder.py, models/sst/*,
-models/backbones/{sst_v2,second}.py and a released IS-Fusion checkpoint loads unchanged.  The arithmetic lives in
-``fusion_encoder.py`` (HIP kernels through the C ABI); the stock 3x3 convolutions stay on PyTorch-ROCm / MIOpen as
-the north_star prescribes.
+"""The HSF / IGF modules with the REFERENCE's sub-module and parameter names (``state_dict()`` keys equal those of
+mmdet3d/models/middle_encoders/fusion_encoder.py, models/sst/*, models/backbones/{sst_v2,second}.py, so a released
+IS-Fusion checkpoint loads unchanged) and the reference's ``forward()`` signatures.  The arithmetic lives in
+``fusion_ops.py`` / ``fusion_encoder.py`` (HIP kernels through the C ABI).  Eval mode, GPU tensors only: a CPU tensor
+or training mode raises.  SSTInputLayerV2 / SSTv2 implement the case the IS-Fusion path feeds them -- EVERY cell of the
+BEV grid is a token (fusion_encoder.py:1167-1181), where window membership is arithmetic -- and raise on a sparse token
+set instead of silently doing something else.
 """
 import torch
 from torch import nn
@@ -69,16 +71,65 @@ class SSTv2(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def forward(self, voxel_info, **kwargs):
+        """sst_v2.py:65-91: voxel_info from SSTInputLayerV2 -> [ [B, d, ny, nx] ] (the recovered BEV map)."""
+        from . import fusion_ops as ops
+        if self.training:
+            raise RuntimeError("isfusion_amd.SSTv2 is the inference path (eval mode)")
+        grid = voxel_info.get("dense_grid")
+        if grid is None:
+            raise _not_dense("SSTv2.forward")
+        B, ny, nx = grid
+        feats = voxel_info["voxel_feats"]
+        ny_o, nx_o = self.output_shape
+        assert (ny, nx) == (ny_o, nx_o) and ny == nx, "output_shape must be the (square) token grid"
+        bev = feats.view(B, ny, nx, feats.size(1)).permute(0, 3, 1, 2)     # read channels-first inside the GEMMs
+        return [ops.sstv2_forward(self, bev, voxel_info["window_shape"][0], voxel_info["pos_temperature"])]
+
+
+def _not_dense(where):
+    from . import _lib
+    return _lib.IsfError(f"{where}: this build implements the dense-grid case of the IS-Fusion path (every BEV cell "
+                         "is a token, in (b, y, x) order: fusion_encoder.py:1167-1173); a sparse token set needs the "
+                         "reference's window batching and is not built")
+
 
 class SSTInputLayerV2(nn.Module):
-    """models/sst/sst_input_layer_v2.py: no parameters; on a dense grid window membership is arithmetic."""
+    """models/sst/sst_input_layer_v2.py:20-110.  No parameters.  On the dense grid of the IS-Fusion path nothing is
+    dropped (max_tokens = the full window) and window membership / in-window position are arithmetic on (y, x), so the
+    voxel_info handed to SSTv2 carries the grid instead of index tensors."""
 
     def __init__(self, window_shape, sparse_shape, drop_info=None, shuffle_voxels=True, pos_temperature=1000,
                  normalize_pos=False, pos_embed=None, **kwargs):
         super().__init__()
         self.window_shape, self.sparse_shape = window_shape, sparse_shape
         self.pos_temperature, self.pos_embed_channels = pos_temperature, pos_embed
+        self.meta_drop_info = drop_info
         assert not normalize_pos
+
+    def forward(self, voxel_feats, voxel_coors, batch_size=None):
+        """voxel_feats [N, C]; voxel_coors [N, 4] (b, z, y, x) -> voxel_info dict (sst_input_layer_v2.py:63-110).
+        N must be B * ny * nx with the rows in (b, y, x) order (checked on the device)."""
+        from . import _lib
+        _lib.require_cuda(voxel_feats, voxel_coors)
+        nx, ny = int(self.sparse_shape[0]), int(self.sparse_shape[1])
+        N = voxel_feats.size(0)
+        B = int(batch_size) if batch_size is not None else N // max(nx * ny, 1)
+        if B <= 0 or N != B * ny * nx:
+            raise _not_dense("SSTInputLayerV2.forward")
+        c = voxel_coors.long()
+        r = torch.arange(N, device=c.device)
+        ok = (c[:, 0] == r // (ny * nx)) & (c[:, 2] == (r // nx) % ny) & (c[:, 3] == r % nx)
+        if not bool(ok.all()):
+            raise _not_dense("SSTInputLayerV2.forward")
+        win = self.window_shape
+        for lvl in (self.meta_drop_info or {}).values() if isinstance(self.meta_drop_info, dict) else ():
+            info = lvl.get(0, lvl) if isinstance(lvl, dict) else lvl
+            if isinstance(info, dict) and info.get("max_tokens", win[0] * win[1]) < win[0] * win[1]:
+                raise _lib.IsfError("SSTInputLayerV2: drop_info would drop tokens of a full window (max_tokens < "
+                                    "window size): region batching with drops is not built")
+        return dict(voxel_feats=voxel_feats.float().contiguous(), voxel_coors=c, dense_grid=(B, ny, nx),
+                    window_shape=tuple(win), pos_temperature=float(self.pos_temperature))
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -97,6 +148,37 @@ class MSDeformAttn(nn.Module):
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """fusion_encoder.py:560-600 (reference_points [..., 2]): -> (output [N, Lq, C], sampling_locations,
+        attention_weights).  Projections on the fused linear kernel, sampling through isf_ms_deform_attn_forward (the
+        mmcv op signature, any number of levels)."""
+        from . import fusion_ops as ops
+        if self.training:
+            raise RuntimeError("isfusion_amd.MSDeformAttn is the inference path (eval mode)")
+        N, Lq, C = query.shape
+        Lin = input_flatten.shape[1]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        assert reference_points.shape[-1] == 2, "reference boxes (last dim 4) are not on the IS-Fusion path"
+        c = ops._cache(self, query.device)
+        if "value" not in c:
+            for name, lin in (("value", self.value_proj), ("off", self.sampling_offsets), ("aw", self.attention_weights),
+                              ("out", self.output_proj)):
+                c[name] = ops.PackedLinear(lin.weight, lin.bias)
+        q2 = query.reshape(N * Lq, C).float().contiguous()
+        value = ops.linear(input_flatten.reshape(N * Lin, C).float().contiguous(), c["value"])
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask.reshape(N * Lin, 1), 0.0)
+        off = ops.linear(q2, c["off"]).view(N, Lq, M, L, P, 2)
+        aw = torch.softmax(ops.linear(q2, c["aw"]).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        shapes = input_spatial_shapes.to(query.device).long()
+        normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).float()
+        loc = reference_points[:, :, None, :, None, :].float() + off / normalizer[None, None, None, :, None, :]
+        out = ops.ms_deform_attn(value.view(N, Lin, M, C // M), shapes, input_level_start_index.to(query.device).long(),
+                                 loc, aw)
+        out = ops.linear(out.view(N * Lq, C), c["out"]).view(N, Lq, C)
+        return out, loc, aw
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
@@ -120,6 +202,18 @@ class InsContextAtt(nn.Module):
         self.query_pos_embed = PositionEmbeddingLearned(2, embed_dims)
         self.key_pos_embed = PositionEmbeddingLearned(2, embed_dims)
 
+    def forward(self, query_feats, query_pos, bev_pos=None, scene_feats=None, **kwargs):
+        """fusion_encoder.py:795-830: query_feats [B, E, Q], query_pos [B, Q, 2] (x, y in cells), bev_pos = the
+        create_2D_grid cell centres [1, H*W, 2] (recomputed here; checked when given), scene_feats [B, E, H, W] in the
+        orientation the REFERENCE passes (it is transposed inside, :797) -> [B, E, Q]."""
+        from . import fusion_ops as ops
+        if self.training:
+            raise RuntimeError("isfusion_amd.InsContextAtt is the inference path (eval mode)")
+        if bev_pos is not None:
+            assert bev_pos.shape[-2] == self.bev_size * self.bev_size, "bev_pos must be the bev_size x bev_size grid"
+        scene_t = scene_feats.permute(0, 1, 3, 2).contiguous()
+        return ops.ins_context_att(self, query_feats, query_pos, scene_t, self.bev_size)
+
 
 class Instane2SceneAtt(nn.Module):
     def __init__(self, d_model, nhead=8):
@@ -127,6 +221,16 @@ class Instane2SceneAtt(nn.Module):
         self.nhead = nhead
         self.multihead_attn = _SelfAttn(d_model)
         self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, query, key, query_scene, bs, bev_size, attn_mask=None):
+        """fusion_encoder.py:480-502: query [B, E, H*W] (conv_ins output, flattened), key [B, E, Q] (instances),
+        query_scene [B, E, H, W] -> [B, E, H, W]."""
+        from . import fusion_ops as ops
+        if self.training:
+            raise RuntimeError("isfusion_amd.Instane2SceneAtt is the inference path (eval mode)")
+        assert attn_mask is None, "attn_mask is not used on the IS-Fusion path"
+        E = query.shape[1]
+        return ops.instance_to_scene(self, query.reshape(bs, E, bev_size, bev_size), key, query_scene, bev_size)
 
 
 class SECONDV2(nn.Module):
@@ -157,12 +261,12 @@ class SECONDV2(nn.Module):
 
     def _packed(self, name, seq):
         from .dense_conv import pack_sequential
-        from .fusion_ops import watch_parameters
+        from .fusion_ops import param_key
         cache = self.__dict__.setdefault("_isf_packed", {})
-        watch_parameters(self)
         dev = next(seq.parameters()).device
-        if cache.get(name, (None,))[0] != dev:
-            cache[name] = (dev, pack_sequential(seq))
+        key = (dev, None if self.__dict__.get("_isf_frozen", False) and name in cache else param_key(seq))
+        if name not in cache or cache[name][0][0] != dev or (key[1] is not None and cache[name][0][1] != key[1]):
+            cache[name] = ((dev, key[1] if key[1] is not None else param_key(seq)), pack_sequential(seq))
         return cache[name][1]
 
     def _run(self, name, seq, x):
@@ -286,7 +390,10 @@ class SECONDFPN(nn.Module):
         if self.dense_conv == "hip" and not self.training:
             from . import fusion_ops as ops
             cache = self.__dict__.setdefault("_isf_packed", {})
-            ops.watch_parameters(self)
+            pk = None if self.__dict__.get("_isf_frozen", False) and cache else ops.param_key(self)
+            if pk is not None and cache.get("_key") != pk:
+                cache.clear()
+                cache["_key"] = pk
 
             def linear_relu(t, w, b):
                 key = (w.shape[0], w.shape[1], t.device)

@@ -80,22 +80,35 @@ def drop_caches(module, *_):
         sub.__dict__.pop("_isf_packed", None)
 
 
-def watch_parameters(module):
-    """Packed weights are cached per device; a load_state_dict() into the module (or into any ancestor: the post
-    hooks run for every module of the recursion, children first) must invalidate them -- otherwise a checkpoint
-    loaded after the first forward would be ignored silently."""
-    if not module.__dict__.get("_isf_watched", False):
-        module.register_load_state_dict_post_hook(drop_caches)
-        module.__dict__["_isf_watched"] = True
+def param_key(module):
+    """(version, address) of every parameter and buffer below `module`: changes whenever one of them is replaced or
+    written in place -- by load_state_dict (mmcv's load_checkpoint recurses over _load_from_state_dict and never fires
+    the post hooks), an optimizer step or a manual copy_()."""
+    return tuple((t._version, t.data_ptr()) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def freeze(module, flag=True):
+    """Inference deployments: skip the per-call "did a parameter change?" scan of the caches below `module`."""
+    for sub in module.modules():
+        sub.__dict__["_isf_frozen"] = bool(flag)
+    return module
 
 
 def _cache(module, device):
+    """Per-module cache of packed weights / tables derived from its parameters, dropped when the device or any
+    parameter / buffer below the module changed (SparseEncoder._c_plan keys its plan the same way)."""
     c = module.__dict__.get("_isf_cache")
-    if c is None or c.get("device") != device:
-        c = {"device": device}
+    frozen = module.__dict__.get("_isf_frozen", False)
+    key = None if (frozen and c is not None) else param_key(module)
+    if c is None or c.get("device") != device or (key is not None and c.get("_key") != key):
+        c = {"device": device, "_key": key if key is not None else param_key(module)}
         module.__dict__["_isf_cache"] = c
-        watch_parameters(module)
     return c
+
+
+def watch_parameters(module):
+    """kept for callers that cache outside _cache(): nothing to register, validity is checked through param_key"""
+    return module
 
 
 def to_tokens(x):
@@ -288,6 +301,37 @@ def msda(value, offsets, logits, ref, B, Q, nhead, hd, npts, H, W):
     out = torch.empty((B * Q, nhead * hd), dtype=torch.float32, device=value.device)
     _lib.check(_lib.load().isf_msda_forward(_lib.ptr(value), _lib.ptr(offsets), _lib.ptr(logits), _lib.ptr(ref), B, Q,
                                             nhead, hd, npts, H, W, _lib.ptr(out), _lib.stream()), "isf_msda_forward")
+    return out
+
+
+def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    """MultiScaleDeformableAttnFunction.forward with mmcv's argument list
+    (multi_scale_deformable_attn_function.py:84-128; im2col_step has no counterpart): value [B, S, M, D],
+    spatial_shapes [L, 2] long (h, w), level_start_index [L] long, sampling_locations [B, Q, M, L, P, 2],
+    attention_weights [B, Q, M, L, P] -> [B, Q, M*D]."""
+    _lib.require_cuda(value, sampling_locations, attention_weights)
+    v = value.float().contiguous()
+    loc, aw = sampling_locations.float().contiguous(), attention_weights.float().contiguous()
+    ss = spatial_shapes.to(v.device).long().contiguous()
+    ls = level_start_index.to(v.device).long().contiguous()
+    B, S, M, D = v.shape
+    Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    assert tuple(loc.shape) == (B, Q, M, L, P, 2) and tuple(aw.shape) == (B, Q, M, L, P) and ss.shape == (L, 2)
+    out = torch.empty((B, Q, M * D), dtype=torch.float32, device=v.device)
+    _lib.check(_lib.load().isf_ms_deform_attn_forward(_lib.ptr(v), _lib.ptr(ss), _lib.ptr(ls), _lib.ptr(loc), _lib.ptr(aw),
+                                                      B, S, M, D, Q, L, P, _lib.ptr(out), _lib.stream()),
+               "isf_ms_deform_attn_forward")
+    return out
+
+
+def ingroup_indices(group_inds):
+    """IngroupIndicesFunction / get_inner_win_inds_cuda (ops/sst/sst_ops.py:197-211): group_inds [N] long ->
+    out_inds [N] long, out_inds[i] = number of earlier elements of the same group (deterministic)."""
+    _lib.require_cuda(group_inds)
+    g = group_inds.long().contiguous()
+    out = torch.empty_like(g)
+    _lib.check(_lib.load().isf_ingroup_indices(_lib.ptr(g), g.numel(), _lib.ptr(out), _lib.stream()),
+               "isf_ingroup_indices")
     return out
 
 

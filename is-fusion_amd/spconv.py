@@ -86,17 +86,6 @@ class Rulebook:
         self.nbr, self.stride = nbr, stride
         self.num_in, self.num_out = num_in, num_out
         self.out_indices, self.out_shape = out_indices, out_shape
-        self._gmask = None
-
-    def group_masks(self):
-        """per-16-row-group tap masks of the table (isf_rulebook_group_masks), built once per rulebook"""
-        if self._gmask is None:
-            K = self.nbr.numel() // self.stride
-            g = torch.empty((self.stride // 16 + 1,), dtype=torch.int32, device=self.nbr.device)
-            _lib.check(_lib.load().isf_rulebook_group_masks(_lib.ptr(self.nbr), self.stride, K, _lib.ptr(g), _lib.stream()),
-                       "isf_rulebook_group_masks")
-            self._gmask = g
-        return self._gmask
 
 
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, subm):
@@ -184,8 +173,7 @@ def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None
     lib = _lib.load()
     _lib.check(lib.isf_sparse_conv_forward_f16x3(
         _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-        _lib.ptr(rb.group_masks()), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys),
-        _lib.stream()),
+        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), _lib.stream()),
         "isf_sparse_conv_forward_f16x3")
     return from_split(ys, (rb.num_out, c_out))
 

@@ -116,11 +116,8 @@ class TransFusionHeadV2(nn.Module):
         return torch.stack([bx, by], 0).view(1, 2, -1).permute(0, 2, 1)
 
     def _packed(self, device):
-        c = self.__dict__.setdefault("_isf_packed", {})
-        ops.watch_parameters(self)
-        if c.get("device") != device:
-            c.clear()
-            c["device"] = device
+        c = ops._cache(self, device)                    # dropped when any parameter / buffer of the head changes
+        if "shared" not in c:
             c["shared"] = PackedConvBN(self.shared_conv, None, relu=False)
             c["hm0"] = PackedConvBN(self.heatmap_head[0].conv, self.heatmap_head[0].bn, relu=True)
             bev_pos = self._bev_pos(device)

@@ -360,3 +360,109 @@ def test_transfusion_head_matches_reference_golden(dev, golden, name, dense):
         assert np.abs(got - g[f"{name}.{k}"]).max() < 1e-3, k      # north_star tolerance (fp32, 1e-3)
     dh = out["dense_heatmap"].reshape(-1).cpu().numpy()
     assert np.abs(dh[g[name + ".dense_heatmap.idx"]] - g[name + ".dense_heatmap.val"]).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------- op / module boundary (8b)
+@pytest.mark.parametrize("B,Q,M,D,shapes,P", [(2, 50, 8, 16, [(20, 30), (10, 15)], 4), (1, 200, 8, 16, [(180, 180)], 16),
+                                              (1, 7, 4, 32, [(9, 5), (5, 3), (3, 2)], 3)])
+def test_ms_deform_attn_with_the_mmcv_signature(dev, B, Q, M, D, shapes, P):
+    """isf_ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight): several levels,
+    any head_dim / point count, locations partly outside the maps -- vs the restatement of the reference kernel"""
+    from isfusion_amd import fusion_ops as ops
+    from oracle import fusion_ops as orc
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = rnd((B, S, M, D), 160)
+    g = torch.Generator().manual_seed(161)
+    loc = torch.rand((B, Q, M, L, P, 2), generator=g) * 1.3 - 0.15
+    aw = torch.rand((B, Q, M, L * P), generator=g).softmax(-1).view(B, Q, M, L, P)
+    ss = torch.tensor(shapes, dtype=torch.long)
+    ls = torch.cat([ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]])
+    out = ops.ms_deform_attn(value.to(dev), ss.to(dev), ls.to(dev), loc.to(dev), aw.to(dev)).cpu()
+    ref = orc.msda_core(value, ss, loc, aw)
+    assert out.shape == ref.shape == (B, Q, M * D)
+    assert (out - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("n,groups,seed", [(1, 1, 0), (5000, 37, 1), (129600, 3844, 2), (777, 5, 3)])
+def test_ingroup_indices_first_come_rank(dev, n, groups, seed):
+    """isf_ingroup_indices == TorchEx ingroup_indices.forward up to the order inside a group (the reference numbers
+    with atomicAdd): every group's numbers are exactly 0..count-1, and here they follow input order"""
+    from isfusion_amd import fusion_ops as ops
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, groups, n).astype(np.int64)
+    if n > 10:
+        g[:3] = groups + 5          # a group id above the others; ids need not be dense
+    out = ops.ingroup_indices(torch.from_numpy(g).to(dev)).cpu().numpy()
+    want = np.zeros(n, np.int64)
+    seen = {}
+    for i, v in enumerate(g.tolist()):
+        want[i] = seen.get(v, 0)
+        seen[v] = want[i] + 1
+    assert np.array_equal(out, want)
+    assert ops.ingroup_indices(torch.zeros((0,), dtype=torch.long, device=dev)).numel() == 0
+
+
+def test_sst_modules_forward_like_the_reference(dev):
+    """SSTInputLayerV2.forward(voxel_feats, voxel_coors, batch_size) -> SSTv2.forward(voxel_info) -> [BEV map]
+    (sst_input_layer_v2.py:63, sst_v2.py:65; the call sequence of fusion_encoder.py:1179-1181) on the dense token grid,
+    vs the restatement; a sparse token set raises instead of computing something else"""
+    from isfusion_amd import _lib
+    from oracle import fusion_ops as orc
+    cfg = CONFIGS["small"]
+    enc, _ = build_modules(cfg, dev)
+    sd, _ = state_dicts(cfg)
+    B, S = cfg["B"], cfg["bev"]
+    x0 = rnd((B, 128, S, S), 170, 0.5)
+    feats = x0.permute(0, 2, 3, 1).reshape(B * S * S, 128).to(dev)
+    bb, yy, xx = torch.meshgrid(torch.arange(B), torch.arange(S), torch.arange(S), indexing="ij")
+    coors = torch.stack([bb, torch.zeros_like(bb), yy, xx], -1).reshape(-1, 4).to(dev)
+    info = enc.get_regions[0](feats, coors, B)
+    assert info["voxel_coors"].dtype == torch.int64 and info["dense_grid"] == (B, S, S)
+    out = enc.grid2region_att[0](info)
+    assert isinstance(out, list) and tuple(out[0].shape) == (B, 128, S, S)
+    ref = orc.sstv2_forward(x0, sd, "grid2region_att.0")
+    assert (out[0].cpu() - ref).abs().max().item() < 1e-4
+    with pytest.raises(_lib.IsfError):
+        enc.get_regions[0](feats[:-5], coors[:-5], B)                      # not every cell is a token
+    with pytest.raises(_lib.IsfError):
+        enc.get_regions[0](feats, coors.flip(0), B)                        # not in (b, y, x) order
+
+
+def test_igf_modules_forward_like_the_reference(dev):
+    """MSDeformAttn.forward / InsContextAtt.forward / Instane2SceneAtt.forward with the reference's argument lists
+    (fusion_encoder.py:560, :795, :480) agree with the restatements"""
+    from isfusion_amd import fusion_ops as ops
+    from oracle import fusion_ops as orc
+    cfg = CONFIGS["small"]
+    enc, _ = build_modules(cfg, dev)
+    sd, _ = state_dicts(cfg)
+    B, S, E, Q = cfg["B"], cfg["bev"], 128, cfg["instance_num"]
+    scene = rnd((B, E, S, S), 180, 0.5)
+    x_ins = rnd((B, E, Q), 181, 0.5)
+    qpos = torch.rand((B, Q, 2), generator=torch.Generator().manual_seed(182)) * S
+    bev_pos = orc.bev_pos_grid(S)
+    got = enc.instance_att(x_ins.to(dev), qpos.to(dev), bev_pos.to(dev), scene_feats=scene.to(dev)).cpu()
+    ref = orc.ins_context_att(x_ins, qpos, bev_pos, scene, sd, "instance_att", S)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-4
+    # MSDeformAttn alone, two levels (more than the path uses)
+    msda = enc.instance_att.layers[0].cross_attn
+    shapes = torch.tensor([[S, S]], dtype=torch.long)
+    src = rnd((B, S * S, E), 183, 0.5)
+    qry = rnd((B, Q, E), 184, 0.5)
+    refp = torch.rand((B, Q, 1, 2), generator=torch.Generator().manual_seed(185))
+    out, loc, aw = msda(qry.to(dev), refp.to(dev), src.to(dev), shapes.to(dev), torch.zeros((1,), dtype=torch.long, device=dev))
+    pre = "instance_att.layers.0.cross_attn."
+    lin = lambda t, n: t @ sd[pre + n + ".weight"].t() + sd[pre + n + ".bias"]
+    value = lin(src, "value_proj").view(B, S * S, 8, 16)
+    off = lin(qry, "sampling_offsets").view(B, Q, 8, 1, msda.n_points, 2)
+    aw_ref = lin(qry, "attention_weights").view(B, Q, 8, msda.n_points).softmax(-1).view(B, Q, 8, 1, msda.n_points)
+    loc_ref = refp[:, :, None, :, None, :] + off / torch.tensor([S, S], dtype=torch.float32)
+    want = lin(orc.msda_core(value, shapes, loc_ref, aw_ref), "output_proj")
+    assert (loc.cpu() - loc_ref).abs().max().item() < 1e-4 and (aw.cpu() - aw_ref).abs().max().item() < 1e-5
+    assert (out.cpu() - want).abs().max().item() < 2e-4
+    # Instane2SceneAtt with the reference's flattened query
+    query = rnd((B, E, S, S), 186, 0.5)
+    got = enc.instance_to_scene_att(query.flatten(2).to(dev), x_ins.to(dev), scene.to(dev), B, S).cpu()
+    ref = orc.instance_to_scene(query.flatten(2), x_ins, scene, sd, "instance_to_scene_att", B, S)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-3

@@ -385,70 +385,6 @@ def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
     assert lb.last_stats.pairs[0] == pairs0 and lb.last_stats.pairs[1] == pairs0
 
 
-RING_SHAPES = [(32, 32), (64, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256)]
-
-
-@pytest.mark.parametrize("cin,cout", RING_SHAPES)
-def test_ring_conv_kernel_reproduces_one_step_kernel_bits(dev, cin, cout):
-    """isf_spconv_ring.hip (multi-stage ring, hidden loads, counted waits) vs the validated one-step-prefetch kernel:
-    same products in the same order => the split outputs must be bit-identical.  SubM 27 taps with residual, a strided
-    conv, and the (3,1,1) conv_out geometry; row counts that leave ragged last tiles for every workgroup shape; every
-    built (waves, row groups, prefetch distance)."""
-    from isfusion_amd import _lib, spconv
-    lib = _lib.load()
-    rng = np.random.default_rng(cin * 7 + cout)
-    B, shape = 2, [11, 40, 40]
-    n = 5000 + int(rng.integers(0, 300))
-    cells = np.sort(rng.choice(B * shape[0] * shape[1] * shape[2], n, replace=False))
-    idx = T(np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32), dev)
-    geoms = [("subm", [3, 3, 3], [1, 1, 1], [1, 1, 1], True), ("s2", [3, 3, 3], [2, 2, 2], [1, 1, 1], False),
-             ("out", [3, 1, 1], [2, 1, 1], [0, 0, 0], False)]
-    nt, kch = min(cout // 16, 8), (cin // 32 if (cin <= 64 and cout <= 64) else 1)
-    configs = [c for c in [(4, 2, 1), (4, 2, 2), (4, 2, 3), (8, 2, 1), (8, 2, 2), (8, 2, 3), (4, 3, 2), (8, 3, 2)]
-               if (kch * nt * 2) % c[0] == 0]
-    try:
-        for name, ks, st, pd, subm in geoms:
-            rb = spconv.build_rulebook(idx, B, shape, ks, st, pd, subm)
-            K = int(np.prod(ks))
-            x = T(rng.normal(size=(rb.num_in, cin)).astype(np.float32), dev)
-            w = T((rng.normal(size=(*ks, cin, cout)) / np.sqrt(K * cin)).astype(np.float32), dev)
-            scale, shift = T(rng.uniform(0.5, 1.5, cout).astype(np.float32), dev), T(rng.normal(size=cout).astype(np.float32), dev)
-            res = spconv.to_split(T(rng.normal(size=(rb.num_out, cout)).astype(np.float32), dev)) if subm else None
-            xs, packed = spconv.to_split(x), spconv.pack_filters_f16x3(w)
-            outs = {}
-            for cfg in [None] + configs:
-                _lib.check(lib.isf_tune_conv_ring(*((0, 0, 0, 0) if cfg is None else (1, *cfg))))
-                ys = torch.full((rb.num_out * cout * 4,), 0xAB, dtype=torch.uint8, device=dev)
-                _lib.check(lib.isf_sparse_conv_forward_f16x3(
-                    _lib.ptr(xs), rb.num_in, cin, _lib.ptr(packed), K, cout, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-                    _lib.ptr(rb.group_masks()), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(res) if res is not None else None,
-                    1, _lib.ptr(ys), _lib.stream()), "conv")
-                outs[cfg] = ys
-            ref = outs[None]
-            assert torch.isfinite(spconv.from_split(ref, (rb.num_out, cout))).all()
-            for cfg in configs:
-                assert torch.equal(outs[cfg], ref), f"{name}: ring {cfg} differs from the one-step kernel"
-    finally:
-        _lib.check(lib.isf_tune_conv_ring(0, 0, 0, 0))
-
-
-def test_lidar_branch_with_ring_kernel_reproduces_default_bits(dev):
-    """the whole LiDAR branch with the ring kernel on every conv layer (group masks built with each rulebook on the
-    geometry stream) == the default kernels, bit for bit, and both prefetch distances agree"""
-    import isfusion_amd as m
-    from isfusion_amd import _lib, synthetic
-    lib = _lib.load()
-    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
-    pl = [T(synthetic.lidar_sweeps(500 + i, 30000), dev) for i in range(2)]
-    want = lb(pl)
-    try:
-        for cfg in ((1, 0, 0, 0), (1, 0, 0, 3), (1, 4, 3, 2)):
-            _lib.check(lib.isf_tune_conv_ring(*cfg))
-            assert torch.equal(lb(pl), want), cfg
-    finally:
-        _lib.check(lib.isf_tune_conv_ring(0, 0, 0, 0))
-
-
 def test_encoder_training_mode_is_loud(dev):
     import isfusion_amd as m
     conv = m.SubMConv3d(16, 16, 3, padding=1, bias=False).to(dev)
@@ -484,9 +420,13 @@ def test_full_size_numeric_parity_cfg2_frame(dev, oracle_mod):
     got = out.cpu().numpy()
     assert got.shape == obev.shape == (1, 512, 180, 180)
     assert st.num_in[0] == len(ovc)
-    assert np.array_equal(got != 0, obev != 0), "non-zero BEV mask differs from the oracle"
     err = np.abs(got - obev).max()
     assert err < 1e-3, err
+    # same occupied BEV cells; element-wise the post-ReLU zero pattern may differ only where both values are ~0
+    # (a pre-activation within rounding distance of zero)
+    assert np.array_equal((got != 0).any(1), (obev != 0).any(1)), "occupied BEV cells differ from the oracle"
+    flips = (got != 0) != (obev != 0)
+    assert np.maximum(np.abs(got), np.abs(obev))[flips].max(initial=0.0) < 1e-4 and flips.mean() < 1e-4
     assert np.abs(obev).max() > 0.5
     others = [T(synthetic.lidar_sweeps(1234 + 2000 + i, P), dev) for i in (1, 2, 3)]
     out4 = lb([others[0], T(pts, dev), others[1], others[2]])

@@ -253,9 +253,11 @@ def test_input_loader_refuses_cpu_and_replays_the_reference_rng():
     assert list(ld._choose(2)) == [0, 1] and list(ld._choose(7)) == [0, 1, 2]
 
 
-def test_load_state_dict_invalidates_packed_weight_caches():
-    """packed weights / tables are cached per module; loading a checkpoint (into the module or an ancestor) after the
-    first forward must drop them, or the new weights would be ignored silently"""
+def test_parameter_changes_invalidate_packed_weight_caches():
+    """packed weights / tables are cached per module, keyed on (version, address) of its parameters and buffers: a
+    checkpoint loaded after the first forward -- through load_state_dict, through mmcv's load_checkpoint (which
+    recurses over _load_from_state_dict and fires no post hooks) or through an in-place copy_ -- must drop them, or the
+    new weights would be ignored silently; freeze() opts out of the scan"""
     import torch
     from isfusion_amd import fusion_ops as ops
     from fusion_common import CONFIGS, encoder_kwargs
@@ -264,14 +266,22 @@ def test_load_state_dict_invalidates_packed_weight_caches():
     sub = enc.grid2region_att[0]
     dev = torch.device("cpu")
     ops._cache(sub, dev)["linear0"] = "stale"               # what a first forward leaves behind
-    enc.__dict__.setdefault("_isf_packed", {})["conv_fusion"] = (dev, "stale")
-    ops.watch_parameters(enc)
     assert ops._cache(sub, dev).get("linear0") == "stale"   # the cache survives ordinary calls
-    enc.load_state_dict(enc.state_dict())                   # ancestor load: children hooks fire too
-    assert "_isf_cache" not in sub.__dict__ and "_isf_packed" not in enc.__dict__
+    enc.load_state_dict(enc.state_dict())                   # ancestor load (in-place copies bump the versions)
+    assert "linear0" not in ops._cache(sub, dev)
     ops._cache(sub, dev)["linear0"] = "stale"
-    sub.load_state_dict(sub.state_dict())                   # direct load into the owner
-    assert "_isf_cache" not in sub.__dict__
+    for name, p in sub.named_parameters():                  # what mmcv's loader does: no hooks, in-place copy
+        with torch.no_grad():
+            p.copy_(p.detach().clone())
+        break
+    assert "linear0" not in ops._cache(sub, dev)
+    ops._cache(sub, dev)["linear0"] = "kept"
+    ops.freeze(sub)
+    with torch.no_grad():
+        next(sub.parameters()).mul_(1.0)
+    assert ops._cache(sub, dev).get("linear0") == "kept"    # frozen: no scan
+    ops.freeze(sub, False)
+    assert "linear0" not in ops._cache(sub, dev)
 
 
 def test_registry_surface_and_build_from_the_unmodified_reference_config():
