@@ -206,7 +206,9 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
 int isf_set_conv_precision(int mode);
 /* TIMING DIAGNOSTICS of the sparse-conv kernel (tools/conv_knockout.sh; never set in production): 0 = off (default),
  * 2 = no activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop.  The convolution RESULTS ARE
- * GARBAGE while a mode is set; only kernel times are meaningful. */
+ * GARBAGE while one of these is set; only kernel times are meaningful.
+ * 16 = gather every row (no neighbour sharing): results VALID and bit-identical to mode 0 -- the reference the sharing
+ * is tested against. */
 int isf_set_conv_diagnostic(int mode);
 
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------

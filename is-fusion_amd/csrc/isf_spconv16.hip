@@ -54,7 +54,8 @@ struct Conv16Smem {
 // split.  Never the default: the headline configuration is fp32-class.
 // MODE bits 2 / 4 / 8 are TIMING DIAGNOSTICS (isf_set_conv_diagnostic, results are garbage): 2 = no activation gathers
 // (A = 0), 4 = no weight DMA, 8 = no main loop (prologue + epilogue only) -- the knock-out decomposition of DESIGN.md
-// section 5 as a permanent tool (tools/conv_knockout.sh).
+// section 5 as a permanent tool (tools/conv_knockout.sh).  MODE bit 16 (valid results) switches the neighbour sharing of
+// the gathers off: the reference the sharing is checked against bit for bit.
 template <int CIN, int NT, int RG, int NW, int MODE = 0>
 __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) void spconv_f16x3_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
@@ -62,6 +63,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, int row_tiles) {
   constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
+  // neighbour sharing of the gathers (load_A below) where it was measured to pay -- the layers whose gathers saturate
+  // the vector-memory path: 64 -> 64 0.91 -> 0.76 ms, 64 -> 32 0.138 -> 0.128, 32 -> 32 0.312 -> 0.301 per step; the
+  // layers with >= 128 output columns (and 32 -> 64) lose 3-5 % to its DPP / select / index work and keep plain gathers
+  // (profiles/r02_call3_sharing.txt).  MODE bit 16 switches it off everywhere (bit-equality reference).
+  constexpr bool SHARE = (MODE & 16) == 0 && NT <= 4 && (CIN >= 64 || NT == 2);
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
   using S = Conv16Smem<NT, RG, KCH, NW>;
   constexpr int NTHR = 64 * NW;
@@ -158,18 +164,50 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // Prefetch pipeline: weights (LDS double buffer, DMA) and A fragments (registers) are both fetched ONE step
   // ahead, issued right after the barrier so that they fly during the MFMAs of the current step.  A 16-row
   // group that has no neighbour through the tap neither gathers nor multiplies (wave-uniform branches).
+  // Neighbour sharing: consecutive taps of a line differ by one cell in x, and consecutive output rows are mostly
+  // x-neighbours, so the row that lane r needs for the NEXT tap is very often the row that lane r+1 holds for the
+  // CURRENT tap (nbr[next][r] == nbr[cur][r+1]).  Those lanes take their fragment from the right-hand lane's
+  // registers (DPP row_shl:1 -- a DPP row is exactly the 16 rows of a row group at one k-group) instead of loading it
+  // again: the gathers are what saturates the CU's vector-memory return path (64 B/clk; knock-outs in
+  // profiles/r02_call1_knockout_variants.txt), and every shared row is a 64-byte request that is never made.  Purely
+  // index-driven, so it needs no knowledge of the kernel geometry and never changes a value: the shared fragment IS
+  // the fragment the load would have returned.
   uint4 a_nxt[RG][KCH][2];  // [row group][chunk of the step][hi, lo]
-  auto load_A = [&](int tap, int cg) {
+  uint4 a_cur[RG][KCH][2];
+  auto shl1 = [](const uint4 v) {   // lane (k-group, col) <- lane (k-group, col + 1); col 15 gets 0
+    uint4 r;
+    r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x101, 0xf, 0xf, true);
+    r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x101, 0xf, 0xf, true);
+    r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x101, 0xf, 0xf, true);
+    r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x101, 0xf, 0xf, true);
+    return r;
+  };
+  // prev_tap >= 0: a_cur holds the fragments of (prev_tap, same chunk group), landed
+  auto load_A = [&](int tap, int cg, int prev_tap) {
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
       if ((rgm[rg] >> tap) & 1u) {
         const int idx = nbr_l[tap * TM + wave * WR + rg * 16 + col];
+        bool share = false;
+        if (SHARE && prev_tap >= 0 && ((rgm[rg] >> prev_tap) & 1u)) {   // wave-uniform condition
+          // the right-hand row's index through the previous tap (the entry after the last row of the group is another
+          // group's or another tap's: col 15 never shares)
+          const int right = nbr_l[prev_tap * TM + wave * WR + rg * 16 + (col < 15 ? col + 1 : col)];
+          share = idx >= 0 && col < 15 && idx == right;
 #pragma unroll
-        for (int kc = 0; kc < KCH; ++kc) {
-          a_nxt[rg][kc][0] = make_uint4(0, 0, 0, 0);
-          a_nxt[rg][kc][1] = make_uint4(0, 0, 0, 0);
+          for (int kc = 0; kc < KCH; ++kc) {
+            const uint4 sh = shl1(a_cur[rg][kc][0]), sl = shl1(a_cur[rg][kc][1]);
+            a_nxt[rg][kc][0] = share ? sh : make_uint4(0, 0, 0, 0);
+            a_nxt[rg][kc][1] = share ? sl : make_uint4(0, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int kc = 0; kc < KCH; ++kc) {
+            a_nxt[rg][kc][0] = make_uint4(0, 0, 0, 0);
+            a_nxt[rg][kc][1] = make_uint4(0, 0, 0, 0);
+          }
         }
-        if (idx >= 0 && !NOGATHER) {
+        if (idx >= 0 && !share && !NOGATHER) {
 #pragma unroll
           for (int kc = 0; kc < KCH; ++kc) {
             const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4) * 2 + kg;   // chunk base + k-group
@@ -198,12 +236,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   Cursor cur{0u, -1, -1};
   if (nsteps > 0) {
     advance(cur);
-    load_A(cur.tap, cur.ch);
+    load_A(cur.tap, cur.ch, -1);
     stage_B(cur.tap, cur.ch, 0);
   }
   for (int s = 0; s < nsteps; ++s) {
-    const int tap = cur.tap;
-    uint4 a_cur[RG][KCH][2];
+    const int tap = cur.tap, ch = cur.ch;
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
@@ -215,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     __syncthreads();  // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
     if (s + 1 < nsteps) {
       advance(cur);
-      load_A(cur.tap, cur.ch);
+      load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);   // a_cur = (tap, ch), landed (vmcnt(0) above)
       stage_B(cur.tap, cur.ch, (s + 1) & 1);
     }
     if ((wmask >> tap) & 1u) {
@@ -348,7 +385,8 @@ static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K,
 // 8 waves x 32 rows (256-row tiles, two workgroups per CU) for the layers with exactly 128 output columns
 // (128 -> 128: 1.13 (4 waves) / 1.02 (16 waves) -> 0.94 ms per 4 launches; 64 -> 128: 0.142 -> 0.130 ms); everything
 // else on 4 waves x 32 rows: the narrow layers lose with wider workgroups (fewer independent workgroups to hide the
-// gather latency) and the 256-column layers of the small deep levels do not have enough tiles (1.41 -> 1.67 ms).
+// gather latency) and the 256-column layers of the small deep levels do not have enough tiles (8 waves: 1.41 -> 1.67 ms;
+// 12 waves = one 384-row workgroup per CU: 1.42 -> 1.55 ms, profiles/r02_call3_sharing.txt).
 template <int CIN, int NT>
 static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
@@ -361,6 +399,9 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
     case 4: return launch16<CIN, NT, 2, 4, 4>(ISF_ARGS16);
     case 6: return launch16<CIN, NT, 2, 4, 6>(ISF_ARGS16);
     case 8: return launch16<CIN, NT, 2, 4, 8>(ISF_ARGS16);
+    case 16:   // no neighbour sharing, production workgroup shapes
+      if (NT == 8 && cout == 128 && n_out >= 8 * 256) return launch16<CIN, (NT == 8 ? NT : 2), 2, 8, 16>(ISF_ARGS16);
+      return launch16<CIN, NT, 2, 4, 16>(ISF_ARGS16);
     default:
       ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (single-pass precision and the diagnostics {2,4,6,8} "
                   "are not combinable)", mode);
@@ -472,7 +513,7 @@ int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t st
 }
 
 int isf_set_conv_diagnostic(int mode) {
-  if (mode != 0 && mode != 2 && mode != 4 && mode != 6 && mode != 8) return ISF_ERR_ARG;
+  if (mode != 0 && mode != 2 && mode != 4 && mode != 6 && mode != 8 && mode != 16) return ISF_ERR_ARG;
   isf::g_conv_diag = mode;
   return ISF_OK;
 }

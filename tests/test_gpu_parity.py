@@ -385,6 +385,26 @@ def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
     assert lb.last_stats.pairs[0] == pairs0 and lb.last_stats.pairs[1] == pairs0
 
 
+def test_conv_neighbour_sharing_reproduces_full_gather_bits(dev):
+    """the conv kernel takes a row's fragment from the right-hand lane's registers when the indices match instead of
+    gathering it again (isf_spconv16.hip, load_A): the shared fragment is the fragment the load would have returned, so
+    the whole LiDAR branch must give the bits of the gather-everything reference (isf_set_conv_diagnostic(16))"""
+    import isfusion_amd as m
+    from isfusion_amd import _lib, synthetic
+    lib = _lib.load()
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n in (30000, 120000):
+        pl = [T(synthetic.lidar_sweeps(500 + i, n), dev) for i in range(2)]
+        got = lb(pl)
+        try:
+            _lib.check(lib.isf_set_conv_diagnostic(16))
+            want = lb(pl)
+        finally:
+            _lib.check(lib.isf_set_conv_diagnostic(0))
+        assert torch.isfinite(got).all() and got.abs().max().item() > 0.5
+        assert torch.equal(got, want), n
+
+
 def test_encoder_training_mode_is_loud(dev):
     import isfusion_amd as m
     conv = m.SubMConv3d(16, 16, 3, padding=1, bias=False).to(dev)
