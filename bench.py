@@ -20,6 +20,9 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                   MFMA peak with --fp32; MI355X_MICROARCH.md) -- plus the per-kernel table;
   "cpu_baseline": the CPU oracle (C port of the reference algorithm, conv loop on all host threads) on one frame.
 
+--config 3 measures BASELINE configs[2] instead (full HSF + IGF point-cloud path, batch 2, camera features precomputed)
+with the same contract and a stage table; the default (--config 2) is the headline.
+
 Diagnostics (never the headline; the line is labelled): --f16 (single-pass f16 kernels, reduced precision) and the
 --conv-diag knock-out kernels (garbage results, timing only; tools/conv_knockout.sh).
 """
@@ -46,7 +49,7 @@ def frames_for_rank(rank, world, batch):
     return [rank * batch + i for i in range(batch)]
 
 
-def make_frames(rank, world, batch, num_points):
+def make_frames(rank, world, batch, num_points, frame_set=0):
     """Seeded synthetic sweeps of this rank.  ISF_BENCH_FRAME_CACHE=<dir> (tuning sweeps only: tools/conv_knockout.sh
     runs bench.py two dozen times) keeps the generated frames on disk; the frames are the same either way."""
     import numpy as np
@@ -54,7 +57,7 @@ def make_frames(rank, world, batch, num_points):
     cache = os.environ.get("ISF_BENCH_FRAME_CACHE", "")
     frames = []
     for f in frames_for_rank(rank, world, batch):
-        seed = 1234 + 1000 * CFG_ID + f
+        seed = 1234 + 1000 * CFG_ID + f + 100000 * frame_set
         path = os.path.join(cache, f"frame_{seed}_{num_points}.npy") if cache else ""
         if path and os.path.exists(path):
             frames.append(np.load(path))
@@ -122,13 +125,218 @@ def cpu_baseline(num_points, seed_frame):
     return dt, int(vf.shape[0])
 
 
+
+# ------------------------------------------------------------------------------------------- --config 3
+def cpu_baseline_fusion(seed):
+    """Oracle ("port": C for the LiDAR branch, torch-CPU restatement for HSF / IGF + backbone stages) on ONE frame of
+    30 k points with the full-size 180 x 180 fusion grid; bounded so that the default run stays within minutes."""
+    import numpy as np
+    import torch
+    import oracle
+    from isfusion_amd import synthetic
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    from isfusion_amd.norm import fold_bn
+    from oracle import fusion_ops as orc
+    oracle.build()
+    net = ISFusionPtsPath().eval()
+    net._lidar.randomize_weights_(0).randomize_bn_(1)
+    net.fusion_encoder.load_state_dict(seeded_state_dict(net.fusion_encoder, 100))
+    net.pts_backbone.load_state_dict(seeded_state_dict(net.pts_backbone, 200))
+    P = 30000
+    p = synthetic.lidar_sweeps(seed, P)
+    inp = synthetic.fusion_inputs(seed, 1)
+    vs, rg = net.voxel_size, net.pc_range
+    vfe = net.pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    sd = {k: v.float() for k, v in net.fusion_encoder.state_dict().items()}
+    sdb = {"bb." + k: v.float() for k, v in net.pts_backbone.state_dict().items()}
+    plan = net.pts_middle_encoder.plan_to_numpy()
+    t0 = time.perf_counter()
+    coors = np.concatenate([np.zeros((P, 1), np.int32), oracle.dynamic_voxelize(p, vs, rg)], 1)
+    vf, vc, _ = oracle.dynamic_vfe(p, coors, vs, rg, vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                   vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    bev, _ = oracle.sparse_encoder_forward(plan, vf, vc, 1)
+    v, c, n = oracle.hard_voxelize(p, net.pillar_size, rg, 12, 60000)
+    pcoors = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
+    with torch.no_grad():
+        img_bev = orc.p2g_sample(torch.from_numpy(v)[..., :3], pcoors, torch.from_numpy(inp["img_feats"][1]),
+                                 torch.from_numpy(inp["lidar2img"]), torch.from_numpy(inp["img_aug_matrix"]),
+                                 torch.from_numpy(inp["lidar_aug_matrix"]), inp["input_shape"], 1, 180)
+        bev_feats = orc.conv_module(torch.cat([img_bev, torch.from_numpy(bev)], 1), sd, "conv_fusion")
+        g0 = orc.sstv2_forward(bev_feats, sd, "grid2region_att.0")
+        ret, _, _ = orc.instance_fusion(bev_feats, g0, sd, 1, 180, 200)
+        nxt, f0 = orc.secondv2_stage(ret, sdb, "bb", "stage1")
+        _, f1 = orc.secondv2_stage(orc.sstv2_forward(nxt, sd, "grid2region_att.1"), sdb, "bb", "stage2")
+    return time.perf_counter() - t0, P
+
+
+def main_fusion(args):
+    """BASELINE configs[2]: full IS-Fusion HSF + IGF forward -- LiDAR branch, pillar voxelization, ISFusionEncoder
+    (Point-to-Grid, conv_fusion, Grid-to-Region x2, instance mining / context / instance-to-scene), SECONDV2 stages,
+    SECONDFPN neck, TransFusionHeadV2.forward -- on B x P-point sweeps + precomputed (random) 6-camera feature maps,
+    fp32-class arithmetic.  Same JSON contract as the headline; stage table from HIP events in a separate pass."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from isfusion_amd import _lib, synthetic
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    net = ISFusionPtsPath().eval()
+    net._lidar.randomize_weights_(0).randomize_bn_(1)
+    for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250), (net.pts_bbox_head, 300)):
+        mod.load_state_dict(seeded_state_dict(mod, seed))
+    net = net.to(dev)
+    net._lidar.freeze()
+    B = args.batch
+    sets = []
+    for fs in range(max(1, args.frame_sets)):
+        pts = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, B, args.points, 10 + fs)]
+        inp = synthetic.fusion_inputs(5 + fs + 100 * rank, B)
+        img_feats = tuple(torch.from_numpy(x).to(dev) for x in inp["img_feats"])
+        kw = dict(lidar2img=torch.from_numpy(inp["lidar2img"]), img_aug_matrix=torch.from_numpy(inp["img_aug_matrix"]),
+                  lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
+        metas = [dict(input_shape=inp["input_shape"]) for _ in range(B)]
+        sets.append((pts, img_feats, metas, kw))
+
+    def step(i):
+        pts, img_feats, metas, kw = sets[i % len(sets)]
+        return net.forward_pts(pts, img_feats, metas, **kw)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    heat = out[0][0]["heatmap"]
+    assert torch.isfinite(heat).all()
+
+    if rank == 0:
+        # ---- stage table (separate pass, HIP events on the launch stream; not part of the timed region)
+        def timed(fn, n=10):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n, r
+        pts, img_feats, metas, kw = sets[0]
+        enc, bb = net.fusion_encoder, net.pts_backbone
+        stages = {}
+        with torch.no_grad():
+            stages["lidar_branch"], x = timed(lambda: net._lidar(pts, want_stats=True, time_layers=True))
+            st, tab = net._lidar.last_stats, net._lidar.conv_layer_table()
+            stages["pillar_voxelize"], (pil, npts, pco) = timed(lambda: net.voxelize(pts, "pillar"))
+            ekw = dict(kw, pts_metas=dict(pillars=pil, pillars_num_points=npts, pillar_coors=pco), img_metas=metas,
+                       pts_backbone=bb)
+            stages["p2g"], img_bev = timed(lambda: enc.img_fv_to_bev([img_feats[1]], B, **ekw))
+            stages["conv_fusion"], bev = timed(lambda: enc.fuse(img_bev, x))
+            stages["grid2region_0"], g0 = timed(lambda: enc.grid2region(0, bev))
+            stages["instance_fusion"], (ret, _) = timed(lambda: enc.instance_fusion(bev, g0, B))
+            stages["second_stage1"], (nxt, _, f0) = timed(lambda: bb([ret], "stage1"))
+            stages["grid2region_1"], g1 = timed(lambda: enc.grid2region(1, nxt))
+            stages["second_stage2"], (_, _, f1) = timed(lambda: bb([g1], "stage2"))
+            stages["neck"], nk = timed(lambda: net.pts_neck([f0, f1]))
+            stages["head"], _ = timed(lambda: net.pts_bbox_head(nk, img_feats, metas))
+        stages = {k: round(v, 3) for k, v in stages.items()}
+        # ---- roofline of the dominant kernel: the sparse-conv kernel family (LiDAR branch layers by template
+        # instantiation; the 3x3 dense convs of conv_fusion / IGF / SECONDV2 run on the same kernels over a dense rulebook)
+        groups = {}
+        for i, (kind, cin, cout, K) in enumerate(tab):
+            by, fl = conv_layer_bytes_flops(kind, cin, cout, K, st.num_in[i], st.num_out[i], st.pairs[i])
+            g = groups.setdefault(f"spconv_mfma<cin={cin},cout={cout}>", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            g["ms"] += float(st.ms[i]); g["flops"] += fl; g["bytes"] += by; g["launches"] += 1
+        # dense 3x3 convs: flops = 2 * 9 * Cin * Cout per output cell (every tap present except at the border)
+        dense = dict(ms=stages["second_stage1"] + stages["second_stage2"], launches=12,
+                     flops=2.0 * 9 * B * (180 * 180 * 128 * 128 * 6 + 90 * 90 * (128 * 256 + 5 * 256 * 256)))
+        name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        t_s = dom["ms"] * 1e-3
+        tfl = dom["flops"] / t_s / 1e12 if t_s > 0 else 0.0
+        roof = dict(bound="mfma", achieved=round(tfl, 3), peak=round(MFMA_F16_PEAK_TFLOPS / 3, 1), unit="TFLOP/s",
+                    frac=round(3 * tfl / MFMA_F16_PEAK_TFLOPS, 4), traffic=None,
+                    arithmetic="f16x3 split MFMA: 3 f16 passes per fp32 product, fp32 accumulate; peak = 2500 / 3",
+                    kernel=name + " (LiDAR branch, the largest single-kernel share of the step)",
+                    launches_per_step=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                    algorithmic_bytes_per_launch=round(dom["bytes"] / dom["launches"]),
+                    per_kernel={k: dict(ms=round(v["ms"], 4), tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 3)
+                                        if v["ms"] > 0 else 0, launches=v["launches"]) for k, v in groups.items()},
+                    dense_conv_stages=dict(ms=round(dense["ms"], 3), launches=dense["launches"],
+                                           tflops=round(dense["flops"] / (dense["ms"] * 1e-3) / 1e12, 2),
+                                           frac=round(3 * dense["flops"] / (dense["ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                                           note="SECONDV2 stage 1 + 2: twelve 3x3 convs on the sparse-conv kernel over "
+                                                "the dense-grid rulebook (includes their layout conversions)"),
+                    stages_ms=stages, stages_sum_ms=round(sum(stages.values()), 3))
+        line = {
+            "metric": "nuScenes frames/sec forward (0.075 voxel), full HSF+IGF point-cloud path incl. neck + head forward",
+            "value": round(B * world * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f16x3 split-precision MFMA, fp32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: full IS-Fusion HSF+IGF forward (LiDAR branch + pillar voxelize + "
+                                   "ISFusionEncoder + SECONDV2 stages + SECONDFPN + TransFusionHeadV2.forward), 6-camera "
+                                   f"feature maps precomputed (random), synthetic {args.points}-pt sweeps, batch={B}/GPU, "
+                                   "random-init weights, eval BN, fp32",
+                       "points_per_frame": args.points, "batch_per_gpu": B, "parallelism": f"dp{world}",
+                       "frame_sets_rotated": len(sets)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cdt, cp = cpu_baseline_fusion(1234 + 1000 * 3)
+            import oracle
+            line["cpu_baseline"] = {
+                "value": round(1.0 / cdt, 4), "unit": f"frames/s ({cp}-pt frame)", "cores": oracle.num_threads(),
+                "kind": "port",
+                "sample": f"oracle composition (C LiDAR branch with the conv loop on {oracle.num_threads()} host "
+                          f"threads + torch-CPU restatement of HSF / IGF / SECONDV2 stages, full 180 x 180 grid, no neck / "
+                          f"head) on 1 frame of {cp} points took {cdt:.2f} s",
+                "sample_seconds": round(cdt, 2)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="2 (default, the headline): BASELINE configs[1], LiDAR-only branch, batch 4; "
+                         "3: BASELINE configs[2], full HSF + IGF forward (camera features precomputed), batch 2")
+    ap.add_argument("--frame-sets", type=int, default=2,
+                    help="distinct input batches rotated through the steps (so a step is not a cache-warm replay of "
+                         "the previous one)")
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU and step (default 4 for --config 2, 2 for 3)")
     ap.add_argument("--cpu-points", type=int, default=300000,
                     help="points of the CPU-baseline sample frame (one full 300 k-point frame: about 30 s on one "
                          "core, about 10 s on 8)")
@@ -141,6 +349,10 @@ def main():
                     help="DIAGNOSTIC ONLY: single-pass f16 conv kernels (fp16-autocast accuracy, BASELINE configs[4] "
                          "dtype); reduced precision, never the headline line")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = BATCH_PER_GPU if args.config == 2 else 2
+    if args.config == 3:
+        return main_fusion(args)
 
     import torch
     import torch.distributed as dist
@@ -161,15 +373,17 @@ def main():
     _lib.check(_lib.load().isf_set_conv_precision(2 if args.f16 else 1 if args.fp32 else 0))
     _lib.check(_lib.load().isf_set_conv_diagnostic(args.conv_diag))
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
-    frames = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
+    frame_sets = [[torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points, fs)]
+                  for fs in range(max(1, args.frame_sets))]
+    frames = frame_sets[0]
     torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        out = lb(frames)
+    for i in range(args.warmup):
+        out = lb(frame_sets[i % len(frame_sets)])
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -179,8 +393,10 @@ def main():
     nl = len(lb.conv_layer_table())
     ms_acc = np.zeros(nl)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = lb(frames, time_layers=True)
+    # (the roofline accounting below uses the geometry of the last step's frame set and the layer times averaged over
+    #  all steps; the sets are the same size class: same generator, different seeds)
+    for step in range(args.steps):
+        out = lb(frame_sets[step % len(frame_sets)], time_layers=True)
         st = lb.last_stats
         ms_acc += np.array([st.ms[i] for i in range(nl)])
     torch.cuda.synchronize()
@@ -255,7 +471,8 @@ def main():
                                    "DynamicVFE + 21-layer SparseEncoder -> BEV [B,512,180,180]), synthetic "
                                    f"nuScenes-shaped {args.points}-pt sweeps, batch={args.batch}/GPU, random-init "
                                    "weights, eval BN, fp32",
-                       "points_per_frame": args.points, "batch_per_gpu": args.batch, "parallelism": f"dp{world}"},
+                       "points_per_frame": args.points, "batch_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "frame_sets_rotated": len(frame_sets)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

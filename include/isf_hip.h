@@ -431,6 +431,15 @@ int isf_assemble_points(const float* raw, const isf_sweep_t* sweeps, int num_swe
                         const float* point_range /* 6 host floats or NULL */, float* points_out,
                         int32_t* sample_offsets, int32_t* sample_offsets_host, isf_stream_t stream);
 
+/* 8f #2  Point-to-Grid backward ---------------------------------------------------------------------------------
+ * replaces autograd through img_fv_to_bev's F.grid_sample (fusion_encoder.py:1049-1056) + the canvas scatter (:989-1003):
+ * grad_out [B, C, bev, bev] -> grad_img_nhwc [B*num_cam, H, W, C] (written completely; fp32 atomics inside).  The
+ * other arguments are isf_p2g_forward's.  No gradient flows to points / calibration (not trainable). */
+int isf_p2g_backward(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
+                     int batch_size, int num_cam, int feat_h, int feat_w, int channels, const float* cam_params,
+                     int input_h, int input_w, int bev_size, const float* grad_out, float* grad_img_nhwc,
+                     isf_stream_t stream);
+
 /* 8f #2  multi-scale deformable attention backward (one level) --------------------------------------------------
  * replaces MultiScaleDeformableAttnFunction.backward -> ms_deform_attn_backward (ops/src/cuda/ms_deform_attn_cuda.cu,
  * ms_deform_im2col_cuda.cuh:301-920) plus the backward of the softmax / location arithmetic isf_msda_forward folds in.

@@ -117,6 +117,8 @@ SIGNATURES = {
     "isf_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_ingroup_indices": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "isf_p2g_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "isf_set_conv_diagnostic": (c_int, [c_int]),
     "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p]),

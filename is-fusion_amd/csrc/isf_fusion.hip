@@ -88,6 +88,73 @@ __global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pill
   for (int c = 0; c < CPL; ++c) o[(size_t)c * bev * bev] = acc[c];
 }
 
+// 8f #2  Point-to-Grid backward: d loss / d img.  Same walk as the forward (one wave per pillar, projection of every
+// (slot, camera) pair, in-view pairs visited wave-uniformly); each bilinear tap scatters weight * grad_canvas[cell]
+// into the NHWC gradient map with hardware fp32 atomics (the reference's F.grid_sample backward does the same).  The
+// sample positions do not depend on trainable tensors (points and calibration), so there is no gradient towards them.
+template <int CPL>
+__global__ __launch_bounds__(256) void p2g_backward_kernel(const float* __restrict__ pillars, int pillar_ld, int T,
+                                                           const int32_t* __restrict__ coors, int M, int num_cam,
+                                                           int H, int W, int C, const float* __restrict__ cam, float in_h,
+                                                           float in_w, int bev, const float* __restrict__ grad_out,
+                                                           float* __restrict__ grad_img /* [B*cam, H, W, C], zeroed */) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= M) return;
+  const int b = coors[4 * p], y = coors[4 * p + 2], x = coors[4 * p + 3];
+  const int c0 = lane * CPL;
+  float g[CPL];
+  const float* go = grad_out + ((size_t)b * C + c0) * bev * bev + (size_t)y * bev + x;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) g[c] = go[(size_t)c * bev * bev];
+  const int pairs = T * num_cam;
+  for (int base0 = 0; base0 < pairs; base0 += 64) {
+    const int pr = base0 + lane;
+    bool ok = false;
+    float ix = 0.f, iy = 0.f;
+    int k = 0;
+    if (pr < pairs) {
+      const int t = pr / num_cam;
+      k = pr - t * num_cam;
+      const float* pt = pillars + ((size_t)p * T + t) * pillar_ld;
+      const float px = pt[0], py = pt[1], pz = pt[2];
+      const float* m = cam + (size_t)(b * num_cam + k) * 20;
+      float cx = m[0] * px + m[1] * py + m[2] * pz + m[9];
+      float cy = m[3] * px + m[4] * py + m[5] * pz + m[10];
+      float cz = m[6] * px + m[7] * py + m[8] * pz + m[11];
+      cz = fminf(fmaxf(cz, 1e-5f), 1e5f);
+      cx /= cz;
+      cy /= cz;
+      const float u = m[12] * cx + m[13] * cy + m[14] * cz + m[18];
+      const float v = m[15] * cx + m[16] * cy + m[17] * cz + m[19];
+      const float gx = (u / in_w - 0.5f) * 2.f, gy = (v / in_h - 0.5f) * 2.f;
+      ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+      iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+      ok = ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H;
+    }
+    unsigned long long live = __ballot(ok);
+    while (live) {
+      const int src_lane = __ffsll((long long)live) - 1;
+      live &= live - 1;
+      const float sx = __shfl(ix, src_lane, 64), sy = __shfl(iy, src_lane, 64);
+      const int sk = __shfl(k, src_lane, 64);
+      const float fx = floorf(sx), fy = floorf(sy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float lx = sx - fx, ly = sy - fy;
+      float* base = grad_img + (size_t)(b * num_cam + sk) * H * W * C + c0;
+#pragma unroll
+      for (int tap = 0; tap < 4; ++tap) {
+        const int xx = x0 + (tap & 1), yy = y0 + (tap >> 1);
+        if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+        const float wgt = ((tap & 1) ? lx : 1.f - lx) * ((tap >> 1) ? ly : 1.f - ly);
+        float* dst = base + ((size_t)yy * W + xx) * C;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) atomicAdd(dst + c, wgt * g[c]);
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // A12  sigmoid -> 3x3 local-maximum suppression (1x1 for the listed classes) -> top-k over all classes
 // (fusion_encoder.py:1100-1131).  The reference materialises the suppressed map and argsorts all K*H*W
@@ -406,6 +473,36 @@ int isf_p2g_forward(const float* pillars, int pillar_ld, int slots, const int32_
     default: set_error("p2g: channels %d not built (64, 128, 256, 512)", channels); return ISF_ERR_UNSUPPORTED;
   }
 #undef ISF_P2G
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_p2g_backward(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
+                     int batch_size, int num_cam, int feat_h, int feat_w, int channels, const float* cam_params,
+                     int input_h, int input_w, int bev_size, const float* grad_out, float* grad_img_nhwc,
+                     isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(num_pillars >= 0 && batch_size > 0 && num_cam > 0 && feat_h > 0 && feat_w > 0 && bev_size > 0 &&
+                  grad_img_nhwc, ISF_ERR_ARG, "p2g_backward: bad arguments");
+  hipStream_t st = as_stream(stream);
+  ISF_HIP_TRY(hipMemsetAsync(grad_img_nhwc, 0, sizeof(float) * (size_t)batch_size * num_cam * feat_h * feat_w * channels, st));
+  if (num_pillars == 0) return ISF_OK;
+  ISF_REQUIRE(pillars && pillar_coors && cam_params && grad_out, ISF_ERR_ARG, "p2g_backward: null pointer");
+  ISF_REQUIRE(channels % 64 == 0 && channels <= 512 && pillar_ld >= 3, ISF_ERR_UNSUPPORTED,
+              "p2g_backward: channels %d (need %%64 == 0, <= 512)", channels);
+  const dim3 grid(ceil_div(num_pillars, 4)), block(256);
+#define ISF_P2GB(CPL)                                                                                                     \
+  hipLaunchKernelGGL((p2g_backward_kernel<CPL>), grid, block, 0, st, pillars, pillar_ld, slots, pillar_coors, num_pillars, \
+                     num_cam, feat_h, feat_w, channels, cam_params, (float)input_h, (float)input_w, bev_size, grad_out,    \
+                     grad_img_nhwc)
+  switch (channels / 64) {
+    case 1: ISF_P2GB(1); break;
+    case 2: ISF_P2GB(2); break;
+    case 4: ISF_P2GB(4); break;
+    case 8: ISF_P2GB(8); break;
+    default: set_error("p2g_backward: channels %d not built (64, 128, 256, 512)", channels); return ISF_ERR_UNSUPPORTED;
+  }
+#undef ISF_P2GB
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

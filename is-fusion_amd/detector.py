@@ -102,6 +102,17 @@ class ISFusionPtsPath(nn.Module):
         feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)
         return (feats, ins_heatmap) if return_heatmap else feats
 
+    def forward_train_pts(self, pts, img_feats, img_metas, **kwargs):
+        """training mode: extract_pts_feat + pts_neck WITH gradients (towards every parameter of the
+        LiDAR branch, the fusion encoder, the backbone stages and the neck, and towards the camera feature maps).  The
+        head's losses / target assignment are the reference's training control plane (out of scope): apply them to the
+        returned neck output."""
+        assert self.training, "call .train() first (eval mode runs the inference engine)"
+        self._lidar.train(True)
+        x = self._lidar(pts)
+        feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)
+        return self.pts_neck(feats), ins_heatmap
+
     @torch.no_grad()
     def forward_pts(self, pts, img_feats, img_metas, **kwargs):
         """extract_pts_feat -> pts_neck -> pts_bbox_head (mvx_two_stage.py simple_test_pts without box decoding):

@@ -118,9 +118,49 @@ class ISFusionEncoder(nn.Module):
         ret = ops.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, S)
         return ret, hm
 
-    @torch.no_grad()
+    def forward_train(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
+        """training mode: the same data flow with gradients -- HIP forward kernels inside autograd
+        Functions (fusion_train.py), the 3x3 convolutions + BatchNorm (batch statistics) on stock PyTorch-ROCm as the
+        north_star prescribes, instance mining without gradient (indices), like the reference."""
+        from . import fusion_train as tr
+        pm = kwargs["pts_metas"]
+        S = self.bev_size
+        img_bev = tr.p2g_sample(pm["pillars"], pm["pillar_coors"], img_mlvl_feats[1], kwargs["lidar2img"],
+                                kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
+                                kwargs["img_metas"][0]["input_shape"], bs, S, self.num_views)
+        bev_feats = self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
+        pts_backbone = kwargs.get("pts_backbone", None)
+        x, ins_hm, feats = bev_feats, None, []
+        for i in range(len(self.get_regions)):
+            win = self.get_regions[i].window_shape[0]
+            x = tr.sstv2_forward(self.grid2region_att[i], x, win, float(self.get_regions[i].pos_temperature))
+            if i == 0:
+                scene_feats = x
+                out = bev_feats.permute(0, 1, 3, 2).contiguous()
+                ins_hm = self.heatmap_head_3(self.heatmap_head_2(self.heatmap_head_1(self.conv_heatmap(out))))
+                x_scene_t = self.conv_scene(out).permute(0, 1, 3, 2).contiguous()
+                q = self.conv_ins(bev_feats)
+                with torch.no_grad():
+                    top_idx = ops.instance_topk(ins_hm.detach(), self.instance_num, self.nms_kernel_size,
+                                                (8, 9) if self.num_views == 6 else (1, 2))
+                self.last_top_idx = top_idx
+                idx_t = (top_idx % S) * S + torch.div(top_idx, S, rounding_mode="floor")
+                x_ins, _ = ops.gather_instances(x_scene_t, idx_t, S)
+                _, query_pos = ops.gather_instances(x_scene_t, top_idx, S)
+                x_ins = tr.ins_context_att(self.instance_att, x_ins, query_pos, x_scene_t, S)
+                x = tr.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, S)
+            nxt, _, this_feat = pts_backbone([x], "stage{}".format(i + 1))
+            feats.append(this_feat)
+            x = nxt
+        return feats, ins_hm
+
     def forward(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
-        assert not self.training, "isfusion_amd.ISFusionEncoder is the inference path (eval mode)"
+        if self.training:
+            return self.forward_train(img_mlvl_feats, lidar_feats, bs, **kwargs)
+        with torch.no_grad():
+            return self.forward_eval(img_mlvl_feats, lidar_feats, bs, **kwargs)
+
+    def forward_eval(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
         img_bev = self.img_fv_to_bev([img_mlvl_feats[1]], bs, **kwargs)
         bev_feats = self.fuse(img_bev, lidar_feats)
         pts_backbone = kwargs.get("pts_backbone", None)

@@ -286,8 +286,14 @@ class SECONDV2(nn.Module):
 
         def nchw(t):
             return t.to_nchw() if isinstance(t, SplitMap) else t
-        if self.training:
-            raise RuntimeError("isfusion_amd.SECONDV2 is the inference path (eval mode)")
+        if self.training:      # training: stock Conv2d + BatchNorm (batch statistics) + ReLU with autograd
+            if stage == "stage1":
+                feat = self.blocks[0](x[0] if isinstance(x, (list, tuple)) else x)
+                return self.ds_layer(feat), None, feat
+            if stage == "stage2":
+                return None, None, self.blocks[1](x[0] if isinstance(x, (list, tuple)) else x)
+            x1 = self.blocks[0](x)
+            return x1, self.blocks[1](self.ds_layer(x1))
         if stage == "stage1":
             feat = self._run("b0", self.blocks[0], x[0] if isinstance(x, (list, tuple)) else x)
             return nchw(self._run("ds", self.ds_layer, feat)), None, nchw(feat)

@@ -113,12 +113,34 @@ class LidarBranch(nn.Module):
         self._vfe_key = key
         return self._vfe_cache
 
-    @torch.no_grad()
+    def forward_train(self, points):
+        """training mode: the reference's composition -- dynamic voxelize, DynamicVFE module path
+        (DynamicScatter with backward, BatchNorm batch statistics), SparseEncoder module by module on the sparse-conv
+        autograd Function -- instead of the one-call inference engine.  -> spatial_features [B, C*D, H, W]"""
+        from .voxelize import dynamic_voxelize_batched
+        pts, coors = dynamic_voxelize_batched(points, self.voxel_size, self.point_cloud_range)
+        keep = (coors[:, 1:] >= 0).all(1)          # the reference's DynamicScatter drops out-of-range points the same way
+        vf, vc = self.pts_voxel_encoder(pts[keep].float(), coors[keep])
+        return self.pts_middle_encoder.forward_modules(vf, vc, len(points))[0]
+
     def forward(self, points, time_layers=False, want_stats=False):
         """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W]."""
-        assert not self.training, "LidarBranch is the inference engine; training composes the sub-modules"
+        if self.training:
+            return self.forward_train(points)
+        with torch.no_grad():
+            return self.forward_eval(points, time_layers, want_stats)
+
+    def forward_eval(self, points, time_layers=False, want_stats=False):
         pts = torch.cat(points, dim=0).contiguous().float()
         _lib.require_cuda(pts)
+        vfe = self.pts_voxel_encoder
+        if pts.size(1) != vfe.raw_in_channels:
+            raise _lib.IsfError(f"LidarBranch: points have {pts.size(1)} columns, the voxel encoder expects "
+                                f"{vfe.raw_in_channels}")
+        if not vfe._fusable():
+            raise _lib.IsfError("LidarBranch: the one-call engine implements the IS-Fusion DynamicVFE configuration "
+                                "(2 layers of 64, cluster + voxel centre, max pooling, no distance feature); build the "
+                                "path from the sub-modules for anything else")
         offs = [0]
         for p in points:
             offs.append(offs[-1] + p.size(0))

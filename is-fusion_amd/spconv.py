@@ -9,7 +9,7 @@ Differences that matter to a maintainer:
   * weights live in the spconv-1 / mmcv layout [kD,kH,kW,Cin,Cout] (bevfusion-ops/spconv/conv.py:100);
     checkpoints in the spconv-2 layout [Cout,kD,kH,kW,Cin] are permuted on load
     (ops/spconv/overwrite_spconv/write_spconv2.py:62-124 does the opposite conversion);
-  * forward only this round: calling a conv with autograd enabled on tensors that require grad raises.
+  * autograd: SparseConvFunction (forward + dX / dW kernels) when a tensor requires grad.
 """
 import ctypes
 import math
@@ -190,9 +190,10 @@ def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=
     return out
 
 
-# Backward kernels (isf_spconv_bwd.hip) were written after round 1's GPU budget was spent: opt-in until
-# tests/test_gpu_next.py has passed on hardware, so that the default behaviour stays the validated one.
-TRAINING_KERNELS = False
+# Backward kernels (isf_spconv_bwd.hip): validated on an MI355X in round 2 (tests/test_gpu_widened.py: dX / dW against the
+# C restatement of indice_conv_backward on the golden geometries, every channel shape, a two-layer training step against
+# dense torch autograd) and on by default since.  False restores the loud NotImplementedError for autograd calls.
+TRAINING_KERNELS = True
 
 
 def transposed_nbr(rb):
@@ -345,9 +346,8 @@ class SparseConvolution(SparseModule):
         training = torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad)
         if training and not TRAINING_KERNELS:
             raise NotImplementedError(
-                "isfusion_amd sparse conv: the backward kernels (SURVEY.md section 8f #2) are built but not yet "
-                "validated on hardware; set isfusion_amd.spconv.TRAINING_KERNELS = True to use them, or call "
-                "under torch.no_grad() / module.eval() with requires_grad_(False)")
+                "isfusion_amd sparse conv: autograd is switched off (isfusion_amd.spconv.TRAINING_KERNELS = False); "
+                "call under torch.no_grad() / module.eval() with requires_grad_(False), or switch it back on")
         rb = self.rulebook_for(input)
         if training:
             # training: the reference's SparseConvFunction / SubMConvFunction (functional.py:22-97) -- conv without
