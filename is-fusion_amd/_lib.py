@@ -224,3 +224,14 @@ def f6(v):
 
 def i3(v):
     return _I3(*[int(x) for x in v])
+
+
+def pow2_rescale(g):
+    """(g * s, s) with s a power of two (a device scalar, no host sync) that brings max|g| to about 2^10.  The f16x3
+    kernels carry fp32 operands as f16 hi + lo halves: exact down to 2^-24 of f16's normal range, so operands must sit
+    inside it -- activations of a normalised network do, gradients (1e-5 and below) do not and would fall into f16's
+    subnormals.  Scaling by a power of two is exact and commutes with the (linear) backward ops."""
+    import torch
+    amax = g.detach().abs().amax().clamp_min(1e-30)
+    s = torch.exp2(10.0 - torch.ceil(torch.log2(amax)))
+    return g * s, s

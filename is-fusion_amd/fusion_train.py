@@ -43,7 +43,8 @@ class LinearFunction(torch.autograd.Function):
         g = gy.contiguous().float()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear(g, ops.PackedLinear(wd.t().contiguous())).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
+            gs, s = _lib.pow2_rescale(g)            # gradients are tiny: keep the GEMM's f16 halves in range (exact)
+            gx = (ops.linear(gs, ops.PackedLinear(wd.t().contiguous())) / s).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
         if ctx.needs_input_grad[1]:
             gw = g.t().matmul(xd)                                                         # dW = dY^T X (library GEMM)
         if ctx.has_bias and ctx.needs_input_grad[2]:

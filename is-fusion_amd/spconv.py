@@ -239,9 +239,13 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nbr_t, st = transposed_nbr(rb)
             grad_in = torch.empty((rb.num_in, c_in), dtype=torch.float32, device=g.device)
-            _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(g), rb.num_out, c_out, _lib.ptr(w), K, c_in,
+            # dX runs on the f16x3 forward kernel over the transposed rulebook: rescale the (tiny) gradient by a power
+            # of two so that its f16 halves stay in the normal range (exact; _lib.pow2_rescale)
+            gs, s = _lib.pow2_rescale(g)
+            _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(gs), rb.num_out, c_out, _lib.ptr(w), K, c_in,
                                                           _lib.ptr(nbr_t), st, rb.num_in, _lib.ptr(grad_in),
                                                           _lib.stream()), "isf_sparse_conv_backward_input")
+            grad_in = grad_in / s
         if ctx.needs_input_grad[1]:
             grad_w = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
             _lib.check(lib.isf_sparse_conv_backward_filter(_lib.ptr(features), rb.num_in, c_in, _lib.ptr(g),

@@ -19,11 +19,14 @@ def rel_err(got, want):
     return (got.detach().cpu().double() - want.detach().double()).abs().max().item() / max(1.0, want.detach().abs().max().item())
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-6])
 @pytest.mark.parametrize("M,K,N,bias", [(300, 128, 128, True), (1000, 256, 64, False), (77, 32, 256, True)])
-def test_linear_function_gradients(dev, M, K, N, bias):
-    """LinearFunction: forward + dX on the f16x3 MFMA GEMM, dW / db as library GEMM / reduction, vs float64 autograd"""
+def test_linear_function_gradients(dev, M, K, N, bias, gscale):
+    """LinearFunction: forward + dX on the f16x3 MFMA GEMM, dW / db as library GEMM / reduction, vs float64 autograd.
+    gscale 1e-6: gradients of the size a real backward pass carries -- they would sit in f16's subnormal range if the
+    dX GEMM split them unscaled (found as a 15 % error on the first G2R layers' gradients)."""
     from isfusion_amd import fusion_train as tr
-    x, w, b, g = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5), rnd((N,), 3), rnd((M, N), 4)
+    x, w, b, g = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5), rnd((N,), 3), rnd((M, N), 4) * gscale
     xd, wd, bd = [t.double().requires_grad_() for t in (x, w, b)]
     ref = xd @ wd.t() + (bd if bias else 0)
     ref.backward(g.double())
@@ -31,9 +34,10 @@ def test_linear_function_gradients(dev, M, K, N, bias):
     out = tr.linear_w(xg, wg, bg if bias else None)
     assert rel_err(out, ref) < 1e-5
     out.backward(g.to(dev))
-    assert rel_err(xg.grad, xd.grad) < 1e-5 and rel_err(wg.grad, wd.grad) < 1e-4
+    rel = lambda got, want: (got.cpu().double() - want).abs().max().item() / want.abs().max().item()
+    assert rel(xg.grad, xd.grad) < 1e-5 and rel(wg.grad, wd.grad) < 1e-4
     if bias:
-        assert rel_err(bg.grad, bd.grad) < 1e-5
+        assert rel(bg.grad, bd.grad) < 1e-5
 
 
 @pytest.mark.parametrize("B,C,R", [(1, 4, 36), (2, 8, 180)])
@@ -117,20 +121,28 @@ def test_fusion_encoder_parameter_gradients_match_oracle_autograd(dev):
         (hm * wh.to(dev)).sum() / rhm.numel()
     assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
     loss.backward()
-    worst = ("", 0.0)
-    checked = 0
+    rows = []
     for name, p in list(enc.named_parameters()) + [("bb." + n, q) for n, q in bb.named_parameters()]:
         ref = (sdb if name.startswith("bb.") else sd)[name].grad
         if ref is None:
             continue
         assert p.grad is not None, f"{name} received no gradient"
-        scale = max(ref.abs().max().item(), 1e-6)
-        err = (p.grad.cpu() - ref).abs().max().item() / scale
-        checked += 1
-        if err > worst[1]:
-            worst = (name, err)
-    assert checked > 100
-    assert worst[1] < 2e-2, worst           # fp32 chains of ~60 layers; typical errors are 1e-4 .. 1e-3
+        rows.append((name, (p.grad.cpu() - ref).abs().max().item(), ref.abs().max().item()))
+    assert len(rows) > 100
+    gmax = max(r[2] for r in rows)
+    # error of a parameter's gradient relative to its own scale, floored at 1e-3 of the largest gradient of the model
+    # (a gradient a thousand times smaller than the others carries the fp32 noise of the chain it hangs on)
+    scored = sorted(((d / max(m, 1e-3 * gmax), n, d, m) for n, d, m in rows), reverse=True)
+    hip_side = [r for r in scored if r[1].startswith(("grid2region_att", "instance_att", "instance_to_scene_att"))]
+    stock = [r for r in scored if r not in hip_side]
+    fmt = lambda rs: "; ".join(f"{n}: err {d:.2e} of {m:.2e}" for _, n, d, m in rs[:5])
+    print("worst (modules on HIP kernels):", fmt(hip_side))
+    print("worst (stock conv / BN stacks):", fmt(stock))
+    assert len(hip_side) > 80
+    assert hip_side[0][0] < 1e-2, fmt(hip_side)          # transformer pieces: fp32-class chains, typically 1e-4 .. 1e-3
+    # the 3x3 conv + BN stacks are stock PyTorch-ROCm (MIOpen) on this side and torch-CPU in the oracle: their own
+    # backward algorithms differ by a few per cent on the smallest gradients
+    assert stock[0][0] < 8e-2, fmt(stock)
     assert rel_err(img_g.grad, img.grad) < 1e-2
 
 

@@ -257,9 +257,11 @@ def test_sparse_conv_backward_vs_oracle_golden_geometries(dev, golden, oracle_mo
     assert np.abs(conv.bias.grad.cpu().numpy() - gout.sum(0)).max() < 1e-3
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-6])
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 64), (128, 256), (256, 256)])
-def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout):
-    """every (Cin, Cout) block shape of the dW kernel and the transposed-filter dX path; several row chunks"""
+def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout, gscale):
+    """every (Cin, Cout) block shape of the dW kernel and the transposed-filter dX path; several row chunks; gradients
+    of O(1) and of the size a real backward pass carries (1e-6: f16-subnormal if the dX kernel split them unscaled)"""
     from isfusion_amd import spconv
     rng = np.random.default_rng(cin * 1000 + cout)
     B, shape = 2, [9, 24, 24]
@@ -270,14 +272,14 @@ def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout):
     feats = rng.normal(size=(n, cin)).astype(np.float32)
     w = (rng.normal(size=(3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
     out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], subm=True)
-    gout = rng.normal(size=(n, cout)).astype(np.float32)
+    gout = (rng.normal(size=(n, cout)) * gscale).astype(np.float32)
     dx, dw = oracle_mod.indice_conv_backward(feats, w, gout, pairs, num)
     rb = spconv.build_rulebook(_T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
     x, wt = _T(feats, dev).requires_grad_(), _T(w, dev).requires_grad_()
     out = spconv.SparseConvFunction.apply(x, wt, rb)
     out.backward(_T(gout, dev))
-    assert np.abs(x.grad.cpu().numpy() - dx).max() < 1e-3 * max(1.0, np.abs(dx).max())
-    assert np.abs(wt.grad.cpu().numpy() - dw).max() < 1e-3 * max(1.0, np.abs(dw).max())
+    assert np.abs(x.grad.cpu().numpy() - dx).max() < 1e-3 * max(gscale, np.abs(dx).max())
+    assert np.abs(wt.grad.cpu().numpy() - dw).max() < 1e-3 * max(gscale, np.abs(dw).max())
     # deterministic: a second backward gives the same bits
     x2, w2 = _T(feats, dev).requires_grad_(), _T(w, dev).requires_grad_()
     spconv.SparseConvFunction.apply(x2, w2, rb).backward(_T(gout, dev))
