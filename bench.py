@@ -343,7 +343,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
     ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16],
-                    help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_set_conv_diagnostic; "
+                    help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_encoder_options.diagnostic; "
                          "results are garbage, the line is labelled)")
     ap.add_argument("--f16", action="store_true",
                     help="DIAGNOSTIC ONLY: single-pass f16 conv kernels (fp16-autocast accuracy, BASELINE configs[4] "
@@ -369,9 +369,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
 
-    from isfusion_amd import _lib
-    _lib.check(_lib.load().isf_set_conv_precision(2 if args.f16 else 1 if args.fp32 else 0))
-    _lib.check(_lib.load().isf_set_conv_diagnostic(args.conv_diag))
+    precision = 2 if args.f16 else 1 if args.fp32 else 0
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
     frame_sets = [[torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points, fs)]
                   for fs in range(max(1, args.frame_sets))]
@@ -383,7 +381,7 @@ def main():
             dist.barrier()
 
     for i in range(args.warmup):
-        out = lb(frame_sets[i % len(frame_sets)])
+        out = lb(frame_sets[i % len(frame_sets)], precision=precision, conv_diag=args.conv_diag)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -396,7 +394,7 @@ def main():
     # (the roofline accounting below uses the geometry of the last step's frame set and the layer times averaged over
     #  all steps; the sets are the same size class: same generator, different seeds)
     for step in range(args.steps):
-        out = lb(frame_sets[step % len(frame_sets)], time_layers=True)
+        out = lb(frame_sets[step % len(frame_sets)], time_layers=True, precision=precision, conv_diag=args.conv_diag)
         st = lb.last_stats
         ms_acc += np.array([st.ms[i] for i in range(nl)])
     torch.cuda.synchronize()

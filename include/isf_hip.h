@@ -189,11 +189,13 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * (same 4 bytes/element as fp32; the 16-byte pieces the four k-group lanes of an MFMA row fetch together are
  * contiguous); isf_f32_to_split / isf_split_to_f32 convert ([N, C] row-major fp32, N*C a multiple of 32).
  * |activation| must be < 65504.  Cin, Cout in {32,64,128,256}.
- * isf_set_conv_precision(0) (default): isf_sparse_encoder_forward / isf_lidar_branch_forward use this path
- * when every layer carries packed16; isf_set_conv_precision(1) forces the fp32 MFMA kernels;
- * isf_set_conv_precision(2) (opt-in, never the default): single-pass f16 -- the same kernels fetch and multiply only
- * the hi halves (f16 operands, fp32 accumulate: the accuracy of the reference's indice_conv_half under fp16 autocast,
- * BASELINE configs[4]); results are still exchanged in the split format. */
+ * `mode` of isf_sparse_conv_forward_f16x3 (per call; there is no process-wide switch): 0 = split precision (default);
+ * 1 = single-pass f16 (opt-in): the same kernels fetch and multiply only the hi halves -- f16 operands, fp32
+ * accumulate, the accuracy of the reference's indice_conv_half under fp16 autocast (BASELINE configs[4]); results are
+ * still exchanged in the split format.  TIMING DIAGNOSTICS (tools/conv_knockout.sh; never in production): 2 = no
+ * activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop -- the RESULTS ARE GARBAGE, only kernel
+ * times are meaningful; 16 = gather every row (no neighbour sharing): results valid and
+ * bit-identical to mode 0, the reference the sharing is tested against. */
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
 int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
                            isf_stream_t stream);
@@ -202,15 +204,7 @@ int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t st
 int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                   const float* scale, const float* shift, const void* residual_split, int relu,
-                                  void* out_split, isf_stream_t stream);
-int isf_set_conv_precision(int mode);
-/* TIMING DIAGNOSTICS of the sparse-conv kernel (tools/conv_knockout.sh; never set in production): 0 = off (default),
- * 2 = no activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop.  The convolution RESULTS ARE
- * GARBAGE while one of these is set; only kernel times are meaningful.
- * 16 = gather every row (no neighbour sharing): results VALID and bit-identical to mode 0 -- the reference the sharing
- * is tested against. */
-int isf_set_conv_diagnostic(int mode);
-
+                                  void* out_split, int mode, isf_stream_t stream);
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
  * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros
  * elsewhere; out [B, C*D, H, W] is written completely (no separate memset).  Asynchronous. */
@@ -241,13 +235,22 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
   int precision;       /* 0 = fp32 MFMA kernels ran, 1 = f16x3 split-precision MFMA kernels ran */
 } isf_encoder_stats;
 
+/* per-call options of the two engine entry points (NULL = all defaults; no process-wide state):
+ * precision  0 = f16x3 split MFMA when every layer carries packed16, else fp32 MFMA (default); 1 = force the fp32 MFMA
+ *            kernels; 2 = single-pass f16 (opt-in, fp16-autocast accuracy: mode 1 of isf_sparse_conv_forward_f16x3);
+ * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16: see isf_sparse_conv_forward_f16x3). */
+typedef struct isf_encoder_options {
+  int precision;
+  int diagnostic;
+} isf_encoder_options;
+
 int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors, int num_voxels,
                                int batch_size, const int sparse_shape_host[3],
                                const isf_conv_layer* layers_host, int num_layers,
                                float* spatial_features, /* [B, C_last*D_last, H_last, W_last] */
                                int out_shape_host[4],   /* C*D, H, W and N_last (may be NULL) */
                                isf_encoder_stats* stats_host /* may be NULL */, int time_layers,
-                               isf_stream_t stream);
+                               const isf_encoder_options* options /* may be NULL */, isf_stream_t stream);
 
 /* LiDAR branch in one call: dynamic voxelize + DynamicVFE + SparseEncoder (isfusion.py:103-111) */
 typedef struct isf_vfe_params {
@@ -260,7 +263,8 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
                              const isf_vfe_params* vfe_host, const int sparse_shape_host[3],
                              const isf_conv_layer* layers_host, int num_layers,
                              float* spatial_features, int out_shape_host[4],
-                             isf_encoder_stats* stats_host, int time_layers, isf_stream_t stream);
+                             isf_encoder_stats* stats_host, int time_layers,
+                             const isf_encoder_options* options /* may be NULL */, isf_stream_t stream);
 
 /* ===================================================================================================
  * HSF / IGF rows (A8, A10-A14).  Dense 3x3 convolutions around them stay stock

@@ -41,6 +41,19 @@ class EncoderStats(ctypes.Structure):
     ]
 
 
+class EncoderOptions(ctypes.Structure):
+    """struct isf_encoder_options: per-call precision (0 auto f16x3 / 1 fp32 MFMA / 2 single-pass f16) and timing
+    diagnostic of the conv kernels (0 off)."""
+    _fields_ = [("precision", c_int), ("diagnostic", c_int)]
+
+
+def encoder_options(precision=0, diagnostic=0):
+    """-> byref(isf_encoder_options) or None for the defaults"""
+    if not precision and not diagnostic:
+        return None
+    return ctypes.byref(EncoderOptions(int(precision), int(diagnostic)))
+
+
 class VfeParams(ctypes.Structure):
     """struct isf_vfe_params."""
     _fields_ = [
@@ -112,22 +125,22 @@ SIGNATURES = {
     "isf_f32_to_split": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_split_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
-                                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "isf_set_conv_precision": (c_int, [c_int]),
+                                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "isf_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_ingroup_indices": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "isf_p2g_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "isf_set_conv_diagnostic": (c_int, [c_int]),
     "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p]),
     "isf_sparse_encoder_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, _I3,
                                            ctypes.POINTER(ConvLayer), c_int, c_void_p, _I4,
-                                           ctypes.POINTER(EncoderStats), c_int, c_void_p]),
+                                           ctypes.POINTER(EncoderStats), c_int, ctypes.POINTER(EncoderOptions),
+                                           c_void_p]),
     "isf_lidar_branch_forward": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), c_int,
                                          ctypes.POINTER(VfeParams), _I3, ctypes.POINTER(ConvLayer), c_int,
-                                         c_void_p, _I4, ctypes.POINTER(EncoderStats), c_int, c_void_p]),
+                                         c_void_p, _I4, ctypes.POINTER(EncoderStats), c_int,
+                                         ctypes.POINTER(EncoderOptions), c_void_p]),
     "isf_packed_linear_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "isf_pack_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "isf_linear_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -273,7 +273,7 @@ int isf_attention_forward(const float* q, int ldq, const float* k, const float* 
   if (num_keys > 512) {   // keys split into <= 512-key chunks + merge
     hipStream_t st = as_stream(stream);
     const int kps = 512, nsplit = ceil_div(num_keys, kps);
-    Arena& a = arena_for_current_device();
+    Arena& a = arena_for_stream(as_stream(stream));
     ISF_TRY(a.reset());
     float* part = nullptr;
     ISF_TRY(a.alloc_n(&part, (size_t)batch_size * num_heads * nsplit * num_queries * (hd + 2)));

@@ -288,7 +288,7 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
                                  (size_t)batch_size * num_keys, st));
     return ISF_OK;
   }
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   float* stat = nullptr;
   ISF_TRY(a.alloc_n(&stat, (size_t)batch_size * num_heads * num_queries * 2));

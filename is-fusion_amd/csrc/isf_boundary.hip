@@ -78,7 +78,7 @@ int isf_ingroup_indices(const int64_t* group_inds, int num, int64_t* out_inds, i
   if (num == 0) return ISF_OK;
   ISF_REQUIRE(group_inds && out_inds, ISF_ERR_ARG, "ingroup_indices: null pointer");
   hipStream_t st = as_stream(stream);
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   int64_t* keys = nullptr;
   int32_t *iota = nullptr, *order = nullptr, *start = nullptr, *seg = nullptr;

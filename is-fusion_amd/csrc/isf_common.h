@@ -39,24 +39,39 @@ void set_error(const char* fmt, ...);
 
 #define ISF_LAUNCH_CHECK() ISF_HIP_TRY(hipGetLastError())
 
-// ----------------------------------------------------------------------------- workspace arena
-// Bump allocator over a few large hipMalloc'd blocks.  reset() at the start of every top-level API
-// call; if more than one block had to be created the arena is coalesced into one block at the next
-// reset (after a device sync), so the steady state is exactly one block and zero hipMalloc calls.
+// ----------------------------------------------------------------------------- per-stream workspace
+// One workspace per (device, caller stream): a bump allocator over a few large hipMalloc'd blocks plus the helper
+// objects a call needs (side stream, recycled events, the persistent byte maps of the level-0 occupancy index).  reset()
+// at the start of every top-level API call; if more than one block had to be created the arena is coalesced into one
+// block at the next reset (after a device sync), so the steady state is exactly one block and zero hipMalloc calls.
+// Calls on DIFFERENT streams (or from different host threads on different streams) never share workspace memory;
+// calls on ONE stream are ordered by the stream, so reusing its workspace from call to call is safe.  The registry is
+// mutex-protected; a single workspace is not: issue the calls of one stream from one host thread at a time.
+struct ByteMaps {
+  unsigned char* fine = nullptr;
+  unsigned char* coarse = nullptr;
+  size_t words = 0;
+};
+
 class Arena {
  public:
   int reset();                              // start of a top-level call
   int alloc(void** out, size_t bytes);      // 256-byte aligned
   template <typename T>
   int alloc_n(T** out, size_t n) { return alloc(reinterpret_cast<void**>(out), n * sizeof(T)); }
-  int release();
+  int release();                            // frees blocks, byte maps, side stream, events
   size_t capacity() const;
+  // helper objects owned by the workspace
+  hipStream_t side = nullptr;               // geometry / rulebook work of the sparse encoder overlaps the convolutions
+  std::vector<hipEvent_t> events;           // recycled hipEventDisableTiming events
+  size_t next_event = 0;
+  ByteMaps bytemaps;
  private:
   struct Block { char* base; size_t cap; size_t off; };
   std::vector<Block> blocks_;
 };
 
-Arena& arena_for_current_device();
+Arena& arena_for_stream(hipStream_t st);    // workspace of (current device, st); created on first use
 
 static inline hipStream_t as_stream(isf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -77,16 +92,16 @@ struct OccIndex {
 
 int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st, bool zero = true);
 // atomic-free marking through persistent byte maps (writes EVERY bitmap word: create with zero = false)
-int occ_mark_coords4_bytemap(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
+int occ_mark_coords4_bytemap(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
 int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
 int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st);                           // prefix + total
 int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
 // coords of all set bits in rank order -> out [total,4]
 int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st);
 int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream sync
-int side_stream(hipStream_t* out);                         // per-device non-blocking helper stream
-int stream_wait_stream(hipStream_t waiter, hipStream_t producer);  // event from a recycled pool
-int pooled_event(hipEvent_t* out);                         // recycled hipEventDisableTiming events
+int side_stream(Arena& a, hipStream_t* out);               // the workspace's non-blocking helper stream
+int stream_wait_stream(Arena& a, hipStream_t waiter, hipStream_t producer);  // event from the workspace's pool
+int pooled_event(Arena& a, hipEvent_t* out);               // recycled hipEventDisableTiming events
 
 __device__ __forceinline__ int occ_lookup(const unsigned long long* __restrict__ bits,
                                           const uint32_t* __restrict__ prefix,
@@ -145,7 +160,7 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out);
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                    const float* shift, const void* residual, int relu, void* ys,
-                                   hipStream_t st);
+                                   int mode /* 0 | 1 single-pass f16 | timing diagnostics */, hipStream_t st);
 int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st);
 int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st);
 int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st);

@@ -133,8 +133,6 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* _
 }
 
 // ----------------------------------------------------------------------------------------- encoder
-int g_conv_precision = 0;  // 0 = auto (f16x3 split MFMA where packed), 1 = force fp32 MFMA, 2 = single-pass f16 (opt-in)
-
 struct LevelState {
   int shape[3];
   int n;                  // active rows (host)
@@ -160,17 +158,23 @@ static int ensure_occ(Arena& a, LevelState& L, int B, hipStream_t st) {
 int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0, int n0, int B,
                                 const int shape0[3], const OccIndex* occ0, const isf_conv_layer* layers,
                                 int num_layers, float* spatial_features, int out_shape[4],
-                                isf_encoder_stats* stats, int time_layers, hipStream_t st,
-                                hipEvent_t geometry_ready = nullptr) {
+                                isf_encoder_stats* stats, int time_layers, const isf_encoder_options* opt,
+                                hipStream_t st, hipEvent_t geometry_ready = nullptr) {
+  const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
+  ISF_REQUIRE(precision >= 0 && precision <= 2 && (diagnostic == 0 || diagnostic == 2 || diagnostic == 4 ||
+                                                   diagnostic == 6 || diagnostic == 8 || diagnostic == 16) &&
+                  !(precision == 2 && diagnostic != 0),
+              ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
+  const int conv_mode = precision == 2 ? 1 : diagnostic;
   ISF_REQUIRE(num_layers > 0 && num_layers <= 32, ISF_ERR_ARG, "sparse_encoder: %d layers (1..32)", num_layers);
   // Geometry (occupancy indexes, output sets, neighbour tables: small integer kernels + the host syncs that size
   // the next level) runs on a side stream and overlaps the convolutions of the previous level on `st`; a
   // convolution waits for the event recorded behind its level's table.  `sg` first waits for everything the
   // caller enqueued on `st` -- or only for `geometry_ready`, the point where the VFE's coordinates are final.
   hipStream_t sg = nullptr;
-  ISF_TRY(side_stream(&sg));
+  ISF_TRY(side_stream(a, &sg));
   if (geometry_ready) ISF_HIP_TRY(hipStreamWaitEvent(sg, geometry_ready, 0));   // coords final: overlap the VFE tail too
-  else ISF_TRY(stream_wait_stream(sg, st));
+  else ISF_TRY(stream_wait_stream(a, sg, st));
   LevelState L;
   for (int j = 0; j < 3; ++j) L.shape[j] = shape0[j];
   L.n = n0;
@@ -179,7 +183,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   if (occ0) { L.occ = *occ0; L.has_occ = true; }
   L.cache_nbr = nullptr;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
-  bool use16 = g_conv_precision != 1;
+  bool use16 = precision != 1;
   for (int i = 0; i < num_layers; ++i)
     use16 = use16 && layers[i].packed16 && sparse_conv_f16x3_supported(layers[i].c_in, layers[i].c_out);
   const void* outputs[32];
@@ -224,7 +228,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_stride = stride;
         for (int j = 0; j < 3; ++j) L.cache_ks[j] = ly.ksize[j];
         L.cache_pairs = -(long long)i - 1;  // pairs live in pair_counts[i]; resolved after the final sync
-        ISF_TRY(stream_wait_stream(st, sg));   // this level's convolutions wait for its table
+        ISF_TRY(stream_wait_stream(a, st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
         stride = L.cache_stride;
@@ -253,7 +257,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       Nx.cache_nbr = nullptr;
       n_out = Nx.n;
       L = Nx;
-      ISF_TRY(stream_wait_stream(st, sg));
+      ISF_TRY(stream_wait_stream(a, st, sg));
     }
     void* y = nullptr;
     ISF_TRY(a.alloc(&y, (size_t)std::max(n_out, 1) * ly.c_out * 4));
@@ -267,7 +271,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i], st));
     if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
-                                             ly.shift, res, ly.relu, y, st));
+                                             ly.shift, res, ly.relu, y, conv_mode, st));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
       ISF_TRY(sparse_conv_forward_packed_impl(reinterpret_cast<const float*>(x), n_in, ly.c_in, ly.packed, K,
                                               ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
@@ -287,7 +291,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   }
   // dense BEV of the last level
   ISF_TRY(ensure_occ(a, L, B, sg));
-  ISF_TRY(stream_wait_stream(st, sg));
+  ISF_TRY(stream_wait_stream(a, st, sg));
   ISF_TRY(sparse_to_dense_bev_impl(a, x, use16, L.coors, L.n, c_last, B, L.shape[0], L.shape[1], L.shape[2],
                                    spatial_features, &L.occ, st));
   if (stats) stats->precision = use16 ? 1 : 0;
@@ -310,18 +314,12 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
 
 extern "C" {
 
-int isf_set_conv_precision(int mode) {
-  if (mode != 0 && mode != 1 && mode != 2) return ISF_ERR_ARG;
-  isf::g_conv_precision = mode;
-  return ISF_OK;
-}
-
 int isf_sparse_to_dense_bev(const float* features, const int32_t* indices, int num_rows, int channels,
                             int batch_size, int D, int H, int W, float* out, isf_stream_t stream) {
   ISF_REQUIRE(num_rows >= 0 && channels > 0 && batch_size > 0 && D > 0 && H > 0 && W > 0 && out, ISF_ERR_ARG,
               "sparse_to_dense_bev: bad arguments");
   ISF_REQUIRE(num_rows == 0 || (features && indices), ISF_ERR_ARG, "sparse_to_dense_bev: null pointer");
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::sparse_to_dense_bev_impl(a, features, false, indices, num_rows, channels, batch_size, D, H, W, out,
                                        nullptr, isf::as_stream(stream));
@@ -331,13 +329,13 @@ int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors
                                int batch_size, const int sparse_shape_host[3],
                                const isf_conv_layer* layers_host, int num_layers, float* spatial_features,
                                int out_shape_host[4], isf_encoder_stats* stats_host, int time_layers,
-                               isf_stream_t stream) {
+                               const isf_encoder_options* options, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(num_voxels > 0 && batch_size > 0 && sparse_shape_host && layers_host && spatial_features &&
                   voxel_features && coors && num_layers > 0,
               ISF_ERR_ARG, "sparse_encoder_forward: bad arguments");
   hipStream_t st = as_stream(stream);
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   // The kernels want rows in rank ((b,z,y,x)-sorted) order, which is what DynamicVFE emits.  Verify it on
   // the device; arbitrary / duplicated input rows (e.g. the reference's shape test feeds random coords)
@@ -377,20 +375,20 @@ int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors
     c = cs;
   }
   return sparse_encoder_forward_impl(a, x, c, n, batch_size, sparse_shape_host, &occ0, layers_host, num_layers,
-                                     spatial_features, out_shape_host, stats_host, time_layers, st);
+                                     spatial_features, out_shape_host, stats_host, time_layers, options, st);
 }
 
 int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_host, int batch_size,
                              const isf_vfe_params* vfe_host, const int sparse_shape_host[3],
                              const isf_conv_layer* layers_host, int num_layers, float* spatial_features,
                              int out_shape_host[4], isf_encoder_stats* stats_host, int time_layers,
-                             isf_stream_t stream) {
+                             const isf_encoder_options* options, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(points && point_offsets_host && batch_size > 0 && vfe_host && sparse_shape_host && layers_host &&
                   spatial_features,
               ISF_ERR_ARG, "lidar_branch_forward: bad arguments");
   hipStream_t st = as_stream(stream);
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   const int64_t P64 = point_offsets_host[batch_size];
   ISF_REQUIRE(P64 > 0 && P64 < (1ll << 31), ISF_ERR_ARG, "lidar_branch_forward: bad point count");
@@ -420,7 +418,7 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
                       occ0.W == sparse_shape_host[2];
   return sparse_encoder_forward_impl(a, vf, vc, n0, batch_size, sparse_shape_host, occ_ok ? &occ0 : nullptr,
                                      layers_host, num_layers, spatial_features, out_shape_host, stats_host,
-                                     time_layers, st, occ_ok ? coords_ready : nullptr);
+                                     time_layers, options, st, occ_ok ? coords_ready : nullptr);
 }
 
 }  // extern "C"

@@ -519,7 +519,7 @@ int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int
   ISF_REQUIRE(k > 0 && k <= 1024 && k <= n && n <= 0x7FFFF, ISF_ERR_UNSUPPORTED,
               "instance_topk: k %d (<= 1024) over %lld cells (<= 524287)", k, n);
   hipStream_t st = as_stream(stream);
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   unsigned long long* cand = nullptr;
   int* count = nullptr;

@@ -198,7 +198,7 @@ int isf_assemble_points(const float* raw, const isf_sweep_t* sweeps, int num_swe
   int live = num_sweeps;
   while (live > 0 && dev[live - 1].num_points == 0) --live;
 
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   SweepDev* d_sweeps;
   AugDev* d_aug = nullptr;

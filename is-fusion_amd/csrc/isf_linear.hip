@@ -429,7 +429,7 @@ int isf_pack_linear(const float* weight, int out_features, int in_features, void
   ISF_REQUIRE(weight && packed && out_features % 16 == 0 && in_features % 32 == 0 && out_features > 0 && in_features > 0,
               ISF_ERR_ARG, "pack_linear: need out %% 16 == 0 and in %% 32 == 0 (got %d, %d)", out_features, in_features);
   hipStream_t st = as_stream(stream);
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   unsigned* amax = nullptr;
   ISF_TRY(a.alloc_n(&amax, 64));

@@ -237,7 +237,7 @@ int isf_build_rulebook(const int32_t* indices, int num_in, int batch_size, const
   const int K = ksize_host[0] * ksize_host[1] * ksize_host[2];
   ISF_REQUIRE(K >= 1 && K <= 27, ISF_ERR_UNSUPPORTED, "build_rulebook: kernel volume %d (max 27)", K);
   hipStream_t st = as_stream(stream);
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   const bool subm = conv_type == ISF_CONV_SUBM;
   *num_out_host = 0;

@@ -1,6 +1,8 @@
 // isf_runtime.hip -- error state, per-device workspace arena, occupancy-index (rank bitmap) kernels.
 #include "isf_common.h"
 
+#include <map>
+#include <memory>
 #include <mutex>
 
 namespace isf {
@@ -60,9 +62,21 @@ int Arena::alloc(void** out, size_t bytes) {
 }
 
 int Arena::release() {
-  if (!blocks_.empty()) ISF_HIP_TRY(hipDeviceSynchronize());
+  if (!blocks_.empty() || bytemaps.fine || side) ISF_HIP_TRY(hipDeviceSynchronize());
   for (auto& b : blocks_) ISF_HIP_TRY(hipFree(b.base));
   blocks_.clear();
+  if (bytemaps.fine) {
+    (void)hipFree(bytemaps.fine);
+    (void)hipFree(bytemaps.coarse);
+    bytemaps = ByteMaps();
+  }
+  for (auto e : events) (void)hipEventDestroy(e);
+  events.clear();
+  next_event = 0;
+  if (side) {
+    (void)hipStreamDestroy(side);
+    side = nullptr;
+  }
   return ISF_OK;
 }
 
@@ -72,57 +86,44 @@ size_t Arena::capacity() const {
   return t;
 }
 
-static Arena g_arenas[16];
+// registry: (device, stream) -> workspace.  Entries live until isf_release_workspace().
+static std::mutex g_mu;
+static std::map<std::pair<int, hipStream_t>, std::unique_ptr<Arena>> g_arenas;
 
-Arena& arena_for_current_device() {
+Arena& arena_for_stream(hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  return g_arenas[dev];
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto& slot = g_arenas[std::make_pair(dev, st)];
+  if (!slot) slot.reset(new Arena());
+  return *slot;
 }
 
-// ---- side stream + event pool (geometry / rulebook work of the sparse encoder overlaps the convolutions)
-struct SideState {
-  hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> events;
-  size_t next = 0;
-};
-static SideState g_side[16];
-
-static SideState& side_for_current_device() {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  return g_side[dev];
-}
-
-int side_stream(hipStream_t* out) {
-  SideState& s = side_for_current_device();
-  if (!s.stream) ISF_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-  *out = s.stream;
+int side_stream(Arena& a, hipStream_t* out) {
+  if (!a.side) ISF_HIP_TRY(hipStreamCreateWithFlags(&a.side, hipStreamNonBlocking));
+  *out = a.side;
   return ISF_OK;
 }
 
 // events are recycled round-robin; 256 is far more than one forward records, so an event is never re-recorded
 // while a wait on its previous recording is still pending in the same call
-int pooled_event(hipEvent_t* out) {
-  SideState& s = side_for_current_device();
-  if (s.events.size() < 256) {
+int pooled_event(Arena& a, hipEvent_t* out) {
+  if (a.events.size() < 256) {
     hipEvent_t e;
     ISF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    s.events.push_back(e);
+    a.events.push_back(e);
     *out = e;
     return ISF_OK;
   }
-  *out = s.events[s.next];
-  s.next = (s.next + 1) % s.events.size();
+  *out = a.events[a.next_event];
+  a.next_event = (a.next_event + 1) % a.events.size();
   return ISF_OK;
 }
 
 // make stream `waiter` wait for everything enqueued on `producer` so far
-int stream_wait_stream(hipStream_t waiter, hipStream_t producer) {
+int stream_wait_stream(Arena& a, hipStream_t waiter, hipStream_t producer) {
   hipEvent_t e;
-  ISF_TRY(pooled_event(&e));
+  ISF_TRY(pooled_event(a, &e));
   ISF_HIP_TRY(hipEventRecord(e, producer));
   ISF_HIP_TRY(hipStreamWaitEvent(waiter, e, 0));
   return ISF_OK;
@@ -249,12 +250,6 @@ int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t 
 // the bitmap word and zero what they read, so both maps are clean again for the next frame; untouched words
 // write 0 (which also replaces the bitmap memset).  HBM traffic per frame: nwords (coarse) + 64 B per touched
 // word, instead of ~1.2 M fabric atomics.
-struct ByteMaps {
-  unsigned char* fine = nullptr;
-  unsigned char* coarse = nullptr;
-  size_t words = 0;
-};
-static ByteMaps g_bytemaps[16];
 
 __global__ void occ_bytemap_mark_kernel(const int32_t* __restrict__ coors4, int n, int B, int D, int H, int W,
                                         unsigned char* __restrict__ fine, unsigned char* __restrict__ coarse) {
@@ -301,10 +296,8 @@ __global__ __launch_bounds__(256) void occ_bytemap_pack_kernel(unsigned char* __
   reinterpret_cast<ulonglong2*>(bits + w0)[1] = make_ulonglong2(out[2], out[3]);
 }
 
-int occ_mark_coords4_bytemap(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st) {
-  int dev = 0;
-  ISF_HIP_TRY(hipGetDevice(&dev));
-  ByteMaps& bm = g_bytemaps[dev & 15];
+int occ_mark_coords4_bytemap(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st) {
+  ByteMaps& bm = a.bytemaps;
   const size_t alloc_words = round_up(occ.nwords, kWordsPerBlock);
   if (bm.words < alloc_words) {  // (re)allocate the persistent maps; zeroed once, kept zero by the pack pass
     ISF_HIP_TRY(hipStreamSynchronize(st));
@@ -465,31 +458,29 @@ int isf_device_count(int* count_host) {
 }
 
 int isf_release_workspace(void) {
-  for (int d = 0; d < 16; ++d) {
-    if (isf::g_bytemaps[d].fine) {
-      int cur = 0;
-      ISF_HIP_TRY(hipGetDevice(&cur));
-      ISF_HIP_TRY(hipSetDevice(d));
-      ISF_HIP_TRY(hipDeviceSynchronize());
-      (void)hipFree(isf::g_bytemaps[d].fine);
-      (void)hipFree(isf::g_bytemaps[d].coarse);
-      isf::g_bytemaps[d] = isf::ByteMaps();
-      ISF_HIP_TRY(hipSetDevice(cur));
-    }
-    if (isf::g_arenas[d].capacity() == 0) continue;
-    int cur = 0;
-    ISF_HIP_TRY(hipGetDevice(&cur));
-    ISF_HIP_TRY(hipSetDevice(d));
-    int r = isf::g_arenas[d].release();
-    ISF_HIP_TRY(hipSetDevice(cur));
-    if (r != ISF_OK) return r;
+  std::lock_guard<std::mutex> lock(isf::g_mu);
+  int cur = 0;
+  ISF_HIP_TRY(hipGetDevice(&cur));
+  int rc = ISF_OK;
+  for (auto& kv : isf::g_arenas) {
+    ISF_HIP_TRY(hipSetDevice(kv.first.first));
+    const int r = kv.second->release();
+    if (r != ISF_OK) rc = r;
   }
-  return ISF_OK;
+  isf::g_arenas.clear();
+  ISF_HIP_TRY(hipSetDevice(cur));
+  return rc;
 }
 
 int isf_workspace_bytes(size_t* bytes_host) {
   if (!bytes_host) return ISF_ERR_ARG;
-  *bytes_host = isf::arena_for_current_device().capacity();
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  std::lock_guard<std::mutex> lock(isf::g_mu);
+  size_t t = 0;
+  for (auto& kv : isf::g_arenas)
+    if (kv.first.first == cur) t += kv.second->capacity();
+  *bytes_host = t;
   return ISF_OK;
 }
 

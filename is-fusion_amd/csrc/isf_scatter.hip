@@ -239,7 +239,7 @@ int isf_dynamic_point_to_voxel_forward(const float* feats, const int32_t* coors,
               ISF_ERR_ARG, "dynamic_point_to_voxel_forward: bad arguments");
   ISF_REQUIRE(num_points == 0 || (feats && coors && reduced_feats && out_coors && coors_map && reduce_count),
               ISF_ERR_ARG, "dynamic_point_to_voxel_forward: null pointer");
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::dynamic_scatter_forward_impl(a, feats, coors, num_points, num_feats, reduce_type,
                                            reduced_feats, out_coors, coors_map, reduce_count,
@@ -255,7 +255,7 @@ int isf_dynamic_point_to_voxel_backward(float* grad_feats, const float* grad_red
               ISF_ERR_ARG, "dynamic_point_to_voxel_backward: bad arguments");
   ISF_REQUIRE(num_points == 0 || (grad_feats && coors_map), ISF_ERR_ARG,
               "dynamic_point_to_voxel_backward: null pointer");
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::dynamic_scatter_backward_impl(a, grad_feats, grad_reduced_feats, feats, reduced_feats,
                                             coors_map, reduce_count, num_points, num_voxels, num_feats,

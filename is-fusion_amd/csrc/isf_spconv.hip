@@ -343,7 +343,7 @@ int isf_sparse_conv_forward(const float* features, int num_in, int c_in, const f
   if (!isf::sparse_conv_mfma_supported(c_in, c_out))
     return isf::sparse_conv_forward_generic_impl(features, c_in, filters, num_taps, c_out, nbr, nbr_stride,
                                                  num_out, scale, shift, residual, relu, out, st);
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   float* packed = nullptr;
   ISF_TRY(a.alloc_n(&packed, (size_t)num_taps * c_in * c_out));

@@ -29,8 +29,6 @@
 
 namespace isf {
 
-extern int g_conv_precision;   // isf_encoder.hip: 0 f16x3 split (default), 1 fp32 MFMA, 2 single-pass f16 (opt-in)
-int g_conv_diag = 0;           // isf_set_conv_diagnostic: knock-out timing modes of the kernel below (results are garbage)
 
 template <int NT, int RG, int KCH, int NW>
 struct Conv16Smem {
@@ -48,11 +46,11 @@ struct Conv16Smem {
 
 // NW waves per workgroup (4, 8 or 16): all of them share one weight stage per step, so the weight bytes a CU pulls
 // through its vector memory path per MFMA fall with NW.
-// MODE bit 1 = single-pass mode (isf_set_conv_precision(2)): only the hi halves of activations and weights are fetched
+// MODE bit 1 = single-pass mode (precision 2 of isf_encoder_options, mode 1 of isf_sparse_conv_forward_f16x3): only the hi halves of activations and weights are fetched
 // and multiplied -- plain f16 operands with fp32 accumulation, the accuracy of the reference under fp16 autocast
 // (indice_conv_half), one MFMA per product instead of three.  Same buffers, same layouts; outputs are still written
 // split.  Never the default: the headline configuration is fp32-class.
-// MODE bits 2 / 4 / 8 are TIMING DIAGNOSTICS (isf_set_conv_diagnostic, results are garbage): 2 = no activation gathers
+// MODE bits 2 / 4 / 8 are TIMING DIAGNOSTICS (the `diagnostic` option / `mode` argument; results are garbage): 2 = no activation gathers
 // (A = 0), 4 = no weight DMA, 8 = no main loop (prologue + epilogue only) -- the knock-out decomposition of DESIGN.md
 // section 5 as a permanent tool (tools/conv_knockout.sh).  MODE bit 16 (valid results) switches the neighbour sharing of
 // the gathers off: the reference the sharing is checked against bit for bit.
@@ -428,7 +426,7 @@ static int dispatch16(int mode, const uint4* xs, const uint4* wpk, const float* 
 // packed16 = K*Cin*Cout*4 bytes of fragments followed by a 64-byte header
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
-                                   const float* shift, const void* residual, int relu, void* ys,
+                                   const float* shift, const void* residual, int relu, void* ys, int mode,
                                    hipStream_t st) {
   if (n_out <= 0) return ISF_OK;
   ISF_REQUIRE(K >= 1 && K <= kMaxTaps, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d taps (max 27)", K);
@@ -441,7 +439,6 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
   const uint4* x = reinterpret_cast<const uint4*>(xs);
   const uint4* r = reinterpret_cast<const uint4*>(residual);
   uint4* y = reinterpret_cast<uint4*>(ys);
-  const int mode = (g_conv_precision == 2 ? 1 : 0) | g_conv_diag;
   switch (c_in) {
     case 32:  return dispatch16<32>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
     case 64:  return dispatch16<64>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
@@ -497,7 +494,7 @@ int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_o
   ISF_REQUIRE(filters && packed16 && num_taps > 0, ISF_ERR_ARG, "pack_filters_f16x3: bad arguments");
   ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "pack_filters_f16x3: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::pack_filters16_impl(a, filters, num_taps, c_in, c_out, packed16, isf::as_stream(stream));
 }
@@ -512,23 +509,19 @@ int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t st
   return isf::split_to_f32_impl(xs, num_elems, x, isf::as_stream(stream));
 }
 
-int isf_set_conv_diagnostic(int mode) {
-  if (mode != 0 && mode != 2 && mode != 4 && mode != 6 && mode != 8 && mode != 16) return ISF_ERR_ARG;
-  isf::g_conv_diag = mode;
-  return ISF_OK;
-}
-
 int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                   const float* scale, const float* shift, const void* residual_split, int relu,
-                                  void* out_split, isf_stream_t stream) {
+                                  void* out_split, int mode, isf_stream_t stream) {
   ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0, ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: bad arguments");
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
+  ISF_REQUIRE(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 6 || mode == 8 || mode == 16, ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, diagnostics 2 / 4 / 6 / 8 / 16)", mode);
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
-                                             num_out, scale, shift, residual_split, relu, out_split,
+                                             num_out, scale, shift, residual_split, relu, out_split, mode,
                                              isf::as_stream(stream));
 }
 

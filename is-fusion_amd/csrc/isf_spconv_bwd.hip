@@ -151,7 +151,7 @@ int isf_sparse_conv_backward_input(const float* grad_out, int num_out, int c_out
     ISF_HIP_TRY(hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)num_in * c_in, st));
     return ISF_OK;
   }
-  Arena& a = arena_for_current_device();
+  Arena& a = arena_for_stream(as_stream(stream));
   ISF_TRY(a.reset());
   const size_t elems = (size_t)num_taps * c_in * c_out;
   float *wt = nullptr, *packed = nullptr;
@@ -198,7 +198,7 @@ int isf_sparse_conv_backward_filter(const float* features, int num_in, int c_in,
   chunks = ceil_div(num_out, rows_per_chunk);
   float* partial = grad_filters;
   if (chunks > 1) {
-    Arena& a = arena_for_current_device();
+    Arena& a = arena_for_stream(as_stream(stream));
     ISF_TRY(a.reset());
     ISF_TRY(a.alloc_n(&partial, elems * chunks));
   }

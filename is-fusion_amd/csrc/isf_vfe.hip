@@ -482,7 +482,7 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   OccIndex occ;
   // d_alloc > grid z lets the sparse encoder (sparse_shape[0] = grid z + 1) reuse this index for level 0
   ISF_TRY(occ_create(a, &occ, B, d_alloc > grid[2] ? d_alloc : grid[2], grid[1], grid[0], st, false));
-  ISF_TRY(occ_mark_coords4_bytemap(occ, coors4, P, st));
+  ISF_TRY(occ_mark_coords4_bytemap(a, occ, coors4, P, st));
   ISF_TRY(occ_scan(a, occ, st));
   float *sc1, *sc2;
   uint2* w1p;
@@ -520,7 +520,7 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
                      occ.bits, occ.prefix, pt2vox, slot, cnt, voxel_coors);
   ISF_LAUNCH_CHECK();
   if (coords_ready) {   // occupancy index + voxel coords are final here: the encoder's geometry can start now
-    ISF_TRY(pooled_event(coords_ready));
+    ISF_TRY(pooled_event(a, coords_ready));
     ISF_HIP_TRY(hipEventRecord(*coords_ready, st));
   }
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
@@ -574,7 +574,7 @@ int isf_dynamic_vfe_forward(const float* points, const int32_t* coors4, int num_
   ISF_REQUIRE(num_points == 0 || (points && coors4 && w1 && scale1 && shift1 && w2 && scale2 && shift2 &&
                                   voxel_feats && voxel_coors),
               ISF_ERR_ARG, "dynamic_vfe_forward: null pointer");
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::dynamic_vfe_impl(a, points, coors4, num_points, in_channels, batch_size, voxel_size_host,
                                coors_range_host, w1, scale1, shift1, c1, w2, scale2, shift2, c2,

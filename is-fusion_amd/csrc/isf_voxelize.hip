@@ -301,7 +301,7 @@ int isf_hard_voxelize(const float* points, int num_points, int num_features,
               ISF_ERR_ARG, "hard_voxelize: bad arguments");
   ISF_REQUIRE(num_points == 0 || (points && voxels && coors && num_points_per_voxel), ISF_ERR_ARG,
               "hard_voxelize: null pointer");
-  isf::Arena& a = isf::arena_for_current_device();
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::hard_voxelize_impl(a, points, num_points, num_features, voxel_size_host,
                                  coors_range_host, max_points, max_voxels, voxels, coors,

@@ -118,7 +118,7 @@ class PackedConvBN:
             _lib.check(lib.isf_sparse_conv_forward_f16x3(
                 _lib.ptr(m.data), m.num_tokens, c, _lib.ptr(pkt if transpose else pk), 9, self.c_out, _lib.ptr(nbr),
                 nstride, n_out, _lib.ptr(self.scale), _lib.ptr(self.shift if last else self.zero_shift),
-                _lib.ptr(acc) if acc is not None else None, int(self.relu and last), _lib.ptr(out), _lib.stream()),
+                _lib.ptr(acc) if acc is not None else None, int(self.relu and last), _lib.ptr(out), 0, _lib.stream()),
                 "isf_sparse_conv_forward_f16x3")
             acc = out
         return SplitMap(acc, m0.B, self.c_out, oh, ow)

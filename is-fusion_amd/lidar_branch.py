@@ -123,14 +123,16 @@ class LidarBranch(nn.Module):
         vf, vc = self.pts_voxel_encoder(pts[keep].float(), coors[keep])
         return self.pts_middle_encoder.forward_modules(vf, vc, len(points))[0]
 
-    def forward(self, points, time_layers=False, want_stats=False):
-        """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W]."""
+    def forward(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0):
+        """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W].
+        precision: 0 = f16x3 split MFMA (default, fp32-class), 1 = fp32 MFMA kernels, 2 = single-pass f16 (opt-in,
+        fp16-autocast accuracy); conv_diag: timing diagnostics of the conv kernels (results garbage except 16)."""
         if self.training:
             return self.forward_train(points)
         with torch.no_grad():
-            return self.forward_eval(points, time_layers, want_stats)
+            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag)
 
-    def forward_eval(self, points, time_layers=False, want_stats=False):
+    def forward_eval(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0):
         pts = torch.cat(points, dim=0).contiguous().float()
         _lib.require_cuda(pts)
         vfe = self.pts_voxel_encoder
@@ -156,7 +158,8 @@ class LidarBranch(nn.Module):
         _lib.check(lib.isf_lidar_branch_forward(
             _lib.ptr(pts), (ctypes.c_int64 * len(offs))(*offs), B, ctypes.byref(vp), _lib.i3(me.sparse_shape),
             arr, n, _lib.ptr(out), oshape, ctypes.byref(stats) if stats is not None else None,
-            int(bool(time_layers)), _lib.stream()), "isf_lidar_branch_forward")
+            int(bool(time_layers)), _lib.encoder_options(precision, conv_diag), _lib.stream()),
+            "isf_lidar_branch_forward")
         self.last_stats = stats
         return out
 

@@ -46,9 +46,9 @@ def dynamic_point_to_voxel_backward(grad_feats, grad_reduced_feats, feats, reduc
     if P == 0:
         return
     lib = _lib.load()
+    grf, f, rf = grad_reduced_feats.contiguous(), feats.contiguous(), reduced_feats.contiguous()   # outlive the C call
     _lib.check(lib.isf_dynamic_point_to_voxel_backward(
-        _lib.ptr(grad_feats), _lib.ptr(grad_reduced_feats.contiguous()), _lib.ptr(feats.contiguous()),
-        _lib.ptr(reduced_feats.contiguous()), _lib.ptr(coors_idx), _lib.ptr(reduce_count), P, M, C,
+        _lib.ptr(grad_feats), _lib.ptr(grf), _lib.ptr(f), _lib.ptr(rf), _lib.ptr(coors_idx), _lib.ptr(reduce_count), P, M, C,
         _lib.REDUCE[reduce_type], _lib.stream()), "isf_dynamic_point_to_voxel_backward")
 
 

@@ -197,18 +197,22 @@ class SparseEncoder(nn.Module):
         return c * shape[0], shape[1], shape[2]
 
     # ------------------------------------------------------------------------------------ forward
-    def forward_fused(self, voxel_features, coors, batch_size, stats=None, time_layers=False):
+    def forward_fused(self, voxel_features, coors, batch_size, stats=None, time_layers=False, precision=0,
+                      conv_diag=0):
+        """precision: 0 = f16x3 split MFMA (default), 1 = fp32 MFMA, 2 = single-pass f16 (opt-in, fp16-autocast
+        accuracy); conv_diag: timing diagnostics of the conv kernels (include/isf_hip.h) -- per call, no global state"""
         _lib.require_cuda(voxel_features, coors)
         arr, n, _keep, _plan = self._c_plan()
         cd, H, W = self.out_channels_and_shape()
         out = torch.empty((batch_size, cd, H, W), dtype=torch.float32, device=voxel_features.device)
         oshape = (ctypes.c_int * 4)()
         lib = _lib.load()
+        vf, vc = voxel_features.contiguous().float(), coors.contiguous().int()   # locals: must outlive the C call
         _lib.check(lib.isf_sparse_encoder_forward(
-            _lib.ptr(voxel_features.contiguous().float()), _lib.ptr(coors.contiguous().int()),
+            _lib.ptr(vf), _lib.ptr(vc),
             voxel_features.size(0), int(batch_size), _lib.i3(self.sparse_shape), arr, n, _lib.ptr(out), oshape,
-            ctypes.byref(stats) if stats is not None else None, int(bool(time_layers)), _lib.stream()),
-            "isf_sparse_encoder_forward")
+            ctypes.byref(stats) if stats is not None else None, int(bool(time_layers)),
+            _lib.encoder_options(precision, conv_diag), _lib.stream()), "isf_sparse_encoder_forward")
         assert (oshape[0], oshape[1], oshape[2]) == (cd, H, W)
         return out
 

@@ -66,8 +66,8 @@ class _SparseToDense(torch.autograd.Function):
         D, H, W = spatial_shape
         C = features.size(1)
         out = torch.empty((batch_size, C * D, H, W), dtype=torch.float32, device=features.device)
-        _lib.check(_lib.load().isf_sparse_to_dense_bev(_lib.ptr(features.detach().contiguous().float()),
-                                                       _lib.ptr(indices.contiguous()), features.size(0), C,
+        f, idx = features.detach().contiguous().float(), indices.contiguous()    # locals: must outlive the C call
+        _lib.check(_lib.load().isf_sparse_to_dense_bev(_lib.ptr(f), _lib.ptr(idx), features.size(0), C,
                                                        batch_size, D, H, W, _lib.ptr(out), _lib.stream()),
                    "isf_sparse_to_dense_bev")
         ctx.save_for_backward(indices)
@@ -164,7 +164,7 @@ def from_split(xs, shape):
 
 
 def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
-                              relu=False):
+                              relu=False, mode=0):
     """fp32 in / fp32 out convenience wrapper around the split-precision kernel (converts at both ends)."""
     _lib.require_cuda(features)
     xs = to_split(features)
@@ -173,7 +173,7 @@ def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None
     lib = _lib.load()
     _lib.check(lib.isf_sparse_conv_forward_f16x3(
         _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), _lib.stream()),
+        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode), _lib.stream()),
         "isf_sparse_conv_forward_f16x3")
     return from_split(ys, (rb.num_out, c_out))
 
@@ -239,13 +239,11 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             nbr_t, st = transposed_nbr(rb)
             grad_in = torch.empty((rb.num_in, c_in), dtype=torch.float32, device=g.device)
-            # dX runs on the f16x3 forward kernel over the transposed rulebook: rescale the (tiny) gradient by a power
-            # of two so that its f16 halves stay in the normal range (exact; _lib.pow2_rescale)
-            gs, s = _lib.pow2_rescale(g)
-            _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(gs), rb.num_out, c_out, _lib.ptr(w), K, c_in,
+            # (dX runs on the fp32-MFMA kernel over the transposed rulebook: no f16 halves, so gradients of any
+            #  magnitude are safe -- unlike the f16x3 dX GEMM of the fused linear, fusion_train.LinearFunction)
+            _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(g), rb.num_out, c_out, _lib.ptr(w), K, c_in,
                                                           _lib.ptr(nbr_t), st, rb.num_in, _lib.ptr(grad_in),
                                                           _lib.stream()), "isf_sparse_conv_backward_input")
-            grad_in = grad_in / s
         if ctx.needs_input_grad[1]:
             grad_w = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
             _lib.check(lib.isf_sparse_conv_backward_filter(_lib.ptr(features), rb.num_in, c_in, _lib.ptr(g),

@@ -30,7 +30,8 @@ class HardSimpleVFE(nn.Module):
         M, T, C = features.shape
         out = torch.empty((M, self.num_features), dtype=torch.float32, device=features.device)
         lib = _lib.load()
-        _lib.check(lib.isf_hard_simple_vfe(_lib.ptr(features), _lib.ptr(num_points.contiguous().int()), M, T,
+        npts = num_points.contiguous().int()                                     # local: must outlive the C call
+        _lib.check(lib.isf_hard_simple_vfe(_lib.ptr(features), _lib.ptr(npts), M, T,
                                            C, self.num_features, _lib.ptr(out), _lib.stream()),
                    "isf_hard_simple_vfe")
         return out.contiguous()

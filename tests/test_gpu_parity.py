@@ -348,11 +348,9 @@ def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
     lb, pl, ovf, ovc, bev, outs = _encoder_case(oracle_mod, dev, P=5000, B=B, seed=7)
     enc = lb.pts_middle_encoder
     # (1) SparseEncoder.forward, fused C call, oracle VFE output as input -- both arithmetic paths
-    lib = _lib.load()
-    for mode in (1, 0):  # 1 = fp32 MFMA kernels, 0 = default (f16x3 split-precision MFMA)
-        _lib.check(lib.isf_set_conv_precision(mode))
+    for mode in (1, 0):  # precision 1 = fp32 MFMA kernels, 0 = default (f16x3 split-precision MFMA); per call
         stats = _lib.EncoderStats()
-        sp = enc.forward_fused(T(ovf, dev), T(ovc, dev), B, stats=stats)
+        sp = enc.forward_fused(T(ovf, dev), T(ovc, dev), B, stats=stats, precision=mode)
         assert stats.precision == (0 if mode == 1 else 1)
         got = sp.cpu().numpy()
         assert got.shape == (B, 512, 180, 180)
@@ -388,19 +386,14 @@ def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
 def test_conv_neighbour_sharing_reproduces_full_gather_bits(dev):
     """the conv kernel takes a row's fragment from the right-hand lane's registers when the indices match instead of
     gathering it again (isf_spconv16.hip, load_A): the shared fragment is the fragment the load would have returned, so
-    the whole LiDAR branch must give the bits of the gather-everything reference (isf_set_conv_diagnostic(16))"""
+    the whole LiDAR branch must give the bits of the gather-everything reference (diagnostic 16 of isf_encoder_options)"""
     import isfusion_amd as m
-    from isfusion_amd import _lib, synthetic
-    lib = _lib.load()
+    from isfusion_amd import synthetic
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
     for n in (30000, 120000):
         pl = [T(synthetic.lidar_sweeps(500 + i, n), dev) for i in range(2)]
         got = lb(pl)
-        try:
-            _lib.check(lib.isf_set_conv_diagnostic(16))
-            want = lb(pl)
-        finally:
-            _lib.check(lib.isf_set_conv_diagnostic(0))
+        want = lb(pl, conv_diag=16)
         assert torch.isfinite(got).all() and got.abs().max().item() > 0.5
         assert torch.equal(got, want), n
 

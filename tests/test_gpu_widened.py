@@ -261,7 +261,7 @@ def test_sparse_conv_backward_vs_oracle_golden_geometries(dev, golden, oracle_mo
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (128, 64), (128, 256), (256, 256)])
 def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout, gscale):
     """every (Cin, Cout) block shape of the dW kernel and the transposed-filter dX path; several row chunks; gradients
-    of O(1) and of the size a real backward pass carries (1e-6: f16-subnormal if the dX kernel split them unscaled)"""
+    of O(1) and of the size a real backward pass carries (1e-6)"""
     from isfusion_amd import spconv
     rng = np.random.default_rng(cin * 1000 + cout)
     B, shape = 2, [9, 24, 24]
@@ -434,7 +434,7 @@ def test_window_attention_backward_matches_torch_autograd(dev, S, d, shift):
 
 # ------------------------------------------------------------------------------------------- single-pass f16 mode
 def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mod):
-    """isf_set_conv_precision(2): the conv kernels multiply only the hi halves (f16 operands, fp32 accumulate) -- the
+    """precision 2 (isf_encoder_options, per call): the conv kernels multiply only the hi halves (f16 operands, fp32 accumulate) -- the
     accuracy class of the reference's indice_conv_half; the default (0) must be restored and stay fp32-class"""
     import isfusion_amd as m
     from isfusion_amd import _lib, synthetic
@@ -453,13 +453,8 @@ def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mo
     obev, _ = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), ovf, ovc, B)
     lb = lb.to(dev)
     pts = [_T(p, dev) for p in pl]
-    lib = _lib.load()
-    try:
-        _lib.check(lib.isf_set_conv_precision(2))
-        half = lb(pts).cpu().numpy()
-    finally:
-        _lib.check(lib.isf_set_conv_precision(0))
-    full = lb(pts).cpu().numpy()
+    half = lb(pts, precision=2).cpu().numpy()
+    full = lb(pts).cpu().numpy()                             # the next call is back on the default: no global state
     scale = np.abs(obev).max()
     err_half, err_full = np.abs(half - obev).max(), np.abs(full - obev).max()
     assert err_full < 1e-3                                   # default path untouched
