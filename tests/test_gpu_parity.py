@@ -398,13 +398,24 @@ def test_conv_neighbour_sharing_reproduces_full_gather_bits(dev):
         assert torch.equal(got, want), n
 
 
-def test_encoder_training_mode_is_loud(dev):
+def test_conv_autograd_switch(dev):
+    """a sparse conv on tensors that require grad runs the autograd Function (forward + dX / dW kernels, validated in
+    tests/test_gpu_widened.py); with spconv.TRAINING_KERNELS = False the same call is a loud NotImplementedError"""
     import isfusion_amd as m
+    from isfusion_amd import spconv
     conv = m.SubMConv3d(16, 16, 3, padding=1, bias=False).to(dev)
     x = m.SparseConvTensor(torch.rand(10, 16, device=dev), torch.zeros((10, 4), dtype=torch.int32, device=dev),
                            [4, 4, 4], 1)
-    with pytest.raises(NotImplementedError):
-        conv(x)
+    x.indices[:, 3] = torch.arange(10, device=dev) % 4
+    x.indices[:, 2] = torch.arange(10, device=dev) // 4
+    conv(x).features.sum().backward()
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
+    spconv.TRAINING_KERNELS = False
+    try:
+        with pytest.raises(NotImplementedError):
+            conv(x)
+    finally:
+        spconv.TRAINING_KERNELS = True
 
 
 # ------------------------------------------------------------------------------------------- full size
