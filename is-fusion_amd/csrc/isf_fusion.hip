@@ -207,32 +207,41 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
   }
 }
 
-// one workgroup (1024 threads) per sample; k <= 1024
-__global__ __launch_bounds__(1024) void topk_select_kernel(const unsigned long long* __restrict__ cand,
-                                                           const int* __restrict__ cand_count, int n, int HW, int k,
-                                                           int32_t* __restrict__ top_mod, int32_t* __restrict__ top_raw) {
-  __shared__ int hist[1024];
-  __shared__ int scan[1024];
-  __shared__ unsigned long long sel[1024];
-  __shared__ unsigned long long s_prefix;
-  __shared__ int s_need, s_cnt;
-  const int b = blockIdx.x, t = threadIdx.x;
-  const unsigned long long* c = cand + (size_t)b * n;
-  const int nc = cand_count[b];
-  const int kk = nc < k ? nc : k;
-  unsigned long long thr = 0;
+// Exact top-k over unique 50-bit keys in two stages (k <= 1024): a single workgroup per sample scanning ~35 k candidates
+// five times took 235 us (two to four workgroups on the whole chip, every pass latency-bound on one CU -- 4 % of the
+// full fusion forward, profiles/r02_v1_cfg3_kernels.txt).  Stage 1: one workgroup per 4096-candidate chunk selects the
+// chunk's top-k (a chunk's losers cannot be in the global top-k) and writes them, zero-padded; stage 2: one workgroup
+// per sample selects the top-k of the chunks' winners and writes the indices.  Key 0 = empty slot (real keys are > 0:
+// positive score bits).
+static constexpr int kTopkChunk = 4096;
+
+// the workgroup's keys c[0..slots) (zeros ignored) -> sel[0..1024) sorted descending (zeros last); returns the number of
+// real keys selected (min(k, number of non-zero keys))
+__device__ int topk_block_select(const unsigned long long* __restrict__ c, int slots, int k, unsigned long long* sel,
+                                 int* hist, int* scan, unsigned long long* s_prefix, int* s_need, int* s_cnt) {
+  const int t = threadIdx.x;
+  if (t == 0) *s_cnt = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = t; i < slots; i += 1024) mine += c[i] != 0ull;
+  if (mine) atomicAdd(s_cnt, mine);
+  __syncthreads();
+  const int nc = *s_cnt;
+  __syncthreads();
+  unsigned long long thr = 1;   // every real key
   if (nc > k) {
-    if (t == 0) { s_prefix = 0; s_need = k; }
+    if (t == 0) { *s_prefix = 0; *s_need = k; }
     __syncthreads();
     // 50-bit keys, 5 digits of 10 bits from the top
     for (int shift = 40; shift >= 0; shift -= 10) {
       hist[t] = 0;
       __syncthreads();
-      const unsigned long long prefix = s_prefix;
-      const int need = s_need;
-      for (int i = t; i < nc; i += 1024) {
+      const unsigned long long prefix = *s_prefix;
+      const int need = *s_need;
+      for (int i = t; i < slots; i += 1024) {
         const unsigned long long key = c[i];
-        if (shift == 40 || (key >> (shift + 10)) == prefix) atomicAdd(&hist[(int)((key >> shift) & 1023)], 1);
+        if (key != 0ull && (shift == 40 || (key >> (shift + 10)) == prefix))
+          atomicAdd(&hist[(int)((key >> shift) & 1023)], 1);
       }
       __syncthreads();
       // inclusive suffix sum over bins (bin 1023 first)
@@ -246,20 +255,20 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const unsigned long l
       }
       const int incl = scan[t], excl = incl - hist[t];
       if (excl < need && need <= incl) {   // exactly one bin
-        s_prefix = (prefix << 10) | (unsigned long long)t;
-        s_need = need - excl;
+        *s_prefix = (prefix << 10) | (unsigned long long)t;
+        *s_need = need - excl;
       }
       __syncthreads();
     }
-    thr = s_prefix;   // the k-th largest key (keys are unique)
+    thr = *s_prefix;   // the k-th largest key (keys are unique)
   }
-  if (t == 0) s_cnt = 0;
+  if (t == 0) *s_cnt = 0;
   sel[t] = 0;
   __syncthreads();
-  for (int i = t; i < nc; i += 1024) {
+  for (int i = t; i < slots; i += 1024) {
     const unsigned long long key = c[i];
     if (key >= thr) {
-      const int pos = atomicAdd(&s_cnt, 1);
+      const int pos = atomicAdd(s_cnt, 1);
       if (pos < 1024) sel[pos] = key;
     }
   }
@@ -276,6 +285,41 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const unsigned long l
       __syncthreads();
     }
   }
+  return nc < k ? nc : k;
+}
+
+// stage 1: grid (chunks, B); partial [B][chunks][k]
+__global__ __launch_bounds__(1024) void topk_partial_kernel(const unsigned long long* __restrict__ cand,
+                                                            const int* __restrict__ cand_count, int n, int k,
+                                                            unsigned long long* __restrict__ partial) {
+  __shared__ int hist[1024];
+  __shared__ int scan[1024];
+  __shared__ unsigned long long sel[1024];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_need, s_cnt;
+  const int b = blockIdx.y, j = blockIdx.x, t = threadIdx.x;
+  const int lo = j * kTopkChunk;
+  int cnt = cand_count[b] - lo;
+  cnt = cnt < 0 ? 0 : (cnt > kTopkChunk ? kTopkChunk : cnt);
+  if (cnt == 0) {   // the candidates are compacted to the front: most chunks are empty
+    if (t < k) partial[((size_t)b * gridDim.x + j) * k + t] = 0ull;
+    return;
+  }
+  (void)topk_block_select(cand + (size_t)b * n + lo, cnt, k, sel, hist, scan, &s_prefix, &s_need, &s_cnt);
+  if (t < k) partial[((size_t)b * gridDim.x + j) * k + t] = sel[t];
+}
+
+// stage 2: one workgroup per sample over the chunks' winners
+__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ partial, int slots, int n,
+                                                          int HW, int k, int32_t* __restrict__ top_mod,
+                                                          int32_t* __restrict__ top_raw) {
+  __shared__ int hist[1024];
+  __shared__ int scan[1024];
+  __shared__ unsigned long long sel[1024];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_need, s_cnt;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int kk = topk_block_select(partial + (size_t)b * slots, slots, k, sel, hist, scan, &s_prefix, &s_need, &s_cnt);
   if (t < kk) {
     const int idx = 0x7FFFF - (int)(sel[t] & 0x7FFFF);
     top_raw[(size_t)b * k + t] = idx;
@@ -529,8 +573,12 @@ int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int
   hipLaunchKernelGGL(nms_candidates_kernel, dim3(ceil_div(n, 256), batch_size), dim3(256), 0, st, heatmap,
                      num_classes, height, width, pool1_class_mask, cand, count, masked_heatmap);
   ISF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(topk_select_kernel, dim3(batch_size), dim3(1024), 0, st, cand, count, (int)n, height * width, k,
-                     top_index, top_index_raw);
+  const int chunks = ceil_div(n, kTopkChunk);   // candidates are compacted to the front: the tail chunks are empty
+  unsigned long long* partial = nullptr;
+  ISF_TRY(a.alloc_n(&partial, (size_t)batch_size * chunks * k));
+  hipLaunchKernelGGL(topk_partial_kernel, dim3(chunks, batch_size), dim3(1024), 0, st, cand, count, (int)n, k, partial);
+  hipLaunchKernelGGL(topk_final_kernel, dim3(batch_size), dim3(1024), 0, st, partial, chunks * k, (int)n, height * width,
+                     k, top_index, top_index_raw);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
