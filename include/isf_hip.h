@@ -291,7 +291,24 @@ int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, c
  * r = b*hw + pos (a BEV map [B, C, H, W], hw = H*W, hw % 4 == 0): the NCHW <-> token transposes of
  * fusion_encoder.py:1163, sst_v2.py:97-133 and :480-496 happen inside the GEMM's loads / stores. */
 
-/* A10/A11  window attention on a dense token grid -------------------------------------------------------
+/* A10/A11  the attention half of an SST encoder layer in ONE kernel on the matrix cores -------------------------------
+ * replaces, for the fusion encoder's dense grids (every cell a token, row = (b*S + y)*S + x), the whole of
+ *   WindowAttention.forward + the residual / norm1 of EncoderLayer.forward (models/sst/sst_basic_block_v2.py:41-75,
+ *   :104-116) incl. flat2window / window2flat / the position embedding add (ops/sst/sst_ops.py:63-143, 219-268):
+ *     y = LayerNorm( x + out_proj( softmax(q k^T / sqrt(hd)) v ) ),  q, k = in_proj(x + pos), v = in_proj(x)
+ * x, y [B*S*S, d] fp32; in_proj_bias [3d]; pos_table [window^2, 3d] = pos_embed @ in_proj_weight[:2d]^T (zeros in the
+ * v columns); packed = isf_pack_window_block(in_proj_weight [3d, d], out_proj_weight [d, d]); shift as in
+ * isf_window_attention_forward.  q, k, v, scores and the attention output never reach memory.  8 heads, 6x6 windows,
+ * d in {128, 256}. */
+size_t isf_packed_window_block_bytes(int embed_dims);
+int isf_pack_window_block(const float* in_proj_weight, const float* out_proj_weight, int embed_dims, int num_heads,
+                          void* packed, isf_stream_t stream);
+int isf_window_block_forward(const float* x, int batch_size, int grid_size, int embed_dims, int num_heads, int window,
+                             int shift, const void* packed, const float* in_proj_bias, const float* pos_table,
+                             const float* out_proj_bias, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                             float* y, isf_stream_t stream);
+
+/* A10/A11  window attention core on a dense token grid (the unfused form; training uses it) -------------------
  * replaces get_window_coors / flat2window / nn.MultiheadAttention / window2flat of
  *   mmdet3d/ops/sst/sst_ops.py:219-268, 63-143 and models/sst/sst_basic_block_v2.py:41-75
  * for the fusion encoder's dense grids (fusion_encoder.py:1151-1189: every cell is a token, token row =

@@ -129,6 +129,10 @@ SIGNATURES = {
     "isf_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_ingroup_indices": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "isf_packed_window_block_bytes": (ctypes.c_size_t, [c_int]),
+    "isf_pack_window_block": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "isf_window_block_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p]),
     "isf_p2g_backward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "isf_sparse_to_dense_bev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

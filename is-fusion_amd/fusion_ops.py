@@ -155,9 +155,37 @@ def _encoder_layer_cache(layer, S, win, shift, temperature, device, B):
         tab[:, :2 * d] = (pos.double() @ w[:2 * d].double().t()).float()
         c[key] = dict(index=index.repeat(B).contiguous(), table=tab.contiguous(), qkv=PackedLinear(w, b),
                       out=PackedLinear(attn.out_proj.weight, attn.out_proj.bias),
+                      block=PackedWindowBlock(w, attn.out_proj.weight, layer.win_attn.nhead),
+                      in_bias=b.contiguous(), out_bias=attn.out_proj.bias.detach().float().contiguous(),
                       l1=PackedLinear(layer.linear1.weight, layer.linear1.bias),
                       l2=PackedLinear(layer.linear2.weight, layer.linear2.bias))
     return c[key]
+
+
+class PackedWindowBlock:
+    """in_proj / out_proj weights of an SST window-attention layer in the streaming order of isf_window_block_forward"""
+
+    def __init__(self, in_proj_weight, out_proj_weight, nhead):
+        _lib.require_cuda(in_proj_weight)
+        w_in = in_proj_weight.detach().float().contiguous()
+        w_out = out_proj_weight.detach().float().contiguous()
+        d = w_out.size(0)
+        lib = _lib.load()
+        self.packed = torch.empty(lib.isf_packed_window_block_bytes(d), dtype=torch.uint8, device=w_in.device)
+        _lib.check(lib.isf_pack_window_block(_lib.ptr(w_in), _lib.ptr(w_out), d, nhead, _lib.ptr(self.packed),
+                                             _lib.stream()), "isf_pack_window_block")
+
+
+def window_block(x, pw, in_proj_bias, table, out_proj_bias, ln, B, S, d, nhead, win, shift):
+    """y = LN(x + out_proj(window attention(in_proj(x + pos)))) on [B*S*S, d] tokens, one kernel (A10/A11)."""
+    _lib.require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (B * S * S, d)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().isf_window_block_forward(
+        _lib.ptr(x), B, S, d, nhead, win, shift, _lib.ptr(pw.packed), _lib.ptr(in_proj_bias), _lib.ptr(table),
+        _lib.ptr(out_proj_bias), _lib.ptr(ln.weight.detach()), _lib.ptr(ln.bias.detach()), float(ln.eps), _lib.ptr(y),
+        _lib.stream()), "isf_window_block_forward")
+    return y
 
 
 def window_attention(qkv, B, S, d, nhead, win, shift):
@@ -167,25 +195,37 @@ def window_attention(qkv, B, S, d, nhead, win, shift):
     return out
 
 
+WINDOW_BLOCK_FUSED = True   # False: the three-launch form (qkv linear -> window attention -> out-projection linear)
+
+
 def sstv2_forward(sst, bev, win, temperature=1000.0):
-    """get_regions[i] + grid2region_att[i] (sst_v2.py:65-133) on a dense grid: [B, C, S, S] -> [B, d, S, S]."""
+    """get_regions[i] + grid2region_att[i] (sst_v2.py:65-133) on a dense grid: [B, C, S, S] -> [B, d, S, S].
+    Per encoder layer: the attention half in one kernel (isf_window_block_forward), the feed-forward half as two fused
+    linears (GELU; residual + LayerNorm)."""
     _lib.require_cuda(bev)
     B, C, S, _ = bev.shape
     fused_io = (S * S) % 4 == 0          # channels-first loads / stores inside the GEMM need hw % 4 == 0
+    fused_block = WINDOW_BLOCK_FUSED
     if hasattr(sst, "linear0"):
         c = _cache(sst, bev.device)
         if "linear0" not in c:
             c["linear0"] = PackedLinear(sst.linear0.weight, sst.linear0.bias)
         x = linear(bev.float() if fused_io else to_tokens(bev.float()), c["linear0"])
+    elif fused_block:                    # the block kernel reads token rows
+        x = to_tokens(bev.float())
     else:   # the first layer reads the map channels-first both as GEMM input and as residual
         x = bev.float().contiguous() if fused_io else to_tokens(bev.float())
     d = x.size(1)
     layers = [(shift, layer) for block in sst.block_list for shift, layer in enumerate(block.encoder_list)]
     for li, (shift, layer) in enumerate(layers):
         p = _encoder_layer_cache(layer, S, win, shift, temperature, bev.device, B)
-        qkv = linear(x, p["qkv"], table=p["table"], index=p["index"])
-        att = window_attention(qkv, B, S, d, layer.win_attn.nhead, win, shift)
-        y = linear(att, p["out"], residual=x, ln=layer.norm1)
+        if fused_block:
+            y = window_block(x, p["block"], p["in_bias"], p["table"], p["out_bias"], layer.norm1, B, S, d,
+                             layer.win_attn.nhead, win, shift)
+        else:
+            qkv = linear(x, p["qkv"], table=p["table"], index=p["index"])
+            att = window_attention(qkv, B, S, d, layer.win_attn.nhead, win, shift)
+            y = linear(att, p["out"], residual=x, ln=layer.norm1)
         h = linear(y, p["l1"], act=ACT_GELU)
         last = li == len(layers) - 1 and fused_io
         x = linear(h, p["l2"], residual=y, ln=layer.norm2, out_nchw=(B, S, S) if last else None)

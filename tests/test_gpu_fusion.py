@@ -466,3 +466,49 @@ def test_igf_modules_forward_like_the_reference(dev):
     got = enc.instance_to_scene_att(query.flatten(2).to(dev), x_ins.to(dev), scene.to(dev), B, S).cpu()
     ref = orc.instance_to_scene(query.flatten(2), x_ins, scene, sd, "instance_to_scene_att", B, S)
     assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-3
+
+
+# ---------------------------------------------------------------------------------- fused window block (A10/A11)
+@pytest.mark.parametrize("shift", [0, 1])
+@pytest.mark.parametrize("S,d,B", [(12, 128, 2), (9, 128, 1), (16, 256, 2), (13, 256, 1), (180, 128, 1), (90, 256, 2)])
+def test_window_block_kernel_matches_unfused_layers(dev, S, d, B, shift):
+    """isf_window_block_forward (qkv projection + position table + attention + out-projection + residual + LayerNorm on
+    the matrix cores, one kernel) vs the three-launch form it replaces and vs float64 torch: full and partial edge
+    windows (grids that are not a multiple of 6, shifted windows), both model widths"""
+    from isfusion_amd import fusion_ops as ops
+    from isfusion_amd.fusion_modules import EncoderLayer, seeded_state_dict
+    layer = EncoderLayer(d, 8, d).eval()
+    layer.load_state_dict(seeded_state_dict(layer, 500 + d + shift))
+    x = rnd((B * S * S, d), 501 + S, 0.7)
+    # ---- float64 reference of the attention half (sst_basic_block_v2.py:41-75, :104-116)
+    index, pos = ops._window_tables(S, 6, shift, d, 1000.0, torch.device("cpu"))
+    attn = layer.win_attn.self_attn
+    w, b = attn.in_proj_weight.detach().double(), attn.in_proj_bias.detach().double()
+    xd = x.double()
+    xp = xd + pos.double()[index.long().repeat(B)]
+    q, k, v = xp @ w[:d].t() + b[:d], xp @ w[d:2 * d].t() + b[d:2 * d], xd @ w[2 * d:].t() + b[2 * d:]
+    off = 3 if shift else 0
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    wid = ((yy + off) // 6) * 64 + (xx + off) // 6
+    wid = (torch.arange(B)[:, None, None] * 4096 + wid[None]).reshape(-1)
+    hd = d // 8
+    att = torch.zeros_like(q)
+    for g in torch.unique(wid):
+        m = (wid == g).nonzero().squeeze(1)
+        qh = q[m].view(-1, 8, hd).transpose(0, 1)
+        kh = k[m].view(-1, 8, hd).transpose(0, 1)
+        vh = v[m].view(-1, 8, hd).transpose(0, 1)
+        p = (qh @ kh.transpose(1, 2) / hd ** 0.5).softmax(-1)
+        att[m] = (p @ vh).transpose(0, 1).reshape(-1, d)
+    ref = torch.nn.functional.layer_norm(xd + att @ attn.out_proj.weight.detach().double().t() + attn.out_proj.bias.detach().double(),
+                                         (d,), layer.norm1.weight.detach().double(), layer.norm1.bias.detach().double(), layer.norm1.eps)
+    # ---- HIP: fused and unfused
+    layer = layer.to(dev)
+    p_ = ops._encoder_layer_cache(layer, S, 6, shift, 1000.0, dev, B)
+    xg = x.to(dev)
+    fused = ops.window_block(xg, p_["block"], p_["in_bias"], p_["table"], p_["out_bias"], layer.norm1, B, S, d, 8, 6, shift)
+    qkv = ops.linear(xg, p_["qkv"], table=p_["table"], index=p_["index"])
+    unfused = ops.linear(ops.window_attention(qkv, B, S, d, 8, 6, shift), p_["out"], residual=xg, ln=layer.norm1)
+    assert torch.isfinite(fused).all()
+    assert (fused.cpu().double() - ref).abs().max().item() < 1e-4
+    assert (unfused.cpu().double() - ref).abs().max().item() < 1e-4
