@@ -299,7 +299,8 @@ int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, c
  * x, y [B*S*S, d] fp32; in_proj_bias [3d]; pos_table [window^2, 3d] = pos_embed @ in_proj_weight[:2d]^T (zeros in the
  * v columns); packed = isf_pack_window_block(in_proj_weight [3d, d], out_proj_weight [d, d]); shift as in
  * isf_window_attention_forward.  q, k, v, scores and the attention output never reach memory.  8 heads, 6x6 windows,
- * d in {128, 256}. */
+ * d = 128 (the 180 x 180 level; the d = 256 level runs linear -> isf_window_attention_forward -> linear, which
+ * measured faster there). */
 size_t isf_packed_window_block_bytes(int embed_dims);
 int isf_pack_window_block(const float* in_proj_weight, const float* out_proj_weight, int embed_dims, int num_heads,
                           void* packed, isf_stream_t stream);

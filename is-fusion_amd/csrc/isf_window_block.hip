@@ -12,8 +12,10 @@
 //   epilogue:  + bias + residual, LayerNorm across the 16 column lanes and the column tiles, row-major fp32 store.
 // All products in the hi/lo f16 split arithmetic of the other kernels (fp32-class; three MFMAs per product).
 // The position embedding enters as (x + pos) W = x W + (pos W): a [36, 2d] table added to the q / k accumulators.
-// Workgroup = 4 waves = 4 windows; the weights of a stage (32 KiB in consumption order, host-packed by
+// Workgroup = 4 waves = 4 windows; the weights of a head (32 KiB in consumption order, host-packed by
 // isf_pack_window_block) are LDS-DMA'd once per workgroup into a double buffer and shared by the 4 waves.
+// Built for d = 128 (head_dim 16), the 180 x 180 level: 0.45 -> 0.36 ms per two-layer block at B = 2, 0.82 -> 0.72 at
+// B = 4 (with its feed-forward linears; profiles/r02_call12_window_block.txt).
 #include "isf_spconv16.h"
 
 namespace isf {
@@ -31,10 +33,11 @@ struct WinCfg {
   static constexpr int CT = D / 16;                       // 16-column tiles of the model dimension
   static constexpr int proj_bytes = HT * KC * 2048;       // one of Wq / Wk / Wv for a head: [u][kc][hi|lo][64][8 halves]
   static constexpr int out_bytes = HT * CT * 1024;        // Wout for a head: [u][ct][hi|lo][64][4 halves]
-  // a head's weights as 32-KiB stages in consumption order: d = 128: {q, k, v, out} in one stage; d = 256: four stages
-  static constexpr int STAGES = (3 * proj_bytes + out_bytes) / kStageBytes;
-  static_assert((3 * proj_bytes + out_bytes) % kStageBytes == 0 && (STAGES == 1 || proj_bytes == kStageBytes), "stage layout");
-  static constexpr bool KEEPX = D <= 128;                 // token fragments stay in registers (d = 256: re-read per head)
+  // a head's weights {q, k, v, out} are ONE 32-KiB stage in consumption order.  (A d = 256 / head_dim 32 variant --
+  // four stages per head, token fragments re-read per head, 474 registers -- was built and measured: 0.79 ms against
+  // 0.42 ms for the three-launch form at S = 90, B = 2: too few windows, one wave per SIMD.  Removed; the wide level
+  // stays on the unfused path.  profiles/r02_call12_window_block.txt)
+  static_assert(3 * proj_bytes + out_bytes == kStageBytes, "one stage per head");
 };
 
 __device__ __forceinline__ void split4(const f32x4 v, h4& hi, h4& lo) {
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
     const float* __restrict__ bout, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps,
     float* __restrict__ y, int num_windows) {
   using C = WinCfg<D, HD>;
-  constexpr int HT = C::HT, KC = C::KC, CT = C::CT, HEADS = C::HEADS, STAGES = C::STAGES;
+  constexpr int HT = C::HT, KC = C::KC, CT = C::CT, HEADS = C::HEADS;
   extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 x 32 KiB weight stages
   const unsigned smem_addr = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   const int lane = threadIdx.x & 63;
@@ -103,13 +106,11 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
     hi = __builtin_convertvector(v, h8);
     lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x8), h8);
   };
-  h8 xh[C::KEEPX ? kTT : 1][C::KEEPX ? KC : 1], xl[C::KEEPX ? kTT : 1][C::KEEPX ? KC : 1];
-  if (C::KEEPX) {
+  h8 xh[kTT][KC], xl[kTT][KC];                            // resident for the whole window: 96 registers at d = 128
 #pragma unroll
-    for (int j = 0; j < kTT; ++j)
+  for (int j = 0; j < kTT; ++j)
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) load_x(j, kc, xh[j][kc], xl[j][kc]);
-  }
+    for (int kc = 0; kc < KC; ++kc) load_x(j, kc, xh[j][kc], xl[j][kc]);
 
   f32x4 yacc[kTT][CT];
 #pragma unroll
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
     for (int ct = 0; ct < CT; ++ct) yacc[j][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- weight stages through a double-buffered LDS ring
-  constexpr int NST = HEADS * STAGES;
+  constexpr int NST = HEADS;
   auto stage_in = [&](int s) {                                            // 32 KiB = 32 LDS-DMA instructions of 1 KiB
     const uint4* src = packed + (size_t)s * (kStageBytes / 16);
     const unsigned dst = smem_addr + (unsigned)((s & 1) * kStageBytes);
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
     }
   };
   const float inv_qkv = header[0], inv_out = header[1];
-  const float qscale = inv_qkv * (1.0f / (HD == 16 ? 4.0f : 5.656854249492381f));   // 1 / sqrt(HD)
+  static_assert(HD == 16, "1 / sqrt(head_dim) below");
+  const float qscale = inv_qkv * 0.25f;                                   // 1 / sqrt(HD)
   stage_in(0);
   int st = 0;                                                             // stage being consumed
   auto next_stage = [&]() {                                               // -> LDS base of stage `st`, prefetches st + 1
@@ -143,13 +145,11 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
 
   for (int head = 0; head < HEADS; ++head) {
     f32x4 qT[HT][kTT], kT[HT][kTT], vv[kTT][HT];                          // Q^T, K^T: [h tile][token tile]; V: [token tile][h tile]
-    const char* wbase = nullptr;
+    const char* wbase = next_stage();
     // ---- projections: which = 0 (Q^T), 1 (K^T), 2 (V)
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
-      if (STAGES == 1) { if (which == 0) wbase = next_stage(); }
-      else wbase = next_stage();
-      const uint4* w = reinterpret_cast<const uint4*>(wbase + (STAGES == 1 ? which * C::proj_bytes : 0)) + lane;
+      const uint4* w = reinterpret_cast<const uint4*>(wbase + which * C::proj_bytes) + lane;
 #pragma unroll
       for (int u = 0; u < HT; ++u) {
         f32x4 acc[kTT];
@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
           const h8 wh = *reinterpret_cast<const h8*>(&whu), wl = *reinterpret_cast<const h8*>(&wlu);
 #pragma unroll
           for (int j = 0; j < kTT; ++j) {
-            h8 ah, al;
-            if (C::KEEPX) { ah = xh[j][kc]; al = xl[j][kc]; } else load_x(j, kc, ah, al);
+            const h8 ah = xh[j][kc], al = xl[j][kc];
             if (which == 2) acc[j] = mma32x3(ah, al, wh, wl, acc[j]);    // V = X Wv^T: tokens are rows
             else acc[j] = mma32x3(wh, wl, ah, al, acc[j]);               // Q^T / K^T = W X^T: tokens are columns
           }
@@ -241,8 +240,7 @@ __global__ __launch_bounds__(256, 1) void window_block_kernel(
       for (int a = 0; a < kTT; ++a) sT[a][b] *= inv;
     }
     // ---- O^T[u][b] = V_u^T P_b^T over the keys; then Y += O Wout_head^T
-    if (STAGES > 1) wbase = next_stage();
-    const uint2* wo = reinterpret_cast<const uint2*>(wbase + (STAGES == 1 ? 3 * C::proj_bytes : 0)) + lane;
+    const uint2* wo = reinterpret_cast<const uint2*>(wbase + 3 * C::proj_bytes) + lane;
     h4 vh[kTT][HT], vl[kTT][HT];
 #pragma unroll
     for (int a = 0; a < kTT; ++a)
@@ -382,8 +380,8 @@ int isf_pack_window_block(const float* in_proj_weight, const float* out_proj_wei
                           void* packed, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(in_proj_weight && out_proj_weight && packed, ISF_ERR_ARG, "pack_window_block: null pointer");
-  ISF_REQUIRE(num_heads == 8 && (embed_dims == 128 || embed_dims == 256), ISF_ERR_UNSUPPORTED,
-              "pack_window_block: built for 8 heads, d in {128, 256} (got %d heads, d %d)", num_heads, embed_dims);
+  ISF_REQUIRE(num_heads == 8 && embed_dims == 128, ISF_ERR_UNSUPPORTED,
+              "pack_window_block: built for 8 heads, d = 128 (got %d heads, d %d)", num_heads, embed_dims);
   hipStream_t st = as_stream(stream);
   Arena& a = arena_for_stream(st);
   ISF_TRY(a.reset());
@@ -392,15 +390,9 @@ int isf_pack_window_block(const float* in_proj_weight, const float* out_proj_wei
   ISF_HIP_TRY(hipMemsetAsync(amax, 0, 2 * sizeof(unsigned), st));
   const size_t n_in = (size_t)3 * embed_dims * embed_dims, n_out = (size_t)embed_dims * embed_dims;
   hipLaunchKernelGGL(absmax2_kernel, dim3(64, 2), dim3(256), 0, st, in_proj_weight, n_in, out_proj_weight, n_out, amax);
-  if (embed_dims == 128) {
-    const long long items = (long long)8 * 3 * 1 * 4 * 64 + (long long)8 * 1 * 8 * 64;
-    hipLaunchKernelGGL((pack_window_block_kernel<128, 16>), dim3(ceil_div(items, 256)), dim3(256), 0, st, in_proj_weight,
-                       out_proj_weight, amax, reinterpret_cast<char*>(packed));
-  } else {
-    const long long items = (long long)8 * 3 * 2 * 8 * 64 + (long long)8 * 2 * 16 * 64;
-    hipLaunchKernelGGL((pack_window_block_kernel<256, 32>), dim3(ceil_div(items, 256)), dim3(256), 0, st, in_proj_weight,
-                       out_proj_weight, amax, reinterpret_cast<char*>(packed));
-  }
+  const long long items = (long long)8 * 3 * 1 * 4 * 64 + (long long)8 * 1 * 8 * 64;
+  hipLaunchKernelGGL((pack_window_block_kernel<128, 16>), dim3(ceil_div(items, 256)), dim3(256), 0, st, in_proj_weight,
+                     out_proj_weight, amax, reinterpret_cast<char*>(packed));
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -414,9 +406,9 @@ int isf_window_block_forward(const float* x, int batch_size, int grid_size, int 
   if (batch_size == 0) return ISF_OK;
   ISF_REQUIRE(x && packed && in_proj_bias && pos_table && out_proj_bias && ln_gamma && ln_beta && y, ISF_ERR_ARG,
               "window_block: null pointer");
-  ISF_REQUIRE(num_heads == 8 && window == 6 && (embed_dims == 128 || embed_dims == 256), ISF_ERR_UNSUPPORTED,
-              "window_block: built for 8 heads, 6x6 windows, d in {128, 256} (got %d heads, win %d, d %d)", num_heads,
-              window, embed_dims);
+  ISF_REQUIRE(num_heads == 8 && window == 6 && embed_dims == 128, ISF_ERR_UNSUPPORTED,
+              "window_block: built for 8 heads, 6x6 windows, d = 128 (got %d heads, win %d, d %d)", num_heads, window,
+              embed_dims);
   const int nwin = shift ? (grid_size - 1 + window / 2) / window + 1 : (grid_size + window - 1) / window;
   const int num_windows = batch_size * nwin * nwin;
   const float* header = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed) +
@@ -426,19 +418,12 @@ int isf_window_block_forward(const float* x, int batch_size, int grid_size, int 
   if (!attr_set) {
     ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_block_kernel<128, 16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
-    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_block_kernel<256, 32>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
     attr_set = true;
   }
   hipStream_t st = as_stream(stream);
-  if (embed_dims == 128)
-    hipLaunchKernelGGL((window_block_kernel<128, 16>), grid, block, 2 * kStageBytes, st, x, batch_size, grid_size, shift,
-                       reinterpret_cast<const uint4*>(packed), header, in_proj_bias, pos_table, out_proj_bias, ln_gamma,
-                       ln_beta, ln_eps, y, num_windows);
-  else
-    hipLaunchKernelGGL((window_block_kernel<256, 32>), grid, block, 2 * kStageBytes, st, x, batch_size, grid_size, shift,
-                       reinterpret_cast<const uint4*>(packed), header, in_proj_bias, pos_table, out_proj_bias, ln_gamma,
-                       ln_beta, ln_eps, y, num_windows);
+  hipLaunchKernelGGL((window_block_kernel<128, 16>), grid, block, 2 * kStageBytes, st, x, batch_size, grid_size, shift,
+                     reinterpret_cast<const uint4*>(packed), header, in_proj_bias, pos_table, out_proj_bias, ln_gamma,
+                     ln_beta, ln_eps, y, num_windows);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

@@ -155,7 +155,7 @@ def _encoder_layer_cache(layer, S, win, shift, temperature, device, B):
         tab[:, :2 * d] = (pos.double() @ w[:2 * d].double().t()).float()
         c[key] = dict(index=index.repeat(B).contiguous(), table=tab.contiguous(), qkv=PackedLinear(w, b),
                       out=PackedLinear(attn.out_proj.weight, attn.out_proj.bias),
-                      block=PackedWindowBlock(w, attn.out_proj.weight, layer.win_attn.nhead),
+                      block=PackedWindowBlock(w, attn.out_proj.weight, layer.win_attn.nhead) if d == 128 else None,
                       in_bias=b.contiguous(), out_bias=attn.out_proj.bias.detach().float().contiguous(),
                       l1=PackedLinear(layer.linear1.weight, layer.linear1.bias),
                       l2=PackedLinear(layer.linear2.weight, layer.linear2.bias))
@@ -205,7 +205,8 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
     _lib.require_cuda(bev)
     B, C, S, _ = bev.shape
     fused_io = (S * S) % 4 == 0          # channels-first loads / stores inside the GEMM need hw % 4 == 0
-    fused_block = WINDOW_BLOCK_FUSED
+    d_model = sst.block_list[0].encoder_list[0].win_attn.self_attn.out_proj.in_features
+    fused_block = WINDOW_BLOCK_FUSED and d_model == 128      # built (and measured faster) for the 128-wide level
     if hasattr(sst, "linear0"):
         c = _cache(sst, bev.device)
         if "linear0" not in c:

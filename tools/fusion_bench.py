@@ -30,8 +30,13 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--pillars", type=int, default=15000)
+    ap.add_argument("--unfused-window", action="store_true",
+                    help="run the three-launch form of the window attention (qkv linear / attention / out-projection)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.unfused_window:
+        from isfusion_amd import fusion_ops
+        fusion_ops.WINDOW_BLOCK_FUSED = False
     cfg = dict(CONFIGS["full"], B=a.batch, num_pillars=a.pillars, seed=31)
     enc, bb = build_modules(cfg, dev)
     t = torch_inputs(cfg, dev)
