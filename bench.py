@@ -342,7 +342,7 @@ def main():
                          "core, about 10 s on 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
-    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16],
+    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48],
                     help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_encoder_options.diagnostic; "
                          "results are garbage, the line is labelled)")
     ap.add_argument("--f16", action="store_true",
@@ -405,7 +405,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    diag = args.conv_diag not in (0, 16)   # timing diagnostics: results are garbage (16 = valid, sharing off)
+    diag = (args.conv_diag & 15) != 0   # timing diagnostics: results are garbage (16 = sharing off, 32 = uniform tiles: valid)
     assert diag or torch.isfinite(out).all()
 
     if rank == 0:

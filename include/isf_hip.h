@@ -195,7 +195,9 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * still exchanged in the split format.  TIMING DIAGNOSTICS (tools/conv_knockout.sh; never in production): 2 = no
  * activation gathers, 4 = no weight streaming, 6 = neither, 8 = no main loop -- the RESULTS ARE GARBAGE, only kernel
  * times are meaningful; 16 = gather every row (no neighbour sharing): results valid and
- * bit-identical to mode 0, the reference the sharing is tested against. */
+ * bit-identical to mode 0, the reference the sharing is tested against; +32 (combinable) = uniform row tiles instead
+ * of the full / half-tile mix that evens out the row groups per SIMD on launches of a single round of workgroups
+ * (results bit-identical: a row's products and their order do not depend on the tile it falls into). */
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
 int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
                            isf_stream_t stream);
@@ -238,7 +240,7 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
 /* per-call options of the two engine entry points (NULL = all defaults; no process-wide state):
  * precision  0 = f16x3 split MFMA when every layer carries packed16, else fp32 MFMA (default); 1 = force the fp32 MFMA
  *            kernels; 2 = single-pass f16 (opt-in, fp16-autocast accuracy: mode 1 of isf_sparse_conv_forward_f16x3);
- * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16: see isf_sparse_conv_forward_f16x3). */
+ * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3). */
 typedef struct isf_encoder_options {
   int precision;
   int diagnostic;

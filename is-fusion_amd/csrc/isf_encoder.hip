@@ -161,11 +161,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 isf_encoder_stats* stats, int time_layers, const isf_encoder_options* opt,
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  ISF_REQUIRE(precision >= 0 && precision <= 2 && (diagnostic == 0 || diagnostic == 2 || diagnostic == 4 ||
-                                                   diagnostic == 6 || diagnostic == 8 || diagnostic == 16) &&
-                  !(precision == 2 && diagnostic != 0),
+  const int dg = diagnostic & ~32;   // bit 32 (uniform conv tiles) combines with the others
+  ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
+                  (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
-  const int conv_mode = precision == 2 ? 1 : diagnostic;
+  const int conv_mode = precision == 2 ? (1 | (diagnostic & 32)) : diagnostic;
   ISF_REQUIRE(num_layers > 0 && num_layers <= 32, ISF_ERR_ARG, "sparse_encoder: %d layers (1..32)", num_layers);
   // Geometry (occupancy indexes, output sets, neighbour tables: small integer kernels + the host syncs that size
   // the next level) runs on a side stream and overlaps the convolutions of the previous level on `st`; a

@@ -55,26 +55,54 @@ __device__ __forceinline__ f32x8 join8(const uint4 hi, const uint4 lo) {
 }
 
 // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2) in
-// linear-id order.  XCD x works through ONE CONTIGUOUS range of row tiles (rows are (b,z,y,x)-sorted, so the
-// y / z neighbours a tile gathers are rows of tiles the same XCD touches a little earlier or later: its L2
-// holds that sliding window instead of every XCD fetching every row), and with two column blocks only ever
-// on column block x & 1, so that the weights it streams are half of the layer's.
+// linear-id order.  XCD x works through ONE CONTIGUOUS range of rows (rows are (b,z,y,x)-sorted, so the y / z
+// neighbours a tile gathers are rows of tiles the same XCD touches a little earlier or later: its L2 holds that
+// sliding window instead of every XCD fetching every row), and with two column blocks only ever on column block
+// x & 1, so that the weights it streams are half of the layer's.
+// A row range ("part": 4 with two column blocks, 8 with one) is cut into `full` tiles of TM rows followed by `half`
+// tiles of TM / 2 rows (every wave of a half tile owns ONE 16-row group instead of two) -- see conv16_plan.
 // -> false when this workgroup has no tile.
-__device__ __forceinline__ bool conv16_tile_of_block(int ncb, int row_tiles, int& cb, int& tile) {
+struct Conv16Plan {
+  int full, half;   // tiles per part
+  int part_rows;    // rows per part (a multiple of 16; the parts split the rows evenly whatever the tile mix)
+};
+
+// -> row_end: first row past this tile's share (the part's end or n_out, whichever comes first)
+__device__ __forceinline__ bool conv16_tile_of_block(int ncb, Conv16Plan plan, int TM, int n_out, int& cb, int& row0,
+                                                     int& row_end, bool& half) {
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  if (ncb == 2) {
-    cb = xcd & 1;
-    tile = (xcd >> 1) * ((row_tiles + 3) >> 2) + j;
-    if (j >= ((row_tiles + 3) >> 2)) return false;
-  } else {
-    cb = 0;
-    tile = xcd * ((row_tiles + 7) >> 3) + j;
-    if (j >= ((row_tiles + 7) >> 3)) return false;
-  }
-  return tile < row_tiles;
+  const int part = ncb == 2 ? xcd >> 1 : xcd;
+  cb = ncb == 2 ? xcd & 1 : 0;
+  if (j >= plan.full + plan.half) return false;
+  half = j >= plan.full;
+  const int off = half ? plan.full * TM + (j - plan.full) * (TM / 2) : j * TM;
+  row0 = part * plan.part_rows + off;
+  row_end = min((part + 1) * plan.part_rows, n_out);
+  return off < plan.part_rows && row0 < n_out;
 }
-static inline int conv16_grid_blocks(int ncb, int row_tiles) {
-  return 8 * (ncb == 2 ? ceil_div(row_tiles, 4) : ceil_div(row_tiles, 8));
+static inline int conv16_grid_blocks(Conv16Plan plan) { return 8 * (plan.full + plan.half); }
+
+// How a launch is cut into tiles.  The matrix pipe is per SIMD and a workgroup puts one wave (NW = 4) on each SIMD of
+// its CU, so what bounds a launch that fits the chip in ONE round of workgroups is the largest number of 16-row groups
+// any SIMD ends up with.  With uniform TM-row tiles that is wgs_per_cu * RG on the CUs that get a full set of
+// workgroups while the others idle: 636 workgroups on 256 CUs x 3 slots = 6 groups per SIMD on 124 CUs, 4 on 132, for
+// an average need of 4.97.  Mixing full and half tiles -- per CU f full + (wgs_per_cu - f) half, dealt in that order:
+// the dispatcher places workgroups round-robin over the CUs of an XCD, every CU gets the same set
+// (tools/probes/wg_placement.hip, profiles/r02_call13_tile_mix.txt) -- brings the maximum down to ceil(need).
+// Launches of several rounds keep uniform tiles (the dispatcher refills slots as they drain).
+static inline Conv16Plan conv16_plan(int n_out, int TM, int ncb, int wgs_per_cu, int cus_per_xcd, bool balance) {
+  const int parts = ncb == 2 ? 4 : 8;
+  const int gt = TM / 16;                                       // 16-row groups per full tile
+  const int groups = ceil_div(ceil_div(n_out, 16), parts);      // per part = per XCD
+  Conv16Plan plan{ceil_div(groups, gt), 0, groups * 16};
+  if (!balance || (gt & 1) || plan.full > wgs_per_cu * cus_per_xcd) return plan;
+  const int per_cu = ceil_div(groups, cus_per_xcd);
+  int f = ceil_div(per_cu - wgs_per_cu * (gt / 2), gt / 2);
+  f = f < 0 ? 0 : (f > wgs_per_cu ? wgs_per_cu : f);
+  plan.full = min(f * cus_per_xcd, ceil_div(groups, gt));
+  const int rest = groups - plan.full * gt;
+  plan.half = rest > 0 ? ceil_div(rest, gt / 2) : 0;
+  return plan;
 }
 
 // Epilogue shared by both kernels: per 16-row group, accumulator (col = lane&15, row = 4*(lane>>4)+t) -> LDS row-major
@@ -95,12 +123,13 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
                                                 int col0 /* first output channel of this workgroup */, int cout,
                                                 float winv, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const uint4* __restrict__ residual,
-                                                uint4* __restrict__ ys, int n_out, int relu) {
+                                                uint4* __restrict__ ys, int n_out, int relu, int groups = RG) {
   using E = Conv16Epi<NT, RG>;
   constexpr int EPN = E::EPN, RS = E::RS;
   const int col = lane & 15, kg = lane >> 4;
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
+    if (rg >= groups) break;                           // half tiles: the upper row groups of the wave do not exist
 #pragma unroll
     for (int ps = 0; ps < NT / EPN; ++ps) {
       constexpr int UNITS = (16 * EPN) / 8;           // 8-channel units per row in this pass

@@ -25,6 +25,7 @@
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 namespace isf {
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
-    uint4* __restrict__ ys, int n_out, int relu, int row_tiles) {
+    uint4* __restrict__ ys, int n_out, int relu, Conv16Plan plan) {
   constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
   // neighbour sharing of the gathers (load_A below) where it was measured to pay -- the layers whose gathers saturate
   // the vector-memory path: 64 -> 64 0.91 -> 0.76 ms, 64 -> 32 0.138 -> 0.128, 32 -> 32 0.312 -> 0.301 per step; the
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kg = lane >> 4;
   const int ncb = cout / BN;
-  int cb, tile;
-  if (!conv16_tile_of_block(ncb, row_tiles, cb, tile)) return;
-  const int row0 = tile * TM;
+  int cb, row0, row_end;
+  bool half_tile;   // every wave owns one 16-row group (rows row0 + 16 * wave ..) instead of RG
+  if (!conv16_tile_of_block(ncb, plan, TM, n_out, cb, row0, row_end, half_tile)) return;
   const int ntiles_total = cout >> 4;
 
   // ---- prologue: neighbour tile -> LDS, per-wave tap mask
@@ -99,7 +100,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
       const int i = tid + it * NTHR;
       const int k = i / TM, r = i - k * TM;
       tmp[it] = -1;   // stride = round_up(n, 128): rows beyond it have no neighbours
-      if (i < K * TM && row0 + r < nbr_stride) tmp[it] = nbr[(size_t)k * nbr_stride + row0 + r];
+      // LDS position r = wave * WR + (row of the wave); in a half tile only the first WR / 2 rows of a wave exist
+      const int rw = r % WR;
+      const int grow = half_tile ? (rw < WR / 2 ? row0 + (r / WR) * (WR / 2) + rw : row_end) : row0 + r;
+      if (i < K * TM && grow < row_end) tmp[it] = nbr[(size_t)k * nbr_stride + grow];   // row_end <= n_out <= stride
     }
 #pragma unroll
     for (int it = 0; it < NB_IT; ++it) {
@@ -289,8 +293,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
-  conv16_epilogue<NT, RG>(acc, tile_l, lane, row0 + wave * WR, cb * BN, cout, *w_inv_scale, scale, shift, residual, ys,
-                          n_out, relu);
+  conv16_epilogue<NT, RG>(acc, tile_l, lane, row0 + wave * (half_tile ? WR / 2 : WR), cb * BN, cout, *w_inv_scale, scale,
+                          shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG);
 }
 
 // ------------------------------------------------------------------------------------------ format kernels
@@ -359,22 +363,29 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
 }
 
 template <int CIN, int NT, int RG, int NW, int MODE = 0>
-static int launch16(const uint4* xs, const uint4* wpk, const float* winv, int K, int cout, const int32_t* nbr,
-                    int nbr_stride, int n_out, const float* scale, const float* shift, const uint4* residual,
-                    int relu, uint4* ys, hipStream_t st) {
+static int launch16(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
+                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
+                    const uint4* residual, int relu, uint4* ys, hipStream_t st) {
   using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
   auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, MODE>;
-  static bool attr_set = false;
-  if (!attr_set && S::bytes > 48 * 1024) {
-    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, S::bytes));
-    attr_set = true;
+  static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};   // of this instantiation on this device family
+  if (wgs_per_cu.load(std::memory_order_acquire) == 0) {
+    if (S::bytes > 48 * 1024)
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, S::bytes));
+    int dev = 0, cus = 0, occ = 0;
+    ISF_HIP_TRY(hipGetDevice(&dev));
+    ISF_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    ISF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, S::bytes));
+    cus_per_xcd.store(cus >= 8 ? cus / 8 : 1, std::memory_order_relaxed);
+    wgs_per_cu.store(occ > 0 ? occ : 1, std::memory_order_release);
   }
-  const int row_tiles = ceil_div(n_out, S::TM);
   const int ncb = cout / (16 * NT);
   ISF_REQUIRE(ncb == 1 || ncb == 2, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d column blocks", ncb);
-  hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(ncb, row_tiles)), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride,
-                     wpk, winv, K, cout, scale, shift, residual, ys, n_out, relu, row_tiles);
+  const Conv16Plan plan = conv16_plan(n_out, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
+                                      cus_per_xcd.load(std::memory_order_relaxed), balance);
+  hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K,
+                     cout, scale, shift, residual, ys, n_out, relu, plan);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -389,8 +400,8 @@ template <int CIN, int NT>
 static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                          const uint4* residual, int relu, uint4* ys, hipStream_t st) {
-#define ISF_ARGS16 xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st
-  switch (mode) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
+#define ISF_ARGS16 (mode & 32) == 0, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st
+  switch (mode & ~32) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
     case 0: break;
     case 1: return launch16<CIN, NT, 2, 4, 1>(ISF_ARGS16);
     case 2: return launch16<CIN, NT, 2, 4, 2>(ISF_ARGS16);
@@ -518,8 +529,9 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  ISF_REQUIRE(mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 6 || mode == 8 || mode == 16, ISF_ERR_ARG,
-              "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, diagnostics 2 / 4 / 6 / 8 / 16)", mode);
+  const int m = mode & ~32;   // bit 32 = uniform tiles (no full / half mix), combinable
+  ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16), ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, diagnostics 2 / 4 / 6 / 8 / 16, +32)", mode);
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
                                              num_out, scale, shift, residual_split, relu, out_split, mode,
                                              isf::as_stream(stream));

@@ -57,7 +57,7 @@ __device__ __forceinline__ f32x4 mma32x3(const h8 ah, const h8 al, const h8 bh, 
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
 }
 
-// packed: [HEADS][STAGES][32 KiB] then the header {1/scale_qkv, 1/scale_out}
+// packed: [HEADS][32 KiB] then the header {1/scale_qkv, 1/scale_out}
 template <int D, int HD>
 __global__ __launch_bounds__(256, 1) void window_block_kernel(
     const float* __restrict__ x, int B, int S, int shift, const uint4* __restrict__ packed,

@@ -398,6 +398,23 @@ def test_conv_neighbour_sharing_reproduces_full_gather_bits(dev):
         assert torch.equal(got, want), n
 
 
+def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
+    """launches that fit the chip in one round of workgroups are cut into full and half-height tiles so that every SIMD
+    gets the same number of 16-row groups (isf_spconv16.h, conv16_plan); a row's products and their order do not depend
+    on the tile it falls into, so the result must equal the uniform-tile kernel's (diagnostic 32) bit for bit -- from
+    tiny inputs (half tiles only) to the full bench size (levels 3 / 4: two full + one half tile per CU)"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(700 + i, n), dev) for i in range(frames)]
+        got = lb(pl)
+        want = lb(pl, conv_diag=32)
+        assert torch.isfinite(got).all() and got.abs().max().item() > 0.1
+        assert torch.equal(got, want), n
+        assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
+
+
 def test_conv_autograd_switch(dev):
     """a sparse conv on tensors that require grad runs the autograd Function (forward + dX / dW kernels, validated in
     tests/test_gpu_widened.py); with spconv.TRAINING_KERNELS = False the same call is a loud NotImplementedError"""
