@@ -3,6 +3,8 @@
 // reads 16 B at row * 128 + kg * 16); at the sparse levels only ~24 % of the rows are live.  Questions:
 //   (1) does a masked-off lane cost anything?            full / q25 (random lanes) / r25 (4 of 16 rows) / h50
 //   (2) what is the rate of the gather pattern against a fully coalesced 1-KiB load?       full vs seq vs adj
+//       adj = 16 consecutive 128-byte rows, 64 B of each (the split format today); adj64 = the same rows if hi and lo
+//       lived in separate planes of 64-byte records (one contiguous KiB)
 //   (3) is the cost per 64-byte piece or per 128-byte line?   pair: both halves of a row's line in ONE instruction
 //       (8 rows x 128 B) vs the conv's two instructions of 16 rows x 64 B
 //   (4) LDS-DMA (global_load_lds_dwordx4) of a contiguous KiB, as the weight stages use
@@ -14,8 +16,8 @@
 #include <vector>
 
 constexpr int ITER = 1024;
-enum { FULL, Q25, R25, H50, NONE, SEQ, ADJ, PAIR, DMA, NMODES };
-static const char* kName[NMODES] = {"full", "q25", "r25", "h50", "none", "seq", "adj", "pair", "dma"};
+enum { FULL, Q25, R25, H50, NONE, SEQ, ADJ, ADJ64, PAIR, DMA, NMODES };
+static const char* kName[NMODES] = {"full", "q25", "r25", "h50", "none", "seq", "adj", "adj64", "pair", "dma"};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ buf, int row_mask, uint4* __restrict__ out) {
@@ -29,6 +31,7 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ buf, int 
   if (MODE == NONE) live = false;
   uint4 acc = make_uint4(0, 0, 0, 0);
   int r = (wave * 977 + col * 131) & row_mask;
+  if (MODE == SEQ || MODE == DMA || MODE == ADJ || MODE == ADJ64) r = (wave * 977) & row_mask;   // wave-uniform walk
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)(stage + wid * 64));
 #pragma unroll 8
   for (int it = 0; it < ITER; ++it) {
@@ -37,6 +40,8 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ buf, int 
       v = buf[(size_t)((r & ~7) & row_mask) * 8 + lane];
     } else if (MODE == ADJ) {     // 16 consecutive rows (consecutive lines), 64 B of each
       v = buf[(size_t)(((r & ~15) + col) & row_mask) * 8 + kg];
+    } else if (MODE == ADJ64) {   // 16 consecutive 64-byte records (hi and lo in separate planes): one contiguous KiB
+      v = buf[(size_t)(((r & ~7) & row_mask) * 8) + col * 4 + kg];
     } else if (MODE == PAIR) {    // 8 random rows, the whole 128-byte line of each (lane = (row = lane & 7, piece = lane >> 3))
       v = buf[(size_t)((r * 7 + (lane & 7) * 61) & row_mask) * 8 + (lane >> 3)];
     } else if (MODE == DMA) {     // contiguous KiB straight into LDS
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void probe(const uint4* __restrict__ buf, int 
       v = buf[(size_t)r * 8 + kg];
     }
     acc.x ^= v.x; acc.y += v.y; acc.z ^= v.z; acc.w += v.w;
-    r = (r * 5 + 1 + (MODE == SEQ || MODE == DMA ? 8 : col)) & row_mask;   // pseudo-random walk (wave-uniform for seq / dma)
+    r = (r * 5 + 1 + (MODE == SEQ || MODE == DMA || MODE == ADJ || MODE == ADJ64 ? 8 : col)) & row_mask;   // pseudo-random walk
   }
   if (MODE == DMA) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -80,7 +85,8 @@ int main() {
     hipMemset(buf, 0, (size_t)rows * 128);
     const float t[NMODES] = {run<FULL>(buf, m, out, grid), run<Q25>(buf, m, out, grid), run<R25>(buf, m, out, grid),
                              run<H50>(buf, m, out, grid),  run<NONE>(buf, m, out, grid), run<SEQ>(buf, m, out, grid),
-                             run<ADJ>(buf, m, out, grid),  run<PAIR>(buf, m, out, grid), run<DMA>(buf, m, out, grid)};
+                             run<ADJ>(buf, m, out, grid),  run<ADJ64>(buf, m, out, grid), run<PAIR>(buf, m, out, grid),
+                             run<DMA>(buf, m, out, grid)};
     printf("table %6d KiB (ns per wave instruction per CU):", rows / 8);
     for (int k = 0; k < NMODES; ++k) printf("  %s %.1f", kName[k], t[k] * 1e6 / (12.0 * ITER));
     printf("\n");

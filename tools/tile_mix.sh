@@ -1,16 +1,13 @@
 #!/bin/bash
-# Full / half-tile mix of the sparse-conv launches (isf_spconv16.h, conv16_plan) against uniform tiles (--conv-diag 32),
-# plus the workgroup-placement probe the plan's "per CU" dealing rests on:
-#   gpurun --timeout 900 -- 'bash tools/tile_mix.sh'
+# A/B of the sparse-conv launch / kernel options on the bench (B=4 x 300 k points, 2 frame sets rotated):
+#   --conv-diag 0 default, 32 uniform tiles (no full / half mix), 16 no neighbour sharing, 64 (experiment) 8-wave
+#   workgroups for the 256-column layers too
+#   gpurun --timeout 900 -- 'bash tools/tile_mix.sh "0 32 16 64"'
 set -u
 mkdir -p gpurun_out
 export ISF_BENCH_FRAME_CACHE=/tmp/isf_bench_frames
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/probes/wg_placement.hip -o /tmp/wg_placement \
-  && timeout 60 /tmp/wg_placement 2>&1 | tee gpurun_out/wg_placement.txt
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-value tools/probes/masked_gather.hip -o /tmp/masked_gather \
-  && timeout 60 /tmp/masked_gather 2>&1 | tee gpurun_out/masked_gather.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -k "tile_mix or sharing or sparse_conv or encoder" 2>&1 | tail -4 | tee gpurun_out/tile_mix_tests.log
-for mode in 0 32 0 32; do
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -p no:cacheprovider -k "tile_mix or sharing or sparse_conv or encoder or full_size" 2>&1 | tail -4 | tee gpurun_out/tile_mix_tests.log
+for mode in ${1:-0 32 0 32}; do
   timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --conv-diag $mode \
       > gpurun_out/mix_$mode.json 2> gpurun_out/mix_$mode.err
   python - "$mode" <<'PY'
@@ -21,6 +18,6 @@ try:
     print("conv-diag %-3s %s frames/s %s ms/step conv %s" % (mode, d["value"], d["ms_per_step"], d["roofline"]["conv_ms_per_step"]),
           {k.replace("spconv_mfma", ""): v["ms"] for k, v in d["roofline"]["per_kernel"].items()})
 except Exception as e:   # noqa: BLE001
-    print(mode, "unreadable:", e)
+    print(mode, "unreadable:", e, open(f"gpurun_out/mix_{mode}.err").read()[-600:])
 PY
 done 2>&1 | tee gpurun_out/tile_mix_bench.txt
