@@ -1,8 +1,7 @@
 #!/bin/bash
 # A/B of the sparse-conv launch / kernel options on the bench (B=4 x 300 k points, 2 frame sets rotated):
-#   --conv-diag 0 default, 32 uniform tiles (no full / half mix), 16 no neighbour sharing, 64 (experiment) 8-wave
-#   workgroups for the 256-column layers too
-#   gpurun --timeout 900 -- 'bash tools/tile_mix.sh "0 32 16 64"'
+#   --conv-diag 0 default, 32 uniform tiles (no full / half mix), 16 no neighbour sharing, 48 both off
+#   gpurun --timeout 900 -- 'bash tools/tile_mix.sh "0 32 16 48"'
 set -u
 mkdir -p gpurun_out
 export ISF_BENCH_FRAME_CACHE=/tmp/isf_bench_frames
