@@ -10,9 +10,10 @@
  *     synchronise the stream once before returning (the reference ops do the same, see each entry).
  *   - Return value: ISF_OK (0) or a negative ISF_ERR_* code; never throws.  isf_last_error() returns a
  *     thread-local message for the last failure.
- *   - Buffers are caller-owned.  Scratch memory comes from a per-device arena owned by the library
- *     (grown on demand with hipMalloc, released by isf_release_workspace()).  One call at a time per
- *     device (the reference ops are likewise called from the single Python thread of the rank).
+ *   - Buffers are caller-owned.  Scratch memory (bump arena, side stream, event pool) is one object per
+ *     (device, stream) owned by the library, grown on demand with hipMalloc and released by
+ *     isf_release_workspace(): calls on different streams are independent; one call at a time per stream.
+ *   - No process-global options and no environment switches: precision / diagnostics travel with the call.
  *   - Voxel coordinates are int32 (z, y, x) or (b, z, y, x) exactly like the reference.
  *
  * Each entry cites the reference interface it replaces (paths relative to the reference root).
@@ -47,7 +48,7 @@ typedef void* isf_stream_t; /* hipStream_t */
 int isf_version(void);                 /* (major<<16)|(minor<<8)|patch */
 const char* isf_last_error(void);      /* message of the last failure on this thread ("" if none) */
 int isf_device_count(int* count_host); /* number of visible HIP devices (0 on a CPU-only host) */
-int isf_release_workspace(void);       /* free the per-device arenas */
+int isf_release_workspace(void);       /* free every (device, stream) workspace */
 int isf_workspace_bytes(size_t* bytes_host); /* current arena size on the current device */
 
 /* A1  dynamic voxelization ------------------------------------------------------------------------

@@ -492,14 +492,16 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(a.alloc_n(&w1p, (size_t)4 * 2 * 64));
   ISF_TRY(a.alloc_n(&w2p, (size_t)4 * 4 * 128));
   hipLaunchKernelGGL(vfe_prep_kernel, dim3(1), dim3(256), 0, st, w1, F, w2, scale1, scale2, w1p, sc1, w2p, sc2);
+  // The one host round trip of the VFE: N sizes every per-voxel buffer.  The read-back is followed by an event, and
+  // everything that does not need N -- the point -> voxel map and the per-voxel point counts (75 us of GPU work at
+  // 1.2 M points, counters allocated for the worst case of one voxel per point) -- is queued behind it BEFORE the host
+  // waits, so the GPU keeps working while the host wakes up and launches the rest (the plain hipStreamSynchronize left
+  // it idle for ~50 us per forward: profiles/r02_call22_timeline_gaps.txt).
   int N = 0;
-  ISF_TRY(read_int(occ.total, &N, st));  // the one host sync of the VFE: sizes every per-voxel buffer
-  *n_host = N;
-  if (occ_out) *occ_out = occ;
-  if (N == 0) {
-    if (pt2vox_out) ISF_HIP_TRY(hipMemsetAsync(pt2vox_out, 0xff, (size_t)P * sizeof(int32_t), st));
-    return ISF_OK;
-  }
+  hipEvent_t n_ready;
+  ISF_HIP_TRY(hipMemcpyAsync(&N, occ.total, sizeof(int), hipMemcpyDeviceToHost, st));
+  ISF_TRY(pooled_event(a, &n_ready));
+  ISF_HIP_TRY(hipEventRecord(n_ready, st));
   int32_t* pt2vox = pt2vox_out;
   if (!pt2vox) ISF_TRY(a.alloc_n(&pt2vox, (size_t)P));
   int32_t* slot;
@@ -509,13 +511,8 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   float* vmax1;
   ISF_TRY(a.alloc_n(&slot, (size_t)P));
   ISF_TRY(a.alloc_n(&recs, (size_t)P * kRec));
-  ISF_TRY(a.alloc_n(&cnt, (size_t)N + 1));
-  ISF_TRY(a.alloc_n(&start, (size_t)N + 2));
-  ISF_TRY(a.alloc_n(&mean4, (size_t)N));
-  ISF_TRY(a.alloc_n(&vmax1, (size_t)N * kC));
-  ISF_HIP_TRY(hipMemsetAsync(cnt, 0, ((size_t)N + 1) * sizeof(uint32_t), st));
-  ISF_HIP_TRY(hipMemsetAsync(vmax1, 0, (size_t)N * kC * sizeof(float), st));
-  ISF_HIP_TRY(hipMemsetAsync(voxel_feats, 0, (size_t)N * kC * sizeof(float), st));
+  ISF_TRY(a.alloc_n(&cnt, (size_t)P + 1));
+  ISF_HIP_TRY(hipMemsetAsync(cnt, 0, ((size_t)P + 1) * sizeof(uint32_t), st));
   hipLaunchKernelGGL(vfe_count_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, coors4, P, occ.D, occ.H, occ.W,
                      occ.bits, occ.prefix, pt2vox, slot, cnt, voxel_coors);
   ISF_LAUNCH_CHECK();
@@ -523,6 +520,15 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
     ISF_TRY(pooled_event(a, coords_ready));
     ISF_HIP_TRY(hipEventRecord(*coords_ready, st));
   }
+  ISF_HIP_TRY(hipEventSynchronize(n_ready));
+  *n_host = N;
+  if (occ_out) *occ_out = occ;
+  if (N == 0) return ISF_OK;   // vfe_count_kernel has marked every point -1
+  ISF_TRY(a.alloc_n(&start, (size_t)N + 2));
+  ISF_TRY(a.alloc_n(&mean4, (size_t)N));
+  ISF_TRY(a.alloc_n(&vmax1, (size_t)N * kC));
+  ISF_HIP_TRY(hipMemsetAsync(vmax1, 0, (size_t)N * kC * sizeof(float), st));
+  ISF_HIP_TRY(hipMemsetAsync(voxel_feats, 0, (size_t)N * kC * sizeof(float), st));
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
   hipLaunchKernelGGL(vfe_order_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, pt2vox, slot, P, start,
                      recs);
