@@ -31,9 +31,11 @@ __global__ void rb_perm_kernel(const int32_t* __restrict__ coors4, int n, int B,
   if (r >= 0) perm[r] = i;
 }
 
-// one thread per (output row, tap): grid (ceil(stride/256), K).  Rows are sorted, so the 256 probes of a
-// block hit neighbouring bitmap words; the two dependent loads of a probe are the whole critical path.
-// Rows >= n_out up to nbr_stride are filled with -1.
+// one thread per (output row, (kz, ky) line of taps): grid (ceil(stride/256), ks[0] * ks[1]).  The ks[2] taps of a line
+// probe x-adjacent cells -- the same 64-bit bitmap word (and prefix entry) except when the line crosses a word
+// boundary -- so a line costs one coordinate load and ONE pair of dependent loads instead of ks[2] of each (the
+// (row, tap) grid of round 1 read every coordinate 27 times: 101 us for 44 MB at level 0).  Rows are sorted, so the
+// 256 probes of a block hit neighbouring bitmap words.  Rows >= n_out up to nbr_stride are filled with -1.
 __global__ __launch_bounds__(256) void rb_nbr_kernel(const int32_t* __restrict__ out_coors4, int n_out,
                                                      RbGeom g,
                                                      const unsigned long long* __restrict__ in_bits,
@@ -42,26 +44,52 @@ __global__ __launch_bounds__(256) void rb_nbr_kernel(const int32_t* __restrict__
                                                      int32_t* __restrict__ nbr, int nbr_stride,
                                                      uint32_t* __restrict__ block_pairs) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
-  int r = -1;
+  const int line = blockIdx.y;
+  const int ky = line % g.ks[1], kz = line / g.ks[1];
+  const int nx = g.ks[2];                                   // <= 3
+  int r[3] = {-1, -1, -1};
   if (o < n_out) {
     const int4 c = reinterpret_cast<const int4*>(out_coors4)[o];
     const int iz = c.y * g.st[0] - g.pd[0] + kz;
     const int iy = c.z * g.st[1] - g.pd[1] + ky;
-    const int ix = c.w * g.st[2] - g.pd[2] + kx;
-    if (c.x >= 0 && c.x < g.batch && iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1] && ix >= 0 &&
-        ix < g.in_shape[2]) {
-      r = occ_lookup(in_bits, in_prefix,
-                     (((unsigned long long)c.x * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2] + ix);
-      if (r >= 0 && perm) r = perm[r];
+    const int ix0 = c.w * g.st[2] - g.pd[2];
+    if (c.x >= 0 && c.x < g.batch && iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1]) {
+      const long long base = (((long long)c.x * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2];
+      long long wcur = -1;
+      unsigned long long word = 0;
+      uint32_t pre = 0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ix0 + kx;
+        if (kx < nx && ix >= 0 && ix < g.in_shape[2]) {
+          const long long cell = base + ix;
+          if ((cell >> 6) != wcur) {
+            wcur = cell >> 6;
+            word = in_bits[wcur];
+            pre = in_prefix[wcur];
+          }
+          const unsigned long long bit = 1ull << (cell & 63);
+          if (word & bit) {
+            const int v = (int)(pre + (uint32_t)__popcll(word & (bit - 1)));
+            r[kx] = perm ? perm[v] : v;
+          }
+        }
+      }
     }
   }
-  if (o < nbr_stride) nbr[(size_t)k * nbr_stride + o] = r;
+  int found = 0;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    if (kx < nx) {
+      if (o < nbr_stride) nbr[(size_t)(line * nx + kx) * nbr_stride + o] = r[kx];
+      found += r[kx] >= 0;
+    }
+  }
   if (block_pairs) {  // per-block partial, no atomics: a single counter word serialises at ~88 updates/us
     __shared__ int wsum[4];
-    const unsigned long long m = __ballot(r >= 0);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = found;
     __syncthreads();
     if (threadIdx.x == 0)
       block_pairs[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (uint32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
@@ -84,27 +112,37 @@ __global__ __launch_bounds__(1024) void rb_sum_pairs_kernel(const uint32_t* __re
   }
 }
 
-// strided conv: every (input voxel, tap) marks the output it feeds; grid (ceil(n_in/256), K)
+// strided conv: every (input voxel, tap) marks the output it feeds.  One thread per (input row, kz): the ks[1] * ks[2]
+// taps of a plane are arithmetic on ONE coordinate load (the (row, tap) grid of round 1 loaded it 27 times), and with
+// stride 2 at most two taps per axis land on an output at all.  grid (ceil(n_in/256), ks[0])
 __global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restrict__ in_coors4, int n_in,
                                                           RbGeom g,
                                                           unsigned long long* __restrict__ out_bits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_in) return;
-  const int k = blockIdx.y;
-  const int kx = k % g.ks[2], ky = (k / g.ks[2]) % g.ks[1], kz = k / (g.ks[2] * g.ks[1]);
+  const int kz = blockIdx.y;
   const int4 c = reinterpret_cast<const int4*>(in_coors4)[i];
   if (c.x < 0 || c.x >= g.batch || c.y < 0 || c.z < 0 || c.w < 0 || c.y >= g.in_shape[0] || c.z >= g.in_shape[1] ||
       c.w >= g.in_shape[2])
     return;
-  const int tz = c.y + g.pd[0] - kz, ty = c.z + g.pd[1] - ky, tx = c.w + g.pd[2] - kx;
-  if (tz < 0 || ty < 0 || tx < 0 || tz % g.st[0] || ty % g.st[1] || tx % g.st[2]) return;
-  const int oz = tz / g.st[0], oy = ty / g.st[1], ox = tx / g.st[2];
-  if (oz >= g.out_shape[0] || oy >= g.out_shape[1] || ox >= g.out_shape[2]) return;
-  const unsigned long long cell =
-      (((unsigned long long)c.x * g.out_shape[0] + oz) * g.out_shape[1] + oy) * g.out_shape[2] + ox;
-  const unsigned long long bit = 1ull << (cell & 63);
-  unsigned long long* p = out_bits + (cell >> 6);
-  if (!(*p & bit)) atomicOr(p, bit);
+  const int tz = c.y + g.pd[0] - kz;
+  if (tz < 0 || tz % g.st[0]) return;
+  const int oz = tz / g.st[0];
+  if (oz >= g.out_shape[0]) return;
+  for (int ky = 0; ky < g.ks[1]; ++ky) {
+    const int ty = c.z + g.pd[1] - ky;
+    if (ty < 0 || ty % g.st[1] || ty / g.st[1] >= g.out_shape[1]) continue;
+    const unsigned long long line =
+        (((unsigned long long)c.x * g.out_shape[0] + oz) * g.out_shape[1] + ty / g.st[1]) * g.out_shape[2];
+    for (int kx = 0; kx < g.ks[2]; ++kx) {
+      const int tx = c.w + g.pd[2] - kx;
+      if (tx < 0 || tx % g.st[2] || tx / g.st[2] >= g.out_shape[2]) continue;
+      const unsigned long long cell = line + tx / g.st[2];
+      const unsigned long long bit = 1ull << (cell & 63);
+      unsigned long long* p = out_bits + (cell >> 6);
+      if (!(*p & bit)) atomicOr(p, bit);
+    }
+  }
 }
 
 static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[3], const int pd[3],
@@ -125,13 +163,14 @@ int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shap
                const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
                int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_) {
   const RbGeom g = make_rb_geom(in_shape, ks, st, pd, subm, in_occ.B);
-  const int K = ks[0] * ks[1] * ks[2], nbx = ceil_div(nbr_stride, 256);
+  const int lines = ks[0] * ks[1], nbx = ceil_div(nbr_stride, 256);
+  ISF_REQUIRE(ks[2] >= 1 && ks[2] <= 3, ISF_ERR_UNSUPPORTED, "rulebook: kernel width %d (1..3)", ks[2]);
   uint32_t* block_pairs = nullptr;
-  if (pair_count) ISF_TRY(a.alloc_n(&block_pairs, (size_t)K * nbx));
-  hipLaunchKernelGGL(rb_nbr_kernel, dim3(nbx, K), dim3(256), 0, st_, out_coors4, n_out, g, in_occ.bits,
+  if (pair_count) ISF_TRY(a.alloc_n(&block_pairs, (size_t)lines * nbx));
+  hipLaunchKernelGGL(rb_nbr_kernel, dim3(nbx, lines), dim3(256), 0, st_, out_coors4, n_out, g, in_occ.bits,
                      in_occ.prefix, perm, nbr, nbr_stride, block_pairs);
   if (pair_count)
-    hipLaunchKernelGGL(rb_sum_pairs_kernel, dim3(1), dim3(1024), 0, st_, block_pairs, K * nbx, pair_count);
+    hipLaunchKernelGGL(rb_sum_pairs_kernel, dim3(1), dim3(1024), 0, st_, block_pairs, lines * nbx, pair_count);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -140,8 +179,8 @@ int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], c
                     const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_) {
   if (n_in <= 0) return ISF_OK;
   const RbGeom g = make_rb_geom(in_shape, ks, st, pd, false, out_occ.B);
-  hipLaunchKernelGGL(rb_mark_out_kernel, dim3(ceil_div(n_in, 256), ks[0] * ks[1] * ks[2]), dim3(256), 0, st_,
-                     in_coors4, n_in, g, out_occ.bits);
+  hipLaunchKernelGGL(rb_mark_out_kernel, dim3(ceil_div(n_in, 256), ks[0]), dim3(256), 0, st_, in_coors4, n_in, g,
+                     out_occ.bits);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
