@@ -266,8 +266,12 @@ def main_fusion(args):
             stages["second_stage1"], (nxt, _, f0) = timed(lambda: bb([ret], "stage1"))
             stages["grid2region_1"], g1 = timed(lambda: enc.grid2region(1, nxt))
             stages["second_stage2"], (_, _, f1) = timed(lambda: bb([g1], "stage2"))
-            stages["neck"], nk = timed(lambda: net.pts_neck([f0, f1]))
-            stages["head"], _ = timed(lambda: net.pts_bbox_head(nk, img_feats, metas))
+            if net.pts_neck.dense_conv == "hip" and net.pts_bbox_head.dense_conv == "hip":   # as forward_pts runs them
+                stages["neck"], nk = timed(lambda: net.pts_neck.forward_split([f0, f1]))
+                stages["head"], _ = timed(lambda: net.pts_bbox_head.forward_split(nk))
+            else:
+                stages["neck"], nk = timed(lambda: net.pts_neck([f0, f1]))
+                stages["head"], _ = timed(lambda: net.pts_bbox_head(nk, img_feats, metas))
         stages = {k: round(v, 3) for k, v in stages.items()}
         # ---- roofline of the dominant kernel: the sparse-conv kernel family (LiDAR branch layers by template
         # instantiation; the 3x3 dense convs of conv_fusion / IGF / SECONDV2 run on the same kernels over a dense rulebook)

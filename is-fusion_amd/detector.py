@@ -117,8 +117,12 @@ class ISFusionPtsPath(nn.Module):
     def forward_pts(self, pts, img_feats, img_metas, **kwargs):
         """extract_pts_feat -> pts_neck -> pts_bbox_head (mvx_two_stage.py simple_test_pts without box decoding):
         the raw head outputs [[dict(center, height, dim, rot, vel, heatmap, query_heatmap_score, dense_heatmap)]]."""
-        x = self.pts_neck(self.extract_pts_feat(pts, img_feats, img_metas, **kwargs))
-        return self.pts_bbox_head(x, img_feats, img_metas)
+        feats = self.extract_pts_feat(pts, img_feats, img_metas, **kwargs)
+        if self.pts_neck.dense_conv == "hip" and self.pts_bbox_head.dense_conv == "hip":
+            # engine-level hand-over: the neck's levels stay split-format token matrices (no [B, 512, H, W] tensor, no
+            # permute copy, no NCHW -> split pass); the public neck / head forwards keep the reference's tensors
+            return (self.pts_bbox_head.forward_split(self.pts_neck.forward_split(feats)),)
+        return self.pts_bbox_head(self.pts_neck(feats), img_feats, img_metas)
 
     @torch.no_grad()
     def simple_test_pts(self, x, x_img, img_metas, rescale=False):

@@ -339,7 +339,7 @@ def seeded_state_dict(module, seed):
 class SECONDFPN(nn.Module):
     """necks/second_fpn.py:10-93 as the IS-Fusion config builds it (use_conv_for_no_stride=True): per level a
     Conv2d(k = 1/stride) or ConvTranspose2d(k = stride) without bias + BN(eps 1e-3) + ReLU, concatenated, and the
-    final `permute(0, 1, 3, 2)`.  Stock PyTorch-ROCm ops (a 1x1 conv and a 2x2 transposed conv per frame)."""
+    final `permute(0, 1, 3, 2)`.  Training: stock PyTorch-ROCm ops (a 1x1 conv and a 2x2 transposed conv per frame)."""
 
     def __init__(self, in_channels=(128, 256), out_channels=(256, 256), upsample_strides=(1, 2),
                  norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), upsample_cfg=dict(type="deconv", bias=False),
@@ -357,11 +357,11 @@ class SECONDFPN(nn.Module):
             blocks.append(nn.Sequential(up, nn.BatchNorm2d(cout, eps=eps, momentum=mom), nn.ReLU(inplace=True)))
         self.deblocks = nn.ModuleList(blocks)
 
-    # "stock": the torch modules above (MIOpen).  "hip" (opt-in until it has run on hardware): both
-    # levels are GEMMs over BEV tokens -- the 1x1 conv is a linear layer, the k = s transposed conv is ONE linear layer
-    # with s*s*Cout outputs whose columns are dealt to the s x s sub-cells -- on the fused f16x3 linear kernel with
-    # BatchNorm folded into weight / bias and ReLU in its epilogue.
-    dense_conv = "stock"
+    # "hip" (default in eval mode): both levels are GEMMs over BEV tokens -- the 1x1 conv is a linear
+    # layer, the k = s transposed conv is ONE linear layer with s*s*Cout outputs whose columns are dealt to the s x s
+    # sub-cells -- on the fused f16x3 linear kernel with BatchNorm folded into weight / bias and ReLU in its epilogue.
+    # "stock": the torch modules above (MIOpen; 0.49 ms per forward at B = 2 against 0.2 ms, tools/glue_profile.py).
+    dense_conv = "hip"
 
     def _folded(self, i):
         """(weight [taps*Cout, Cin], bias [taps*Cout], stride) of level i with eval BatchNorm folded in"""
@@ -380,35 +380,64 @@ class SECONDFPN(nn.Module):
     def forward_tokens(self, x, linear_relu):
         """the "hip" data path with the GEMM injected: linear_relu(x [B, Cin, H, W], weight, bias) -> relu(tokens W^T +
         b) as [B*H*W, N] rows ((b, y, x) order).  (tests/test_host.py runs it with a torch GEMM against the modules.)"""
-        ups = []
+        out = None
+        c0 = 0
         for i in range(len(self.deblocks)):
             w, b, s = self._folded(i)
             B, _, H, W = x[i].shape
-            y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout]
+            y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout], column = (dy*s + dx)*Cout + co
             cout = y.shape[1] // (s * s)
-            y = y.view(B, H, W, s, s, cout).permute(0, 5, 1, 3, 2, 4).reshape(B, cout, H * s, W * s)
-            ups.append(y)
-        out = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
-        return [out.permute(0, 1, 3, 2).contiguous()]
+            if out is None:
+                out = y.new_empty((B, sum(self.out_channels), W * s, H * s))
+            # the concatenated map AND the reference's final permute(0, 1, 3, 2) in one copy per level:
+            # out[b, c0 + co, w*s + dx, h*s + dy] = y[b, h, w, dy, dx, co]
+            out[:, c0:c0 + cout].view(B, cout, W, s, H, s).copy_(y.view(B, H, W, s, s, cout).permute(0, 5, 2, 4, 1, 3))
+            c0 += cout
+        return [out]
+
+    def _linear_relu(self):
+        """the injected GEMM of forward_tokens on the fused linear kernel, weights packed once per parameter version"""
+        from . import fusion_ops as ops
+        cache = self.__dict__.setdefault("_isf_packed", {})
+        pk = None if self.__dict__.get("_isf_frozen", False) and cache else ops.param_key(self)
+        if pk is not None and cache.get("_key") != pk:
+            cache.clear()
+            cache["_key"] = pk
+
+        def linear_relu(t, w, b):
+            key = (w.shape[0], w.shape[1], t.device)
+            if key not in cache:
+                cache[key] = ops.PackedLinear(w.to(t.device), b.to(t.device))
+            return ops.linear(t.float(), cache[key], act=ops.ACT_RELU)
+        return linear_relu
+
+    @torch.no_grad()
+    def forward_split(self, x):
+        """engine-level hand-over to the detection head (ISFusionPtsPath.forward_pts): the levels as split-format token
+        matrices (dense_conv.SplitMap, token = (b*H + y)*W + x of the UN-permuted map, one map per level = per
+        <= 256-channel group of the concatenation).  No [B, 512, H, W] tensor, no permute copy, no NCHW -> split pass:
+        the head applies its 3x3 convolutions with transposed taps instead (TransFusionHeadV2.forward_split)."""
+        from .dense_conv import SplitMap
+        from .spconv import to_split
+        assert len(x) == len(self.in_channels) and not self.training
+        linear_relu = self._linear_relu()
+        maps = []
+        for i in range(len(self.deblocks)):
+            w, b, s = self._folded(i)
+            B, _, H, W = x[i].shape
+            y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout], column = (dy*s + dx)*Cout + co
+            cout = y.shape[1] // (s * s)
+            if s > 1:                                                     # sub-cells to their tokens: 1-KiB runs
+                y = y.view(B, H, W, s, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(B * H * s * W * s, cout)
+            maps.append(SplitMap(to_split(y), B, cout, H * s, W * s))
+        assert all((m.H, m.W) == (maps[0].H, maps[0].W) for m in maps)
+        return maps
 
     def forward(self, x, **kwargs):
         assert len(x) == len(self.in_channels)
         if self.dense_conv == "hip" and not self.training:
-            from . import fusion_ops as ops
-            cache = self.__dict__.setdefault("_isf_packed", {})
-            pk = None if self.__dict__.get("_isf_frozen", False) and cache else ops.param_key(self)
-            if pk is not None and cache.get("_key") != pk:
-                cache.clear()
-                cache["_key"] = pk
-
-            def linear_relu(t, w, b):
-                key = (w.shape[0], w.shape[1], t.device)
-                if key not in cache:
-                    cache[key] = ops.PackedLinear(w.to(t.device), b.to(t.device))
-                return ops.linear(t.float(), cache[key], act=ops.ACT_RELU)
-
             with torch.no_grad():
-                return self.forward_tokens(x, linear_relu)
+                return self.forward_tokens(x, self._linear_relu())
         ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
         out = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         return [out.permute(0, 1, 3, 2).contiguous()]

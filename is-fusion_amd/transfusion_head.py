@@ -138,29 +138,98 @@ class TransFusionHeadV2(nn.Module):
                     c_out=ops.PackedLinear(ca.out_proj.weight, ca.out_proj.bias),
                     l1=ops.PackedLinear(l.linear1.weight, l.linear1.bias),
                     l2=ops.PackedLinear(l.linear2.weight, l.linear2.bias)))
+            c["pred"] = [self._pack_prediction_heads(ffn) for ffn in self.prediction_heads]
         return c
 
+    @staticmethod
+    def _pack_prediction_heads(ffn):
+        """The per-output Conv1d stacks of an FFN (transfusion_head_v2.py:505-590; kernel size 1 = per-proposal linear
+        layers) as GEMM pairs: the first layers of a GROUP of outputs side by side (eval BatchNorm folded, ReLU in the
+        epilogue), their last layers as one block-diagonal matrix.  Groups of 4 / 2 / 1 outputs keep the hidden width
+        (64 each) inside what the linear kernel tiles (<= 256): the shipped six outputs are 4 + 2 = four launches for 12
+        convolutions + 6 BatchNorms + 6 ReLUs.  -> None when a stack is not the shipped (conv-bn-relu, conv) shape or
+        width; the caller then runs the modules."""
+        heads = []
+        for name in ffn.heads:
+            seq = getattr(ffn, name)
+            if len(seq) != 2 or not isinstance(seq[0], _ConvModule1d) or not isinstance(seq[1], nn.Conv1d):
+                return None
+            conv, bn, last = seq[0].conv, seq[0].bn, seq[1]
+            if conv.weight.shape[0] != 64 or conv.weight.shape[1] not in (32, 64, 128, 256):
+                return None
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+            heads.append((name, conv.weight.detach().float()[:, :, 0] * scale[:, None],
+                          (bn.bias - bn.running_mean * scale).detach().float(), last.weight.detach().float()[:, :, 0],
+                          last.bias.detach().float()))
+        groups, i = [], 0
+        while i < len(heads):
+            n = 4 if len(heads) - i >= 4 else 2 if len(heads) - i >= 2 else 1
+            grp = heads[i:i + n]
+            i += n
+            hid = 64 * n
+            n_out = sum(h[3].shape[0] for h in grp)
+            w2 = grp[0][1].new_zeros(((n_out + 15) // 16 * 16, hid))      # the linear kernel writes 16-column tiles
+            b2 = grp[0][1].new_zeros((w2.shape[0],))
+            cols, r = [], 0
+            for k, (name, _, _, w, b) in enumerate(grp):
+                w2[r:r + w.shape[0], 64 * k:64 * (k + 1)] = w
+                b2[r:r + w.shape[0]] = b
+                cols.append((name, r, r + w.shape[0]))
+                r += w.shape[0]
+            groups.append(dict(l1=ops.PackedLinear(torch.cat([h[1] for h in grp], 0), torch.cat([h[2] for h in grp], 0)),
+                               l2=ops.PackedLinear(w2, b2), cols=cols))
+        return groups
+
     @torch.no_grad()
-    def forward_single(self, inputs, img_inputs=None, metas=None):
+    def forward_split(self, maps):
+        """engine-level entry (ISFusionPtsPath.forward_pts): `maps` = SECONDFPN.forward_split(...) -- the neck output as
+        split-format token matrices of the UN-permuted BEV map M [B, C, H, W] (the reference hands over
+        P = M.permute(0, 1, 3, 2)).  Same result as forward_single(P): the 3x3 convolutions run with transposed taps on
+        M's tokens and only the 10-channel heat-map is permuted."""
+        assert self.dense_conv == "hip", "forward_split is the HIP path"
+        return [self.forward_single(None, maps_yx=maps)[0]]
+
+    @torch.no_grad()
+    def forward_single(self, inputs, img_inputs=None, metas=None, maps_yx=None):
         """inputs [B, in_channels, X, Y] -> [dict(center, height, dim, rot, vel, heatmap, query_heatmap_score,
         dense_heatmap)] (one dict: num_decoder_layers results concatenated along the proposal axis when auxiliary)"""
         assert not self.training, "isfusion_amd.TransFusionHeadV2 is the inference path (eval mode)"
-        B, _, X, Y = inputs.shape
-        HW = X * Y
-        c = self._packed(inputs.device)
         E = self.shared_conv.out_channels
-        if self.dense_conv == "hip":
-            maps = [SplitMap.from_nchw(inputs, off, min(256, inputs.size(1) - off))
-                    for off in range(0, inputs.size(1), 256)]
-            feat = c["shared"](maps)                                              # SplitMap [B, E, X, Y]
-            hm_mid = c["hm0"](feat).to_nchw()
-            feat_tok = from_split(feat.data, (B * HW, E))                         # token-major fp32
-            lidar_feat = None
+        tok_of_cell = None      # BEV cell x*Y + y (the head's indexing) -> row of feat_tok; None = identity
+        if maps_yx is not None:
+            m0 = maps_yx[0]
+            B, X, Y = m0.B, m0.W, m0.H                                             # the head's X is M's W axis
+            HW = X * Y
+            dev = m0.data.device
+            c = self._packed(dev)
+            feat = c["shared"](maps_yx, transpose=True)                            # SplitMap of M: token (b, y, x)
+            hm_mid = c["hm0"](feat, transpose=True).to_nchw()                      # [B, E, H, W]
+            feat_tok = from_split(feat.data, (B * HW, E))
+            h1 = self.heatmap_head[1]
+            dense_heatmap = torch.nn.functional.conv2d(hm_mid, h1.weight.transpose(2, 3), h1.bias, 1, 1)
+            dense_heatmap = dense_heatmap.permute(0, 1, 3, 2).contiguous()         # [B, classes, X, Y]
+            key = ("tok_of_cell", X, Y)
+            if key not in c:
+                cell = torch.arange(HW, device=dev)
+                c[key] = (cell % Y) * X + torch.div(cell, Y, rounding_mode="floor")           # (x, y) -> y*W + x
+                c[("cell_of_tok", X, Y)] = ((cell % X) * Y + torch.div(cell, X, rounding_mode="floor")).int()
+            tok_of_cell = c[key]
         else:
-            lidar_feat = self.shared_conv(inputs)
-            hm_mid = self.heatmap_head[0](lidar_feat)
-            feat_tok = ops.to_tokens(lidar_feat)
-        dense_heatmap = self.heatmap_head[1](hm_mid)
+            B, _, X, Y = inputs.shape
+            HW = X * Y
+            dev = inputs.device
+            c = self._packed(dev)
+            if self.dense_conv == "hip":
+                maps = [SplitMap.from_nchw(inputs, off, min(256, inputs.size(1) - off))
+                        for off in range(0, inputs.size(1), 256)]
+                feat = c["shared"](maps)                                          # SplitMap [B, E, X, Y]
+                hm_mid = c["hm0"](feat).to_nchw()
+                feat_tok = from_split(feat.data, (B * HW, E))                     # token-major fp32
+            else:
+                lidar_feat = self.shared_conv(inputs)
+                hm_mid = self.heatmap_head[0](lidar_feat)
+                feat_tok = ops.to_tokens(lidar_feat)
+            dense_heatmap = self.heatmap_head[1](hm_mid)
         pool1 = (8, 9) if self.test_cfg["dataset"] == "nuScenes" else (1, 2)
         top_index, top_raw, masked = ops.instance_topk(dense_heatmap, self.num_proposals, self.nms_kernel_size, pool1,
                                                        return_masked=True)
@@ -168,7 +237,8 @@ class TransFusionHeadV2(nn.Module):
         self.last_top_index = top_index   # BEV cell of every proposal (for inspection)
         bev_pos = c["bev_pos"].expand(B, -1, -1)
         query_pos = bev_pos.gather(1, top_index[:, :, None].expand(-1, -1, 2))                      # [B, P, 2]
-        rows = (top_index + torch.arange(B, device=inputs.device)[:, None] * HW).reshape(-1)
+        rows = top_index if tok_of_cell is None else tok_of_cell[top_index]
+        rows = (rows + torch.arange(B, device=dev)[:, None] * HW).reshape(-1)
         query = feat_tok[rows]                                                                       # [B*P, E]
         # class_encoding(one_hot) = column `class` of the 1x1 conv + bias
         ce = self.class_encoding
@@ -184,14 +254,25 @@ class TransFusionHeadV2(nn.Module):
             query = ops.linear(att, p["s_out"], residual=query, ln=l.norm1)
             # cross attention over the BEV map (:104-108)
             qc = ops.linear(query + qpe, p["c_q"])
-            idx = c.setdefault(("kv_index", B, HW), torch.arange(HW, device=inputs.device, dtype=torch.int32).repeat(B))
+            if tok_of_cell is None:
+                idx = c.setdefault(("kv_index", B, HW), torch.arange(HW, device=dev, dtype=torch.int32).repeat(B))
+            else:   # key token (b, y, x) takes the position row of its cell x*Y + y
+                idx = c.setdefault(("kv_index_yx", B, X, Y), c[("cell_of_tok", X, Y)].repeat(B))
             kv = ops.linear(feat_tok, p["c_kv"], table=p["kv_table"], index=idx)                     # [B*HW, 2E]
             att = ops.attention(qc, kv, kv[:, E:], B, P, HW, E, l.nhead, ldkv=2 * E)
             query = ops.linear(att, p["c_out"], residual=query, ln=l.norm2)
             h = ops.linear(query, p["l1"], act=ops.ACT_RELU)
             query = ops.linear(h, p["l2"], residual=query, ln=l.norm3)
-            qf = query.view(B, P, E).transpose(1, 2).contiguous()                                   # [B, E, P]
-            res = self.prediction_heads[i](qf)
+            pp = c["pred"][i] if self.dense_conv == "hip" else None
+            if pp is not None:
+                res = {}
+                for grp in pp:
+                    o = ops.linear(ops.linear(query, grp["l1"], act=ops.ACT_RELU), grp["l2"]).view(B, P, -1)
+                    for n, a, b in grp["cols"]:
+                        res[n] = o[:, :, a:b].transpose(1, 2).contiguous()
+                res = {n: res[n] for n in self.prediction_heads[i].heads}      # the reference's key order
+            else:
+                res = self.prediction_heads[i](query.view(B, P, E).transpose(1, 2).contiguous())       # [B, E, P]
             res["center"] = res["center"] + query_pos.permute(0, 2, 1)
             ret_dicts.append(res)
             query_pos = res["center"].detach().clone().permute(0, 2, 1)

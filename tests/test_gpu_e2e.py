@@ -72,6 +72,7 @@ def test_extract_pts_feat_matches_oracle_composition(dev, oracle_mod):
     from isfusion_amd.fusion_modules import SECONDFPN
     head_out = net.forward_pts([torch.from_numpy(p).to(dev) for p in pts], img_feats, metas, **kw)[0][0]
     neck = SECONDFPN().eval()
+    neck.dense_conv = "stock"
     neck.load_state_dict({k: v.cpu() for k, v in net.pts_neck.state_dict().items()})
     with torch.no_grad():
         x = neck([f0, f1])[0]
@@ -103,3 +104,33 @@ def test_extract_pts_feat_matches_oracle_composition(dev, oracle_mod):
                 assert err < 5e-2, (k, b, i, j, err)
             matched += 1
     assert matched >= 20, f"only {matched} proposals selected by both sides"
+
+
+def test_engine_neck_head_handover_matches_the_module_path(dev):
+    """ISFusionPtsPath.forward_pts hands the neck's levels to the head as split-format token matrices of the un-permuted
+    BEV map (SECONDFPN.forward_split -> TransFusionHeadV2.forward_split: transposed-tap convolutions, permuted cell /
+    token indices) instead of the reference's permuted [B, 512, X, Y] tensor; the public module forwards
+    (pts_neck(...) -> pts_bbox_head(...)) keep that tensor.  Both must give the same head outputs."""
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    net = ISFusionPtsPath().eval()
+    net.pts_neck.load_state_dict(seeded_state_dict(net.pts_neck, 250))
+    net.pts_bbox_head.load_state_dict(seeded_state_dict(net.pts_bbox_head, 300))
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    # dense random maps: heat-map scores are all distinct by far more than the two paths' rounding difference (they add
+    # the nine taps in different orders), so both must select the same 200 cells
+    feats = [torch.randn((B, 128, 180, 180), generator=g).to(dev), torch.randn((B, 256, 90, 90), generator=g).to(dev)]
+    with torch.no_grad():
+        via_modules = net.pts_bbox_head(net.pts_neck(feats))[0][0]
+        top_modules = net.pts_bbox_head.last_top_index.clone()
+        via_engine = net.pts_bbox_head.forward_split(net.pts_neck.forward_split(feats))[0]
+        top_engine = net.pts_bbox_head.last_top_index.clone()
+    assert set(via_engine) == set(via_modules)
+    scale = max(1.0, via_modules["dense_heatmap"].abs().max().item())
+    assert (via_engine["dense_heatmap"] - via_modules["dense_heatmap"]).abs().max().item() < 1e-4 * scale
+    assert torch.equal(top_engine, top_modules)
+    for key in ("center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score"):
+        a, w = via_engine[key], via_modules[key]
+        assert a.shape == w.shape and (a - w).abs().max().item() < 1e-3 * max(1.0, w.abs().max().item()), key

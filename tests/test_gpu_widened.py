@@ -474,10 +474,11 @@ def test_neck_on_linear_kernel_matches_stock_modules(dev):
     neck = neck.to(dev)
     g = torch.Generator().manual_seed(1)
     x = [torch.randn((2, 128, 180, 180), generator=g).to(dev), torch.randn((2, 256, 90, 90), generator=g).to(dev)]
+    assert neck.dense_conv == "hip"    # the default
     with torch.no_grad():
-        want = neck(x)[0]
-        neck.dense_conv = "hip"
         got = neck(x)[0]
+        neck.dense_conv = "stock"
+        want = neck(x)[0]
     assert got.shape == want.shape == (2, 512, 180, 180)
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
 
