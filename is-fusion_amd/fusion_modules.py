@@ -377,13 +377,13 @@ class SECONDFPN(nn.Module):
         assert up.kernel_size == (1, 1) and up.stride == (1, 1) and up.bias is None
         return w[:, :, 0, 0] * scale[:, None], shift, 1
 
-    def forward_tokens(self, x, linear_relu):
+    def forward_tokens(self, x, linear_relu, cached=False):
         """the "hip" data path with the GEMM injected: linear_relu(x [B, Cin, H, W], weight, bias) -> relu(tokens W^T +
         b) as [B*H*W, N] rows ((b, y, x) order).  (tests/test_host.py runs it with a torch GEMM against the modules.)"""
         out = None
         c0 = 0
         for i in range(len(self.deblocks)):
-            w, b, s = self._folded(i)
+            w, b, s = self._folded_cached(i) if cached else self._folded(i)
             B, _, H, W = x[i].shape
             y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout], column = (dy*s + dx)*Cout + co
             cout = y.shape[1] // (s * s)
@@ -411,6 +411,13 @@ class SECONDFPN(nn.Module):
             return ops.linear(t.float(), cache[key], act=ops.ACT_RELU)
         return linear_relu
 
+    def _folded_cached(self, i):
+        """_folded(i) once per parameter version (the cache _linear_relu() has just validated)"""
+        cache = self.__dict__.setdefault("_isf_packed", {})
+        if ("folded", i) not in cache:
+            cache[("folded", i)] = self._folded(i)
+        return cache[("folded", i)]
+
     @torch.no_grad()
     def forward_split(self, x):
         """engine-level hand-over to the detection head (ISFusionPtsPath.forward_pts): the levels as split-format token
@@ -423,7 +430,7 @@ class SECONDFPN(nn.Module):
         linear_relu = self._linear_relu()
         maps = []
         for i in range(len(self.deblocks)):
-            w, b, s = self._folded(i)
+            w, b, s = self._folded_cached(i)
             B, _, H, W = x[i].shape
             y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout], column = (dy*s + dx)*Cout + co
             cout = y.shape[1] // (s * s)
@@ -437,7 +444,7 @@ class SECONDFPN(nn.Module):
         assert len(x) == len(self.in_channels)
         if self.dense_conv == "hip" and not self.training:
             with torch.no_grad():
-                return self.forward_tokens(x, self._linear_relu())
+                return self.forward_tokens(x, self._linear_relu(), cached=True)
         ups = [d(x[i]) for i, d in enumerate(self.deblocks)]
         out = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         return [out.permute(0, 1, 3, 2).contiguous()]

@@ -479,12 +479,17 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
                 qk=PackedLinear(w[:2 * E], b[:2 * E]), v=PackedLinear(w[2 * E:], b[2 * E:]),
                 out=PackedLinear(sa.out_proj.weight, sa.out_proj.bias),
                 value=PackedLinear(ca.value_proj.weight, ca.value_proj.bias),
+                # value_proj(scene + key_pos) = value_proj(scene) + key_pos W^T: the position term is input independent
+                # -> a per-cell table added in the GEMM epilogue (the sum was a transposing 33-MB pass per forward)
+                vtable=(c["key_pos"].double() @ ca.value_proj.weight.detach().double().t()).float().contiguous(),
                 off=PackedLinear(ca.sampling_offsets.weight, ca.sampling_offsets.bias),
                 aw=PackedLinear(ca.attention_weights.weight, ca.attention_weights.bias),
                 oproj=PackedLinear(ca.output_proj.weight, ca.output_proj.bias),
                 l1=PackedLinear(l.linear1.weight, l.linear1.bias), l2=PackedLinear(l.linear2.weight, l.linear2.bias)))
     H, W = scene.shape[2:]
-    src = (scene.flatten(2).transpose(1, 2) + c["key_pos"][None]).reshape(B * H * W, E).contiguous()
+    cell = c.setdefault(("cell_index", B, H * W), torch.arange(H * W, device=dev, dtype=torch.int32).repeat(B))
+    # read channels-first inside the GEMM (no token copy) when the kernel's 4-row groups stay inside a sample
+    scene = scene.float().contiguous() if (H * W) % 4 == 0 else to_tokens(scene.float())
     out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
     ref = (query_pos / bev_size).reshape(B * Q, 2).contiguous()
     qpe = _pos_embed(mod.query_pos_embed, ref.view(B, Q, 2)).reshape(B * Q, E)
@@ -498,7 +503,7 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
         att = attention(qk, qk[:, E:].contiguous(), v, B, Q, Q, E, nhead)
         out = linear(att, p["out"], residual=out, ln=l.norm2)
         q = out + qpe
-        value = linear(src, p["value"])
+        value = linear(scene, p["value"], table=p["vtable"], index=cell)
         off = linear(q, p["off"])
         aw = linear(q, p["aw"])
         t2 = msda(value, off, aw, ref, B, Q, nhead, E // nhead, npts, H, W)

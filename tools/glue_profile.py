@@ -34,7 +34,8 @@ def main():
     torch.cuda.synchronize()
     n = 5
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True,
+                 experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:   # verbose: python frames
         for _ in range(n):
             net.forward_pts(pts, img_feats, metas, **kw)
         torch.cuda.synchronize()
@@ -48,7 +49,7 @@ def main():
             continue
         site = "?"
         for fr in ev.stack or []:
-            if "is-fusion_amd" in fr or "isfusion_amd" in fr:
+            if "is-fusion_amd/" in fr:
                 site = fr.split("is-fusion_amd/")[-1]
                 break
         key = (site, ev.name)
