@@ -8,6 +8,8 @@
 //      all cells' smallest indices -> one bitmap over point indices + the popcount-prefix scan;
 //   3. one gather pass writes voxels / coors / num_points for ids < max_voxels.
 // All of it is HBM/L2-bound integer work: O(P * max_points) atomics worst case, O(P) typical.
+#include <hipcub/hipcub.hpp>
+
 #include "isf_common.h"
 
 namespace isf {
@@ -109,54 +111,42 @@ __global__ void hv_pack_bytes_kernel(const unsigned char* __restrict__ seen, siz
   bits[w] = v;
 }
 
-// points of a cell: count -> scan -> fill (CSR lists in arbitrary order) -> per cell, one wave selects the T smallest
-// point indices in increasing order (order-independent result => deterministic).  Replaces an atomicMin bubble
-// insertion that issued up to T dependent atomics per point on the cell's slots (720 us for 300 k points in pillars).
-__global__ void hv_count_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
-                                const unsigned long long* __restrict__ cbits, const uint32_t* __restrict__ cprefix,
-                                int* __restrict__ row_of_point, uint32_t* __restrict__ cnt) {
+// points of a cell = one segment of the point indices STABLY sorted by the cell's rank (hipcub radix sort over the
+// rank's bits): inside a segment the indices ascend, so a cell's T smallest point indices -- what the reference's
+// sequential scan keeps (voxelization_cpu.cpp:54-69) -- are the first T of its segment.  Deterministic, no atomics.
+// History: v1 atomicMin bubble insertion (720 us per 300 k points in pillars), v2 count -> scan -> fill -> select with
+// one atomic per point per pass (90 + 16 + 90 + 55 us: the pillar grid's hot cells serialise the atomics).
+__global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+                               const unsigned long long* __restrict__ cbits, const uint32_t* __restrict__ cprefix,
+                               uint32_t none, uint32_t* __restrict__ keys, int* __restrict__ idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   int cx, cy, cz;
-  int row = -1;
-  if (voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx, cy, cz)) {
-    row = occ_lookup(cbits, cprefix, ((unsigned long long)cz * g.gy + cy) * g.gx + cx);
-    atomicAdd(&cnt[row], 1u);
-  }
-  row_of_point[i] = row;
+  uint32_t key = none;   // points outside the grid sort behind every cell (none = row capacity > any rank)
+  if (voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx, cy, cz))
+    key = (uint32_t)occ_lookup(cbits, cprefix, ((unsigned long long)cz * g.gy + cy) * g.gx + cx);
+  keys[i] = key;
+  idx[i] = i;
 }
 
-__global__ void hv_fill_kernel(const int* __restrict__ row_of_point, int P, const uint32_t* __restrict__ off,
-                               uint32_t* __restrict__ cursor, int* __restrict__ list) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int row = row_of_point[i];
-  if (row < 0) return;
-  list[off[row] + atomicAdd(&cursor[row], 1u)] = i;
+// first sorted position of every cell
+__global__ void hv_segment_heads_kernel(const uint32_t* __restrict__ keys, int P, uint32_t none,
+                                        uint32_t* __restrict__ start) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  const uint32_t k = keys[j];
+  if (k != none && (j == 0 || keys[j - 1] != k)) start[k] = (uint32_t)j;
 }
 
-__global__ __launch_bounds__(256) void hv_select_kernel(const int* __restrict__ list, const uint32_t* __restrict__ off,
-                                                        const uint32_t* __restrict__ cnt,
-                                                        const int* __restrict__ nrows, int T,
-                                                        int* __restrict__ slots /*[rows][T], pre-filled kEmpty*/) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= *nrows) return;
-  const int n = (int)cnt[row];
-  const int* l = list + off[row];
-  int prev = -1;
-  const int rounds = n < T ? n : T;
-  for (int t = 0; t < rounds; ++t) {
-    int m = kEmpty;
-    for (int j = lane; j < n; j += 64) {
-      const int v = l[j];
-      if (v > prev && v < m) m = v;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, 64));
-    if (lane == 0) slots[(size_t)row * T + t] = m;
-    prev = m;
-  }
+__global__ void hv_segment_slots_kernel(const uint32_t* __restrict__ keys, const int* __restrict__ idx, int P,
+                                        const uint32_t* __restrict__ start, uint32_t none, int T,
+                                        int* __restrict__ slots /*[rows][T], pre-filled kEmpty*/) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  const uint32_t k = keys[j];
+  if (k == none) return;
+  const uint32_t t = (uint32_t)j - start[k];
+  if (t < (uint32_t)T) slots[(size_t)k * T + t] = idx[j];
 }
 
 __global__ void hv_mark_first_kernel(const int* __restrict__ slots, const int* __restrict__ nrows,
@@ -230,23 +220,29 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
   OccIndex pocc;  // bitmap over POINT indices: rank of a cell's first point = its voxel id
   ISF_TRY(occ_create(a, &pocc, 1, 1, 1, P, st));
   {
-    int* row_of_point = nullptr;
-    int* list = nullptr;
-    uint32_t *cnt = nullptr, *off = nullptr, *cursor = nullptr;
-    ISF_TRY(a.alloc_n(&row_of_point, (size_t)P));
-    ISF_TRY(a.alloc_n(&list, (size_t)P));
-    ISF_TRY(a.alloc_n(&cnt, (size_t)row_cap + 1));
-    ISF_TRY(a.alloc_n(&off, (size_t)row_cap + 1));
-    ISF_TRY(a.alloc_n(&cursor, (size_t)row_cap + 1));
-    ISF_HIP_TRY(hipMemsetAsync(cnt, 0, ((size_t)row_cap + 1) * sizeof(uint32_t), st));
-    ISF_HIP_TRY(hipMemsetAsync(cursor, 0, ((size_t)row_cap + 1) * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(hv_count_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, cocc.bits,
-                       cocc.prefix, row_of_point, cnt);
+    uint32_t *keys = nullptr, *keys_sorted = nullptr, *start = nullptr;
+    int *idx = nullptr, *idx_sorted = nullptr;
+    ISF_TRY(a.alloc_n(&keys, (size_t)P));
+    ISF_TRY(a.alloc_n(&keys_sorted, (size_t)P));
+    ISF_TRY(a.alloc_n(&idx, (size_t)P));
+    ISF_TRY(a.alloc_n(&idx_sorted, (size_t)P));
+    ISF_TRY(a.alloc_n(&start, (size_t)row_cap + 1));
+    const uint32_t none = (uint32_t)row_cap;           // ranks are < row_cap
+    int key_bits = 1;
+    while ((1ull << key_bits) <= (unsigned long long)none) ++key_bits;
+    hipLaunchKernelGGL(hv_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, cocc.bits,
+                       cocc.prefix, none, keys, idx);
     ISF_LAUNCH_CHECK();
-    ISF_TRY(scan_u32_exclusive(a, cnt, off, (size_t)row_cap, st));
-    hipLaunchKernelGGL(hv_fill_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, row_of_point, P, off, cursor, list);
-    hipLaunchKernelGGL(hv_select_kernel, dim3(ceil_div(row_cap, 4)), dim3(256), 0, st, list, off, cnt, cocc.total,
-                       max_points, slots);
+    size_t temp_bytes = 0;
+    ISF_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, idx, idx_sorted, P, 0,
+                                                   key_bits, st));
+    void* temp = nullptr;
+    ISF_TRY(a.alloc(&temp, temp_bytes));
+    ISF_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, idx, idx_sorted, P, 0, key_bits,
+                                                   st));
+    hipLaunchKernelGGL(hv_segment_heads_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, keys_sorted, P, none, start);
+    hipLaunchKernelGGL(hv_segment_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, keys_sorted, idx_sorted, P,
+                       start, none, max_points, slots);
   }
   hipLaunchKernelGGL(hv_mark_first_kernel, dim3(ceil_div(row_cap, 256)), dim3(256), 0, st, slots,
                      cocc.total, max_points, pocc.bits);
