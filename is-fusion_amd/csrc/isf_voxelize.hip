@@ -8,7 +8,9 @@
 //      all cells' smallest indices -> one bitmap over point indices + the popcount-prefix scan;
 //   3. one gather pass writes voxels / coors / num_points for ids < max_voxels.
 // All of it is HBM/L2-bound integer work: O(P * max_points) atomics worst case, O(P) typical.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "isf_common.h"
 
@@ -114,6 +116,7 @@ __global__ void hv_pack_bytes_kernel(const unsigned char* __restrict__ seen, siz
 // points of a cell = one segment of the point indices STABLY sorted by the cell's rank (hipcub radix sort over the
 // rank's bits): inside a segment the indices ascend, so a cell's T smallest point indices -- what the reference's
 // sequential scan keeps (voxelization_cpu.cpp:54-69) -- are the first T of its segment.  Deterministic, no atomics.
+// (rocprim radix sort, the engine under hipcub::DeviceRadixSort.)
 // History: v1 atomicMin bubble insertion (720 us per 300 k points in pillars), v2 count -> scan -> fill -> select with
 // one atomic per point per pass (90 + 16 + 90 + 55 us: the pillar grid's hot cells serialise the atomics).
 __global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
@@ -233,13 +236,16 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
     hipLaunchKernelGGL(hv_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, cocc.bits,
                        cocc.prefix, none, keys, idx);
     ISF_LAUNCH_CHECK();
+    // Onesweep radix sort forced (rocprim's default picks a merge sort below 1 M items: 21 launches, 115 us here)
+    using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                  rocprim::default_config, 4096>;
     size_t temp_bytes = 0;
-    ISF_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, idx, idx_sorted, P, 0,
-                                                   key_bits, st));
+    ISF_HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, temp_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)P,
+                                                      0u, (unsigned)key_bits, st));
     void* temp = nullptr;
     ISF_TRY(a.alloc(&temp, temp_bytes));
-    ISF_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, idx, idx_sorted, P, 0, key_bits,
-                                                   st));
+    ISF_HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)P, 0u,
+                                                      (unsigned)key_bits, st));
     hipLaunchKernelGGL(hv_segment_heads_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, keys_sorted, P, none, start);
     hipLaunchKernelGGL(hv_segment_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, keys_sorted, idx_sorted, P,
                        start, none, max_points, slots);
