@@ -415,6 +415,41 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
 
 
+def test_concurrent_streams_have_independent_workspaces(dev):
+    """the library's scratch memory (bump arena, side stream, event pool, byte maps) is one object per (device, stream):
+    two host threads driving the LiDAR branch on two streams at the same time must each get the bits a lone call gives
+    (round 1 had one arena per device: concurrent calls would have overwritten each other's workspace)"""
+    import threading
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
+    inputs = {"a": [T(synthetic.lidar_sweeps(900 + i, 50000), dev) for i in range(2)],
+              "b": [T(synthetic.lidar_sweeps(950 + i, 80000), dev) for i in range(1)]}
+    want = {k: lb(v).clone() for k, v in inputs.items()}
+    torch.cuda.synchronize()
+    got, errors = {}, []
+
+    def run(name):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for _ in range(4):                      # several calls each, so the two threads really overlap
+                    out = lb(inputs[name])
+                stream.synchronize()
+            got[name] = out
+        except Exception as e:   # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in inputs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in inputs:
+        assert torch.equal(got[k], want[k]), k
+
+
 def test_conv_autograd_switch(dev):
     """a sparse conv on tensors that require grad runs the autograd Function (forward + dX / dW kernels, validated in
     tests/test_gpu_widened.py); with spconv.TRAINING_KERNELS = False the same call is a loud NotImplementedError"""
