@@ -11,6 +11,11 @@ import torch
 
 from . import _lib
 
+# the HIP kernels compute in fp32: under torch.autocast (the reference trains with mixed precision) inputs are cast
+# to fp32 on the way in and autocast is off inside forward / backward
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
@@ -382,6 +387,7 @@ class MSDAFunction(torch.autograd.Function):
     -> gradients for value, offsets and logits (SURVEY.md 8f #2; not yet validated on hardware)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, value, offsets, logits, ref, B, Q, nhead, hd, npts, H, W):
         _lib.require_cuda(value, offsets, logits, ref)
         args = [t.detach().float().contiguous() for t in (value, offsets, logits, ref)]
@@ -390,6 +396,7 @@ class MSDAFunction(torch.autograd.Function):
         return msda(*args, B, Q, nhead, hd, npts, H, W)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         value, offsets, logits, ref = ctx.saved_tensors
         B, Q, nhead, hd, npts, H, W = ctx.dims
@@ -407,6 +414,7 @@ class AttentionFunction(torch.autograd.Function):
     q [B*Lq, E], k / v [B*Lk, E] row-major."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q, k, v, B, Lq, Lk, E, nhead):
         _lib.require_cuda(q, k, v)
         q, k, v = [t.detach().float().contiguous() for t in (q, k, v)]
@@ -416,6 +424,7 @@ class AttentionFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         q, k, v, out = ctx.saved_tensors
         B, Lq, Lk, E, nhead = ctx.dims
@@ -434,6 +443,7 @@ class WindowAttentionFunction(torch.autograd.Function):
     qkv [B*S*S, 3d] -> [B*S*S, d]."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, qkv, B, S, d, nhead, win, shift):
         _lib.require_cuda(qkv)
         qkv = qkv.detach().float().contiguous()
@@ -442,6 +452,7 @@ class WindowAttentionFunction(torch.autograd.Function):
         return window_attention(qkv, B, S, d, nhead, win, shift)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         (qkv,) = ctx.saved_tensors
         B, S, d, nhead, win, shift = ctx.dims

@@ -23,11 +23,17 @@ import torch.nn.functional as F
 from . import _lib
 from . import fusion_ops as ops
 
+# the HIP kernels compute in fp32: under torch.autocast (the reference trains with mixed precision) inputs are cast
+# to fp32 on the way in and autocast is off inside forward / backward
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 class LinearFunction(torch.autograd.Function):
     """y = x W^T (+ b).  x [M, K], weight [N, K] (nn.Linear layout), bias [N] or None."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, bias):
         _lib.require_cuda(x, weight)
         xd, wd = x.detach().float().contiguous(), weight.detach().float().contiguous()
@@ -38,6 +44,7 @@ class LinearFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         xd, wd = ctx.saved_tensors
         g = gy.contiguous().float()
@@ -67,12 +74,14 @@ class ChannelAttentionFunction(torch.autograd.Function):
     runs four batched GEMMs."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, qs, qi):
         qs, qi = qs.detach().float().contiguous(), qi.detach().float().contiguous()
         ctx.save_for_backward(qs, qi)
         return ops.channel_attention(qs, qi)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         qs, qi = ctx.saved_tensors
         B, C, H, W = qs.shape
@@ -89,6 +98,7 @@ class P2GFunction(torch.autograd.Function):
     """img_fv_to_bev (fusion_encoder.py:965-1013) with a gradient towards the camera feature map."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, img_feat, pillars, pillar_coors, cam, input_shape, bs, bev, num_cam):
         _lib.require_cuda(img_feat)
         dev = img_feat.device
@@ -106,6 +116,7 @@ class P2GFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         pil, coors, cam = ctx.saved_tensors
         bs, num_cam, H, W, C, ih, iw, bev = ctx.dims

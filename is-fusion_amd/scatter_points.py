@@ -11,6 +11,11 @@ from torch.autograd import Function
 
 from . import _lib
 
+# the HIP kernels compute in fp32: under torch.autocast (the reference trains with mixed precision) inputs are cast
+# to fp32 on the way in and autocast is off inside forward / backward
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 def dynamic_point_to_voxel_forward(feats, coors, reduce_type):
     """-> [reduced_feats, out_coors, coors_map int32, reduce_count int32] (voxelization.h:108-121)."""
@@ -55,6 +60,7 @@ def dynamic_point_to_voxel_backward(grad_feats, grad_reduced_feats, feats, reduc
 class _dynamic_scatter(Function):
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, feats, coors, reduce_type="max"):
         voxel_feats, voxel_coors, point2voxel_map, voxel_points_count = dynamic_point_to_voxel_forward(
             feats, coors, reduce_type)
@@ -64,6 +70,7 @@ class _dynamic_scatter(Function):
         return voxel_feats, voxel_coors
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_voxel_feats, grad_voxel_coors=None):
         feats, voxel_feats, point2voxel_map, voxel_points_count = ctx.saved_tensors
         grad_feats = torch.zeros_like(feats)

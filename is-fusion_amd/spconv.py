@@ -20,6 +20,11 @@ from torch import nn
 
 from . import _lib
 
+# the HIP kernels compute in fp32: under torch.autocast (the reference trains with mixed precision) inputs are cast
+# to fp32 on the way in and autocast is off inside forward / backward
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 class SparseConvTensor:
     """structure.py:21-63 (same attributes / methods)."""
@@ -62,6 +67,7 @@ class _SparseToDense(torch.autograd.Function):
     active sites (what autograd derives for the reference's scatter_nd, structure.py:8-25)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, features, indices, spatial_shape, batch_size):
         D, H, W = spatial_shape
         C = features.size(1)
@@ -74,6 +80,7 @@ class _SparseToDense(torch.autograd.Function):
         return out.view(batch_size, C, D, H, W)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad):
         idx = ctx.saved_tensors[0].long()
         return grad[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].contiguous(), None, None, None
@@ -215,6 +222,7 @@ class SparseConvFunction(torch.autograd.Function):
     module parameter [kD, kH, kW, Cin, Cout]."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, features, weight, rb):
         _lib.require_cuda(features, weight)
         K = int(np.prod(weight.shape[:-2]))
@@ -229,6 +237,7 @@ class SparseConvFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_out):
         features, w = ctx.saved_tensors
         rb = ctx.rb

@@ -167,4 +167,7 @@ class DynamicVFE(nn.Module):
         coors = coors.contiguous().int()
         if self._fusable() and not features.requires_grad:
             return self._forward_fused(features, coors)
-        return self._forward_composed(features, coors)
+        # the reference forces this module to fp32 under mixed precision (@force_fp32, voxel_encoder.py:452): its
+        # BatchNorm (naiveSyncBN) asserts fp32 inputs.  Same here under torch.autocast.
+        with torch.autocast("cuda", enabled=False):
+            return self._forward_composed(features, coors)

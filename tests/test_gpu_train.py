@@ -146,12 +146,13 @@ def test_fusion_encoder_parameter_gradients_match_oracle_autograd(dev):
     assert rel_err(img_g.grad, img.grad) < 1e-2
 
 
-@pytest.mark.parametrize("cam_dtype", [torch.float32, torch.bfloat16])
-def test_whole_path_training_step(dev, cam_dtype):
+@pytest.mark.parametrize("cam_dtype,autocast", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True)])
+def test_whole_path_training_step(dev, cam_dtype, autocast):
     """ISFusionPtsPath.forward_train_pts: LiDAR branch (DynamicVFE modules + sparse-conv autograd Function + BatchNorm
     batch statistics), pillar voxelization, fusion encoder, backbone stages, neck -- loss.backward() reaches every
     trainable tensor, an SGD step changes the weights, and a second forward gives a different (finite) loss.
-    bfloat16 camera features (the reference's autocast dtype) are accepted; gradients come back in bf16."""
+    bfloat16 camera features (the reference's autocast dtype) are accepted; gradients come back in bf16.  autocast=True
+    runs the step under torch.autocast(bfloat16)."""
     from detector_common import build_path, detector_inputs
     net = build_path().to(dev).train()
     pts, inp, kw, metas = detector_inputs()
@@ -160,8 +161,11 @@ def test_whole_path_training_step(dev, cam_dtype):
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=1e-3)
 
     def loss_of():
-        out, hm = net.forward_train_pts(pts, img, metas, **kw)
-        return (out[0] ** 2).mean() + hm.float().sigmoid().mean()
+        # autocast: the reference's mixed-precision training (BASELINE configs[3]) -- stock convolutions / linears run
+        # in bfloat16, the HIP autograd Functions cast their inputs to fp32 (torch.amp.custom_fwd)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out, hm = net.forward_train_pts(pts, img, metas, **kw)
+            return (out[0].float() ** 2).mean() + hm.float().sigmoid().mean()
 
     loss = loss_of()
     assert torch.isfinite(loss)

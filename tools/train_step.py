@@ -2,7 +2,7 @@
 all-reduce over xGMI on the GRADIENTS only -- the forward has no collective):
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29540 \
-        tools/train_step.py [--batch 2] [--points 60000] [--steps 3] [--bf16]
+        tools/train_step.py [--batch 2] [--points 60000] [--steps 3] [--bf16] [--autocast]
 
 One process per GPU; every rank draws its own synthetic frames.  The module is wrapped in DistributedDataParallel
 (bucketed gradient all-reduce overlapped with the backward); BatchNorm layers use the batch statistics of the local
@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--points", type=int, default=60000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--bf16", action="store_true", help="camera features in bfloat16 (the reference's autocast dtype)")
+    ap.add_argument("--autocast", action="store_true",
+                    help="run forward + loss under torch.autocast(bfloat16): stock convs / linears in bf16, the HIP "
+                         "autograd Functions cast their inputs to fp32")
     a = ap.parse_args()
     from isfusion_amd import synthetic
     from isfusion_amd.detector import ISFusionPtsPath
@@ -69,8 +72,9 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-        out, hm = ddp(pts, img, metas, kw)
-        loss = (out[0] ** 2).mean() + hm.float().sigmoid().mean()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.autocast):
+            out, hm = ddp(pts, img, metas, kw)
+            loss = (out[0].float() ** 2).mean() + hm.float().sigmoid().mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()                                              # bucketed RCCL all-reduce inside
         opt.step()
@@ -79,7 +83,7 @@ def main():
     dist.barrier()
     dt = (time.perf_counter() - t0) / max(a.steps, 1)
     if rank == 0:
-        print(json.dumps({"world_size": world, "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16,
+        print(json.dumps({"world_size": world, "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16, "autocast_bf16": a.autocast,
                           "ms_per_train_step": round(dt * 1e3, 2), "losses": [round(v, 5) for v in losses]}))
     dist.destroy_process_group()
 
