@@ -108,6 +108,8 @@ class ISFusionPtsPath(nn.Module):
         head's losses / target assignment are the reference's training control plane (out of scope): apply them to the
         returned neck output."""
         assert self.training, "call .train() first (eval mode runs the inference engine)"
+        from .fusion_train import pack_stock_convs
+        pack_stock_convs(self)
         self._lidar.train(True)
         x = self._lidar(pts)
         feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)

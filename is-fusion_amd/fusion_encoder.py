@@ -123,6 +123,9 @@ class ISFusionEncoder(nn.Module):
         Functions (fusion_train.py), the 3x3 convolutions + BatchNorm (batch statistics) on stock PyTorch-ROCm as the
         north_star prescribes, instance mining without gradient (indices), like the reference."""
         from . import fusion_train as tr
+        tr.pack_stock_convs(self)
+        if kwargs.get("pts_backbone", None) is not None:
+            tr.pack_stock_convs(kwargs["pts_backbone"])
         pm = kwargs["pts_metas"]
         S = self.bev_size
         img_bev = tr.p2g_sample(pm["pillars"], pm["pillar_coors"], img_mlvl_feats[1], kwargs["lidar2img"],

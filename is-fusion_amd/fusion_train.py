@@ -29,6 +29,47 @@ _amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 
 
+def _weight_grad(g, x):
+    """dW = g^T x for g [M, N], x [M, K] with M in the tens of thousands and N, K <= 1024: the library GEMM picks ONE
+    256 x 256 macro tile for the whole reduction (7 ms for 64800 x 128 x 128: tools/train_step.py profile), so the rows
+    are cut into chunks reduced side by side (batched GEMM) and summed."""
+    M = g.shape[0]
+    chunk = 2048
+    S = M // chunk
+    if S < 4:
+        return g.t().matmul(x)
+    main = S * chunk
+    gw = torch.bmm(g[:main].view(S, chunk, -1).transpose(1, 2), x[:main].view(S, chunk, -1)).sum(0)
+    if main < M:
+        gw = gw + g[main:].t().matmul(x[main:])
+    return gw
+
+
+class _PackedGrad(torch.autograd.Function):
+    """identity whose backward hands on a CONTIGUOUS gradient"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.contiguous()
+
+
+def pack_stock_convs(module):
+    """Stock Conv2d / ConvTranspose2d layers of the training path see packed tensors only: their inputs are made
+    contiguous and so is the gradient arriving at their outputs.  The token-major HIP ops around them hand over
+    permuted VIEWS ([B, H, W, C] storage seen as [B, C, H, W]), for which MIOpen falls back to its
+    `naive_conv_ab_nonpacked_*` kernels -- 20-40 ms per call, 80 % of a training step before this hook.  Idempotent."""
+    for m in module.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and not getattr(m, "_isf_packed_io", False):
+            m.register_forward_pre_hook(lambda mod, args: tuple(a.contiguous() if torch.is_tensor(a) else a for a in args))
+            m.register_forward_hook(lambda mod, args, out: _PackedGrad.apply(out))
+            m._isf_packed_io = True
+    return module
+
+
 class LinearFunction(torch.autograd.Function):
     """y = x W^T (+ b).  x [M, K], weight [N, K] (nn.Linear layout), bias [N] or None."""
 
@@ -53,7 +94,7 @@ class LinearFunction(torch.autograd.Function):
             gs, s = _lib.pow2_rescale(g)            # gradients are tiny: keep the GEMM's f16 halves in range (exact)
             gx = (ops.linear(gs, ops.PackedLinear(wd.t().contiguous())) / s).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
         if ctx.needs_input_grad[1]:
-            gw = g.t().matmul(xd)                                                         # dW = dY^T X (library GEMM)
+            gw = _weight_grad(g, xd)                                                      # dW = dY^T X (library GEMM)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         return gx, gw, gb

@@ -216,6 +216,17 @@ def transposed_nbr(rb):
     return rb.nbr_t, rb.stride_t
 
 
+def _f16x3_shape(c_in, c_out):
+    return c_in in (32, 64, 128, 256) and c_out in (32, 64, 128, 256)
+
+
+class _TransposedRulebook:
+    """the view of a Rulebook the dX pass needs: rows of the conv's OUTPUT feed rows of its INPUT"""
+
+    def __init__(self, nbr_t, stride_t, num_out, num_in):
+        self.nbr, self.stride, self.num_in, self.num_out = nbr_t, stride_t, num_out, num_in
+
+
 class SparseConvFunction(torch.autograd.Function):
     """SparseConvFunction / SubMConvFunction of the reference (ops/spconv/functional.py:22-97): forward =
     indice_conv, backward = indice_conv_backward -> (input_bp, filters_bp), on the HIP kernels.  `weight` is the
@@ -228,10 +239,14 @@ class SparseConvFunction(torch.autograd.Function):
         K = int(np.prod(weight.shape[:-2]))
         c_in, c_out = weight.shape[-2], weight.shape[-1]
         w = weight.detach().float().contiguous()
-        out = torch.empty((rb.num_out, c_out), dtype=torch.float32, device=features.device)
-        _lib.check(_lib.load().isf_sparse_conv_forward(
-            _lib.ptr(features), rb.num_in, c_in, _lib.ptr(w), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-            None, None, None, 0, _lib.ptr(out), _lib.stream()), "isf_sparse_conv_forward")
+        features = features.detach().float().contiguous()
+        if _f16x3_shape(c_in, c_out):      # the inference kernel (f16x3 split MFMA): 3-4x the fp32-MFMA kernel's rate
+            out = sparse_conv_forward_f16x3(features, pack_filters_f16x3(w), K, c_in, c_out, rb)
+        else:
+            out = torch.empty((rb.num_out, c_out), dtype=torch.float32, device=features.device)
+            _lib.check(_lib.load().isf_sparse_conv_forward(
+                _lib.ptr(features), rb.num_in, c_in, _lib.ptr(w), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+                None, None, None, 0, _lib.ptr(out), _lib.stream()), "isf_sparse_conv_forward")
         ctx.save_for_backward(features, w)
         ctx.rb, ctx.wshape = rb, tuple(weight.shape)
         return out
@@ -247,12 +262,19 @@ class SparseConvFunction(torch.autograd.Function):
         grad_in = grad_w = None
         if ctx.needs_input_grad[0]:
             nbr_t, st = transposed_nbr(rb)
-            grad_in = torch.empty((rb.num_in, c_in), dtype=torch.float32, device=g.device)
-            # (dX runs on the fp32-MFMA kernel over the transposed rulebook: no f16 halves, so gradients of any
-            #  magnitude are safe -- unlike the f16x3 dX GEMM of the fused linear, fusion_train.LinearFunction)
-            _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(g), rb.num_out, c_out, _lib.ptr(w), K, c_in,
-                                                          _lib.ptr(nbr_t), st, rb.num_in, _lib.ptr(grad_in),
-                                                          _lib.stream()), "isf_sparse_conv_backward_input")
+            if _f16x3_shape(c_out, c_in):
+                # dX[i] = sum_k g[nbr_t[k][i]] W_k^T: the forward kernel over the transposed rulebook with the
+                # per-tap transposed filters.  Its operands travel as f16 hi + lo halves, so the gradient is brought
+                # into f16's normal range by a power of two first (exact; see _lib.pow2_rescale) and scaled back
+                gs, sc = _lib.pow2_rescale(g)
+                wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*ctx.wshape[:-2], c_out, c_in)
+                rbt = _TransposedRulebook(nbr_t, st, rb.num_out, rb.num_in)
+                grad_in = sparse_conv_forward_f16x3(gs, pack_filters_f16x3(wt), K, c_out, c_in, rbt) / sc
+            else:   # fp32-MFMA kernel: no f16 halves, gradients of any magnitude are safe
+                grad_in = torch.empty((rb.num_in, c_in), dtype=torch.float32, device=g.device)
+                _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(g), rb.num_out, c_out, _lib.ptr(w), K, c_in,
+                                                              _lib.ptr(nbr_t), st, rb.num_in, _lib.ptr(grad_in),
+                                                              _lib.stream()), "isf_sparse_conv_backward_input")
         if ctx.needs_input_grad[1]:
             grad_w = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
             _lib.check(lib.isf_sparse_conv_backward_filter(_lib.ptr(features), rb.num_in, c_in, _lib.ptr(g),

@@ -238,17 +238,14 @@ def test_sparse_conv_backward_vs_oracle_golden_geometries(dev, golden, oracle_mo
     with torch.no_grad():
         conv.weight.copy_(_T(w, dev))
     x = _T(feats, dev).requires_grad_()
-    spconv.TRAINING_KERNELS = True
-    try:
-        out = conv(m.SparseConvTensor(x, _T(idx, dev), shape, B))
-        # rows of the strided output are sorted (b,z,y,x); the oracle numbers them first-come
-        oi = out.indices.cpu().numpy()
-        key = {tuple(r): i for i, r in enumerate(out_idx.tolist())}
-        perm = np.array([key[tuple(r)] for r in oi.tolist()])
-        gout = np.random.default_rng(5).normal(size=(out_idx.shape[0], w.shape[-1])).astype(np.float32)
-        out.features.backward(_T(gout[perm], dev))
-    finally:
-        spconv.TRAINING_KERNELS = False
+    assert spconv.TRAINING_KERNELS          # the default since the backward kernels were validated on hardware
+    out = conv(m.SparseConvTensor(x, _T(idx, dev), shape, B))
+    # rows of the strided output are sorted (b,z,y,x); the oracle numbers them first-come
+    oi = out.indices.cpu().numpy()
+    key = {tuple(r): i for i, r in enumerate(out_idx.tolist())}
+    perm = np.array([key[tuple(r)] for r in oi.tolist()])
+    gout = np.random.default_rng(5).normal(size=(out_idx.shape[0], w.shape[-1])).astype(np.float32)
+    out.features.backward(_T(gout[perm], dev))
     y = oracle_mod.indice_conv(feats, w, pairs, num, out_idx.shape[0])
     assert np.abs(out.features.detach().cpu().numpy() - (y[perm] + conv.bias.detach().cpu().numpy())).max() < 2e-4
     dx, dw = oracle_mod.indice_conv_backward(feats, w, gout, pairs, num)
@@ -301,17 +298,14 @@ def test_sparse_encoder_training_step_matches_torch_dense_autograd(dev):
              m.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="subm1").to(dev)]
     bns = [torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01).to(dev) for _ in convs]
     x = _T(feats, dev).requires_grad_()
-    spconv.TRAINING_KERNELS = True
-    try:
-        t = m.SparseConvTensor(x, _T(idx, dev), shape, B)
-        for conv, bn in zip(convs, bns):
-            t = conv(t)
-            t.features = torch.relu(bn(t.features))
-        dense = t.dense()
-        loss = (dense ** 2).mean()
-        loss.backward()
-    finally:
-        spconv.TRAINING_KERNELS = False
+    assert spconv.TRAINING_KERNELS
+    t = m.SparseConvTensor(x, _T(idx, dev), shape, B)
+    for conv, bn in zip(convs, bns):
+        t = conv(t)
+        t.features = torch.relu(bn(t.features))
+    dense = t.dense()
+    loss = (dense ** 2).mean()
+    loss.backward()
     # dense torch reference on the same parameters
     ii = _T(idx, dev).long()
     xr = _T(feats, dev).requires_grad_()
