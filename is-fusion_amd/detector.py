@@ -84,9 +84,10 @@ class ISFusionPtsPath(nn.Module):
             coors.append(torch.nn.functional.pad(c, (1, 0), mode="constant", value=i))
         return torch.cat(voxels, 0), torch.cat(num_points, 0), torch.cat(coors, 0)
 
-    def isfusion(self, pts, pts_feats, img_feats, img_metas, batch_size, **kwargs):
-        """isfusion.py:83-101"""
-        pillars, pillars_num_points, pillar_coors = self.voxelize(pts, voxel_type="pillar")
+    def isfusion(self, pts, pts_feats, img_feats, img_metas, batch_size, pillars=None, **kwargs):
+        """isfusion.py:83-101.  pillars: a (pillars, num_points, coors) triple voxelized ahead of time
+        (extract_pts_feat does it on a side stream while the LiDAR branch runs)."""
+        pillars, pillars_num_points, pillar_coors = pillars or self.voxelize(pts, voxel_type="pillar")
         pts_metas = dict(pillars=pillars, pillars_num_points=pillars_num_points, pillar_coors=pillar_coors, pts=pts,
                          pillar_size=self.pillar_size)
         kwargs.update(dict(pts_metas=pts_metas, img_metas=img_metas, pts_backbone=self.pts_backbone))
@@ -98,8 +99,28 @@ class ISFusionPtsPath(nn.Module):
         voxelization, ISFusionEncoder with the SECONDV2 stages."""
         assert not self.training, "inference path (eval mode)"
         self._lidar.train(False)
+        if "p2g_cam" not in kwargs and all(k in kwargs for k in ("lidar2img", "img_aug_matrix", "lidar_aug_matrix")):
+            # host-side fold of the camera matrices BEFORE anything is queued: it overlaps nothing otherwise
+            from . import fusion_ops as ops
+            kwargs["p2g_cam"] = ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
+                                                      kwargs["lidar_aug_matrix"]).to(pts[0].device, non_blocking=True)
+        # The pillar voxelization has a host round trip per sample (the voxel count sizes its outputs).  Issued after the
+        # LiDAR branch on the same stream, each of them waits for the whole branch and then leaves the GPU idle until
+        # the host has launched the next piece (tools/timeline_gaps.py: ~0.25 ms per forward).  On a side stream --
+        # the library's workspaces are per (device, stream) -- they wait for the pillar kernels only, while the
+        # branch's convolutions keep the GPU busy.
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_side_streams", {}).setdefault(pts[0].device, None)
+        if side is None:
+            side = self._side_streams[pts[0].device] = torch.cuda.Stream(device=pts[0].device)
+        side.wait_stream(main)                       # the points are ready on the main stream
         x = self._lidar(pts)
-        feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)
+        with torch.cuda.stream(side):
+            pil = self.voxelize(pts, voxel_type="pillar")
+        main.wait_stream(side)
+        for t in pil:
+            t.record_stream(main)                    # allocated on the side stream, consumed on the main one
+        feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), pillars=pil, **kwargs)
         return (feats, ins_heatmap) if return_heatmap else feats
 
     def forward_train_pts(self, pts, img_feats, img_metas, **kwargs):

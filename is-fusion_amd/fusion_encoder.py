@@ -68,7 +68,8 @@ class ISFusionEncoder(nn.Module):
         pm = kwargs["pts_metas"]
         return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs["lidar2img"],
                               kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
-                              kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views)
+                              kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views,
+                              cam=kwargs.get("p2g_cam"))
 
     def fuse(self, img_bev, lidar_feats):
         """conv_fusion(cat([img_bev, lidar_feats])) (fusion_encoder.py:1163-1165) -> [B, E, S, S]"""

@@ -18,6 +18,7 @@ python tools/rocpd_summary.py /tmp/prof/trace/bench_results.db --pmc fetch=/tmp/
 python tools/rocpd_summary.py /tmp/prof/trace/bench_results.db --pmc sq=/tmp/prof/sq/bench_results.db 2>/dev/null | grep -A400 "PMC pass" | grep "spconv\|PMC\|kernel " | cut -c1-260 > gpurun_out/pmc_sq.txt
 python tools/rocpd_summary.py /tmp/prof/trace3/bench_results.db | cut -c1-200 > gpurun_out/cfg3_kernels.txt
 python tools/timeline_gaps.py /tmp/prof/trace/bench_results.db vfe_prep_kernel 4 4 | cut -c1-200 > gpurun_out/timeline_gaps.txt
+python tools/timeline_gaps.py /tmp/prof/trace3/bench_results.db vfe_prep_kernel 4 4 | cut -c1-200 > gpurun_out/timeline_gaps_cfg3.txt
 python bench.py --config 3 2>/dev/null | tail -1 > gpurun_out/bench_line_cfg3.json
 head -40 gpurun_out/round_profile.txt
 cut -c1-300 gpurun_out/bench_line.json
