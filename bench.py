@@ -199,7 +199,7 @@ def main_fusion(args):
     for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250), (net.pts_bbox_head, 300)):
         mod.load_state_dict(seeded_state_dict(mod, seed))
     net = net.to(dev)
-    net._lidar.freeze()
+    net.freeze()              # inference deployment: weights are static, the caches skip their change scans
     B = args.batch
     sets = []
     for fs in range(max(1, args.frame_sets)):

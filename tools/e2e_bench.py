@@ -30,7 +30,7 @@ def main():
     net.pts_neck.load_state_dict(seeded_state_dict(net.pts_neck, 250))
     net.pts_bbox_head.load_state_dict(seeded_state_dict(net.pts_bbox_head, 300))
     net = net.to(dev)
-    net._lidar.freeze()
+    net.freeze()              # inference deployment: weights are static, the caches skip their change scans
     pts = [torch.from_numpy(p).to(dev) for p in synthetic.batch(2, a.batch, a.points)]
     inp = synthetic.fusion_inputs(5, a.batch)
     img_feats = tuple(torch.from_numpy(x).to(dev) for x in inp["img_feats"])

@@ -21,7 +21,7 @@ def main():
     for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250), (net.pts_bbox_head, 300)):
         mod.load_state_dict(seeded_state_dict(mod, seed))
     net = net.to(dev)
-    net._lidar.freeze()
+    net.freeze()              # inference deployment: weights are static, the caches skip their change scans
     B = 2
     pts = [torch.from_numpy(p).to(dev) for p in bench.make_frames(0, 1, B, 300000, 10)]
     inp = synthetic.fusion_inputs(5, B)
