@@ -7,8 +7,8 @@
 //                     instance self-attention (fusion_encoder.py:664) and the 32400 x 200 instance-to-scene
 //                     cross attention (fusion_encoder.py:489-494).
 //  (the per-channel map attention of A14 lives in isf_channel_attn.hip)
-// All fp32 VALU: these are small (<= 3 GFLOP / sample) next to the projections, which run on MFMA
-// (isf_linear.hip).
+// head_dim 16 (every use on the IS-Fusion path) runs attention_mfma16_kernel on the matrix cores; the fp32 VALU kernels
+// serve head_dim 32 and the window attention of the d = 256 level.
 #include "isf_common.h"
 
 namespace isf {
@@ -201,6 +201,120 @@ __global__ __launch_bounds__(256) void split_key_attention_kernel(const float* _
   for (int c = 0; c < HD; ++c) pp[2 + c] = o[c];
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// head_dim 16 on the matrix cores (both shapes above: few keys / many queries, and key splits of many keys).  A wave
+// owns a 16-query tile and walks the workgroup's keys (LDS resident) 16 at a time, flash style:
+//     S^T = K Q^T   (v_mfma_f32_16x16x16_f16, f16x3 split: lane (q = lane & 15, g = lane >> 4) gets the scores of
+//                    query q against keys 4g .. 4g+3 of the tile)
+//     online softmax: tile maximum / sum of a query = its 4 registers + two cross-lane steps (lanes q, q+16, q+32, q+48)
+//     O^T += V^T P^T (the score registers ARE the B operand; V^T comes transposed out of LDS; the accumulator of lane
+//                    (q, g) holds O[q][4g .. 4g+3]: one 16-byte store per lane)
+// The VALU kernels spent 157 us on the 32400 x 200 instance-to-scene attention and 223 us on the head's 200 x 32400
+// cross attention; their head_dim-32 instantiations remain for other widths.
+typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
+typedef float af4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void attn_split4(const af4 v, ah4& hi, ah4& lo) {
+  hi = __builtin_convertvector(v, ah4);
+  lo = __builtin_convertvector(v - __builtin_convertvector(hi, af4), ah4);
+}
+
+__device__ __forceinline__ af4 attn_mma3(const ah4 ah, const ah4 al, const ah4 bh, const ah4 bl, af4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+}
+
+static constexpr int kAttnLs = 20;           // LDS row stride in floats: 16-byte reads of 16 consecutive rows hit 64 banks once
+static constexpr float kAttnNegBig = -3.0e38f;   // finite "-inf": exp(kAttnNegBig - m) == 0 without inf - inf
+
+// grid (ceil(Lq / 256), heads, B * nsplit); workgroup = 4 waves x 4 query tiles; keys [k0, k0 + kn) of split sp.
+// PARTIAL: write (max, sum, unnormalised O) for merge_key_splits_kernel instead of the normalised output.
+template <bool PARTIAL>
+__global__ __launch_bounds__(256) void attention_mfma16_kernel(const float* __restrict__ q, int ldq,
+                                                               const float* __restrict__ k, const float* __restrict__ v,
+                                                               int ldk, int Lq, int Lk, int kps, int nsplit, float scale,
+                                                               float* __restrict__ out, int ldo, float* __restrict__ part) {
+  constexpr int HD = 16, LS = kAttnLs;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int head = blockIdx.y, b = blockIdx.z / nsplit, sp = blockIdx.z % nsplit;
+  const int k0 = sp * kps;
+  const int kn = min(kps, Lk - k0);
+  const int ktiles = (kn + 15) >> 4;
+  float* ks = smem;                                   // [ktiles * 16][LS]
+  float* vs = smem + (size_t)ktiles * 16 * LS;
+  for (int i = threadIdx.x; i < ktiles * 16 * (HD / 4); i += blockDim.x) {
+    const int j = i >> 2, c = (i & 3) * 4;
+    float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;     // rows past kn: zeros (their scores are masked below)
+    if (j < kn) {
+      const size_t off = ((size_t)b * Lk + k0 + j) * ldk + head * HD + c;
+      kk = *reinterpret_cast<const float4*>(k + off);
+      vv = *reinterpret_cast<const float4*>(v + off);
+    }
+    *reinterpret_cast<float4*>(ks + j * LS + c) = kk;
+    *reinterpret_cast<float4*>(vs + j * LS + c) = vv;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int qtiles = (Lq + 15) >> 4;
+  const int qt_end = min(qtiles, ((int)blockIdx.x + 1) * 16);
+  for (int qt = blockIdx.x * 16 + wave; qt < qt_end; qt += 4) {
+    const int qi = qt * 16 + col;
+    af4 qv = {0.f, 0.f, 0.f, 0.f};
+    if (qi < Lq) {
+      const float4 t = *reinterpret_cast<const float4*>(q + ((size_t)b * Lq + qi) * ldq + head * HD + 4 * g);
+      qv = af4{t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+    }
+    ah4 qh, ql;
+    attn_split4(qv, qh, ql);
+    float m = kAttnNegBig, l = 0.f;
+    af4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const float4 kr = *reinterpret_cast<const float4*>(ks + (kt * 16 + col) * LS + 4 * g);   // A: K[key = col][4g ..]
+      ah4 kh, kl;
+      attn_split4(af4{kr.x, kr.y, kr.z, kr.w}, kh, kl);
+      af4 sc = attn_mma3(kh, kl, qh, ql, af4{0.f, 0.f, 0.f, 0.f});      // S^T[key 4g + t][q = col]
+      const int kbase = kt * 16 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (kbase + t >= kn) sc[t] = kAttnNegBig;
+      float tmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m, tmax);
+      const float corr = __expf(m - mn);
+      af4 pr;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) pr[t] = __expf(sc[t] - mn);
+      float ps = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      l = l * corr + ps;
+      acc *= corr;
+      m = mn;
+      // A: V^T[d = col][key 4g + t] -- transposed read of the LDS tile (16 consecutive banks per register)
+      const float* vp = vs + (kbase)*LS + col;
+      ah4 vh, vl, ph, pl;
+      attn_split4(af4{vp[0], vp[LS], vp[2 * LS], vp[3 * LS]}, vh, vl);
+      attn_split4(pr, ph, pl);                                         // B: P^T[key 4g + t][q = col] = the score registers
+      acc = attn_mma3(vh, vl, ph, pl, acc);                            // O^T[d = 4g + t][q = col]
+    }
+    if (qi < Lq) {
+      if (PARTIAL) {
+        float* pp = part + ((((size_t)b * gridDim.y + head) * nsplit + sp) * Lq + qi) * (HD + 2);
+        if (g == 0) { pp[0] = m; pp[1] = l; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pp[2 + 4 * g + t] = acc[t];
+      } else {
+        const float inv = 1.f / l;
+        *reinterpret_cast<float4*>(out + ((size_t)b * Lq + qi) * ldo + head * HD + 4 * g) =
+            make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+      }
+    }
+  }
+}
+
 template <int HD>
 __global__ void merge_key_splits_kernel(const float* __restrict__ part, int B, int heads, int nsplit, int Lq,
                                         float* __restrict__ out, int ldo) {
@@ -270,6 +384,37 @@ int isf_attention_forward(const float* q, int ldq, const float* k, const float* 
               "attention: strides must be multiples of 4 floats");
   const int hd = embed_dims / num_heads;
   ISF_REQUIRE(hd == 16 || hd == 32, ISF_ERR_UNSUPPORTED, "attention: built for head_dim 16 / 32 (got %d)", hd);
+  if (hd == 16) {   // matrix-core kernel: the keys of a workgroup (all of them, or a <= 512-key split) resident in LDS
+    hipStream_t st = as_stream(stream);
+    const int kps = num_keys > 512 ? 512 : num_keys, nsplit = ceil_div(num_keys, kps);
+    const float scale = 0.25f;   // 1 / sqrt(16)
+    const dim3 grid(ceil_div(num_queries, 256), num_heads, batch_size * nsplit), block(256);
+    const size_t lds = (size_t)round_up(kps, 16) * kAttnLs * 2 * sizeof(float);
+    static bool mfma_attr_set = false;
+    if (!mfma_attr_set) {   // 512 keys x 20 floats x (k, v) = 80 KiB
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma16_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma16_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      mfma_attr_set = true;
+    }
+    if (nsplit == 1) {
+      hipLaunchKernelGGL((attention_mfma16_kernel<false>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries, num_keys,
+                         kps, 1, scale, out, ldo, static_cast<float*>(nullptr));
+    } else {
+      Arena& a = arena_for_stream(st);
+      ISF_TRY(a.reset());
+      float* part = nullptr;
+      ISF_TRY(a.alloc_n(&part, (size_t)batch_size * num_heads * nsplit * num_queries * (hd + 2)));
+      hipLaunchKernelGGL((attention_mfma16_kernel<true>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries, num_keys,
+                         kps, nsplit, scale, out, ldo, part);
+      const long long total = (long long)batch_size * num_heads * num_queries * hd;
+      hipLaunchKernelGGL((merge_key_splits_kernel<16>), dim3(ceil_div(total, 256)), dim3(256), 0, st, part, batch_size,
+                         num_heads, nsplit, num_queries, out, ldo);
+    }
+    ISF_LAUNCH_CHECK();
+    return ISF_OK;
+  }
   if (num_keys > 512) {   // keys split into <= 512-key chunks + merge
     hipStream_t st = as_stream(stream);
     const int kps = 512, nsplit = ceil_div(num_keys, kps);
