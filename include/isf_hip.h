@@ -322,10 +322,11 @@ int isf_window_block_forward(const float* x, int batch_size, int grid_size, int 
 int isf_window_attention_forward(const float* qkv, int batch_size, int grid_size, int embed_dims, int num_heads,
                                  int window, int shift, float* out, isf_stream_t stream);
 
-/* A13/A14  multi-head attention core with few keys ------------------------------------------------------
- * replaces the softmax(QK^T)V part of multi_head_attention_forward (fusion_encoder.py:371-470) for
- * num_keys <= 512: q [B*Lq, ldq], k / v [B*Lk, ldkv] (already projected; head h = columns h*hd..),
- * out [B*Lq, ldo]. */
+/* A13/A14  multi-head attention core --------------------------------------------------------------------
+ * replaces the softmax(QK^T)V part of multi_head_attention_forward (fusion_encoder.py:371-470; the head's
+ * cross attention, transfusion_head_v2.py:104-108): q [B*Lq, ldq], k / v [B*Lk, ldkv] (already projected; head h =
+ * columns h*hd..), out [B*Lq, ldo].  head_dim 16 (the IS-Fusion configuration): matrix-core kernel, keys resident in
+ * LDS (up to 512 per workgroup; more keys are split and merged); head_dim 32: fp32 vector kernels.  Asynchronous. */
 int isf_attention_forward(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
                           int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
                           isf_stream_t stream);
