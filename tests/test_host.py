@@ -340,3 +340,63 @@ def test_neck_gemm_formulation_equals_the_conv_modules():
         got = neck.forward_tokens(x, linear_relu)[0]
     assert got.shape == want.shape == (2, 512, 12, 12)
     assert (got - want).abs().max().item() < 1e-4
+
+
+def test_camera_matrix_fold_batched_equals_the_per_camera_chain():
+    """fusion_ops.p2g_camera_params folds lidar2img . inverse(lidar_aug) and the image augmentation of every (sample,
+    camera) in one batched float64 pass; it must reproduce the per-camera chain of img_point_sampling
+    (fusion_encoder.py:1030-1047) written out one camera at a time"""
+    import torch
+    from isfusion_amd import fusion_ops as ops, synthetic
+    inp = synthetic.fusion_inputs(5, 3)
+    l2i, ia, la = [torch.from_numpy(inp[k]).double() for k in ("lidar2img", "img_aug_matrix", "lidar_aug_matrix")]
+    B, ncam = l2i.shape[:2]
+    want = torch.empty((B, ncam, 20), dtype=torch.float64)
+    for b in range(B):
+        rinv = torch.inverse(la[b, :3, :3])
+        for k in range(ncam):
+            m = l2i[b, k, :3, :3] @ rinv
+            want[b, k, :9] = m.reshape(-1)
+            want[b, k, 9:12] = l2i[b, k, :3, 3] - m @ la[b, :3, 3]
+            want[b, k, 12:18] = ia[b, k, :2, :3].reshape(-1)
+            want[b, k, 18:20] = ia[b, k, :2, 3]
+    got = ops.p2g_camera_params(inp["lidar2img"], inp["img_aug_matrix"], inp["lidar_aug_matrix"])
+    assert got.shape == (B * ncam, 20) and got.dtype == torch.float32
+    assert (got.double() - want.reshape(B * ncam, 20)).abs().max().item() < 1e-6 * max(1.0, want.abs().max().item())
+
+
+def test_prediction_heads_as_grouped_gemms_equal_the_conv1d_stacks(monkeypatch):
+    """TransFusionHeadV2._pack_prediction_heads: the six Conv1d(k=1) + BN + ReLU + Conv1d(k=1) stacks of an FFN as two
+    groups (4 + 2 outputs) of [first layers side by side | block-diagonal last layers] GEMMs -- with a torch GEMM
+    standing in for the HIP linear kernel, against the module stacks"""
+    import torch
+    from isfusion_amd import fusion_ops as ops, transfusion_head as th
+    from isfusion_amd.fusion_modules import seeded_state_dict
+
+    class PL:
+        def __init__(self, w, b=None):
+            self.w, self.bias = w.float(), b
+
+    def lin(x, pl, act=0, **kw):
+        y = x @ pl.w.t() + (pl.bias if pl.bias is not None else 0)
+        return torch.relu(y) if act == ops.ACT_RELU else y
+
+    monkeypatch.setattr(ops, "PackedLinear", PL)
+    head = th.TransFusionHeadV2().eval()
+    head.load_state_dict(seeded_state_dict(head, 300))
+    ffn = head.prediction_heads[0]
+    groups = th.TransFusionHeadV2._pack_prediction_heads(ffn)
+    assert [len(g["cols"]) for g in groups] == [4, 2]
+    assert all(g["l2"].w.shape[0] % 16 == 0 and g["l1"].w.shape[0] in (64, 128, 256) for g in groups)
+    B, P, E = 2, 50, 128
+    q = torch.randn(B * P, E, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        want = ffn(q.view(B, P, E).transpose(1, 2).contiguous())
+        got = {}
+        for g in groups:
+            o = lin(lin(q, g["l1"], act=ops.ACT_RELU), g["l2"]).view(B, P, -1)
+            for n, a, b in g["cols"]:
+                got[n] = o[:, :, a:b].transpose(1, 2)
+    assert set(got) == set(want)
+    for k in want:
+        assert (got[k] - want[k]).abs().max().item() < 1e-5, k
