@@ -67,18 +67,25 @@ struct Conv16Plan {
   int part_rows;    // rows per part (a multiple of 16; the parts split the rows evenly whatever the tile mix)
 };
 
-// -> row_end: first row past this tile's share (the part's end or n_out, whichever comes first)
-__device__ __forceinline__ bool conv16_tile_of_block(int ncb, Conv16Plan plan, int TM, int n_out, int& cb, int& row0,
-                                                     int& row_end, bool& half) {
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int part = ncb == 2 ? xcd >> 1 : xcd;
-  cb = ncb == 2 ? xcd & 1 : 0;
+// tile j of part `part` -> its first row, the first row past its share (the part's end or n_out, whichever comes
+// first) and whether it is a half tile; false when the tile is empty.  Host and device: tests/test_tile_plan.py walks
+// the same arithmetic the kernel uses.
+__host__ __device__ inline bool conv16_tile_rows(Conv16Plan plan, int TM, int n_out, int part, int j, int& row0,
+                                                 int& row_end, bool& half) {
   if (j >= plan.full + plan.half) return false;
   half = j >= plan.full;
   const int off = half ? plan.full * TM + (j - plan.full) * (TM / 2) : j * TM;
   row0 = part * plan.part_rows + off;
-  row_end = min((part + 1) * plan.part_rows, n_out);
+  const int part_end = (part + 1) * plan.part_rows;
+  row_end = part_end < n_out ? part_end : n_out;
   return off < plan.part_rows && row0 < n_out;
+}
+
+__device__ __forceinline__ bool conv16_tile_of_block(int ncb, Conv16Plan plan, int TM, int n_out, int& cb, int& row0,
+                                                     int& row_end, bool& half) {
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  cb = ncb == 2 ? xcd & 1 : 0;
+  return conv16_tile_rows(plan, TM, n_out, ncb == 2 ? xcd >> 1 : xcd, j, row0, row_end, half);
 }
 static inline int conv16_grid_blocks(Conv16Plan plan) { return 8 * (plan.full + plan.half); }
 
