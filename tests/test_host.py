@@ -400,3 +400,44 @@ def test_prediction_heads_as_grouped_gemms_equal_the_conv1d_stacks(monkeypatch):
     assert set(got) == set(want)
     for k in want:
         assert (got[k] - want[k]).abs().max().item() < 1e-5, k
+
+
+def test_training_helpers_chunked_weight_grad_and_packed_conv_io():
+    """fusion_train._weight_grad (dW = g^T x as a chunked batched GEMM) equals the plain product for row counts around
+    the chunk size; fusion_train.pack_stock_convs makes a stock conv see contiguous inputs and contiguous output
+    gradients (the token-major ops around it hand over permuted views)"""
+    import torch
+    from isfusion_amd import fusion_train as tr
+    g = torch.Generator().manual_seed(0)
+    for M in (100, 8191, 8192, 20000, 64800):
+        gy, x = torch.randn((M, 48), generator=g), torch.randn((M, 32), generator=g)
+        want = gy.double().t() @ x.double()
+        assert (tr._weight_grad(gy, x).double() - want).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
+    conv = tr.pack_stock_convs(torch.nn.Conv2d(8, 8, 3, padding=1))
+    assert tr.pack_stock_convs(conv) is conv and conv._isf_packed_io          # idempotent
+    seen = {}
+
+    def see_input(mod, args):                      # runs after pack_stock_convs' own pre-hook (registration order)
+        seen["in_contig"] = args[0].is_contiguous()
+
+    conv.register_forward_pre_hook(see_input)
+    x = torch.randn((2, 6, 5, 8), generator=g).permute(0, 3, 1, 2).requires_grad_()     # channels-last storage, NCHW view
+    assert not x.is_contiguous()
+    conv(x).permute(0, 2, 3, 1).reshape(-1, 8).sum(0).sum().backward()
+    assert seen == {"in_contig": True} and x.grad is not None and torch.isfinite(x.grad).all()
+    # the gradient that reaches the producer of a guarded tensor is contiguous although the consumer hands back a view
+    t = torch.randn((2, 8, 5, 6), generator=g).requires_grad_()
+    mid = t * 1.0
+
+    def see_grad(gr):
+        seen["grad_contig"] = gr.is_contiguous()
+
+    mid.register_hook(see_grad)
+    w = torch.randn((2, 5, 6, 8), generator=g).permute(0, 3, 1, 2)                        # non-contiguous [2, 8, 5, 6]
+    (tr._PackedGrad.apply(mid) * 1.0).backward(w)
+    assert seen["grad_contig"] is True
+    seen.clear()
+    mid2 = t * 1.0
+    mid2.register_hook(see_grad)
+    (mid2 * 1.0).backward(w)
+    assert seen["grad_contig"] is False                                                   # what the guard is for
