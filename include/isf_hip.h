@@ -208,6 +208,25 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                   const float* scale, const float* shift, const void* residual_split, int relu,
                                   void* out_split, int mode, isf_stream_t stream);
+/* The same convolution with the tile's input rows staged in LDS ("LDS staging of active-voxel tiles"; the reference's
+ * gather stage: bevfusion-ops/spconv/include/spconv/reordering.cu.h:21-97 -> staging buffer -> GEMM, spconv_ops.h:300-345).
+ * isf_rulebook_stage_tables derives the staging tables of a neighbour table once per rulebook: for every unit of
+ * isf_stage_unit_rows() (64) consecutive output rows, ulist [nbr_stride / 64][isf_stage_unit_cap()] = the distinct
+ * input rows the unit's taps name (ascending), ucount [nbr_stride / 64] = how many, and slots [num_taps][nbr_stride]
+ * (uint16) = the position of nbr[k][o] in its unit's list, 0xFFFF where nbr is -1.  isf_sparse_conv_forward_staged
+ * copies the listed rows global -> LDS once per tile and 32-channel chunk (row-coalesced LDS-DMA) and reads the A
+ * operands of all taps from LDS; `stage_rows` = LDS rows per 128-row tile (clamped to what 160 KiB hold; list entries
+ * beyond a unit's share are gathered from memory, so every value is correct).  Results are bit-identical to
+ * isf_sparse_conv_forward_f16x3 (same products, same order).  mode: 0 | 1 (single-pass f16), +32 uniform tiles. */
+int isf_stage_unit_rows(void);
+int isf_stage_unit_cap(void);
+int isf_rulebook_stage_tables(const int32_t* nbr, int nbr_stride, int num_taps, uint16_t* slots, int32_t* ulist,
+                              int32_t* ucount, isf_stream_t stream);
+int isf_sparse_conv_forward_staged(const void* features_split, int num_in, int c_in, const void* packed16,
+                                   int num_taps, int c_out, const uint16_t* slots, int nbr_stride,
+                                   const int32_t* ulist, const int32_t* ucount, int num_out, const float* scale,
+                                   const float* shift, const void* residual_split, int relu, void* out_split,
+                                   int stage_rows, int mode, isf_stream_t stream);
 /* A7  SparseConvTensor.dense() + view(N, C*D, H, W) ---------------------------------------------------
  * replaces structure.py:49-59 + sparse_encoder.py:133-136: out[b, c*D+z, y, x] = feats[i,c], zeros
  * elsewhere; out [B, C*D, H, W] is written completely (no separate memset).  Asynchronous. */
@@ -241,10 +260,14 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
 /* per-call options of the two engine entry points (NULL = all defaults; no process-wide state):
  * precision  0 = f16x3 split MFMA when every layer carries packed16, else fp32 MFMA (default); 1 = force the fp32 MFMA
  *            kernels; 2 = single-pass f16 (opt-in, fp16-autocast accuracy: mode 1 of isf_sparse_conv_forward_f16x3);
- * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3). */
+ * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3);
+ *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;
   int diagnostic;
+  int stage_rows;  /* LDS-staged input rows per 128-row conv tile (isf_sparse_conv_forward_staged); 0 = the library's
+                      per-layer default, -1 = staging off (every layer on the gather kernel) */
+  int stage_mask;  /* with stage_rows > 0: bit i = layer i runs staged (tuning); 0 = every layer */
 } isf_encoder_options;
 
 int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors, int num_voxels,
@@ -370,6 +393,19 @@ int isf_ms_deform_attn_forward(const float* value, const int64_t* spatial_shapes
                                const float* sampling_loc, const float* attn_weight, int batch_size, int num_keys,
                                int num_heads, int head_dim, int num_queries, int num_levels, int num_points,
                                float* out, isf_stream_t stream);
+
+/* ... and its backward, with the op's own contract:
+ * replaces ext_module.ms_deform_attn_backward(value, value_spatial_shapes, value_level_start_index,
+ *   sampling_locations, attention_weights, grad_output, grad_value, grad_sampling_loc, grad_attn_weight, im2col_step)
+ *   (multi_scale_deformable_attn_function.py:150-160; kernels ms_deform_im2col_cuda.cuh:301-920).
+ * grad_output [B, Q, heads*hd]; grad_value [B, num_keys, heads, hd], grad_sampling_loc [B, Q, heads, L, P, 2] and
+ * grad_attn_weight [B, Q, heads, L, P] are ZEROED BY THE CALLER (as the reference does, :142-144) and accumulated
+ * into.  isf_msda_backward is the fused single-level form the mirror's InsContextAtt trains through. */
+int isf_ms_deform_attn_backward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                const float* sampling_loc, const float* attn_weight, const float* grad_output,
+                                int batch_size, int num_keys, int num_heads, int head_dim, int num_queries,
+                                int num_levels, int num_points, float* grad_value, float* grad_sampling_loc,
+                                float* grad_attn_weight, isf_stream_t stream);
 
 /* A10  in-group (in-window) indices -------------------------------------------------------------------------
  * replaces TorchEx ingroup_indices.forward(group_inds, out_inds)

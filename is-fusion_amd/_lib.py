@@ -44,14 +44,15 @@ class EncoderStats(ctypes.Structure):
 class EncoderOptions(ctypes.Structure):
     """struct isf_encoder_options: per-call precision (0 auto f16x3 / 1 fp32 MFMA / 2 single-pass f16) and timing
     diagnostic of the conv kernels (0 off)."""
-    _fields_ = [("precision", c_int), ("diagnostic", c_int)]
+    _fields_ = [("precision", c_int), ("diagnostic", c_int), ("stage_rows", c_int), ("stage_mask", c_int)]
 
 
-def encoder_options(precision=0, diagnostic=0):
-    """-> byref(isf_encoder_options) or None for the defaults"""
-    if not precision and not diagnostic:
+def encoder_options(precision=0, diagnostic=0, stage_rows=0, stage_mask=0):
+    """-> byref(isf_encoder_options) or None for the defaults.  stage_rows: LDS-staged input rows per conv tile
+    (0 = library default, -1 = off); stage_mask: layers that run staged when stage_rows > 0 (0 = all)."""
+    if not precision and not diagnostic and not stage_rows and not stage_mask:
         return None
-    return ctypes.byref(EncoderOptions(int(precision), int(diagnostic)))
+    return ctypes.byref(EncoderOptions(int(precision), int(diagnostic), int(stage_rows), int(stage_mask)))
 
 
 class VfeParams(ctypes.Structure):
@@ -126,8 +127,16 @@ SIGNATURES = {
     "isf_split_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "isf_stage_unit_rows": (c_int, []),
+    "isf_stage_unit_cap": (c_int, []),
+    "isf_rulebook_stage_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isf_sparse_conv_forward_staged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                               c_int, c_int, c_void_p]),
     "isf_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_ms_deform_attn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isf_ingroup_indices": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "isf_packed_window_block_bytes": (ctypes.c_size_t, [c_int]),
     "isf_pack_window_block": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -249,6 +258,9 @@ def pow2_rescale(g):
     inside it -- activations of a normalised network do, gradients (1e-5 and below) do not and would fall into f16's
     subnormals.  Scaling by a power of two is exact and commutes with the (linear) backward ops."""
     import torch
-    amax = g.detach().abs().amax().clamp_min(1e-30)
+    a = g.detach().abs()
+    # the scale comes from the largest FINITE entry: an inf / NaN in one row must stay in that row (amax = inf would give
+    # s = 0 and turn the whole tensor into NaN through g * 0 / 0); non-finite entries pass through the scaling unchanged
+    amax = torch.where(torch.isfinite(a), a, torch.zeros_like(a)).amax().clamp_min(1e-30)
     s = torch.exp2(10.0 - torch.ceil(torch.log2(amax)))
     return g * s, s

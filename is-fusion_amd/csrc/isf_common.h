@@ -161,6 +161,14 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                    const float* shift, const void* residual, int relu, void* ys,
                                    int mode /* 0 | 1 single-pass f16 | timing diagnostics */, hipStream_t st);
+// isf_spconv_stage.hip (LDS-staged input rows; staging tables of a rulebook)
+int stage_tables_impl(const int32_t* nbr, int nbr_stride, int K, uint16_t* slots, int32_t* ulist, int32_t* ucount,
+                      hipStream_t st);
+int sparse_conv_forward_staged_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
+                                    const uint16_t* slots, int nbr_stride, const int32_t* ulist,
+                                    const int32_t* ucount, int n_out, const float* scale, const float* shift,
+                                    const void* residual, int relu, void* ys, int stage_rows, int mode,
+                                    hipStream_t st);
 int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st);
 int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st);
 int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st);

@@ -133,6 +133,12 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* _
 }
 
 // ----------------------------------------------------------------------------------------- encoder
+struct StageTables {
+  uint16_t* slots = nullptr;
+  int32_t* ulist = nullptr;
+  int32_t* ucount = nullptr;
+};
+
 struct LevelState {
   int shape[3];
   int n;                  // active rows (host)
@@ -144,7 +150,24 @@ struct LevelState {
   int32_t* cache_nbr;
   int cache_stride;
   long long cache_pairs;
+  StageTables cache_stage;   // staging tables of cache_nbr (slots == nullptr: not built)
 };
+
+// staging tables of one neighbour table (isf_spconv_stage.hip), built behind it on the geometry stream
+static int build_stage_tables(Arena& a, const int32_t* nbr, int stride, int K, StageTables* t, hipStream_t sg) {
+  const int units = stride / isf_stage_unit_rows();
+  ISF_TRY(a.alloc_n(&t->slots, (size_t)K * stride));
+  ISF_TRY(a.alloc_n(&t->ulist, (size_t)units * isf_stage_unit_cap()));
+  ISF_TRY(a.alloc_n(&t->ucount, (size_t)units));
+  return stage_tables_impl(nbr, stride, K, t->slots, t->ulist, t->ucount, sg);
+}
+
+// LDS rows per 128-row tile a layer stages by default (0 = the gather kernel): measured choice per channel shape
+// (profiles/r03_*).
+static int default_stage_rows(const isf_conv_layer& ly) {
+  (void)ly;
+  return 0;
+}
 
 static int ensure_occ(Arena& a, LevelState& L, int B, hipStream_t st) {
   if (L.has_occ) return ISF_OK;
@@ -166,6 +189,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   const int conv_mode = precision == 2 ? (1 | (diagnostic & 32)) : diagnostic;
+  const int stage_opt = opt ? opt->stage_rows : 0;
+  const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
+  ISF_REQUIRE(stage_opt >= -1, ISF_ERR_ARG, "sparse_encoder: stage_rows %d", stage_opt);
   ISF_REQUIRE(num_layers > 0 && num_layers <= 32, ISF_ERR_ARG, "sparse_encoder: %d layers (1..32)", num_layers);
   // Geometry (occupancy indexes, output sets, neighbour tables: small integer kernels + the host syncs that size
   // the next level) runs on a side stream and overlaps the convolutions of the previous level on `st`; a
@@ -215,6 +241,12 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     int stride = 0;
     int n_out = L.n;
     int n_in = L.n;
+    // LDS rows this layer stages (0 = gather kernel); the timing diagnostics exist on the gather kernel only
+    int srows = 0;
+    if (use16 && dg == 0 && stage_opt >= 0 && sparse_conv_f16x3_supported(ly.c_in, ly.c_out))
+      srows = stage_opt == 0 ? default_stage_rows(ly)
+                             : ((stage_mask == 0 || ((stage_mask >> i) & 1u)) ? stage_opt : 0);
+    StageTables stg;
     if (ly.conv_type == ISF_CONV_SUBM) {
       const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
                        L.cache_ks[2] == ly.ksize[2];
@@ -228,11 +260,18 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_stride = stride;
         for (int j = 0; j < 3; ++j) L.cache_ks[j] = ly.ksize[j];
         L.cache_pairs = -(long long)i - 1;  // pairs live in pair_counts[i]; resolved after the final sync
+        L.cache_stage = StageTables();
+        if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
         ISF_TRY(stream_wait_stream(a, st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
         stride = L.cache_stride;
+        if (srows > 0 && !L.cache_stage.slots) {   // an earlier layer of the level ran unstaged: build the tables now
+          ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
+          ISF_TRY(stream_wait_stream(a, st, sg));
+        }
       }
+      stg = L.cache_stage;
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
     } else {
       ISF_TRY(ensure_occ(a, L, B, sg));
@@ -253,6 +292,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
       ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
                          stride, pair_counts + i, sg));
+      if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_nbr = nullptr;
       n_out = Nx.n;
@@ -269,7 +309,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       res = outputs[ly.residual_from];
     }
     if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i], st));
-    if (use16)
+    if (use16 && srows > 0)
+      ISF_TRY(sparse_conv_forward_staged_impl(x, ly.c_in, ly.packed16, K, ly.c_out, stg.slots, stride, stg.ulist,
+                                              stg.ucount, n_out, ly.scale, ly.shift, res, ly.relu, y, srows, conv_mode,
+                                              st));
+    else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y, conv_mode, st));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))

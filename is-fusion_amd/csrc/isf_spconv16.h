@@ -97,10 +97,13 @@ static inline int conv16_grid_blocks(Conv16Plan plan) { return 8 * (plan.full + 
 // the dispatcher places workgroups round-robin over the CUs of an XCD, every CU gets the same set
 // (tools/probes/wg_placement.hip, profiles/r02_call13_tile_mix.txt) -- brings the maximum down to ceil(need).
 // Launches of several rounds keep uniform tiles (the dispatcher refills slots as they drain).
-static inline Conv16Plan conv16_plan(int n_out, int TM, int ncb, int wgs_per_cu, int cus_per_xcd, bool balance) {
+// align_groups: every tile starts at a multiple of 16 * align_groups rows (the LDS-staged kernel works on 64-row units
+// of the rulebook's staging tables: align_groups = 4; TM / 2 must be a multiple of it too).
+static inline Conv16Plan conv16_plan(int n_out, int TM, int ncb, int wgs_per_cu, int cus_per_xcd, bool balance,
+                                     int align_groups = 1) {
   const int parts = ncb == 2 ? 4 : 8;
   const int gt = TM / 16;                                       // 16-row groups per full tile
-  const int groups = ceil_div(ceil_div(n_out, 16), parts);      // per part = per XCD
+  const int groups = ceil_div(ceil_div(ceil_div(n_out, 16), parts), align_groups) * align_groups;   // per part = per XCD
   Conv16Plan plan{ceil_div(groups, gt), 0, groups * 16};
   if (!balance || (gt & 1) || plan.full > wgs_per_cu * cus_per_xcd) return plan;
   const int per_cu = ceil_div(groups, cus_per_xcd);

@@ -40,11 +40,12 @@ class SplitMap:
                                                  _lib.stream()), "isf_nchw_to_split")
         return SplitMap(out, B, C, H, W)
 
-    def to_nchw(self):
+    def to_nchw(self, channels=None):
+        """[B, C, H, W] fp32; channels: keep only the first `channels` (a view of the converted map)"""
         out = torch.empty((self.B, self.C, self.H, self.W), dtype=torch.float32, device=self.data.device)
         _lib.check(_lib.load().isf_split_to_nchw(_lib.ptr(self.data), self.B, self.C, self.H * self.W, _lib.ptr(out),
                                                  _lib.stream()), "isf_split_to_nchw")
-        return out
+        return out if channels is None else out[:, :channels]
 
 
 _grids = {}
@@ -74,19 +75,28 @@ class PackedConvBN:
         w = conv.weight.detach().float()
         _lib.require_cuda(w)
         assert tuple(w.shape[2:]) == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-        self.c_out, self.c_in = w.shape[:2]
+        self.c_out_real, self.c_in = w.shape[:2]
         self.stride = conv.stride[0]
         self.relu = relu
-        if self.c_out not in SUPPORTED:
-            raise _lib.IsfError(f"dense conv: {self.c_out} output channels not built {SUPPORTED}")
         dev = w.device
         if bn is not None:
             self.scale, self.shift = fold_bn(bn)
         else:
-            self.scale = torch.ones(self.c_out, dtype=torch.float32, device=dev)
-            self.shift = torch.zeros(self.c_out, dtype=torch.float32, device=dev)
+            self.scale = torch.ones(self.c_out_real, dtype=torch.float32, device=dev)
+            self.shift = torch.zeros(self.c_out_real, dtype=torch.float32, device=dev)
         if conv.bias is not None:
             self.shift = (self.shift + conv.bias.detach().float() * self.scale).contiguous()
+        self.c_out = self.c_out_real
+        if self.c_out_real < SUPPORTED[0]:
+            # fewer output channels than the narrowest MFMA column tile (the 10-class heat-map convs): zero columns up
+            # to 32; the caller keeps channels [:c_out_real] of the result (SplitMap.to_nchw(channels=...))
+            self.c_out = SUPPORTED[0]
+            pad = self.c_out - self.c_out_real
+            w = torch.cat([w, w.new_zeros((pad,) + tuple(w.shape[1:]))], 0)
+            self.scale = torch.cat([self.scale, self.scale.new_ones(pad)]).contiguous()
+            self.shift = torch.cat([self.shift, self.shift.new_zeros(pad)]).contiguous()
+        if self.c_out not in SUPPORTED:
+            raise _lib.IsfError(f"dense conv: {self.c_out} output channels not built {SUPPORTED}")
         self.zero_shift = torch.zeros(self.c_out, dtype=torch.float32, device=dev)
         self.groups = []   # (channel offset, channels, packed weights, packed weights for the transposed map)
         off = 0

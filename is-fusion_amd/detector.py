@@ -72,7 +72,6 @@ class ISFusionPtsPath(nn.Module):
                                              voxel_size=self.pillar_size, max_voxels=(30000, 60000),
                                              point_cloud_range=self.pc_range)
 
-    @torch.no_grad()
     def freeze(self, flag=True):
         """Inference deployment (weights static): every module below skips its per-call "did a parameter change?" scan
         of the packed-weight caches -- about 0.4 ms of host time per forward, which at small batch is GPU idle time."""
@@ -81,6 +80,7 @@ class ISFusionPtsPath(nn.Module):
         ops.freeze(self, flag)
         return self
 
+    @torch.no_grad()
     def voxelize(self, points, voxel_type="pillar"):
         """isfusion.py:148-176 (pillar branch): per-sample hard voxelization, batch index prepended."""
         assert voxel_type == "pillar", "the fine grid is voxelized dynamically inside the LiDAR branch"

@@ -8,7 +8,9 @@ Same constructor kwargs, sub-module / parameter names and ``forward`` signature
 Custom arithmetic runs in libisf_hip.so (``fusion_ops``).  The 3x3 dense convolutions (conv_fusion, heatmap head,
 conv_scene, conv_ins) run on the sparse encoder's f16x3 MFMA kernel over the dense grid (``dense_conv``,
 SURVEY.md 8f #4; ``dense_conv="stock"`` keeps them on PyTorch-ROCm / MIOpen as the north_star's minimum prescribes).
-Inference only (eval-mode BN, dropout off); the training-only ``random_noise`` branch (:992-995) is not built.
+``forward`` is the inference engine (eval-mode BN, dropout off); ``forward_train`` (training mode) applies the reference's
+residual dropouts and the ``random_noise`` Point-to-Grid jitter (:992-995) -- see fusion_train.py for the one stochastic
+op that is not reproduced (dropout on the attention probabilities).
 """
 import torch
 from torch import nn
@@ -43,6 +45,7 @@ class ISFusionEncoder(nn.Module):
             self.grid2region_att.append(SSTv2(d_model=[d] * 4, nhead=[8] * 4, num_blocks=1,
                                               dim_feedforward=[d] * 4, output_shape=grid_size[l][:2],
                                               in_channel=E if l == 0 else None))
+        self.random_noise = 1.0          # fusion_encoder.py:859 (training only)
         self.instance_num = kwargs.get("instance_num", 200)
         self.nms_kernel_size = 3
         self.conv_ins = ConvModule(E, E)
@@ -58,6 +61,11 @@ class ISFusionEncoder(nn.Module):
     def _conv(self, name):
         """ConvModule `name` packed for the f16x3 kernel (cached per device)"""
         mod = getattr(self, name)
+        if isinstance(mod, nn.Conv2d):                  # heatmap_head_3: plain conv with bias, no BN / ReLU
+            c = ops._cache(mod, mod.weight.device)
+            if "packed" not in c:
+                c["packed"] = PackedConvBN(mod, None, relu=False)
+            return c["packed"]
         c = ops._cache(mod, mod.conv.weight.device)     # dropped when the conv / BN tensors change
         if "packed" not in c:
             c["packed"] = PackedConvBN(mod.conv, mod.bn, relu=True)
@@ -94,12 +102,12 @@ class ISFusionEncoder(nn.Module):
         if self.dense_conv == "hip":
             m = SplitMap.from_nchw(bev_feats)
             t = self._conv("heatmap_head_2")(self._conv("heatmap_head_1")(self._conv("conv_heatmap")(m, True), True),
-                                             True).to_nchw()                         # un-transposed orientation
-            # 64 -> 10 channels (below the MFMA tile): stock conv, again with the transposed taps on the contiguous
-            # un-transposed map (a permuted *view* would send MIOpen to its naive non-packed kernel: 3 ms), then the
-            # 10-channel result is transposed into the orientation the reference returns
+                                             True)                                   # un-transposed orientation
+            # 64 -> 10 channels: the same kernel with the output columns zero-padded to its narrowest tile (32), again
+            # with the transposed taps on the un-transposed tokens; the 10-channel result is then transposed into the
+            # orientation the reference returns (round 2 ran this conv on MIOpen: three extra library kernels)
             h3 = self.heatmap_head_3
-            hm = torch.nn.functional.conv2d(t, h3.weight.transpose(2, 3).contiguous(), h3.bias, 1, 1)
+            hm = self._conv("heatmap_head_3")(t, True).to_nchw(h3.out_channels)
             hm = hm.permute(0, 1, 3, 2).contiguous()
             x_scene_t = self._conv("conv_scene")(m, True).to_nchw()                   # = conv_scene(out)^T
             q = self._conv("conv_ins")(m).to_nchw()
@@ -129,9 +137,16 @@ class ISFusionEncoder(nn.Module):
             tr.pack_stock_convs(kwargs["pts_backbone"])
         pm = kwargs["pts_metas"]
         S = self.bev_size
+        noise = None
+        if self.random_noise is not None and self.training:
+            # one draw per sample, from the same two generators in the same order as the reference (:992-995)
+            import random
+            import numpy as np
+            noise = [random.uniform(-self.random_noise, self.random_noise) if np.random.rand() > 0.5 else 0.0
+                     for _ in range(bs)]
         img_bev = tr.p2g_sample(pm["pillars"], pm["pillar_coors"], img_mlvl_feats[1], kwargs["lidar2img"],
                                 kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
-                                kwargs["img_metas"][0]["input_shape"], bs, S, self.num_views)
+                                kwargs["img_metas"][0]["input_shape"], bs, S, self.num_views, noise)
         bev_feats = self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
         pts_backbone = kwargs.get("pts_backbone", None)
         x, ins_hm, feats = bev_feats, None, []

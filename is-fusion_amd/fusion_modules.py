@@ -182,8 +182,11 @@ class MSDeformAttn(nn.Module):
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
-    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points):
+    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points, dropout=0.1):
         super().__init__()
+        # dropout1..4 of the reference layer (fusion_encoder.py:604-668, p = 0.1 from :779): parameter-free, so the
+        # state-dict keys are unchanged; applied by the training path (fusion_train.ins_context_att)
+        self.dropout = dropout
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.norm1 = nn.LayerNorm(d_model)
         self.self_attn = _SelfAttn(d_model)
@@ -216,9 +219,10 @@ class InsContextAtt(nn.Module):
 
 
 class Instane2SceneAtt(nn.Module):
-    def __init__(self, d_model, nhead=8):
+    def __init__(self, d_model, nhead=8, dropout=0.1):
         super().__init__()
         self.nhead = nhead
+        self.dropout = dropout   # nn.Dropout on the residual branch (fusion_encoder.py:478, :492); training path only
         self.multihead_attn = _SelfAttn(d_model)
         self.norm = nn.LayerNorm(d_model)
 
@@ -261,10 +265,10 @@ class SECONDV2(nn.Module):
 
     def _packed(self, name, seq):
         from .dense_conv import pack_sequential
-        from .fusion_ops import param_key
+        from .fusion_ops import frozen, param_key
         cache = self.__dict__.setdefault("_isf_packed", {})
         dev = next(seq.parameters()).device
-        key = (dev, None if self.__dict__.get("_isf_frozen", False) and name in cache else param_key(seq))
+        key = (dev, None if name in cache and frozen(self) else param_key(seq))
         if name not in cache or cache[name][0][0] != dev or (key[1] is not None and cache[name][0][1] != key[1]):
             cache[name] = ((dev, key[1] if key[1] is not None else param_key(seq)), pack_sequential(seq))
         return cache[name][1]
@@ -399,7 +403,7 @@ class SECONDFPN(nn.Module):
         """the injected GEMM of forward_tokens on the fused linear kernel, weights packed once per parameter version"""
         from . import fusion_ops as ops
         cache = self.__dict__.setdefault("_isf_packed", {})
-        pk = None if self.__dict__.get("_isf_frozen", False) and cache else ops.param_key(self)
+        pk = None if cache and ops.frozen(self) else ops.param_key(self)
         if pk is not None and cache.get("_key") != pk:
             cache.clear()
             cache["_key"] = pk

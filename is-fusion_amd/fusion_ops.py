@@ -92,19 +92,46 @@ def param_key(module):
     return tuple((t._version, t.data_ptr()) for t in list(module.parameters()) + list(module.buffers()))
 
 
+def _unfreeze_on_load(module, *_):
+    """load_state_dict pre-hook (fires inside every module's _load_from_state_dict, so also under mmcv's
+    load_checkpoint): new weights are coming, the packed copies must be re-derived."""
+    freeze(module.__dict__.get("_isf_freeze_root", module), False)
+
+
 def freeze(module, flag=True):
-    """Inference deployments: skip the per-call "did a parameter change?" scan of the caches below `module`."""
+    """Inference deployments: skip the per-call "did a parameter change?" scan of the caches below `module`.
+    The skip ends by itself when weights can change: a load_state_dict anywhere below `module`, or a forward in
+    training mode (see frozen()), clears it -- call freeze() again once the weights are final."""
     for sub in module.modules():
         sub.__dict__["_isf_frozen"] = bool(flag)
+        if hasattr(sub, "_frozen"):          # SparseEncoder / LidarBranch keep their own flag
+            sub._frozen = bool(flag)
+        if flag and "_isf_freeze_root" not in sub.__dict__:
+            sub.__dict__["_isf_freeze_root"] = module
+            sub._register_load_state_dict_pre_hook(_unfreeze_on_load, with_module=True)
+        elif flag:
+            sub.__dict__["_isf_freeze_root"] = module
     return module
+
+
+def frozen(module):
+    """True when `module`'s caches may be used without checking the parameters.  A module seen in training mode loses
+    the flag (an optimizer step is about to change its weights; a later eval() then re-validates by key)."""
+    if not module.__dict__.get("_isf_frozen", False):
+        return False
+    if module.training:
+        module.__dict__["_isf_frozen"] = False
+        if hasattr(module, "_frozen"):
+            module._frozen = False
+        return False
+    return True
 
 
 def _cache(module, device):
     """Per-module cache of packed weights / tables derived from its parameters, dropped when the device or any
     parameter / buffer below the module changed (SparseEncoder._c_plan keys its plan the same way)."""
     c = module.__dict__.get("_isf_cache")
-    frozen = module.__dict__.get("_isf_frozen", False)
-    key = None if (frozen and c is not None) else param_key(module)
+    key = None if (c is not None and frozen(module)) else param_key(module)
     if c is None or c.get("device") != device or (key is not None and c.get("_key") != key):
         c = {"device": device, "_key": key if key is not None else param_key(module)}
         module.__dict__["_isf_cache"] = c
@@ -239,7 +266,7 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
 
 
 # ------------------------------------------------------------------------------------------------------ A8
-def p2g_camera_params(lidar2img, img_aug, lidar_aug):
+def p2g_camera_params(lidar2img, img_aug, lidar_aug, noise=None):
     """Fold the per-(sample, camera) 4x4 chain of img_point_sampling (fusion_encoder.py:1030-1047) into the 20
     floats isf_p2g_forward takes (float64 on the host, rounded once).  Batched over samples and cameras: a handful of
     host ops (the per-camera Python loop it replaces took 0.4 ms, during which the GPU sat idle)."""
@@ -250,6 +277,8 @@ def p2g_camera_params(lidar2img, img_aug, lidar_aug):
     rinv = torch.linalg.inv(la[:, :3, :3])                                   # [B, 3, 3]
     m = l2i[:, :, :3, :3] @ rinv[:, None]                                    # [B, ncam, 3, 3]
     v = l2i[:, :, :3, 3] - (m @ la[:, None, :3, 3, None]).squeeze(-1)        # [B, ncam, 3]
+    if noise is not None:   # training-time jitter: one scalar per sample added to all camera-frame coordinates (:992-995)
+        v = v + torch.as_tensor(noise, dtype=torch.float64).reshape(B, 1, 1)
     out = torch.cat([m.reshape(B, ncam, 9), v, ia[:, :, :2, :3].reshape(B, ncam, 6), ia[:, :, :2, 3]], dim=-1)
     return out.float().reshape(B * ncam, 20)
 
@@ -347,24 +376,51 @@ def msda(value, offsets, logits, ref, B, Q, nhead, hd, npts, H, W):
     return out
 
 
+class MultiScaleDeformableAttnFunction(torch.autograd.Function):
+    """MultiScaleDeformableAttnFunction_fp32 (multi_scale_deformable_attn_function.py:90-163) over the two native ops with
+    mmcv's argument lists: forward = isf_ms_deform_attn_forward, backward = isf_ms_deform_attn_backward (grad_value,
+    grad_sampling_loc, grad_attn_weight zero-filled here and accumulated by the kernel, as the reference does :142-160)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+        _lib.require_cuda(value, sampling_locations, attention_weights)
+        v = value.float().contiguous()
+        loc, aw = sampling_locations.float().contiguous(), attention_weights.float().contiguous()
+        ss = spatial_shapes.to(v.device).long().contiguous()
+        ls = level_start_index.to(v.device).long().contiguous()
+        B, S, M, D = v.shape
+        Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        assert tuple(loc.shape) == (B, Q, M, L, P, 2) and tuple(aw.shape) == (B, Q, M, L, P) and ss.shape == (L, 2)
+        out = torch.empty((B, Q, M * D), dtype=torch.float32, device=v.device)
+        _lib.check(_lib.load().isf_ms_deform_attn_forward(_lib.ptr(v), _lib.ptr(ss), _lib.ptr(ls), _lib.ptr(loc),
+                                                          _lib.ptr(aw), B, S, M, D, Q, L, P, _lib.ptr(out),
+                                                          _lib.stream()), "isf_ms_deform_attn_forward")
+        ctx.save_for_backward(v, ss, ls, loc, aw)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, grad_output):
+        v, ss, ls, loc, aw = ctx.saved_tensors
+        B, S, M, D = v.shape
+        Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        go = grad_output.float().contiguous()
+        gv, gl, gw = torch.zeros_like(v), torch.zeros_like(loc), torch.zeros_like(aw)
+        _lib.check(_lib.load().isf_ms_deform_attn_backward(_lib.ptr(v), _lib.ptr(ss), _lib.ptr(ls), _lib.ptr(loc),
+                                                           _lib.ptr(aw), _lib.ptr(go), B, S, M, D, Q, L, P, _lib.ptr(gv),
+                                                           _lib.ptr(gl), _lib.ptr(gw), _lib.stream()),
+                   "isf_ms_deform_attn_backward")
+        return gv, None, None, gl, gw
+
+
 def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
-    """MultiScaleDeformableAttnFunction.forward with mmcv's argument list
-    (multi_scale_deformable_attn_function.py:84-128; im2col_step has no counterpart): value [B, S, M, D],
+    """MultiScaleDeformableAttnFunction.apply with mmcv's argument list
+    (multi_scale_deformable_attn_function.py:84-163; im2col_step has no counterpart): value [B, S, M, D],
     spatial_shapes [L, 2] long (h, w), level_start_index [L] long, sampling_locations [B, Q, M, L, P, 2],
-    attention_weights [B, Q, M, L, P] -> [B, Q, M*D]."""
-    _lib.require_cuda(value, sampling_locations, attention_weights)
-    v = value.float().contiguous()
-    loc, aw = sampling_locations.float().contiguous(), attention_weights.float().contiguous()
-    ss = spatial_shapes.to(v.device).long().contiguous()
-    ls = level_start_index.to(v.device).long().contiguous()
-    B, S, M, D = v.shape
-    Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
-    assert tuple(loc.shape) == (B, Q, M, L, P, 2) and tuple(aw.shape) == (B, Q, M, L, P) and ss.shape == (L, 2)
-    out = torch.empty((B, Q, M * D), dtype=torch.float32, device=v.device)
-    _lib.check(_lib.load().isf_ms_deform_attn_forward(_lib.ptr(v), _lib.ptr(ss), _lib.ptr(ls), _lib.ptr(loc), _lib.ptr(aw),
-                                                      B, S, M, D, Q, L, P, _lib.ptr(out), _lib.stream()),
-               "isf_ms_deform_attn_forward")
-    return out
+    attention_weights [B, Q, M, L, P] -> [B, Q, M*D]; differentiable in value, locations and weights."""
+    return MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
+                                                  attention_weights)
 
 
 def ingroup_indices(group_inds):
@@ -462,8 +518,21 @@ class WindowAttentionFunction(torch.autograd.Function):
 
 
 def _pos_embed(mod, xy):
-    """PositionEmbeddingLearned (fusion_encoder.py:173-189): stock Conv1d/BN1d stack on [B, N, 2] -> [B, N, E]"""
-    return mod.position_embedding_head(xy.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
+    """PositionEmbeddingLearned (fusion_encoder.py:173-189): Conv1d(k=1) / BN1d / ReLU / Conv1d(k=1) on [B, N, 2] ->
+    [B, N, E].  In eval mode the two kernel-size-1 convolutions are what they are -- two small GEMMs with the BN folded
+    (library GEMMs: K = 2 and K = E are far below the MFMA tile of the fused linear kernel) -- instead of four MIOpen
+    launches with layout transposes; training mode runs the stock modules (batch statistics)."""
+    seq = mod.position_embedding_head
+    if seq.training:
+        return seq(xy.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
+    from .norm import fold_bn
+    c1, bn, _, c2 = seq
+    scale, shift = fold_bn(bn)
+    w1 = c1.weight[:, :, 0] * scale[:, None]                               # [E, 2]
+    b1 = (c1.bias if c1.bias is not None else 0.0) * scale + shift
+    h = torch.relu(torch.addmm(b1, xy.reshape(-1, xy.shape[-1]).float(), w1.t()))
+    out = torch.addmm(c2.bias, h, c2.weight[:, :, 0].t()) if c2.bias is not None else h @ c2.weight[:, :, 0].t()
+    return out.view(*xy.shape[:-1], -1)
 
 
 def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
@@ -495,7 +564,10 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
                 oproj=PackedLinear(ca.output_proj.weight, ca.output_proj.bias),
                 l1=PackedLinear(l.linear1.weight, l.linear1.bias), l2=PackedLinear(l.linear2.weight, l.linear2.bias)))
     H, W = scene.shape[2:]
-    cell = c.setdefault(("cell_index", B, H * W), torch.arange(H * W, device=dev, dtype=torch.int32).repeat(B))
+    ck = ("cell_index", B, H * W)
+    if ck not in c:
+        c[ck] = torch.arange(H * W, device=dev, dtype=torch.int32).repeat(B)
+    cell = c[ck]
     # read channels-first inside the GEMM (no token copy) when the kernel's 4-row groups stay inside a sample
     scene = scene.float().contiguous() if (H * W) % 4 == 0 else to_tokens(scene.float())
     out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()

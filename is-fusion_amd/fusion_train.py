@@ -16,6 +16,12 @@ The reference does the same composition with torch modules (sst_basic_block_v2.p
 :560-600, :795-830).  Mixed precision: bf16 / fp16 inputs are accepted and promoted -- the kernels compute fp32-class
 (>= the reference's autocast arithmetic); gradients come back in the input dtype.
 
+Training-time stochastic ops of the reference: the residual / feed-forward Dropouts (p = 0.1) of
+DeformableTransformerDecoderLayer (dropout1..4, fusion_encoder.py:604-668) and Instane2SceneAtt (:478, :492) and the
+Point-to-Grid `random_noise` jitter (:992-995) are applied in training mode.  NOT applied: the dropout on the attention
+PROBABILITIES inside the two nn.MultiheadAttention modules (:614, :476 -> :458) -- the flash-style HIP attention core
+never materialises the probability matrix; reproducing it needs an in-kernel random stream (not built).
+
 No CPU fallback: tensors must live on a GPU."""
 import torch
 import torch.nn.functional as F
@@ -57,16 +63,42 @@ class _PackedGrad(torch.autograd.Function):
         return g.contiguous()
 
 
+def _contiguous_inputs(mod, args):
+    return tuple(a.contiguous() if torch.is_tensor(a) else a for a in args)
+
+
+def _packed_output_grad(mod, args, out):
+    return _PackedGrad.apply(out) if mod.training else out
+
+
 def pack_stock_convs(module):
     """Stock Conv2d / ConvTranspose2d layers of the training path see packed tensors only: their inputs are made
     contiguous and so is the gradient arriving at their outputs.  The token-major HIP ops around them hand over
     permuted VIEWS ([B, H, W, C] storage seen as [B, C, H, W]), for which MIOpen falls back to its
-    `naive_conv_ab_nonpacked_*` kernels -- 20-40 ms per call, 80 % of a training step before this hook.  Idempotent."""
+    `naive_conv_ab_nonpacked_*` kernels -- 20-40 ms per call, 80 % of a training step before this hook.
+    Registered once per conv (module-level functions: the model stays picklable), handles kept in
+    `module._isf_conv_hooks`; `unpack_stock_convs` removes them.  The output hook is the identity in eval mode."""
+    if getattr(module, "_isf_convs_packed", False):
+        return module
+    handles = []
     for m in module.modules():
         if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) and not getattr(m, "_isf_packed_io", False):
-            m.register_forward_pre_hook(lambda mod, args: tuple(a.contiguous() if torch.is_tensor(a) else a for a in args))
-            m.register_forward_hook(lambda mod, args, out: _PackedGrad.apply(out))
+            handles.append(m.register_forward_pre_hook(_contiguous_inputs))
+            handles.append(m.register_forward_hook(_packed_output_grad))
             m._isf_packed_io = True
+    module.__dict__["_isf_conv_hooks"] = handles
+    module.__dict__["_isf_convs_packed"] = True
+    return module
+
+
+def unpack_stock_convs(module):
+    """remove the hooks of pack_stock_convs (e.g. before exporting an inference model)"""
+    for h in module.__dict__.pop("_isf_conv_hooks", []):
+        h.remove()
+    for m in module.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            m.__dict__.pop("_isf_packed_io", None)
+    module.__dict__["_isf_convs_packed"] = False
     return module
 
 
@@ -169,8 +201,11 @@ class P2GFunction(torch.autograd.Function):
         return (gi.permute(0, 3, 1, 2).to(ctx.in_dtype),) + (None,) * 7
 
 
-def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, input_shape, bs, bev, num_cam=6):
-    cam = ops.p2g_camera_params(lidar2img, img_aug, lidar_aug).to(img_feat.device)
+def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, input_shape, bs, bev, num_cam=6,
+               noise=None):
+    """noise: per-sample camera-frame offsets of the reference's training-time `random_noise` jitter
+    (fusion_encoder.py:992-995; ISFusionEncoder.forward_train draws them), or None"""
+    cam = ops.p2g_camera_params(lidar2img, img_aug, lidar_aug, noise).to(img_feat.device)
     return P2GFunction.apply(img_feat, pillars, pillar_coors, cam, tuple(input_shape), bs, bev, num_cam)
 
 
@@ -229,16 +264,19 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
     for l in mod.layers:
         ca = l.cross_attn
         nhead, npts = ca.n_heads, ca.n_points
+        p, tr = getattr(l, "dropout", 0.0), l.training      # dropout1..4 of the reference layer (:604-668, p = 0.1)
         qk_in = out + qpe
-        out = F.layer_norm(out + _mha(qk_in, qk_in, out, l.self_attn, B, Q, Q, nhead), (E,), l.norm2.weight, l.norm2.bias,
-                           l.norm2.eps)
+        out = F.layer_norm(out + F.dropout(_mha(qk_in, qk_in, out, l.self_attn, B, Q, Q, nhead), p, tr), (E,),
+                           l.norm2.weight, l.norm2.bias, l.norm2.eps)                                       # dropout2
         q = out + qpe
         value = linear(src, ca.value_proj)
         off, aw = linear(q, ca.sampling_offsets), linear(q, ca.attention_weights)
         t2 = ops.MSDAFunction.apply(value.view(B, H * W, E), off, aw, ref, B, Q, nhead, E // nhead, npts, H, W)
-        out = F.layer_norm(out + linear(t2, ca.output_proj), (E,), l.norm1.weight, l.norm1.bias, l.norm1.eps)
-        h = F.relu(linear(out, l.linear1))
-        out = F.layer_norm(out + linear(h, l.linear2), (E,), l.norm3.weight, l.norm3.bias, l.norm3.eps)
+        out = F.layer_norm(out + F.dropout(linear(t2, ca.output_proj), p, tr), (E,), l.norm1.weight, l.norm1.bias,
+                           l.norm1.eps)                                                                     # dropout1
+        h = F.dropout(F.relu(linear(out, l.linear1)), p, tr)                                                # dropout3
+        out = F.layer_norm(out + F.dropout(linear(h, l.linear2), p, tr), (E,), l.norm3.weight, l.norm3.bias,
+                           l.norm3.eps)                                                                     # dropout4
     return out.view(B, Q, E).transpose(1, 2).contiguous()
 
 
@@ -249,6 +287,7 @@ def instance_to_scene(mod, query, x_ins, scene_feats, bev_size):
     Q = x_ins.size(2)
     xq = ops.to_tokens(query.float())
     xk = x_ins.float().transpose(1, 2).reshape(B * Q, E)
-    y = F.layer_norm(xq + _mha(xq, xk, xk, mod.multihead_attn, B, H * W, Q, mod.nhead), (E,), mod.norm.weight,
-                     mod.norm.bias, mod.norm.eps)
+    att = F.dropout(_mha(xq, xk, xk, mod.multihead_attn, B, H * W, Q, mod.nhead), getattr(mod, "dropout", 0.0),
+                    mod.training)                                               # self.dropout (:478, :492)
+    y = F.layer_norm(xq + att, (E,), mod.norm.weight, mod.norm.bias, mod.norm.eps)
     return ChannelAttentionFunction.apply(scene_feats, ops.from_tokens(y, B, H, W))

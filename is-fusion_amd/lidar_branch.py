@@ -84,14 +84,17 @@ class LidarBranch(nn.Module):
         return self
 
     def freeze(self, flag=True):
-        """Skip the per-call parameter-change scans (weights are static at inference)."""
-        self.pts_middle_encoder.freeze(flag)
+        """Skip the per-call parameter-change scans (weights are static at inference).  Ends by itself on a
+        load_state_dict below this module or a forward in training mode (fusion_ops.freeze / frozen)."""
+        from . import fusion_ops as ops
         self._frozen = bool(flag)
+        ops.freeze(self, flag)
         return self
 
     def _vfe_params(self):
         vfe = self.pts_voxel_encoder
-        if getattr(self, "_frozen", False) and self._vfe_cache is not None:
+        from .fusion_ops import frozen
+        if self._vfe_cache is not None and getattr(self, "_frozen", False) and frozen(self):
             return self._vfe_cache
         key = tuple((p._version, p.data_ptr()) for p in list(vfe.parameters()) + list(vfe.buffers()))
         if self._vfe_cache is not None and self._vfe_key == key:
@@ -123,16 +126,19 @@ class LidarBranch(nn.Module):
         vf, vc = self.pts_voxel_encoder(pts[keep].float(), coors[keep])
         return self.pts_middle_encoder.forward_modules(vf, vc, len(points))[0]
 
-    def forward(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0):
+    def forward(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0, stage_rows=0,
+                stage_mask=0):
         """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W].
         precision: 0 = f16x3 split MFMA (default, fp32-class), 1 = fp32 MFMA kernels, 2 = single-pass f16 (opt-in,
-        fp16-autocast accuracy); conv_diag: timing diagnostics of the conv kernels (results garbage except 16)."""
+        fp16-autocast accuracy); conv_diag: timing diagnostics of the conv kernels (results garbage except 16);
+        stage_rows / stage_mask: LDS staging of the conv input rows (isf_encoder_options; 0 = library default)."""
         if self.training:
             return self.forward_train(points)
         with torch.no_grad():
-            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag)
+            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag, stage_rows, stage_mask)
 
-    def forward_eval(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0):
+    def forward_eval(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0, stage_rows=0,
+                     stage_mask=0):
         pts = torch.cat(points, dim=0).contiguous().float()
         _lib.require_cuda(pts)
         vfe = self.pts_voxel_encoder
@@ -158,7 +164,7 @@ class LidarBranch(nn.Module):
         _lib.check(lib.isf_lidar_branch_forward(
             _lib.ptr(pts), (ctypes.c_int64 * len(offs))(*offs), B, ctypes.byref(vp), _lib.i3(me.sparse_shape),
             arr, n, _lib.ptr(out), oshape, ctypes.byref(stats) if stats is not None else None,
-            int(bool(time_layers)), _lib.encoder_options(precision, conv_diag), _lib.stream()),
+            int(bool(time_layers)), _lib.encoder_options(precision, conv_diag, stage_rows, stage_mask), _lib.stream()),
             "isf_lidar_branch_forward")
         self.last_stats = stats
         return out

@@ -142,13 +142,17 @@ class SparseEncoder(nn.Module):
         return dict(sparse_shape=plan["sparse_shape"], layers=out)
 
     def freeze(self, flag=True):
-        """Inference deployments: skip the per-call "did a parameter change?" scan (about 130 tensors)."""
+        """Inference deployments: skip the per-call "did a parameter change?" scan (about 130 tensors).  Ends by itself
+        on a load_state_dict below this module or a forward in training mode (fusion_ops.freeze / frozen)."""
+        from . import fusion_ops as ops
         self._frozen = bool(flag)
+        ops.freeze(self, flag)
         return self
 
     def _c_plan(self):
         """ctypes array of isf_conv_layer, rebuilt when a parameter / buffer changed."""
-        if self._frozen and self._plan is not None:
+        from .fusion_ops import frozen
+        if self._plan is not None and self._frozen and frozen(self):
             return self._plan
         key = tuple((p._version, p.data_ptr()) for p in list(self.parameters()) + list(self.buffers()))
         if self._plan is not None and self._plan_key == key:
@@ -198,7 +202,7 @@ class SparseEncoder(nn.Module):
 
     # ------------------------------------------------------------------------------------ forward
     def forward_fused(self, voxel_features, coors, batch_size, stats=None, time_layers=False, precision=0,
-                      conv_diag=0):
+                      conv_diag=0, stage_rows=0, stage_mask=0):
         """precision: 0 = f16x3 split MFMA (default), 1 = fp32 MFMA, 2 = single-pass f16 (opt-in, fp16-autocast
         accuracy); conv_diag: timing diagnostics of the conv kernels (include/isf_hip.h) -- per call, no global state"""
         _lib.require_cuda(voxel_features, coors)
@@ -212,7 +216,8 @@ class SparseEncoder(nn.Module):
             _lib.ptr(vf), _lib.ptr(vc),
             voxel_features.size(0), int(batch_size), _lib.i3(self.sparse_shape), arr, n, _lib.ptr(out), oshape,
             ctypes.byref(stats) if stats is not None else None, int(bool(time_layers)),
-            _lib.encoder_options(precision, conv_diag), _lib.stream()), "isf_sparse_encoder_forward")
+            _lib.encoder_options(precision, conv_diag, stage_rows, stage_mask), _lib.stream()),
+            "isf_sparse_encoder_forward")
         assert (oshape[0], oshape[1], oshape[2]) == (cd, H, W)
         return out
 

@@ -185,6 +185,40 @@ def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None
     return from_split(ys, (rb.num_out, c_out))
 
 
+def stage_tables(rb):
+    """(slots uint16 [K, stride], ulist int32 [stride / 64, cap], ucount int32 [stride / 64]) of a Rulebook
+    (isf_rulebook_stage_tables), cached on it: the distinct input rows of every 64-row unit and where each table entry
+    sits in that list -- what the LDS-staged conv kernel copies once per tile."""
+    if getattr(rb, "_stage", None) is None:
+        lib = _lib.load()
+        K = rb.nbr.numel() // rb.stride
+        units = rb.stride // lib.isf_stage_unit_rows()
+        dev = rb.nbr.device
+        slots = torch.empty((K, rb.stride), dtype=torch.int16, device=dev)
+        ulist = torch.empty((units, lib.isf_stage_unit_cap()), dtype=torch.int32, device=dev)
+        ucount = torch.empty((units,), dtype=torch.int32, device=dev)
+        _lib.check(lib.isf_rulebook_stage_tables(_lib.ptr(rb.nbr), rb.stride, K, _lib.ptr(slots), _lib.ptr(ulist),
+                                                 _lib.ptr(ucount), _lib.stream()), "isf_rulebook_stage_tables")
+        rb._stage = (slots, ulist, ucount)
+    return rb._stage
+
+
+def sparse_conv_forward_staged(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
+                               relu=False, stage_rows=512, mode=0):
+    """sparse_conv_forward_f16x3 with the tile's input rows staged in LDS (isf_sparse_conv_forward_staged)."""
+    _lib.require_cuda(features)
+    xs = to_split(features)
+    rs = to_split(residual) if residual is not None else None
+    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)
+    slots, ulist, ucount = stage_tables(rb)
+    lib = _lib.load()
+    _lib.check(lib.isf_sparse_conv_forward_staged(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(slots), rb.stride, _lib.ptr(ulist),
+        _lib.ptr(ucount), rb.num_out, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys),
+        int(stage_rows), int(mode), _lib.stream()), "isf_sparse_conv_forward_staged")
+    return from_split(ys, (rb.num_out, c_out))
+
+
 def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False):
     """isf_sparse_conv_forward_packed wrapper (conv + optional folded BN / residual / ReLU)."""
     _lib.require_cuda(features)

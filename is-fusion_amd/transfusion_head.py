@@ -120,6 +120,7 @@ class TransFusionHeadV2(nn.Module):
         if "shared" not in c:
             c["shared"] = PackedConvBN(self.shared_conv, None, relu=False)
             c["hm0"] = PackedConvBN(self.heatmap_head[0].conv, self.heatmap_head[0].bn, relu=True)
+            c["hm1"] = PackedConvBN(self.heatmap_head[1], None, relu=False)   # 128 -> 10 (columns zero-padded to 32)
             bev_pos = self._bev_pos(device)
             c["bev_pos"] = bev_pos
             c["layers"] = []
@@ -203,10 +204,9 @@ class TransFusionHeadV2(nn.Module):
             dev = m0.data.device
             c = self._packed(dev)
             feat = c["shared"](maps_yx, transpose=True)                            # SplitMap of M: token (b, y, x)
-            hm_mid = c["hm0"](feat, transpose=True).to_nchw()                      # [B, E, H, W]
+            hm_mid = c["hm0"](feat, transpose=True)                                # SplitMap [B, E, H, W]
             feat_tok = from_split(feat.data, (B * HW, E))
-            h1 = self.heatmap_head[1]
-            dense_heatmap = torch.nn.functional.conv2d(hm_mid, h1.weight.transpose(2, 3), h1.bias, 1, 1)
+            dense_heatmap = c["hm1"](hm_mid, transpose=True).to_nchw(self.heatmap_head[1].out_channels)
             dense_heatmap = dense_heatmap.permute(0, 1, 3, 2).contiguous()         # [B, classes, X, Y]
             key = ("tok_of_cell", X, Y)
             if key not in c:
@@ -223,13 +223,12 @@ class TransFusionHeadV2(nn.Module):
                 maps = [SplitMap.from_nchw(inputs, off, min(256, inputs.size(1) - off))
                         for off in range(0, inputs.size(1), 256)]
                 feat = c["shared"](maps)                                          # SplitMap [B, E, X, Y]
-                hm_mid = c["hm0"](feat).to_nchw()
+                dense_heatmap = c["hm1"](c["hm0"](feat)).to_nchw(self.heatmap_head[1].out_channels).contiguous()
                 feat_tok = from_split(feat.data, (B * HW, E))                     # token-major fp32
             else:
                 lidar_feat = self.shared_conv(inputs)
-                hm_mid = self.heatmap_head[0](lidar_feat)
+                dense_heatmap = self.heatmap_head[1](self.heatmap_head[0](lidar_feat))
                 feat_tok = ops.to_tokens(lidar_feat)
-            dense_heatmap = self.heatmap_head[1](hm_mid)
         pool1 = (8, 9) if self.test_cfg["dataset"] == "nuScenes" else (1, 2)
         top_index, top_raw, masked = ops.instance_topk(dense_heatmap, self.num_proposals, self.nms_kernel_size, pool1,
                                                        return_masked=True)

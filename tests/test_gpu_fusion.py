@@ -382,6 +382,35 @@ def test_ms_deform_attn_with_the_mmcv_signature(dev, B, Q, M, D, shapes, P):
     ref = orc.msda_core(value, ss, loc, aw)
     assert out.shape == ref.shape == (B, Q, M * D)
     assert (out - ref).abs().max().item() < 5e-5
+    # isf_ms_deform_attn_backward (the op's own contract: caller-zeroed gradients) vs autograd through the restatement
+    v64, l64, a64 = (t.double().requires_grad_() for t in (value, loc, aw))
+    gout = rnd((B, Q, M * D), 162)
+    orc.msda_core(v64, ss, l64, a64).backward(gout.double())
+    vd, ld, ad = (t.to(dev).requires_grad_() for t in (value, loc, aw))
+    ops.ms_deform_attn(vd, ss.to(dev), ls.to(dev), ld, ad).backward(gout.to(dev))
+    for got, want in ((vd.grad, v64.grad), (ld.grad, l64.grad), (ad.grad, a64.grad)):
+        assert (got.cpu().double() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("name,B,Q,H", [("small", 1, 20, 12), ("edge", 2, 16, 7)])
+def test_ms_deform_attn_backward_op_vs_reference_autograd_golden(dev, golden, name, B, Q, H):
+    """isf_ms_deform_attn_backward called as the reference calls ext_module.ms_deform_attn_backward
+    (multi_scale_deformable_attn_function.py:150-160) vs tests/golden/msda_grad_ref.npz = autograd through the REFERENCE's
+    own pure-torch core (ms_deform_attn_core_pytorch), in the op's own layouts"""
+    from fusion_common import msda_grad_inputs
+    from isfusion_amd import fusion_ops as ops
+    g = golden("msda_grad_ref.npz")
+    value, loc, aw, gout = msda_grad_inputs(B, Q, H)
+    ss = torch.tensor([[H, H]], dtype=torch.long)
+    ls = torch.zeros((1,), dtype=torch.long)
+    vd, ld, ad = (t.float().to(dev).requires_grad_() for t in (value, loc, aw))
+    out = ops.ms_deform_attn(vd, ss.to(dev), ls.to(dev), ld, ad)
+    assert np.abs(out.detach().cpu().numpy() - g[name + ".out"]).max() < 5e-5
+    out.backward(gout.float().to(dev))
+    for got, key in ((vd.grad, "grad_value"), (ld.grad, "grad_loc"), (ad.grad, "grad_weight")):
+        want = g[f"{name}.{key}"]
+        assert got.shape == want.shape
+        assert np.abs(got.cpu().numpy() - want).max() < 1e-4 * max(1.0, np.abs(want).max()), key
 
 
 @pytest.mark.parametrize("n,groups,seed", [(1, 1, 0), (5000, 37, 1), (129600, 3844, 2), (777, 5, 3)])

@@ -271,6 +271,86 @@ def test_sparse_conv_f16x3_split_precision_vs_oracle(dev, oracle_mod, cin, cout)
         assert (y >= 0).all()
 
 
+def _random_geometry(rng, B, shape, n):
+    cells = B * int(np.prod(shape))
+    lin = np.sort(rng.choice(cells, n, replace=False))
+    D, H, W = shape
+    return np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+
+
+def test_stage_tables_reconstruct_the_neighbour_table(dev):
+    """isf_rulebook_stage_tables: per 64-row unit the distinct input rows (ascending) and, per table entry, its position
+    in that list -- ulist[unit(o)][slots[k][o]] == nbr[k][o] wherever nbr >= 0, 0xFFFF elsewhere (rows past num_out too)."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(21)
+    B, shape = 2, [9, 40, 36]
+    idx = _random_geometry(rng, B, shape, 5000)
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                             (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+        rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+        slots, ulist, ucount = (t.cpu().numpy() for t in sp.stage_tables(rb))
+        nbr = rb.nbr.cpu().numpy()
+        slots = slots.view(np.uint16)
+        K, stride = nbr.shape
+        assert slots.shape == (K, stride) and ulist.shape[0] == stride // 64 == ucount.shape[0]
+        for u in range(stride // 64):
+            blk = nbr[:, u * 64:(u + 1) * 64]
+            want = np.unique(blk[blk >= 0])
+            assert ucount[u] == want.size and np.array_equal(ulist[u, :want.size], want), u
+            sl = slots[:, u * 64:(u + 1) * 64]
+            assert np.array_equal(sl == 0xFFFF, blk < 0)
+            assert np.array_equal(ulist[u][sl[blk >= 0].astype(np.int64)], blk[blk >= 0])
+        assert (nbr[:, rb.num_out:] < 0).all()
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 256),
+                                      (256, 256)])
+def test_staged_conv_bit_identical_to_gather_kernel(dev, cin, cout):
+    """LDS-staged input rows (isf_sparse_conv_forward_staged) == the gather kernel, bit for bit: same products, same
+    order.  Small LDS budgets exercise the fall-back gathers of list entries beyond a unit's share, 1 << 20 the clamp
+    to what 160 KiB hold; 5000 rows over 8 XCD parts give full and half tiles and part ends inside a tile."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin * 11 + cout)
+    B, shape = 2, [9, 40, 36]
+    idx = _random_geometry(rng, B, shape, 5000)
+    feats = rng.normal(0, 1, (5000, cin)).astype(np.float32)
+    for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                             (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+        K = int(np.prod(ks))
+        w = rng.normal(0, (1.0 / (6 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32)
+        scale = T(rng.random(cout, dtype=np.float32) + 0.5, dev)
+        shift = T(rng.normal(0, 0.2, cout).astype(np.float32), dev)
+        rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+        res = T(rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32), dev)
+        p16 = sp.pack_filters_f16x3(T(w, dev))
+        x = T(feats, dev)
+        for mode in (0, 1, 32):
+            ref = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, scale, shift, res, relu=True, mode=mode)
+            assert ref.abs().max() > 0.5
+            for rows in (32, 96, 256, 1 << 20):
+                got = sp.sparse_conv_forward_staged(x, p16, K, cin, cout, rb, scale, shift, res, relu=True,
+                                                    stage_rows=rows, mode=mode)
+                assert torch.equal(got, ref), (cin, cout, subm, mode, rows, (got - ref).abs().max().item())
+
+
+def test_staged_conv_large_level_and_wide_tiles(dev):
+    """the 8-wave / 256-row tile shape (128 output columns on a level of >= 2048 rows) and a dense cluster whose units
+    list more rows than any LDS share"""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(5)
+    B, shape = 1, [12, 48, 48]
+    idx = _random_geometry(rng, B, shape, 12000)      # 43 % occupancy: ~12 neighbours per voxel
+    for cin, cout in ((128, 128), (64, 128), (32, 32)):
+        feats = T(rng.normal(0, 1, (12000, cin)).astype(np.float32), dev)
+        w = rng.normal(0, (1.0 / (12 * cin)) ** 0.5, (3, 3, 3, cin, cout)).astype(np.float32)
+        rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+        p16 = sp.pack_filters_f16x3(T(w, dev))
+        ref = sp.sparse_conv_forward_f16x3(feats, p16, 27, cin, cout, rb)
+        for rows in (64, 640, 1 << 20):
+            got = sp.sparse_conv_forward_staged(feats, p16, 27, cin, cout, rb, stage_rows=rows)
+            assert torch.equal(got, ref), (cin, cout, rows)
+
+
 def test_split_format_roundtrip(dev):
     from isfusion_amd import spconv as sp
     x = torch.randn(1000, 64, device=dev) * torch.logspace(-6, 4, 64, device=dev)
@@ -413,6 +493,22 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         assert torch.isfinite(got).all() and got.abs().max().item() > 0.1
         assert torch.equal(got, want), n
         assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
+
+
+def test_lidar_branch_with_lds_staged_convs_reproduces_gather_bits(dev):
+    """every conv of the LiDAR branch on the LDS-staged kernel (isf_encoder_options.stage_rows; staging tables built on
+    the geometry stream) == the gather kernels, bit for bit: small LDS shares (fall-back gathers inside every tile), a
+    generous one, a layer subset (tables built late for a level whose first conv ran unstaged), and the staging-off switch"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(800 + i, n), dev) for i in range(frames)]
+        want = lb(pl, stage_rows=-1)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        assert torch.equal(lb(pl), want), n                     # library default
+        for rows, mask in ((64, 0), (448, 0), (1 << 20, 0), (320, 0b101010101010101010100)):
+            assert torch.equal(lb(pl, stage_rows=rows, stage_mask=mask), want), (n, rows, mask)
 
 
 def test_concurrent_streams_have_independent_workspaces(dev):

@@ -75,13 +75,75 @@ def test_p2g_backward_matches_autograd_of_the_restatement(dev):
     assert rel_err(img_g.grad, img.grad) < 1e-3
 
 
-def _frozen_bn_train(mod):
-    """training mode with frozen BatchNorm statistics (the oracle restates eval-mode BN)"""
+def _frozen_bn_train(mod, stochastic=False):
+    """training mode with frozen BatchNorm statistics (the oracle restates eval-mode BN) and, unless asked for, without
+    the reference's stochastic training ops (residual dropouts p = 0.1, Point-to-Grid random_noise): the oracle
+    comparison is deterministic"""
     mod.train()
     for m in mod.modules():
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
             m.eval()
+        if not stochastic:
+            if isinstance(getattr(m, "dropout", None), float):
+                m.dropout = 0.0
+            if hasattr(m, "random_noise"):
+                m.random_noise = None
     return mod
+
+
+def test_training_mode_applies_the_reference_dropouts_and_p2g_noise(dev):
+    """ISFusionEncoder.forward_train: DeformableTransformerDecoderLayer.dropout1..4 and Instane2SceneAtt.dropout
+    (fusion_encoder.py:604-668, :478-492; p = 0.1) and the random_noise jitter of the camera-frame points (:992-995)
+    are live in training mode: two calls differ, a re-seeded call repeats, and with both switched off the training
+    forward equals itself call after call"""
+    import random
+    cfg = CONFIGS["small"]
+    enc, bb = build_modules(cfg, dev)
+    t = torch_inputs(cfg)
+    B = cfg["B"]
+
+    def run():
+        feats, _ = enc((t["img_feats"][0].to(dev), t["img_feats"][1].to(dev)), t["lidar_feats"].to(dev), B,
+                       pts_metas=dict(pillars=t["pillars"].to(dev), pillar_coors=t["pillar_coors"].to(dev)),
+                       img_metas=[dict(input_shape=t["input_shape"])], pts_backbone=bb, lidar2img=t["lidar2img"],
+                       img_aug_matrix=t["img_aug_matrix"], lidar_aug_matrix=t["lidar_aug_matrix"])
+        return feats[0].detach().clone()
+
+    def seed(v):
+        torch.manual_seed(v); np.random.seed(v); random.seed(v)
+
+    _frozen_bn_train(enc, stochastic=True)
+    _frozen_bn_train(bb, stochastic=True)
+    assert enc.random_noise == 1.0 and enc.instance_to_scene_att.dropout == 0.1
+    assert all(l.dropout == 0.1 for l in enc.instance_att.layers)
+    run()                       # warm-up: the stock convolutions pick their algorithm on the first call
+    scale = run().abs().max().item()
+
+    # "same" up to the rounding of the stock (MIOpen) convolutions, "differs" by far more than that
+    def same(x, y):
+        return (x - y).abs().max().item() < 1e-4 * scale
+
+    def differs(x, y):
+        return (x - y).abs().max().item() > 1e-2 * scale
+
+    seed(1); a = run()
+    seed(2); b = run()
+    seed(1); c = run()
+    assert torch.isfinite(a).all() and differs(a, b) and same(a, c)
+    # only the dropouts (noise off): still stochastic; only the noise (dropouts off): the projection moves
+    enc.random_noise = None
+    seed(3); d = run()
+    seed(4); e = run()
+    assert differs(d, e)
+    _frozen_bn_train(enc)   # both off
+    seed(5); f = run()
+    seed(6); g = run()
+    assert same(f, g)
+    enc.random_noise = 1.0
+    outs = []
+    for v in range(7, 13):      # the jitter fires with probability 1/2 per sample
+        seed(v); outs.append(run())
+    assert any(differs(o, f) for o in outs)
 
 
 def test_fusion_encoder_parameter_gradients_match_oracle_autograd(dev):
@@ -185,10 +247,14 @@ def test_whole_path_training_step(dev, cam_dtype, autocast):
 
 
 def test_sync_bn_and_gradient_allreduce_over_rccl_world1(dev):
-    """naiveSyncBN statistics exchange and a DDP gradient all-reduce on the RCCL backend with a single rank (the GPU box
-    has one device; the world-2 exchange is covered on gloo by tests/test_host.py): the collective path executes."""
+    """naiveSyncBN's statistics exchange (`norm._sync_bn`: ONE all_reduce of [2C], forward and backward) and a DDP
+    gradient all-reduce EXECUTED on the RCCL backend with a single rank -- the GPU box has one device; the world-2
+    exchange is covered on gloo by tests/test_host.py.  The module's own forward skips the exchange when world_size
+    is 1 (norm.py `_needs_sync`, as the reference does, ops/norm.py:173-175), so `_sync_bn` is called directly here:
+    with one rank its result must equal plain batch-statistics BN, gradients included."""
     import os
     import torch.distributed as dist
+    from isfusion_amd import norm
     from isfusion_amd.norm import NaiveSyncBatchNorm1d as naiveSyncBN1d
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -197,7 +263,18 @@ def test_sync_bn_and_gradient_allreduce_over_rccl_world1(dev):
         bn = naiveSyncBN1d(16).to(dev).train()
         x = torch.randn(64, 16, device=dev)
         ref = torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
+        assert not norm._needs_sync(bn)                      # world size 1: the module takes the plain-BN path
         assert (bn(x) - ref).abs().max().item() < 1e-5
+        # the collective path itself, over RCCL
+        xs = x.clone().requires_grad_()
+        xr = x.clone().requires_grad_()
+        y = norm._sync_bn(bn, xs, (0,))
+        yr = torch.nn.functional.batch_norm(xr, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
+        assert (y - yr).abs().max().item() < 1e-5
+        g = torch.randn_like(y)
+        y.backward(g)
+        yr.backward(g)
+        assert (xs.grad - xr.grad).abs().max().item() < 1e-5
         lin = torch.nn.parallel.DistributedDataParallel(torch.nn.Linear(16, 4).to(dev), device_ids=[dev.index])
         lin(x).sum().backward()
         assert lin.module.weight.grad is not None and torch.isfinite(lin.module.weight.grad).all()

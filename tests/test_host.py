@@ -276,7 +276,7 @@ def test_parameter_changes_invalidate_packed_weight_caches():
         break
     assert "linear0" not in ops._cache(sub, dev)
     ops._cache(sub, dev)["linear0"] = "kept"
-    ops.freeze(sub)
+    ops.freeze(sub.eval())                                  # an inference-deployment switch: eval mode
     with torch.no_grad():
         next(sub.parameters()).mul_(1.0)
     assert ops._cache(sub, dev).get("linear0") == "kept"    # frozen: no scan
@@ -441,3 +441,45 @@ def test_training_helpers_chunked_weight_grad_and_packed_conv_io():
     mid2.register_hook(see_grad)
     (mid2 * 1.0).backward(w)
     assert seen["grad_contig"] is False                                                   # what the guard is for
+
+
+def test_pow2_rescale_keeps_non_finite_entries_local():
+    """_lib.pow2_rescale (gradient range shift in front of the f16x3 dX GEMMs): exact power-of-two scale from the largest
+    finite entry; one inf no longer zeroes the scale (g * 0 / 0 made the whole dX tensor NaN)"""
+    import torch
+    from isfusion_amd import _lib
+    g = torch.tensor([[1e-7, -3e-6], [2e-9, 5e-8]])
+    gs, s = _lib.pow2_rescale(g)
+    assert float(torch.log2(s)) == round(float(torch.log2(s))) and 512 <= gs.abs().max().item() <= 1024
+    assert torch.equal(gs / s, g)
+    g2 = g.clone()
+    g2[0, 0] = float("inf")
+    gs2, s2 = _lib.pow2_rescale(g2)
+    assert torch.isfinite(s2) and s2.item() > 0
+    back = gs2 / s2
+    assert torch.isinf(back[0, 0]) and torch.equal(back[1], g[1]) and back[0, 1] == g[0, 1]
+    gs3, s3 = _lib.pow2_rescale(torch.zeros(3, 3))
+    assert torch.isfinite(s3) and torch.equal(gs3, torch.zeros(3, 3))
+
+
+def test_freeze_ends_when_weights_can_change():
+    """fusion_ops.freeze skips the per-call parameter scans of the packed-weight caches; a load_state_dict anywhere below
+    the frozen module, or a forward in training mode, must end the skip (stale packed weights survived both)"""
+    import torch
+    from isfusion_amd import fusion_ops as ops
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Sequential(torch.nn.Linear(4, 4))).eval()
+    ops.freeze(net)
+    assert all(ops.frozen(m) for m in net.modules())
+    c0 = ops._cache(net[0], torch.device("cpu"))
+    with torch.no_grad():
+        net[0].weight.add_(1.0)
+    assert ops._cache(net[0], torch.device("cpu")) is c0            # frozen: the scan is skipped (documented contract)
+    net[1].load_state_dict(net[1].state_dict())                     # weights (re)loaded somewhere below the root
+    assert not any(ops.frozen(m) for m in net.modules())
+    assert ops._cache(net[0], torch.device("cpu")) is not c0        # re-validated by key: the stale cache is dropped
+    ops.freeze(net)
+    net.train()
+    assert not ops.frozen(net[0]) and not ops.frozen(net[0].eval())  # seen in training mode: stays unfrozen after eval()
+    import pickle
+    pickle.dumps(net)                                               # hooks are module-level functions
+

@@ -5,9 +5,9 @@ all-reduce over xGMI on the GRADIENTS only -- the forward has no collective):
         tools/train_step.py [--batch 2] [--points 60000] [--steps 3] [--bf16] [--autocast]
 
 One process per GPU; every rank draws its own synthetic frames.  The module is wrapped in DistributedDataParallel
-(bucketed gradient all-reduce overlapped with the backward); BatchNorm layers use the batch statistics of the local
-shard, or the cross-rank statistics with --sync-bn (isfusion_amd.norm.NaiveSyncBatchNorm: one all_reduce of [2C] per
-layer, the reference's naiveSyncBN).  The loss is a stand-in (feature energy + heat-map mean): the detection losses and
+(bucketed gradient all-reduce overlapped with the backward); the path's BatchNorm layers are the config's:
+isfusion_amd.norm.NaiveSyncBatchNorm where the reference uses naiveSyncBN (cross-rank statistics, one all_reduce of
+[2C] per layer, whenever the world size is > 1), plain BatchNorm (local-shard statistics) elsewhere.  The loss is a stand-in (feature energy + heat-map mean): the detection losses and
 target assignment are the reference's training control plane.  Prints one JSON line per rank 0 with ms per step.
 Also runs on a single GPU without torchrun (world size 1)."""
 import argparse
