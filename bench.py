@@ -92,9 +92,9 @@ def pmc_traffic(cin, cout):
     return None
 
 
-def conv_layer_bytes_flops(kind, cin, cout, K, n_in, n_out, pairs):
-    """SURVEY.md section 8d algorithmic (compulsory) traffic of one sparse-conv layer, fp32."""
-    s = 4
+def conv_layer_bytes_flops(kind, cin, cout, K, n_in, n_out, pairs, s=4):
+    """SURVEY.md section 8d algorithmic (compulsory) traffic of one sparse-conv layer; s = bytes per element (4: fp32 /
+    split rows, 2: the f16 storage mode)."""
     by = n_in * cin * s + n_out * cout * s + pairs * 8 + K * cin * cout * s
     fl = 2.0 * pairs * cin * cout
     return by, fl
@@ -212,6 +212,9 @@ def fusion_leg(args, rank, world, dev, B, steps, warmup, with_cpu_baseline):
         mod.load_state_dict(seeded_state_dict(mod, seed))
     net = net.to(dev)
     net.freeze()              # inference deployment: weights are static, the caches skip their change scans
+    if args.graph:
+        net.enable_graph()    # everything behind Point-to-Grid replays as one HIP graph per batch size (measured: no
+                              # gain -- 7.95 vs 7.89 ms, profiles/r03_call10_graph.txt -- so off by default)
     sets = []
     for fs in range(max(1, args.frame_sets)):
         pts = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, B, args.points, 10 + fs)]
@@ -335,6 +338,9 @@ def fusion_leg(args, rank, world, dev, B, steps, warmup, with_cpu_baseline):
                           f"threads + torch-CPU restatement of HSF / IGF / SECONDV2 stages, full 180 x 180 grid, no neck / "
                           f"head) on 1 frame of {cp} points took {cdt:.2f} s",
                 "sample_seconds": round(cdt, 2)}
+        line["config"]["hip_graph"] = ("off" if not args.graph else
+                                       "ISFusionPtsPath.enable_graph(): conv_fusion .. head (shape-static per batch size) "
+                                       "captured once and replayed; LiDAR branch, pillar voxelization and Point-to-Grid eager")
         line["config"]["frozen_caches"] = ("net.freeze(): inference deployment, the packed-weight caches skip their "
                                            "per-call parameter-change scan (about 0.4 ms of host time per forward)")
         return line
@@ -361,6 +367,9 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true",
                     help="skip the BASELINE configs[2] leg the default run appends to the headline line as \"cfg3\"")
     ap.add_argument("--cfg3-steps", type=int, default=30)
+    ap.add_argument("--graph", action="store_true",
+                    help="config 3: replay the shape-static tail (conv_fusion .. head) as one HIP graph instead of ~330 "
+                         "eager launches")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
     ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48],
                     help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_encoder_options.diagnostic; "
@@ -370,9 +379,13 @@ def main():
                          "per-layer default, -1 = staging off, N = N rows on the layers of --stage-mask")
     ap.add_argument("--stage-mask", type=lambda v: int(v, 0), default=0,
                     help="with --stage-rows N: bit i = conv layer i runs the staged kernel (0 = every layer)")
+    ap.add_argument("--voxel", type=float, default=0.075,
+                    help="DIAGNOSTIC: x / y voxel size; 0.05 with --points 500000 --f16 is BASELINE configs[4] (the HBM-bound "
+                         "stress run); the headline is 0.075")
     ap.add_argument("--f16", action="store_true",
-                    help="DIAGNOSTIC ONLY: single-pass f16 conv kernels (fp16-autocast accuracy, BASELINE configs[4] "
-                         "dtype); reduced precision, never the headline line")
+                    help="DIAGNOSTIC ONLY: f16 storage + single-pass f16 conv kernels (isf_encoder_options.precision 2: the "
+                         "reference's indice_conv_half data types, BASELINE configs[4] dtype); reduced precision, never "
+                         "the headline line")
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = BATCH_PER_GPU if args.config == 2 else 2
@@ -396,7 +409,14 @@ def main():
 
     precision = 2 if args.f16 else 1 if args.fp32 else 0
     stage_kw = dict(stage_rows=args.stage_rows, stage_mask=args.stage_mask)
-    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
+    if abs(args.voxel - 0.075) > 1e-9:   # BASELINE configs[4]: 0.05 m voxels -> sparse shape [41, 2160, 2160], BEV 270 x 270
+        me = dict(m.ISFUSION_0075["pts_middle_encoder"])
+        side = int(round(108.0 / args.voxel))
+        me["sparse_shape"] = [41, side, side]
+        lb = m.LidarBranch(voxel_size=[args.voxel, args.voxel, 0.2], pts_middle_encoder=me)
+    else:
+        lb = m.LidarBranch()
+    lb = lb.randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
     frame_sets = [[torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points, fs)]
                   for fs in range(max(1, args.frame_sets))]
     frames = frame_sets[0]
@@ -449,7 +469,7 @@ def main():
         tot_bytes = tot_flops = 0.0
         for ms, n_in, n_out, pairs in samples:                               # per-step figures: averaged over the samples
             for i, (kind, cin, cout, K) in enumerate(tab):
-                by, fl = conv_layer_bytes_flops(kind, cin, cout, K, n_in[i], n_out[i], pairs[i])
+                by, fl = conv_layer_bytes_flops(kind, cin, cout, K, n_in[i], n_out[i], pairs[i], 2 if args.f16 else 4)
                 tot_bytes += by / ns
                 tot_flops += fl / ns
                 g = groups.setdefault(f"spconv_mfma<cin={cin},cout={cout}>", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
@@ -500,13 +520,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "DIAGNOSTIC (--conv-diag knock-out kernels: results are garbage, timing only)" if diag
-            else "f16 operands, fp32 accumulate (DIAGNOSTIC: reduced precision, not the headline)" if args.f16
+            else "f16 storage, f16 operands, fp32 accumulate (DIAGNOSTIC: reduced precision, not the headline)" if args.f16
             else "f32 (f16x3 split-precision MFMA, fp32 accumulate)" if st.precision == 1 else "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: isfusion_0075voxel LiDAR-only branch (dynamic voxelize + "
-                                   "DynamicVFE + 21-layer SparseEncoder -> BEV [B,512,180,180]), synthetic "
-                                   f"nuScenes-shaped {args.points}-pt sweeps, batch={args.batch}/GPU, random-init "
-                                   "weights, eval BN, fp32",
+            "config": {"workload": ("BASELINE configs[1]: isfusion_0075voxel LiDAR-only branch (dynamic voxelize + "
+                                    "DynamicVFE + 21-layer SparseEncoder -> BEV [B,512,180,180]), synthetic "
+                                    f"nuScenes-shaped {args.points}-pt sweeps, batch={args.batch}/GPU, random-init "
+                                    "weights, eval BN, fp32") if abs(args.voxel - 0.075) < 1e-9 and not args.f16 else
+                                   (f"DIAGNOSTIC (BASELINE configs[4] shape when --voxel 0.05 --points 500000 --f16): LiDAR "
+                                    f"branch at {args.voxel} m voxels, {args.points}-pt sweeps, batch={args.batch}/GPU, "
+                                    + ("f16 storage" if args.f16 else "fp32-class")),
                        "points_per_frame": args.points, "batch_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "frame_sets_rotated": len(frame_sets),
                        "frozen_caches": "lb.freeze(): inference deployment, the packed-weight caches skip their per-call "

@@ -204,6 +204,13 @@ int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_o
                            isf_stream_t stream);
 int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream);
 int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream);
+/* f16 STORAGE (mode 257 = 256 | 1 of isf_sparse_conv_forward_f16x3; isf_encoder_options.precision = 2): features,
+ * residual and output rows are plain f16, [N, C] row-major, 2 bytes per element -- the data type of the reference's
+ * indice_conv_half / indice_conv_backward_half end to end (mmdet3d/ops/bevfusion-ops/spconv/src/all.cc:35-37; BASELINE
+ * configs[4] "fp16, HBM-bound") -- with f16 operands and fp32 accumulation; every layer moves half the activation
+ * bytes of the split format.  isf_f32_to_half / isf_half_to_f32 convert (num_elems a multiple of 8). */
+int isf_f32_to_half(const float* x, size_t num_elems, void* xh, isf_stream_t stream);
+int isf_half_to_f32(const void* xh, size_t num_elems, float* x, isf_stream_t stream);
 int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_in, const void* packed16,
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                   const float* scale, const float* shift, const void* residual_split, int relu,
@@ -259,7 +266,8 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
 
 /* per-call options of the two engine entry points (NULL = all defaults; no process-wide state):
  * precision  0 = f16x3 split MFMA when every layer carries packed16, else fp32 MFMA (default); 1 = force the fp32 MFMA
- *            kernels; 2 = single-pass f16 (opt-in, fp16-autocast accuracy: mode 1 of isf_sparse_conv_forward_f16x3);
+ *            kernels; 2 = f16 storage + single-pass f16 arithmetic (opt-in, the reference's fp16 mode: activations are
+ *            f16 rows between the layers, mode 257 of isf_sparse_conv_forward_f16x3);
  * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {

@@ -125,6 +125,8 @@ SIGNATURES = {
     "isf_pack_filters_f16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_f32_to_split": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_split_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
+    "isf_f32_to_half": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
+    "isf_half_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "isf_stage_unit_rows": (c_int, []),

@@ -172,8 +172,11 @@ int sparse_conv_forward_staged_impl(const void* xs, int c_in, const void* packed
 int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st);
 int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st);
 int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st);
+int f32_to_half_impl(const float* x, size_t n_elems, void* xh, hipStream_t st);   // [N][C] f16 rows (f16 storage mode)
+int half_to_f32_impl(const void* xh, size_t n_elems, float* x, hipStream_t st);
 // isf_encoder.hip
-int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int32_t* indices, int n, int C,
+// fmt: 0 = fp32 rows, 1 = split rows, 2 = f16 rows
+int sparse_to_dense_bev_impl(Arena& a, const void* feats, int fmt, const int32_t* indices, int n, int C,
                              int B, int D, int H, int W, float* out, const OccIndex* occ,
                              hipStream_t st);
 

@@ -11,7 +11,7 @@ namespace isf {
 // through LDS and writes 256-B runs; every output element is written exactly once (no memset pass).
 static constexpr int kDenseX = 64;
 
-template <bool SPLIT>
+template <int FMT>   // 0 fp32 rows, 1 split rows, 2 f16 rows
 __global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__ feats_v, int C, int D,
                                                         int H, int W,
                                                         const unsigned long long* __restrict__ bits,
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__
     }
     __syncthreads();
     for (int c0 = 0; c0 < C; c0 += 64) {
-      if (SPLIT) {
-        // split format: row = C/8 units of (hi8 | lo8) f16; thread -> (row xx = t/8 + 32*j, unit t%8)
+      if (FMT != 0) {
+        // split format: row = C/8 units of (hi8 | lo8) f16 (f16 rows: hi8 only); thread -> (row xx = t/8 + 32*j, unit t%8)
         const uint4* fs = reinterpret_cast<const uint4*>(feats_v);
         const int u = t & 7;
 #pragma unroll
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__
           const int r = rows[xx];
           float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if (r >= 0 && c0 + u * 8 < C) {
-            const size_t o = split_hi_index((size_t)r, C >> 3, (c0 >> 3) + u);
-            const uint4 hi = fs[o], lo = fs[o + 4];
+            const size_t o = FMT == 2 ? (size_t)r * (C >> 3) + (c0 >> 3) + u : split_hi_index((size_t)r, C >> 3, (c0 >> 3) + u);
+            const uint4 hi = fs[o], lo = FMT == 2 ? make_uint4(0, 0, 0, 0) : fs[o + 4];
             const _Float16* h = reinterpret_cast<const _Float16*>(&hi);
             const _Float16* l = reinterpret_cast<const _Float16*>(&lo);
 #pragma unroll
@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void dense_bev_kernel(const void* __restrict__
   }
 }
 
-int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int32_t* indices, int n, int C,
+int sparse_to_dense_bev_impl(Arena& a, const void* feats, int fmt, const int32_t* indices, int n, int C,
                              int B, int D, int H, int W, float* out, const OccIndex* occ_in, hipStream_t st) {
-  ISF_REQUIRE(C % (split ? 32 : 4) == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of %d", C,
-              split ? 32 : 4);
+  ISF_REQUIRE(C % (fmt ? 32 : 4) == 0, ISF_ERR_UNSUPPORTED, "dense: channels %d not a multiple of %d", C,
+              fmt ? 32 : 4);
   OccIndex occ;
   const int32_t* perm = nullptr;
   if (occ_in) {
@@ -103,11 +103,14 @@ int sparse_to_dense_bev_impl(Arena& a, const void* feats, bool split, const int3
     perm = p;
   }
   dim3 grid(ceil_div(W, kDenseX), H, B);
-  if (split)
-    hipLaunchKernelGGL(dense_bev_kernel<true>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
+  if (fmt == 1)
+    hipLaunchKernelGGL(dense_bev_kernel<1>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
+                       perm, out);
+  else if (fmt == 2)
+    hipLaunchKernelGGL(dense_bev_kernel<2>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
                        perm, out);
   else
-    hipLaunchKernelGGL(dense_bev_kernel<false>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
+    hipLaunchKernelGGL(dense_bev_kernel<0>, grid, dim3(256), 0, st, feats, C, D, H, W, occ.bits, occ.prefix,
                        perm, out);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
@@ -188,7 +191,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
-  const int conv_mode = precision == 2 ? (1 | (diagnostic & 32)) : diagnostic;
+  // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : diagnostic;
+  const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
   ISF_REQUIRE(stage_opt >= -1, ISF_ERR_ARG, "sparse_encoder: stage_rows %d", stage_opt);
@@ -219,7 +224,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   if (use16) {  // inter-layer activations live in the split (hi8|lo8 f16) format: same bytes as fp32
     void* xs0 = nullptr;
     ISF_TRY(a.alloc(&xs0, (size_t)std::max(n0, 1) * layers[0].c_in * 4));
-    ISF_TRY(f32_to_split_impl(x0, (size_t)n0 * layers[0].c_in, xs0, st));
+    if (f16io) ISF_TRY(f32_to_half_impl(x0, (size_t)n0 * layers[0].c_in, xs0, st));
+    else ISF_TRY(f32_to_split_impl(x0, (size_t)n0 * layers[0].c_in, xs0, st));
     x = xs0;
     x_in0 = xs0;
   }
@@ -243,7 +249,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     int n_in = L.n;
     // LDS rows this layer stages (0 = gather kernel); the timing diagnostics exist on the gather kernel only
     int srows = 0;
-    if (use16 && dg == 0 && stage_opt >= 0 && sparse_conv_f16x3_supported(ly.c_in, ly.c_out))
+    if (use16 && dg == 0 && !f16io && stage_opt >= 0 && sparse_conv_f16x3_supported(ly.c_in, ly.c_out))
       srows = stage_opt == 0 ? default_stage_rows(ly)
                              : ((stage_mask == 0 || ((stage_mask >> i) & 1u)) ? stage_opt : 0);
     StageTables stg;
@@ -336,8 +342,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // dense BEV of the last level
   ISF_TRY(ensure_occ(a, L, B, sg));
   ISF_TRY(stream_wait_stream(a, st, sg));
-  ISF_TRY(sparse_to_dense_bev_impl(a, x, use16, L.coors, L.n, c_last, B, L.shape[0], L.shape[1], L.shape[2],
-                                   spatial_features, &L.occ, st));
+  ISF_TRY(sparse_to_dense_bev_impl(a, x, use16 ? (f16io ? 2 : 1) : 0, L.coors, L.n, c_last, B, L.shape[0], L.shape[1],
+                                   L.shape[2], spatial_features, &L.occ, st));
   if (stats) stats->precision = use16 ? 1 : 0;
   if (out_shape) { out_shape[0] = c_last * L.shape[0]; out_shape[1] = L.shape[1]; out_shape[2] = L.shape[2]; out_shape[3] = L.n; }
   if (stats) {
@@ -365,7 +371,7 @@ int isf_sparse_to_dense_bev(const float* features, const int32_t* indices, int n
   ISF_REQUIRE(num_rows == 0 || (features && indices), ISF_ERR_ARG, "sparse_to_dense_bev: null pointer");
   isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
-  return isf::sparse_to_dense_bev_impl(a, features, false, indices, num_rows, channels, batch_size, D, H, W, out,
+  return isf::sparse_to_dense_bev_impl(a, features, 0, indices, num_rows, channels, batch_size, D, H, W, out,
                                        nullptr, isf::as_stream(stream));
 }
 

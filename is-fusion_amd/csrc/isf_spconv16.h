@@ -128,7 +128,9 @@ struct Conv16Epi {
   static constexpr int wave_bytes = 16 * RS * 4;
 };
 
-template <int NT, int RG>
+// F16IO: residual and output rows are plain f16 ([N][C] halves, 2 bytes per element: the "half format" of the f16
+// storage mode) instead of split rows: one 16-byte piece per 8-channel unit at row * (C / 8) + unit.
+template <int NT, int RG, bool F16IO = false>
 __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], float* tile_l, int lane, int row0w,
                                                 int col0 /* first output channel of this workgroup */, int cout,
                                                 float winv, const float* __restrict__ scale,
@@ -154,9 +156,14 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
           res_hi[it] = make_uint4(0, 0, 0, 0);
           res_lo[it] = make_uint4(0, 0, 0, 0);
           if (i < 16 * UNITS && grow < n_out) {
-            const size_t o = split_hi_index((size_t)grow, cout >> 3, (col0 + ps * (16 * EPN)) / 8 + i % UNITS);
-            res_hi[it] = residual[o];
-            res_lo[it] = residual[o + 4];
+            const int unit = (col0 + ps * (16 * EPN)) / 8 + i % UNITS;
+            if (F16IO) {
+              res_hi[it] = residual[(size_t)grow * (cout >> 3) + unit];
+            } else {
+              const size_t o = split_hi_index((size_t)grow, cout >> 3, unit);
+              res_hi[it] = residual[o];
+              res_lo[it] = residual[o + 4];
+            }
           }
         }
       }
@@ -183,16 +190,20 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
           if (shift) sh8 = *reinterpret_cast<const f32x8*>(shift + gc);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], scale ? sc8[j] * winv : winv, sh8[j]);
-          const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
-          if (residual) v += join8(res_hi[it], res_lo[it]);
+          if (residual) v += join8(res_hi[it], res_lo[it]);   // F16IO: res_lo is zero
           if (relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
           }
           uint4 hi, lo;
           split8(v, hi, lo);
-          ys[o] = hi;
-          ys[o + 4] = lo;
+          if (F16IO) {
+            ys[(size_t)grow * (cout >> 3) + (gc >> 3)] = hi;   // round-to-nearest f16 of the fp32 result
+          } else {
+            const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
+            ys[o] = hi;
+            ys[o + 4] = lo;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -62,6 +62,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, Conv16Plan plan) {
   constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
+  // MODE bit 256 (with bit 1): F16 STORAGE -- input, residual and output rows are plain f16 (2 bytes per element, the
+  // reference's indice_conv_half data type end to end: src/all.cc:35-37) instead of 4-byte split rows; half the
+  // activation bytes of every layer (BASELINE configs[4], the HBM-bound run).  isf_encoder_options.precision = 2.
+  constexpr bool F16IO = (MODE & 256) != 0;
+  static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   // neighbour sharing of the gathers (load_A below) where it was measured to pay -- the layers whose gathers saturate
   // the vector-memory path: 64 -> 64 0.91 -> 0.76 ms, 64 -> 32 0.138 -> 0.128, 32 -> 32 0.312 -> 0.301 per step; the
   // layers with >= 128 output columns (and 32 -> 64) lose 3-5 % to its DPP / select / index work and keep plain gathers
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         if (idx >= 0 && !share && !NOGATHER) {
 #pragma unroll
           for (int kc = 0; kc < KCH; ++kc) {
-            const uint4* p = xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4) * 2 + kg;   // chunk base + k-group
+            const uint4* p = F16IO ? xs + (size_t)idx * CH8 + (cg * KCH + kc) * 4 + kg
+                                   : xs + ((size_t)idx * CH8 + (cg * KCH + kc) * 4) * 2 + kg;   // chunk base + k-group
             a_nxt[rg][kc][0] = p[0];   // 4 contiguous hi pieces per row and instruction
             if (!HALF) a_nxt[rg][kc][1] = p[4];   // 4 contiguous lo pieces
           }
@@ -293,8 +299,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
-  conv16_epilogue<NT, RG>(acc, tile_l, lane, row0 + wave * (half_tile ? WR / 2 : WR), cb * BN, cout, *w_inv_scale, scale,
-                          shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG);
+  conv16_epilogue<NT, RG, F16IO>(acc, tile_l, lane, row0 + wave * (half_tile ? WR / 2 : WR), cb * BN, cout, *w_inv_scale,
+                                 scale, shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG);
 }
 
 // ------------------------------------------------------------------------------------------ format kernels
@@ -314,6 +320,23 @@ __global__ void split_to_f32_kernel(const uint4* __restrict__ xs, size_t n8, flo
   if (i >= n8) return;
   const size_t o = (i >> 2) * 8 + (i & 3);
   *reinterpret_cast<f32x8*>(x + i * 8) = join8(xs[o], xs[o + 4]);
+}
+
+// half format: [N][C] f16 row-major (C a multiple of 8), 16 bytes per 8-channel unit
+__global__ void f32_to_half_kernel(const float* __restrict__ x, size_t n8, uint4* __restrict__ xh) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const f32x8 v = *reinterpret_cast<const f32x8*>(x + i * 8);
+  const h8 h = __builtin_convertvector(v, h8);
+  xh[i] = *reinterpret_cast<const uint4*>(&h);
+}
+
+__global__ void half_to_f32_kernel(const uint4* __restrict__ xh, size_t n8, float* __restrict__ x) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 u = xh[i];
+  const h8 h = *reinterpret_cast<const h8*>(&u);
+  *reinterpret_cast<f32x8*>(x + i * 8) = __builtin_convertvector(h, f32x8);
 }
 
 __global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned* __restrict__ out) {
@@ -408,6 +431,9 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
     case 4: return launch16<CIN, NT, 2, 4, 4>(ISF_ARGS16);
     case 6: return launch16<CIN, NT, 2, 4, 6>(ISF_ARGS16);
     case 8: return launch16<CIN, NT, 2, 4, 8>(ISF_ARGS16);
+    case 257:   // f16 storage (+ single-pass f16 arithmetic), production workgroup shapes
+      if (NT == 8 && cout == 128 && n_out >= 8 * 256) return launch16<CIN, (NT == 8 ? NT : 2), 2, 8, 257>(ISF_ARGS16);
+      return launch16<CIN, NT, 2, 4, 257>(ISF_ARGS16);
     case 16:   // no neighbour sharing, production workgroup shapes
       if (NT == 8 && cout == 128 && n_out >= 8 * 256) return launch16<CIN, (NT == 8 ? NT : 2), 2, 8, 16>(ISF_ARGS16);
       return launch16<CIN, NT, 2, 4, 16>(ISF_ARGS16);
@@ -483,6 +509,24 @@ int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st) 
   return ISF_OK;
 }
 
+int f32_to_half_impl(const float* x, size_t n_elems, void* xh, hipStream_t st) {
+  if (n_elems == 0) return ISF_OK;
+  ISF_REQUIRE(n_elems % 8 == 0, ISF_ERR_ARG, "f32_to_half: element count must be a multiple of 8");
+  hipLaunchKernelGGL(f32_to_half_kernel, dim3(ceil_div((long long)(n_elems / 8), 256)), dim3(256), 0, st, x,
+                     n_elems / 8, reinterpret_cast<uint4*>(xh));
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int half_to_f32_impl(const void* xh, size_t n_elems, float* x, hipStream_t st) {
+  if (n_elems == 0) return ISF_OK;
+  ISF_REQUIRE(n_elems % 8 == 0, ISF_ERR_ARG, "half_to_f32: element count must be a multiple of 8");
+  hipLaunchKernelGGL(half_to_f32_kernel, dim3(ceil_div((long long)(n_elems / 8), 256)), dim3(256), 0, st,
+                     reinterpret_cast<const uint4*>(xh), n_elems / 8, x);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st) {
   if (n_elems == 0) return ISF_OK;
   ISF_REQUIRE(n_elems % 32 == 0, ISF_ERR_ARG, "split_to_f32: element count must be a multiple of 32");
@@ -515,6 +559,16 @@ int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t st
   return isf::f32_to_split_impl(x, num_elems, xs, isf::as_stream(stream));
 }
 
+int isf_f32_to_half(const float* x, size_t num_elems, void* xh, isf_stream_t stream) {
+  ISF_REQUIRE(num_elems == 0 || (x && xh), ISF_ERR_ARG, "f32_to_half: null pointer");
+  return isf::f32_to_half_impl(x, num_elems, xh, isf::as_stream(stream));
+}
+
+int isf_half_to_f32(const void* xh, size_t num_elems, float* x, isf_stream_t stream) {
+  ISF_REQUIRE(num_elems == 0 || (x && xh), ISF_ERR_ARG, "half_to_f32: null pointer");
+  return isf::half_to_f32_impl(xh, num_elems, x, isf::as_stream(stream));
+}
+
 int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream) {
   ISF_REQUIRE(num_elems == 0 || (x && xs), ISF_ERR_ARG, "split_to_f32: null pointer");
   return isf::split_to_f32_impl(xs, num_elems, x, isf::as_stream(stream));
@@ -530,8 +584,9 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
   const int m = mode & ~32;   // bit 32 = uniform tiles (no full / half mix), combinable
-  ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16), ISF_ERR_ARG,
-              "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, diagnostics 2 / 4 / 6 / 8 / 16, +32)", mode);
+  ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "
+              "8 / 16, +32)", mode);
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
                                              num_out, scale, shift, residual_split, relu, out_split, mode,
                                              isf::as_stream(stream));

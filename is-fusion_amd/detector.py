@@ -11,6 +11,8 @@ Same method names (``dynamic_voxelize`` is folded into the one-call LiDAR branch
 keys load unchanged.  The image backbone / necks and the bbox head stay stock (out of scope).
 """
 import torch
+
+from . import _lib
 from torch import nn
 
 from .fusion_encoder import ISFusionEncoder
@@ -131,6 +133,35 @@ class ISFusionPtsPath(nn.Module):
         feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), pillars=pil, **kwargs)
         return (feats, ins_heatmap) if return_heatmap else feats
 
+    def _forward_pts_graph(self, pts, img_feats, img_metas, **kwargs):
+        """extract_pts_feat's eager head (LiDAR branch || pillar voxelization -> Point-to-Grid) writing into the input
+        buffers of the captured tail, then one graph launch"""
+        from . import fusion_ops as ops
+        assert not self.training, "inference path (eval mode)"
+        self._lidar.train(False)
+        dev = pts[0].device
+        B = len(pts)
+        g, img_bev, x, out = self._graph_for(B, dev, img_feats[1].shape[1], self._lidar.pts_middle_encoder.out_channels_and_shape()[0])
+        cam = kwargs.get("p2g_cam")
+        if cam is None:
+            cam = ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
+                                        kwargs["lidar_aug_matrix"]).to(dev, non_blocking=True)
+        main = torch.cuda.current_stream()
+        side = self.__dict__.setdefault("_side_streams", {}).setdefault(dev, None)
+        if side is None:
+            side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        self._lidar(pts, out=x)
+        with torch.cuda.stream(side):
+            pil = self.voxelize(pts, voxel_type="pillar")
+        main.wait_stream(side)
+        for t in pil:
+            t.record_stream(main)
+        ops.p2g_sample(pil[0], pil[2], img_feats[1], None, None, None, img_metas[0]["input_shape"], B,
+                       self.fusion_encoder.bev_size, self.fusion_encoder.num_views, cam=cam, out=img_bev)
+        g.replay()
+        return out
+
     def forward_train_pts(self, pts, img_feats, img_metas, **kwargs):
         """training mode: extract_pts_feat + pts_neck WITH gradients (towards every parameter of the
         LiDAR branch, the fusion encoder, the backbone stages and the neck, and towards the camera feature maps).  The
@@ -144,10 +175,56 @@ class ISFusionPtsPath(nn.Module):
         feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), **kwargs)
         return self.pts_neck(feats), ins_heatmap
 
+    # ------------------------------------------------------------------------------------------- HIP graph
+    def enable_graph(self, flag=True):
+        """Inference deployment: `forward_pts` replays everything behind Point-to-Grid -- conv_fusion, Grid-to-Region,
+        instance fusion, SECONDV2 stages, neck, head: ~330 launches whose shapes depend on the batch size only -- as ONE
+        HIP graph per batch size (captured on the first call), so the host no longer paces those launches (the GPU was
+        idle 10-14 % of a step between them).  The LiDAR branch, the pillar voxelization and Point-to-Grid (their sizes
+        depend on the frame) stay eager and write straight into the graph's input buffers.  Weights must be final
+        (freeze()); a load_state_dict or train() drops the captured graphs."""
+        self.__dict__["_graph_on"] = bool(flag)
+        self.__dict__["_graphs"] = {}
+        return self
+
+    def _tail(self, img_bev, x, bs):
+        enc = self.fusion_encoder
+        feats, _ = enc.forward_tail(img_bev, x, bs, pts_backbone=self.pts_backbone)
+        return self.pts_bbox_head.forward_split(self.pts_neck.forward_split(feats))
+
+    def _graph_for(self, bs, dev, c_img, c_lidar):
+        from . import fusion_ops as ops
+        if not ops.frozen(self):            # weights may have changed: captured kernels hold the old packed copies
+            self._graphs.clear()
+            raise _lib.IsfError("ISFusionPtsPath.enable_graph: call freeze() after the weights are final (eval mode)")
+        key = (bs, str(dev))
+        if key in self._graphs:
+            return self._graphs[key]
+        S = self.fusion_encoder.bev_size
+        main = torch.cuda.current_stream()
+        cap = torch.cuda.Stream(device=dev)          # private capture stream: its library workspace is never used eagerly
+        img_bev = torch.zeros((bs, c_img, S, S), dtype=torch.float32, device=dev)
+        x = torch.zeros((bs, c_lidar, S, S), dtype=torch.float32, device=dev)
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
+            for _ in range(3):                       # warm-up on the capture stream: workspace, packed caches, tables
+                self._tail(img_bev, x, bs)
+        cap.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap):
+            out = self._tail(img_bev, x, bs)
+        main.wait_stream(cap)
+        self._graphs[key] = (g, img_bev, x, out)
+        return self._graphs[key]
+
     @torch.no_grad()
     def forward_pts(self, pts, img_feats, img_metas, **kwargs):
         """extract_pts_feat -> pts_neck -> pts_bbox_head (mvx_two_stage.py simple_test_pts without box decoding):
-        the raw head outputs [[dict(center, height, dim, rot, vel, heatmap, query_heatmap_score, dense_heatmap)]]."""
+        the raw head outputs [[dict(center, height, dim, rot, vel, heatmap, query_heatmap_score, dense_heatmap)]].
+        With enable_graph(): the outputs live in the graph's static buffers (valid until the next call)."""
+        if self.__dict__.get("_graph_on", False) and self.pts_neck.dense_conv == "hip" and \
+                self.pts_bbox_head.dense_conv == "hip" and self.fusion_encoder.dense_conv == "hip":
+            return (self._forward_pts_graph(pts, img_feats, img_metas, **kwargs),)
         feats = self.extract_pts_feat(pts, img_feats, img_metas, **kwargs)
         if self.pts_neck.dense_conv == "hip" and self.pts_bbox_head.dense_conv == "hip":
             # engine-level hand-over: the neck's levels stay split-format token matrices (no [B, 512, H, W] tensor, no

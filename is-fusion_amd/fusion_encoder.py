@@ -77,7 +77,7 @@ class ISFusionEncoder(nn.Module):
         return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs["lidar2img"],
                               kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
                               kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views,
-                              cam=kwargs.get("p2g_cam"))
+                              cam=kwargs.get("p2g_cam"), out=kwargs.get("p2g_out"))
 
     def fuse(self, img_bev, lidar_feats):
         """conv_fusion(cat([img_bev, lidar_feats])) (fusion_encoder.py:1163-1165) -> [B, E, S, S]"""
@@ -123,7 +123,8 @@ class ISFusionEncoder(nn.Module):
         idx_t = (top_idx % S) * S + torch.div(top_idx, S, rounding_mode="floor")
         x_ins, _ = ops.gather_instances(x_scene_t, idx_t, S)
         _, query_pos = ops.gather_instances(x_scene_t, top_idx, S)
-        x_ins = ops.ins_context_att(self.instance_att, x_ins, query_pos, x_scene_t, S)
+        # query_pos = (x' + .5, y' + .5) of cell top_idx = y'*S + x' = create_2D_grid cell x'*S + y' = idx_t
+        x_ins = ops.ins_context_att(self.instance_att, x_ins, query_pos, x_scene_t, S, query_cells=idx_t)
         ret = ops.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, S)
         return ret, hm
 
@@ -181,6 +182,11 @@ class ISFusionEncoder(nn.Module):
 
     def forward_eval(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
         img_bev = self.img_fv_to_bev([img_mlvl_feats[1]], bs, **kwargs)
+        return self.forward_tail(img_bev, lidar_feats, bs, **kwargs)
+
+    def forward_tail(self, img_bev, lidar_feats, bs, **kwargs):
+        """everything behind Point-to-Grid: shape-static for a given batch size (no pillar count in it), which is what
+        ISFusionPtsPath captures in a HIP graph"""
         bev_feats = self.fuse(img_bev, lidar_feats)
         pts_backbone = kwargs.get("pts_backbone", None)
         x = bev_feats

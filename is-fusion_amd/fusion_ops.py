@@ -283,7 +283,8 @@ def p2g_camera_params(lidar2img, img_aug, lidar_aug, noise=None):
     return out.float().reshape(B * ncam, 20)
 
 
-def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, input_shape, bs, bev, num_cam=6, cam=None):
+def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, input_shape, bs, bev, num_cam=6, cam=None,
+               out=None):
     """img_fv_to_bev (fusion_encoder.py:965-1013): pillars [M, T, >=3], pillar_coors [M, 4] (b, z, y, x),
     img_feat [bs*num_cam, C, H, W] -> [bs, C, bev, bev].  cam: p2g_camera_params(...) already on the device (the
     detector computes it before it queues the LiDAR branch, so the host work hides behind GPU work)."""
@@ -295,7 +296,9 @@ def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, i
     if cam is None:
         cam = p2g_camera_params(lidar2img, img_aug, lidar_aug).to(dev)
     C, H, W = img_feat.shape[1:]
-    out = torch.empty((bs, C, bev, bev), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((bs, C, bev, bev), dtype=torch.float32, device=dev)
+    assert tuple(out.shape) == (bs, C, bev, bev) and out.is_contiguous() and out.dtype == torch.float32
     _lib.check(_lib.load().isf_p2g_forward(_lib.ptr(pillars), pillars.size(2), pillars.size(1), _lib.ptr(coors),
                                            pillars.size(0), _lib.ptr(nhwc), bs, num_cam, H, W, C, _lib.ptr(cam),
                                            int(input_shape[0]), int(input_shape[1]), bev, _lib.ptr(out),
@@ -535,10 +538,12 @@ def _pos_embed(mod, xy):
     return out.view(*xy.shape[:-1], -1)
 
 
-def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
+def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None):
     """InsContextAtt.forward (fusion_encoder.py:795-830), eval mode.  x_ins [B, E, Q], query_pos [B, Q, 2] (x, y),
     scene [B, E, H, W] = the reference's `x_scene.permute(0, 1, 3, 2)` (:806; the caller holds the map in that
-    orientation already) -> [B, E, Q]."""
+    orientation already) -> [B, E, Q].  query_cells [B, Q] long (optional): the queries sit on cell centres of the
+    create_2D_grid lattice, query_pos = bev_pos[query_cells] -- then their position embedding is a row of a per-cell
+    table computed once (the same MLP on the same inputs) instead of two GEMMs + glue per forward."""
     _lib.require_cuda(scene)
     dev = scene.device
     B, E, Q = x_ins.shape
@@ -548,6 +553,7 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
         bx, by = torch.meshgrid(g, g, indexing="ij")
         bev_pos = torch.stack([bx, by], 0).view(1, 2, -1).permute(0, 2, 1)
         c["key_pos"] = _pos_embed(mod.key_pos_embed, bev_pos / bev_size)[0].contiguous()          # [HW, E]
+        c["query_pos_table"] = _pos_embed(mod.query_pos_embed, bev_pos / bev_size)[0].contiguous()  # [HW, E]
         c["layers"] = []
         for l in mod.layers:
             sa, ca = l.self_attn, l.cross_attn
@@ -572,7 +578,10 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
     scene = scene.float().contiguous() if (H * W) % 4 == 0 else to_tokens(scene.float())
     out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
     ref = (query_pos / bev_size).reshape(B * Q, 2).contiguous()
-    qpe = _pos_embed(mod.query_pos_embed, ref.view(B, Q, 2)).reshape(B * Q, E)
+    if query_cells is not None:
+        qpe = c["query_pos_table"][query_cells.reshape(-1)]
+    else:
+        qpe = _pos_embed(mod.query_pos_embed, ref.view(B, Q, 2)).reshape(B * Q, E)
     for l, p in zip(mod.layers, c["layers"]):
         nhead, npts = l.cross_attn.n_heads, l.cross_attn.n_points
         qk_in = out + qpe

@@ -127,7 +127,7 @@ class LidarBranch(nn.Module):
         return self.pts_middle_encoder.forward_modules(vf, vc, len(points))[0]
 
     def forward(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0, stage_rows=0,
-                stage_mask=0):
+                stage_mask=0, out=None):
         """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W].
         precision: 0 = f16x3 split MFMA (default, fp32-class), 1 = fp32 MFMA kernels, 2 = single-pass f16 (opt-in,
         fp16-autocast accuracy); conv_diag: timing diagnostics of the conv kernels (results garbage except 16);
@@ -135,10 +135,10 @@ class LidarBranch(nn.Module):
         if self.training:
             return self.forward_train(points)
         with torch.no_grad():
-            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag, stage_rows, stage_mask)
+            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag, stage_rows, stage_mask, out)
 
     def forward_eval(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0, stage_rows=0,
-                     stage_mask=0):
+                     stage_mask=0, out=None):
         pts = torch.cat(points, dim=0).contiguous().float()
         _lib.require_cuda(pts)
         vfe = self.pts_voxel_encoder
@@ -157,7 +157,9 @@ class LidarBranch(nn.Module):
         arr, n, _keep, _plan = me._c_plan()
         vp, _keep2 = self._vfe_params()
         cd, H, W = me.out_channels_and_shape()
-        out = torch.empty((B, cd, H, W), dtype=torch.float32, device=pts.device)
+        if out is None:    # out: a caller-owned [B, C*D, H, W] buffer (the detector's HIP-graph input)
+            out = torch.empty((B, cd, H, W), dtype=torch.float32, device=pts.device)
+        assert tuple(out.shape) == (B, cd, H, W) and out.is_contiguous() and out.dtype == torch.float32
         oshape = (ctypes.c_int * 4)()
         stats = _lib.EncoderStats() if (want_stats or time_layers) else None
         lib = _lib.load()

@@ -170,10 +170,34 @@ def from_split(xs, shape):
     return out
 
 
+def to_half(x):
+    """fp32 [N, C] -> f16 rows (the f16 storage mode's format; opaque uint8 tensor of N*C*2 bytes)"""
+    x = x.contiguous().float()
+    out = torch.empty(x.numel() * 2, dtype=torch.uint8, device=x.device)
+    _lib.check(_lib.load().isf_f32_to_half(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.stream()))
+    return out
+
+
+def from_half(xh, shape):
+    out = torch.empty(shape, dtype=torch.float32, device=xh.device)
+    _lib.check(_lib.load().isf_half_to_f32(_lib.ptr(xh), out.numel(), _lib.ptr(out), _lib.stream()))
+    return out
+
+
 def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
                               relu=False, mode=0):
-    """fp32 in / fp32 out convenience wrapper around the split-precision kernel (converts at both ends)."""
+    """fp32 in / fp32 out convenience wrapper around the split-precision kernel (converts at both ends); mode 257 (f16
+    storage) converts through f16 rows instead of split rows."""
     _lib.require_cuda(features)
+    if (mode & ~32) == 257:
+        xs = to_half(features)
+        rs = to_half(residual) if residual is not None else None
+        ys = torch.empty(rb.num_out * c_out * 2, dtype=torch.uint8, device=features.device)
+        _lib.check(_lib.load().isf_sparse_conv_forward_f16x3(
+            _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode), _lib.stream()),
+            "isf_sparse_conv_forward_f16x3")
+        return from_half(ys, (rb.num_out, c_out))
     xs = to_split(features)
     rs = to_split(residual) if residual is not None else None
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)

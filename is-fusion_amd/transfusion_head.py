@@ -132,13 +132,16 @@ class TransFusionHeadV2(nn.Module):
                 # key = value = feat + key_pos_embed (:104-106): (feat + pos) W + b = feat W + (pos W + b), the second
                 # term is input independent -> per-cell table added in the GEMM epilogue
                 kpe = ops._pos_embed(l.cross_posembed, bev_pos)[0]                    # [HW, E]
+                # the proposals sit on cell centres (query_pos = bev_pos[top_index]): their self-attention position
+                # embedding is a row of this per-cell table (same MLP, same inputs) -- no GEMMs per forward
+                qtab = ops._pos_embed(l.self_posembed, bev_pos)[0].contiguous()
                 table = (kpe.double() @ wc[E:].double().t()).float().contiguous()     # [HW, 2E]
                 c["layers"].append(dict(
                     s_qkv=ops.PackedLinear(ws, bs), s_out=ops.PackedLinear(sa.out_proj.weight, sa.out_proj.bias),
                     c_q=ops.PackedLinear(wc[:E], bc[:E]), c_kv=ops.PackedLinear(wc[E:], bc[E:]), kv_table=table,
                     c_out=ops.PackedLinear(ca.out_proj.weight, ca.out_proj.bias),
                     l1=ops.PackedLinear(l.linear1.weight, l.linear1.bias),
-                    l2=ops.PackedLinear(l.linear2.weight, l.linear2.bias)))
+                    l2=ops.PackedLinear(l.linear2.weight, l.linear2.bias), qpe_table=qtab))
             c["pred"] = [self._pack_prediction_heads(ffn) for ffn in self.prediction_heads]
         return c
 
@@ -245,7 +248,10 @@ class TransFusionHeadV2(nn.Module):
         P = self.num_proposals
         ret_dicts = []
         for i, (l, p) in enumerate(zip(self.decoder, c["layers"])):
-            qpe = ops._pos_embed(l.self_posembed, query_pos).reshape(B * P, E)
+            if i == 0:   # = self_posembed(query_pos): the proposals sit on cell centres; later layers use refined centres
+                qpe = p["qpe_table"][top_index.reshape(-1)]
+            else:
+                qpe = ops._pos_embed(l.self_posembed, query_pos).reshape(B * P, E)
             # self attention: q = k = v = query + pos (:98-101)
             x = query + qpe
             qkv = ops.linear(x, p["s_qkv"])

@@ -134,3 +134,48 @@ def test_engine_neck_head_handover_matches_the_module_path(dev):
     for key in ("center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score"):
         a, w = via_engine[key], via_modules[key]
         assert a.shape == w.shape and (a - w).abs().max().item() < 1e-3 * max(1.0, w.abs().max().item()), key
+
+
+def test_hip_graph_tail_reproduces_the_eager_forward(dev):
+    """ISFusionPtsPath.enable_graph(): conv_fusion .. head captured once per batch size and replayed as one HIP graph,
+    the LiDAR branch / pillar voxelization / Point-to-Grid eager and writing into the graph's input buffers.  Same
+    kernels on the same data => the head outputs are bit-identical to the eager forward_pts, for two different frame
+    sets in a row (the replay must see the new inputs) and after an eager call in between."""
+    from isfusion_amd import synthetic
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    B = 2
+    net = ISFusionPtsPath().eval()
+    net._lidar.randomize_weights_(0).randomize_bn_(1)
+    for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250), (net.pts_bbox_head, 300)):
+        mod.load_state_dict(seeded_state_dict(mod, seed))
+    net = net.to(dev)
+    sets = []
+    for fs in range(2):
+        pts = [torch.from_numpy(synthetic.lidar_sweeps(7000 + 10 * fs + i, 20000)).to(dev) for i in range(B)]
+        inp = synthetic.fusion_inputs(80 + fs, B)
+        img_feats = tuple(torch.from_numpy(a).to(dev) for a in inp["img_feats"])
+        kw = dict(lidar2img=torch.from_numpy(inp["lidar2img"]), img_aug_matrix=torch.from_numpy(inp["img_aug_matrix"]),
+                  lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
+        sets.append((pts, img_feats, [dict(input_shape=inp["input_shape"]) for _ in range(B)], kw))
+    keys = ("center", "height", "dim", "rot", "vel", "heatmap", "query_heatmap_score", "dense_heatmap")
+
+    def run(i):
+        pts, img_feats, metas, kw = sets[i]
+        out = net.forward_pts(pts, img_feats, metas, **kw)[0][0]
+        return {k: out[k].clone() for k in keys}, net.pts_bbox_head.last_top_index.clone()
+
+    eager = [run(0), run(1)]
+    assert not torch.equal(eager[0][0]["dense_heatmap"], eager[1][0]["dense_heatmap"])
+    with pytest.raises(Exception):
+        net.enable_graph()
+        run(0)                       # weights not declared final: refused
+    net.freeze().enable_graph()
+    for i in (0, 1, 0, 1):
+        got, top = run(i)
+        assert torch.equal(top, eager[i][1])
+        for k in keys:
+            assert torch.equal(got[k], eager[i][0][k]), (i, k)
+    net.enable_graph(False)
+    got, _ = run(1)                  # eager again (frozen caches)
+    assert all(torch.equal(got[k], eager[1][0][k]) for k in keys)

@@ -426,12 +426,59 @@ def test_window_attention_backward_matches_torch_autograd(dev, S, d, shift):
     assert err < 2e-4 * max(1.0, x.grad.abs().max().item()), err
 
 
-# ------------------------------------------------------------------------------------------- single-pass f16 mode
-def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mod):
-    """precision 2 (isf_encoder_options, per call): the conv kernels multiply only the hi halves (f16 operands, fp32 accumulate) -- the
-    accuracy class of the reference's indice_conv_half; the default (0) must be restored and stay fp32-class"""
+# ------------------------------------------------------------------------------------------- f16 storage mode
+def _f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def lexsort4(idx):
+    return np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))
+
+
+def _oracle_encoder_f16_storage(oracle_mod, plan, vf, vc, B):
+    """the oracle's SparseEncoder with the data types of the reference's fp16 path (indice_conv_half, src/all.cc:35-37):
+    f16 features between the layers, f16 weights (scaled by a power of two first, as the packed filters are: exact),
+    fp32 accumulation, BN / residual / ReLU in fp32, f16 result"""
+    feats, idx, shape = _f16(vf), vc, list(plan["sparse_shape"])
+    outs, cache = [], {}
+    first = feats
+    for L in plan["layers"]:
+        subm = L["kind"] == "subm"
+        key = ("subm", tuple(shape), tuple(L["ksize"]))
+        if subm and key in cache:
+            out_idx, pairs, num = cache[key]
+        else:
+            out_idx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, L["ksize"], L["stride"], L["padding"], subm=subm)
+            if subm:
+                cache[key] = (out_idx, pairs, num)
+        w = np.asarray(L["weight"], np.float32)
+        amax = np.abs(w).max()
+        sw = 2.0 ** (13 - int(np.frexp(amax)[1])) if amax > 0 else 1.0      # pack_filters16_kernel: max|w| 2^sw in [2^12, 2^13)
+        y = oracle_mod.indice_conv(feats, _f16(w * sw) / sw, pairs, num, out_idx.shape[0])
+        res = None
+        if L.get("residual_from") is not None:
+            r = L["residual_from"]
+            res = outs[r] if r >= 0 else first
+        feats = _f16(oracle_mod.bn_act(y, L["scale"], L["shift"], res, L["relu"]))
+        if not subm:
+            shape = oracle_mod.conv_out_shape(shape, L["ksize"], L["stride"], L["padding"])
+            cache = {}
+        idx = out_idx
+        outs.append(feats)
+    return oracle_mod.dense_bev(feats, idx, B, shape)
+
+
+def test_f16_storage_mode_matches_the_f16_oracle_and_is_off_by_default(dev, oracle_mod):
+    """precision 2 (isf_encoder_options, per call; BASELINE configs[4] dtype): activations travel between the layers as
+    f16 rows (2 bytes per element), f16 operands, fp32 accumulation -- the reference's indice_conv_half.  Checked
+    against the oracle run with exactly those data types (the only differences left are summation order and the
+    occasional double rounding), and loosely against the fp32 oracle; the next call is back on the default."""
     import isfusion_amd as m
-    from isfusion_amd import _lib, synthetic
+    from isfusion_amd import synthetic
     from isfusion_amd.norm import fold_bn
     B = 2
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval()
@@ -444,19 +491,49 @@ def test_single_pass_f16_mode_is_fp16_accurate_and_off_by_default(dev, oracle_mo
     ovf, ovc, _ = oracle_mod.dynamic_vfe(np.concatenate(pl), coors, VS, RG,
                                          vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
                                          vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
-    obev, _ = oracle_mod.sparse_encoder_forward(lb.pts_middle_encoder.plan_to_numpy(), ovf, ovc, B)
+    plan = lb.pts_middle_encoder.plan_to_numpy()
+    obev, _ = oracle_mod.sparse_encoder_forward(plan, ovf, ovc, B)
+    obev16 = _oracle_encoder_f16_storage(oracle_mod, plan, ovf, ovc, B)
     lb = lb.to(dev)
     pts = [_T(p, dev) for p in pl]
     half = lb(pts, precision=2).cpu().numpy()
     full = lb(pts).cpu().numpy()                             # the next call is back on the default: no global state
     scale = np.abs(obev).max()
-    err_half, err_full = np.abs(half - obev).max(), np.abs(full - obev).max()
-    assert err_full < 1e-3                                   # default path untouched
-    assert err_half < 3e-2 * scale, (err_half, scale)        # 21 layers of f16 rounding (2^-11 relative per operand)
-    assert err_half > 10 * err_full                          # the mode really ran (it is NOT fp32-class)
-    # (CPU emulation of the mode -- f16-rounded operands through the oracle -- gives 2.7e-3 on this case, 6e-4 of
-    #  the feature scale; ReLU outputs next to zero may flip, so the supports are only almost equal)
-    assert ((half != 0) != (obev != 0)).mean() < 1e-3
+    assert np.abs(full - obev).max() < 1e-3                  # default path untouched
+    err16 = np.abs(half - obev16).max()
+    assert err16 < 4e-3 * scale, (err16, scale)              # same data types: a few f16 ulps of the largest features
+    err32 = np.abs(half - obev).max()
+    assert 10 * 1e-3 < err32 + 1e-2 and err32 < 3e-2 * scale and err32 > 10 * np.abs(full - obev).max()   # not fp32-class
+    assert ((half != 0) != (obev16 != 0)).mean() < 1e-3      # ReLU outputs next to zero may flip
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (32, 32), (64, 64), (128, 128), (256, 256)])
+def test_f16_storage_conv_op(dev, oracle_mod, cin, cout):
+    """isf_sparse_conv_forward_f16x3 mode 257: f16 rows in (features, residual), f16 rows out"""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin + 3 * cout)
+    B, shape = 2, [9, 24, 20]
+    n = 1500
+    lin = np.sort(rng.choice(B * int(np.prod(shape)), n, replace=False))
+    D, H, W = shape
+    idx = np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+    feats = _f16(rng.normal(0, 1, (n, cin)))
+    w = rng.normal(0, (1.0 / (6 * cin)) ** 0.5, (3, 3, 3, cin, cout)).astype(np.float32)
+    sw = 2.0 ** (13 - int(np.frexp(np.abs(w).max())[1]))
+    scale = (rng.random(cout, dtype=np.float32) + 0.5)
+    shift = rng.normal(0, 0.2, cout).astype(np.float32)
+    for subm, st, pd in ((True, [1, 1, 1], [1, 1, 1]), (False, [2, 2, 2], [1, 1, 1])):
+        rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], st, pd, subm)
+        oidx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, [3, 3, 3], st, pd, subm=subm)
+        res = _f16(rng.normal(0, 1, (rb.num_out, cout)))
+        out_idx = rb.out_indices.cpu().numpy()
+        o1, o2 = lexsort4(out_idx), lexsort4(oidx)
+        raw = oracle_mod.indice_conv(feats, _f16(w * sw) / sw, pairs, num, len(oidx))[o2]
+        want = _f16(oracle_mod.bn_act(raw, scale, shift, res[o1], relu=True))
+        got = sp.sparse_conv_forward_f16x3(T(feats, dev), sp.pack_filters_f16x3(T(w, dev)), 27, cin, cout, rb,
+                                           T(scale, dev), T(shift, dev), T(res, dev), relu=True, mode=257).cpu().numpy()
+        # one f16 ulp of the result (fp32 sums agree to 1e-6; rounding to f16 may land on either neighbour)
+        assert np.abs(got[o1] - want).max() <= 2.0 ** -10 * max(1.0, np.abs(want).max()), (cin, cout, subm)
 
 
 # ------------------------------------------------------------------------------------------- neck on the linear kernel
