@@ -300,6 +300,24 @@ __device__ __forceinline__ void vfe_segmented_max(int myvox, int vprev, int vnex
   flush(63);
 }
 
+// The segmented max writes a voxel's row with ONE store when the voxel's run of records lies inside a wave, and with
+// atomicMax when a wave boundary (every 64 records) cuts it -- which needs a zero row to start from.  Only those rows are
+// zeroed: one wave per boundary clears the rows of the voxel that straddles it, in both destination buffers (at most
+// P / 64 rows; round 2 zero-filled both [N, 64] buffers: two 92-MB fills per forward).
+__global__ __launch_bounds__(256) void vfe_zero_cut_rows_kernel(const float* __restrict__ recs,
+                                                                const int* __restrict__ n_valid,
+                                                                float* __restrict__ a, float* __restrict__ b) {
+  const int lane = threadIdx.x & 63;
+  const long long k = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;   // boundary between records 64k - 1 and 64k
+  const long long j = k * 64;
+  const long long nv = *n_valid;
+  if (j >= nv) return;
+  const int v0 = __float_as_int(recs[(size_t)(j - 1) * 8 + 7]), v1 = __float_as_int(recs[(size_t)j * 8 + 7]);
+  if (v0 != v1 || v0 < 0) return;
+  a[(size_t)v0 * 64 + lane] = 0.f;
+  b[(size_t)v0 * 64 + lane] = 0.f;
+}
+
 // voxel id stored in record j (wave-uniform scalar load), -1 outside [0, n)
 __device__ __forceinline__ int vfe_record_voxel(const float* __restrict__ recs, long long j, uint32_t n) {
   return (j >= 0 && j < (long long)n) ? __float_as_int(recs[(size_t)j * kRec + kRec - 1]) : -1;
@@ -527,13 +545,15 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(a.alloc_n(&start, (size_t)N + 2));
   ISF_TRY(a.alloc_n(&mean4, (size_t)N));
   ISF_TRY(a.alloc_n(&vmax1, (size_t)N * kC));
-  ISF_HIP_TRY(hipMemsetAsync(vmax1, 0, (size_t)N * kC * sizeof(float), st));
-  ISF_HIP_TRY(hipMemsetAsync(voxel_feats, 0, (size_t)N * kC * sizeof(float), st));
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
   hipLaunchKernelGGL(vfe_order_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, pt2vox, slot, P, start,
                      recs);
   hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(N, 256)), dim3(256), 0, st, recs, start, N, mean4);
   const int* n_valid = reinterpret_cast<const int*>(start + N);
+  // rows of the voxels cut by a 64-record boundary start from zero (atomicMax), every other row is stored whole
+  static_assert(kRec == 8 && kC == 64, "vfe_zero_cut_rows_kernel indexes records / rows with these sizes");
+  hipLaunchKernelGGL(vfe_zero_cut_rows_kernel, dim3(ceil_div(ceil_div(P, 64), 4)), dim3(256), 0, st, recs, n_valid, vmax1,
+                     voxel_feats);
   hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, recs,
                      voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1);
   hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st, recs,
