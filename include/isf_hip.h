@@ -215,6 +215,29 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
                                   int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                   const float* scale, const float* shift, const void* residual_split, int relu,
                                   void* out_split, int mode, isf_stream_t stream);
+/* TILE ORDER of a launch that is resident in one round of workgroups.  Such a launch ends when its busiest CU does; the
+ * tiles a CU gets in launch order (slots j, j + 32, j + 64 of its XCD) add up unevenly because the work of a tile -- the
+ * (16-row group, tap) pairs that have a neighbour -- varies ~3x across a LiDAR sweep.  isf_sparse_conv_tile_order counts
+ * that work per tile of the launch isf_sparse_conv_forward_f16x3 would make for (c_in, c_out, mode, num_out) and hands
+ * the tiles out longest-first to the least-loaded CU with a free slot; `order` (and the scratch `work`) hold at most
+ * 8 * 255 ints, *num_entries = how many were written (0: the launch is not a single round -- pass order = NULL).
+ * One table serves every layer of that channel shape on the rulebook (isf_sparse_encoder_forward builds it per level
+ * behind the neighbour table).  isf_sparse_conv_forward_f16x3_ordered = the same convolution with workgroup slot j
+ * working on tile order[j]: results bit-identical to isf_sparse_conv_forward_f16x3 (the same tiles compute the same
+ * rows).  Replaces nothing in the reference (its gather -> GEMM -> scatter has no tiles); measured in DESIGN.md
+ * section 5.1.  isf_sparse_conv_trace: DIAGNOSTIC -- the production launch of a 128 -> 128 or 256 -> 256 layer that also
+ * writes 8 int64 per workgroup (trace [grid_blocks * 8], zero it first: 100 MHz time stamps at entry / after the
+ * prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half tile << 32); tools/conv_trace.py. */
+int isf_sparse_conv_tile_order(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
+                               int mode, int32_t* work, int32_t* order, int* num_entries, isf_stream_t stream);
+int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in, int c_in, const void* packed16,
+                                          int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                                          const float* scale, const float* shift, const void* residual_split, int relu,
+                                          void* out_split, int mode, const int32_t* order, isf_stream_t stream);
+int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                          int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                          const float* shift, const void* residual_split, int relu, void* out_split,
+                          const int32_t* order, long long* trace, int* grid_blocks, isf_stream_t stream);
 /* The same convolution with the tile's input rows staged in LDS ("LDS staging of active-voxel tiles"; the reference's
  * gather stage: bevfusion-ops/spconv/include/spconv/reordering.cu.h:21-97 -> staging buffer -> GEMM, spconv_ops.h:300-345).
  * isf_rulebook_stage_tables derives the staging tables of a neighbour table once per rulebook: for every unit of
@@ -268,7 +291,8 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  * precision  0 = f16x3 split MFMA when every layer carries packed16, else fp32 MFMA (default); 1 = force the fp32 MFMA
  *            kernels; 2 = f16 storage + single-pass f16 arithmetic (opt-in, the reference's fp16 mode: activations are
  *            f16 rows between the layers, mode 257 of isf_sparse_conv_forward_f16x3);
- * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3);
+ * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3;
+ *            +64 = tiles in launch order, no isf_sparse_conv_tile_order tables -- results bit-identical);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

@@ -129,6 +129,14 @@ SIGNATURES = {
     "isf_half_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "isf_sparse_conv_tile_order": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                           ctypes.POINTER(c_int), c_void_p]),
+    "isf_sparse_conv_forward_f16x3_ordered": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                                      c_void_p, c_void_p]),
+    "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int),
+                                      c_void_p]),
     "isf_stage_unit_rows": (c_int, []),
     "isf_stage_unit_cap": (c_int, []),
     "isf_rulebook_stage_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

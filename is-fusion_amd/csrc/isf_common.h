@@ -160,7 +160,24 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out);
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                    const float* shift, const void* residual, int relu, void* ys,
-                                   int mode /* 0 | 1 single-pass f16 | timing diagnostics */, hipStream_t st);
+                                   int mode /* 0 | 1 single-pass f16 | timing diagnostics */, hipStream_t st,
+                                   const int32_t* order = nullptr, struct Conv16LaunchInfo* query = nullptr);
+// How a launch of that kernel is cut into tiles (query != nullptr: filled instead of launching), and the per-part tile
+// order that evens out the work of the tiles sharing a CU (conv16_tile_order_impl; nullptr = slot j works on tile j).
+struct Conv16LaunchInfo {
+  int full, half, part_rows;   // Conv16Plan
+  int TM, ncb, wgs_per_cu, cus_per_xcd;
+};
+static inline int conv16_order_parts(const Conv16LaunchInfo& i) { return i.ncb == 2 ? 4 : 8; }
+static inline int conv16_order_tiles(const Conv16LaunchInfo& i) { return i.full + i.half; }
+// a reordering only helps a launch that is resident in one round with CUs that hold more than one tile
+static inline bool conv16_order_applies(const Conv16LaunchInfo& i) {
+  const int t = i.full + i.half;
+  return t > i.cus_per_xcd && t <= i.wgs_per_cu * i.cus_per_xcd && t <= 255 && i.cus_per_xcd <= 64;
+}
+int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
+                           int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
+                           hipStream_t st);
 // isf_spconv_stage.hip (LDS-staged input rows; staging tables of a rulebook)
 int stage_tables_impl(const int32_t* nbr, int nbr_stride, int K, uint16_t* slots, int32_t* ulist, int32_t* ucount,
                       hipStream_t st);

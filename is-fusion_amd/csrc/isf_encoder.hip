@@ -154,7 +154,27 @@ struct LevelState {
   int cache_stride;
   long long cache_pairs;
   StageTables cache_stage;   // staging tables of cache_nbr (slots == nullptr: not built)
+  const int32_t* cache_order;   // tile order of cache_nbr for a (cache_order_cin -> cache_order_cout) launch, or nullptr
+  int cache_order_cin, cache_order_cout;
 };
+
+// tile order of one conv launch over a neighbour table (conv16_tile_order_impl), built behind the table on the
+// geometry stream; *order stays nullptr when the launch is not a single resident round
+static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int32_t* nbr, int stride, int n_out,
+                            int mode, const int32_t** order, hipStream_t sg) {
+  *order = nullptr;
+  Conv16LaunchInfo info;
+  ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, nullptr,
+                                         nullptr, nullptr, 0, nullptr, mode, sg, nullptr, &info));
+  if (!conv16_order_applies(info)) return ISF_OK;
+  const size_t n = (size_t)conv16_order_parts(info) * conv16_order_tiles(info);
+  int32_t *work = nullptr, *ord = nullptr;
+  ISF_TRY(a.alloc_n(&work, n));
+  ISF_TRY(a.alloc_n(&ord, n));
+  ISF_TRY(conv16_tile_order_impl(nbr, stride, K, n_out, info, work, ord, sg));
+  *order = ord;
+  return ISF_OK;
+}
 
 // staging tables of one neighbour table (isf_spconv_stage.hip), built behind it on the geometry stream
 static int build_stage_tables(Arena& a, const int32_t* nbr, int stride, int K, StageTables* t, hipStream_t sg) {
@@ -187,12 +207,13 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 isf_encoder_stats* stats, int time_layers, const isf_encoder_options* opt,
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~32;   // bit 32 (uniform conv tiles) combines with the others
+  const int dg = diagnostic & ~(32 | 64);   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const bool tile_order = (diagnostic & 64) == 0;
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : diagnostic;
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~64);
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -213,6 +234,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.has_occ = false;
   if (occ0) { L.occ = *occ0; L.has_occ = true; }
   L.cache_nbr = nullptr;
+  L.cache_order = nullptr;
+  L.cache_order_cin = L.cache_order_cout = 0;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
   bool use16 = precision != 1;
   for (int i = 0; i < num_layers; ++i)
@@ -253,6 +276,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       srows = stage_opt == 0 ? default_stage_rows(ly)
                              : ((stage_mask == 0 || ((stage_mask >> i) & 1u)) ? stage_opt : 0);
     StageTables stg;
+    const int32_t* order = nullptr;
+    const bool want_order = use16 && tile_order && srows == 0;
     if (ly.conv_type == ISF_CONV_SUBM) {
       const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
                        L.cache_ks[2] == ly.ksize[2];
@@ -268,6 +293,13 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_pairs = -(long long)i - 1;  // pairs live in pair_counts[i]; resolved after the final sync
         L.cache_stage = StageTables();
         if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
+        L.cache_order = nullptr;
+        L.cache_order_cin = L.cache_order_cout = 0;
+        if (want_order) {
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, &L.cache_order, sg));
+          L.cache_order_cin = ly.c_in;
+          L.cache_order_cout = ly.c_out;
+        }
         ISF_TRY(stream_wait_stream(a, st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
@@ -276,8 +308,15 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
+        if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, &L.cache_order, sg));
+          L.cache_order_cin = ly.c_in;
+          L.cache_order_cout = ly.c_out;
+          ISF_TRY(stream_wait_stream(a, st, sg));
+        }
       }
       stg = L.cache_stage;
+      if (want_order) order = L.cache_order;
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
     } else {
       ISF_TRY(ensure_occ(a, L, B, sg));
@@ -299,8 +338,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
                          stride, pair_counts + i, sg));
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
+      if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, &order, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_nbr = nullptr;
+      Nx.cache_order = nullptr;
+      Nx.cache_order_cin = Nx.cache_order_cout = 0;
       n_out = Nx.n;
       L = Nx;
       ISF_TRY(stream_wait_stream(a, st, sg));
@@ -321,7 +363,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                               st));
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
-                                             ly.shift, res, ly.relu, y, conv_mode, st));
+                                             ly.shift, res, ly.relu, y, conv_mode, st, order));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
       ISF_TRY(sparse_conv_forward_packed_impl(reinterpret_cast<const float*>(x), n_in, ly.c_in, ly.packed, K,
                                               ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,

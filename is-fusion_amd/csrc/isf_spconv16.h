@@ -81,11 +81,17 @@ __host__ __device__ inline bool conv16_tile_rows(Conv16Plan plan, int TM, int n_
   return off < plan.part_rows && row0 < n_out;
 }
 
+// order (optional): [parts][full + half] -- the tile workgroup slot j of a part works on (a permutation per part, built
+// by conv16_tile_order_impl so that the tiles sharing a CU add up to about the same work).
 __device__ __forceinline__ bool conv16_tile_of_block(int ncb, Conv16Plan plan, int TM, int n_out, int& cb, int& row0,
-                                                     int& row_end, bool& half) {
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+                                                     int& row_end, bool& half,
+                                                     const int32_t* __restrict__ order = nullptr) {
+  const int xcd = blockIdx.x & 7;
+  int j = blockIdx.x >> 3;
   cb = ncb == 2 ? xcd & 1 : 0;
-  return conv16_tile_rows(plan, TM, n_out, ncb == 2 ? xcd >> 1 : xcd, j, row0, row_end, half);
+  const int part = ncb == 2 ? xcd >> 1 : xcd;
+  if (order) j = order[part * (plan.full + plan.half) + j];
+  return conv16_tile_rows(plan, TM, n_out, part, j, row0, row_end, half);
 }
 static inline int conv16_grid_blocks(Conv16Plan plan) { return 8 * (plan.full + plan.half); }
 

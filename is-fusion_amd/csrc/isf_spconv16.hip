@@ -60,7 +60,13 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride,
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
-    uint4* __restrict__ ys, int n_out, int relu, Conv16Plan plan) {
+    uint4* __restrict__ ys, int n_out, int relu, Conv16Plan plan, const int32_t* __restrict__ order,
+    long long* __restrict__ trace) {
+  // MODE bit 512: per-workgroup trace (isf_sparse_conv_trace): 8 x int64 per workgroup -- constant-clock time stamps at
+  // entry / after the prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half << 32
+  constexpr bool TRACE = (MODE & 512) != 0;
+  long long t_entry = 0, t_pro = 0, t_loop = 0;
+  if (TRACE) t_entry = wall_clock64();
   constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
   // MODE bit 256 (with bit 1): F16 STORAGE -- input, residual and output rows are plain f16 (2 bytes per element, the
   // reference's indice_conv_half data type end to end: src/all.cc:35-37) instead of 4-byte split rows; half the
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   const int ncb = cout / BN;
   int cb, row0, row_end;
   bool half_tile;   // every wave owns one 16-row group (rows row0 + 16 * wave ..) instead of RG
-  if (!conv16_tile_of_block(ncb, plan, TM, n_out, cb, row0, row_end, half_tile)) return;
+  if (!conv16_tile_of_block(ncb, plan, TM, n_out, cb, row0, row_end, half_tile, order)) return;
   const int ntiles_total = cout >> 4;
 
   // ---- prologue: neighbour tile -> LDS, per-wave tap mask
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   wg_mask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int ntaps = __popc(wg_mask);
   const int nsteps = NOLOOP ? 0 : ntaps * NCG;
+  if (TRACE) t_pro = wall_clock64();
 
   f32x4 acc[RG][NT];
 #pragma unroll
@@ -297,10 +304,22 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
+  if (TRACE) t_loop = wall_clock64();
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
   conv16_epilogue<NT, RG, F16IO>(acc, tile_l, lane, row0 + wave * (half_tile ? WR / 2 : WR), cb * BN, cout, *w_inv_scale,
                                  scale, shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG);
+  if (TRACE) {
+    __syncthreads();
+    if (tid == 0) {
+      unsigned hw_id, xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      long long* t = trace + (size_t)blockIdx.x * 8;
+      t[0] = t_entry; t[1] = t_pro; t[2] = t_loop; t[3] = wall_clock64();
+      t[4] = nsteps; t[5] = hw_id; t[6] = xcc_id; t[7] = (long long)row0 | ((long long)half_tile << 32);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ format kernels
@@ -388,7 +407,8 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
 template <int CIN, int NT, int RG, int NW, int MODE = 0>
 static int launch16(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                     const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
-                    const uint4* residual, int relu, uint4* ys, hipStream_t st) {
+                    const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
+                    Conv16LaunchInfo* query, long long* trace = nullptr) {
   using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
   auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, MODE>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};   // of this instantiation on this device family
@@ -407,8 +427,13 @@ static int launch16(bool balance, const uint4* xs, const uint4* wpk, const float
   ISF_REQUIRE(ncb == 1 || ncb == 2, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d column blocks", ncb);
   const Conv16Plan plan = conv16_plan(n_out, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
                                       cus_per_xcd.load(std::memory_order_relaxed), balance);
+  if (query) {   // what this launch would look like (conv16_tile_order_impl works on exactly these tiles)
+    *query = Conv16LaunchInfo{plan.full, plan.half, plan.part_rows, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
+                              cus_per_xcd.load(std::memory_order_relaxed)};
+    return ISF_OK;
+  }
   hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K,
-                     cout, scale, shift, residual, ys, n_out, relu, plan);
+                     cout, scale, shift, residual, ys, n_out, relu, plan, order, trace);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -422,8 +447,9 @@ static int launch16(bool balance, const uint4* xs, const uint4* wpk, const float
 template <int CIN, int NT>
 static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
-                         const uint4* residual, int relu, uint4* ys, hipStream_t st) {
-#define ISF_ARGS16 (mode & 32) == 0, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st
+                         const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
+                         Conv16LaunchInfo* query) {
+#define ISF_ARGS16 (mode & 32) == 0, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
   switch (mode & ~32) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
     case 0: break;
     case 1: return launch16<CIN, NT, 2, 4, 1>(ISF_ARGS16);
@@ -450,12 +476,13 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
 template <int CIN>
 static int dispatch16(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                       const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
-                      const uint4* residual, int relu, uint4* ys, hipStream_t st) {
+                      const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
+                      Conv16LaunchInfo* query) {
   switch (cout) {
-    case 32:  return launch16_rows<CIN, 2>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
-    case 64:  return launch16_rows<CIN, 4>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 32:  return launch16_rows<CIN, 2>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
+    case 64:  return launch16_rows<CIN, 4>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
     case 128:
-    case 256: return launch16_rows<CIN, 8>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st);
+    case 256: return launch16_rows<CIN, 8>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
   }
   return ISF_ERR_UNSUPPORTED;
 }
@@ -464,8 +491,11 @@ static int dispatch16(int mode, const uint4* xs, const uint4* wpk, const float* 
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                    const float* shift, const void* residual, int relu, void* ys, int mode,
-                                   hipStream_t st) {
-  if (n_out <= 0) return ISF_OK;
+                                   hipStream_t st, const int32_t* order, Conv16LaunchInfo* query) {
+  if (n_out <= 0) {
+    if (query) *query = Conv16LaunchInfo{0, 0, 0, 0, 0, 0, 0};
+    return ISF_OK;
+  }
   ISF_REQUIRE(K >= 1 && K <= kMaxTaps, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d taps (max 27)", K);
   ISF_REQUIRE(sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "sparse_conv16: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
@@ -477,12 +507,137 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
   const uint4* r = reinterpret_cast<const uint4*>(residual);
   uint4* y = reinterpret_cast<uint4*>(ys);
   switch (c_in) {
-    case 32:  return dispatch16<32>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
-    case 64:  return dispatch16<64>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
-    case 128: return dispatch16<128>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
-    case 256: return dispatch16<256>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st);
+    case 32:  return dispatch16<32>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
+    case 64:  return dispatch16<64>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
+    case 128: return dispatch16<128>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
+    case 256: return dispatch16<256>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
   }
   return ISF_ERR_UNSUPPORTED;
+}
+
+// per-workgroup trace of one launch (production workgroup shape of the two deep channel shapes): where the time of a
+// launch goes -- tools/conv_trace.py
+int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
+                           int nbr_stride, int n_out, const float* scale, const float* shift, const void* residual,
+                           int relu, void* ys, const int32_t* order, long long* trace, int* grid_blocks,
+                           hipStream_t st) {
+  ISF_REQUIRE((c_in == 256 && c_out == 256) || (c_in == 128 && c_out == 128), ISF_ERR_UNSUPPORTED,
+              "sparse_conv_trace: built for 128 -> 128 and 256 -> 256, got %d -> %d", c_in, c_out);
+  ISF_REQUIRE(K >= 1 && K <= kMaxTaps && n_out > 0 && nbr_stride % 128 == 0 && nbr_stride >= n_out, ISF_ERR_ARG,
+              "sparse_conv_trace: bad arguments");
+  const uint4* w = reinterpret_cast<const uint4*>(packed16);
+  const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
+  const uint4* x = reinterpret_cast<const uint4*>(xs);
+  const uint4* r = reinterpret_cast<const uint4*>(residual);
+  uint4* y = reinterpret_cast<uint4*>(ys);
+  Conv16LaunchInfo info;
+  const bool wide = c_out == 128 && n_out >= 8 * 256;
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0: the launch shape (grid size), pass 1: launch
+    Conv16LaunchInfo* q = pass == 0 ? &info : nullptr;
+    int rc;
+    if (c_in == 256) rc = launch16<256, 8, 2, 4, 512>(true, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    else if (wide) rc = launch16<128, 8, 2, 8, 512>(true, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    else rc = launch16<128, 8, 2, 4, 512>(true, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    ISF_TRY(rc);
+  }
+  *grid_blocks = 8 * (info.full + info.half);
+  return ISF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- tile order
+// A launch that is resident in one round is as slow as its busiest CU: the matrix pipe of a CU is shared by the tiles
+// the dispatcher placed on it (slots j, j + cus, j + 2 cus of the XCD: round-robin, tools/probes/wg_placement.hip),
+// and the work of a tile -- the (16-row group, tap) pairs that have a neighbour, which is what it issues MFMAs for --
+// varies 3x between the sparse rim and the dense middle of a LiDAR sweep.  In launch order the tiles of one CU are
+// ~4000 rows apart and add up unevenly: busiest CU 1.23x (256 -> 256) / 1.29x (128 -> 128) the mean on the benchmark
+// geometry.  conv16_tile_order_impl hands out the SAME tiles longest-first to the least-loaded CU with a free slot
+// (LPT): 1.06x / 1.15x in the same model (profiles/r03_tile_order_lpt.txt).  The result of a layer does not change (the
+// same tiles compute the same rows in the same order of operations); only which workgroup slot runs which tile.
+__global__ __launch_bounds__(256) void conv16_tile_work_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K,
+                                                               int n_out, Conv16Plan plan, int TM,
+                                                               int32_t* __restrict__ work) {
+  const int tiles = plan.full + plan.half;
+  const int part = blockIdx.x / tiles, t = blockIdx.x - part * tiles;
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  int row0 = 0, row_end = 0;
+  bool half = false;
+  int mine = 0;
+  if (conv16_tile_rows(plan, TM, n_out, part, t, row0, row_end, half)) {
+    const int rows = half ? TM / 2 : TM;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int seg = 0; seg * 64 < rows; ++seg) {          // 64 rows = four 16-row groups per ballot
+      const int row = row0 + seg * 64 + lane;
+      const bool in = seg * 64 + lane < rows && row < row_end;
+      for (int k = wave; k < K; k += 4) {
+        const bool has = in && nbr[(size_t)k * nbr_stride + row] >= 0;
+        const unsigned long long m = __ballot(has);
+        mine += ((m & 0xffffull) != 0) + ((m & 0xffff0000ull) != 0) + ((m & 0xffff00000000ull) != 0) +
+                ((m & 0xffff000000000000ull) != 0);
+      }
+    }
+    if (lane == 0 && mine) atomicAdd(&total, mine);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) work[blockIdx.x] = total;
+}
+
+// one wave per part: longest tile first, to the CU with the least work among those with a free slot
+__global__ __launch_bounds__(64) void conv16_tile_order_kernel(const int32_t* __restrict__ work, int tiles, int cus,
+                                                               int32_t* __restrict__ order) {
+  const int part = blockIdx.x, lane = threadIdx.x;
+  // four candidate tiles per lane (tiles <= 255); key = work << 8 | (255 - tile): ties go to the lower tile index and
+  // no live key is 0 (= taken)
+  unsigned key[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = lane + 64 * q;
+    key[q] = t < tiles ? ((unsigned)work[part * tiles + t] << 8) | (unsigned)(255 - t) : 0u;
+  }
+  const int cap = lane < cus ? (tiles - lane + cus - 1) / cus : 0;   // lane c < cus is CU c: slots c, c + cus, ...
+  int used = 0;
+  unsigned load = 0;
+  for (int it = 0; it < tiles; ++it) {
+    unsigned best = key[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) best = key[q] > best ? key[q] : best;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)best, o);
+      best = other > best ? other : best;
+    }
+    const int tile = 255 - (int)(best & 255u);
+    const unsigned w = best >> 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (key[q] == best) key[q] = 0u;   // keys are unique (the tile index is part of them)
+    unsigned ck = used < cap ? (load << 6) | (unsigned)lane : 0xffffffffu;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)ck, o);
+      ck = other < ck ? other : ck;
+    }
+    const int cu = (int)(ck & 63u);
+    if (lane == cu) {
+      order[part * tiles + cu + cus * used] = tile;
+      ++used;
+      load += w;
+    }
+  }
+}
+
+int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
+                           int32_t* work, int32_t* order, hipStream_t st) {
+  ISF_REQUIRE(conv16_order_applies(info), ISF_ERR_ARG, "tile order: launch of %d + %d tiles per part on %d x %d slots",
+              info.full, info.half, info.wgs_per_cu, info.cus_per_xcd);
+  const int parts = conv16_order_parts(info), tiles = conv16_order_tiles(info);
+  const Conv16Plan plan{info.full, info.half, info.part_rows};
+  hipLaunchKernelGGL(conv16_tile_work_kernel, dim3(parts * tiles), dim3(256), 0, st, nbr, nbr_stride, K, n_out, plan,
+                     info.TM, work);
+  hipLaunchKernelGGL(conv16_tile_order_kernel, dim3(parts), dim3(64), 0, st, work, tiles, info.cus_per_xcd, order);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
 }
 
 int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st) {
@@ -592,4 +747,48 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
                                              isf::as_stream(stream));
 }
 
+int isf_sparse_conv_tile_order(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
+                               int mode, int32_t* work, int32_t* order, int* num_entries, isf_stream_t stream) {
+  ISF_REQUIRE(nbr && work && order && num_entries && num_out >= 0, ISF_ERR_ARG, "sparse_conv_tile_order: bad arguments");
+  *num_entries = 0;
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
+              "sparse_conv_tile_order: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
+  isf::Conv16LaunchInfo info;
+  ISF_TRY(isf::sparse_conv_forward_f16x3_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
+                                              nullptr, nullptr, 0, nullptr, mode, isf::as_stream(stream), nullptr, &info));
+  if (!isf::conv16_order_applies(info)) return ISF_OK;
+  *num_entries = isf::conv16_order_parts(info) * isf::conv16_order_tiles(info);
+  return isf::conv16_tile_order_impl(nbr, nbr_stride, num_taps, num_out, info, work, order, isf::as_stream(stream));
+}
+
+int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in, int c_in, const void* packed16,
+                                          int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                                          const float* scale, const float* shift, const void* residual_split, int relu,
+                                          void* out_split, int mode, const int32_t* order, isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0, ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3_ordered: bad arguments");
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
+              ISF_ERR_ARG, "sparse_conv_forward_f16x3_ordered: null pointer");
+  const int m = mode & ~32;
+  ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 16 || m == 257), ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3_ordered: mode %d (0, 1, 16, 257, +32)", mode);
+  return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
+                                             num_out, scale, shift, residual_split, relu, out_split, mode,
+                                             isf::as_stream(stream), order);
+}
+
+int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                          int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                          const float* shift, const void* residual_split, int relu, void* out_split,
+                          const int32_t* order, long long* trace, int* grid_blocks, isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && features_split && packed16 && nbr && out_split && trace && grid_blocks &&
+                  ((scale == nullptr) == (shift == nullptr)), ISF_ERR_ARG, "sparse_conv_trace: bad arguments");
+  return isf::sparse_conv_trace_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
+                                     shift, residual_split, relu, out_split, order, trace, grid_blocks,
+                                     isf::as_stream(stream));
+}
+
 }  // extern "C"
+

@@ -184,29 +184,60 @@ def from_half(xh, shape):
     return out
 
 
+def tile_order(rb, c_in, c_out, mode=0):
+    """int32 tile order of the launch sparse_conv_forward_f16x3 makes for this rulebook and channel shape
+    (isf_sparse_conv_tile_order), or None when the launch is not a single resident round.  Cached on the rulebook."""
+    cache = rb.__dict__.setdefault("_tile_order", {})
+    key = (int(c_in), int(c_out), int(mode))
+    if key not in cache:
+        lib = _lib.load()
+        K = rb.nbr.numel() // rb.stride
+        dev = rb.nbr.device
+        work = torch.empty(8 * 255, dtype=torch.int32, device=dev)
+        order = torch.empty(8 * 255, dtype=torch.int32, device=dev)
+        n = ctypes.c_int(0)
+        _lib.check(lib.isf_sparse_conv_tile_order(_lib.ptr(rb.nbr), rb.stride, K, rb.num_out, c_in, c_out, int(mode),
+                                                  _lib.ptr(work), _lib.ptr(order), ctypes.byref(n), _lib.stream()),
+                   "isf_sparse_conv_tile_order")
+        cache[key] = (order[:n.value], work[:n.value]) if n.value else None
+    return cache[key][0] if cache[key] is not None else None
+
+
 def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
-                              relu=False, mode=0):
+                              relu=False, mode=0, order=None):
     """fp32 in / fp32 out convenience wrapper around the split-precision kernel (converts at both ends); mode 257 (f16
-    storage) converts through f16 rows instead of split rows."""
+    storage) converts through f16 rows instead of split rows.  order: tile_order(rb, c_in, c_out, mode) or None."""
     _lib.require_cuda(features)
-    if (mode & ~32) == 257:
-        xs = to_half(features)
-        rs = to_half(residual) if residual is not None else None
-        ys = torch.empty(rb.num_out * c_out * 2, dtype=torch.uint8, device=features.device)
-        _lib.check(_lib.load().isf_sparse_conv_forward_f16x3(
-            _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode), _lib.stream()),
-            "isf_sparse_conv_forward_f16x3")
-        return from_half(ys, (rb.num_out, c_out))
-    xs = to_split(features)
-    rs = to_split(residual) if residual is not None else None
-    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)
+    f16io = (mode & ~32) == 257
+    xs = to_half(features) if f16io else to_split(features)
+    rs = None if residual is None else (to_half(residual) if f16io else to_split(residual))
+    ys = torch.empty(rb.num_out * c_out * (2 if f16io else 4), dtype=torch.uint8, device=features.device)
     lib = _lib.load()
-    _lib.check(lib.isf_sparse_conv_forward_f16x3(
-        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode), _lib.stream()),
-        "isf_sparse_conv_forward_f16x3")
-    return from_split(ys, (rb.num_out, c_out))
+    args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+            _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode))
+    if order is None:
+        _lib.check(lib.isf_sparse_conv_forward_f16x3(*args, _lib.stream()), "isf_sparse_conv_forward_f16x3")
+    else:
+        _lib.check(lib.isf_sparse_conv_forward_f16x3_ordered(*args, _lib.ptr(order), _lib.stream()),
+                   "isf_sparse_conv_forward_f16x3_ordered")
+    return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
+
+
+def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,
+                      order=None):
+    """DIAGNOSTIC (isf_sparse_conv_trace): one production launch of a 128 -> 128 / 256 -> 256 layer on split rows `xs`
+    -> (out_split, trace int64 [workgroups, 8]): time stamps (100 MHz) at entry / after the prologue / after the
+    multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half tile << 32."""
+    _lib.require_cuda(xs)
+    lib = _lib.load()
+    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
+    trace = torch.zeros((8 * 255 * 8,), dtype=torch.int64, device=xs.device)
+    n = ctypes.c_int(0)
+    _lib.check(lib.isf_sparse_conv_trace(_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr),
+                                         rb.stride, rb.num_out, _lib.ptr(scale), _lib.ptr(shift),
+                                         _lib.ptr(residual_split), int(bool(relu)), _lib.ptr(ys), _lib.ptr(order),
+                                         _lib.ptr(trace), ctypes.byref(n), _lib.stream()), "isf_sparse_conv_trace")
+    return ys, trace[:n.value * 8].view(n.value, 8)
 
 
 def stage_tables(rb):

@@ -495,6 +495,73 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
 
 
+def test_conv_tile_order_is_a_per_part_permutation_and_keeps_the_bits(dev):
+    """isf_sparse_conv_tile_order hands the tiles of a one-round launch to the workgroup slots longest first / least
+    loaded CU first: per XCD part a permutation of the tiles, the first 32 slots (one per CU) holding the 32 heaviest
+    tiles; the ordered launch computes the same tiles, so its output equals the launch-order kernel's bit for bit.
+    A level too small (every CU holds at most one tile) or too large (several rounds) gets no table."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(77)
+    B, shape = 2, [16, 96, 96]
+    for n, cin, cout, applies in ((40000, 256, 256, True), (40000, 128, 128, True), (40000, 64, 64, True),
+                                  (3000, 256, 256, False), (200000, 64, 64, False)):
+        # dense blob + sparse rim: tile work varies
+        cells = B * int(np.prod(shape))
+        zz, yy, xx = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+        blob = (np.abs(yy - 48) < 20) & (np.abs(xx - 48) < 20) & (zz < 8)
+        p = np.tile(np.where(blob, 12.0, 1.0).ravel(), B)
+        lin = np.sort(rng.choice(cells, n, replace=False, p=p / p.sum()))
+        D, H, W = shape
+        idx = np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
+        rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+        order = sp.tile_order(rb, cin, cout)
+        assert (order is not None) == applies, (n, cin, cout)
+        if order is None:
+            continue
+        parts = 4 if cout == 256 else 8
+        o = order.cpu().numpy().reshape(parts, -1)
+        work = rb._tile_order[(cin, cout, 0)][1].cpu().numpy().reshape(parts, -1)
+        tiles = o.shape[1]
+        assert tiles > 32
+        for q in range(parts):
+            assert np.array_equal(np.sort(o[q]), np.arange(tiles)), q
+            # replay: longest tile first (ties: lower index), to the least-loaded CU (ties: lower CU) with a free slot
+            cap = [(tiles - c + 31) // 32 for c in range(32)]
+            used, load, want = [0] * 32, [0] * 32, np.full(tiles, -1)
+            for t in sorted(range(tiles), key=lambda t: (-work[q][t], t)):
+                c = min((c for c in range(32) if used[c] < cap[c]), key=lambda c: (load[c], c))
+                want[c + 32 * used[c]] = t
+                used[c] += 1
+                load[c] += work[q][t]
+            assert np.array_equal(o[q], want), q
+        assert work.min() >= 0 and work.max() <= 27 * 16
+        x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+        w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (3, 3, 3, cin, cout)).astype(np.float32), dev)
+        p16 = sp.pack_filters_f16x3(w)
+        res = T(rng.normal(0, 1, (n, cout)).astype(np.float32), dev)
+        for mode in (0, 1, 257):
+            om = sp.tile_order(rb, cin, cout, mode)
+            ref = sp.sparse_conv_forward_f16x3(x, p16, 27, cin, cout, rb, None, None, res, relu=True, mode=mode)
+            got = sp.sparse_conv_forward_f16x3(x, p16, 27, cin, cout, rb, None, None, res, relu=True, mode=mode, order=om)
+            assert ref.abs().max() > 0.5 and torch.equal(got, ref), (cin, cout, mode)
+
+
+def test_lidar_branch_tile_order_reproduces_launch_order_bits(dev):
+    """the encoder builds a tile-order table per level behind the neighbour table (geometry stream) and runs the deep
+    levels' convolutions through it; diagnostic 64 switches the tables off -- same bits, at sizes where no level, the
+    last level and the last two levels qualify"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(900 + i, n), dev) for i in range(frames)]
+        want = lb(pl, conv_diag=64)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        assert torch.equal(lb(pl), want), n
+        assert torch.equal(lb(pl, conv_diag=96), want), n       # uniform tiles, no order
+        assert torch.equal(lb(pl, precision=2), lb(pl, precision=2, conv_diag=64)), n
+
+
 def test_lidar_branch_with_lds_staged_convs_reproduces_gather_bits(dev):
     """every conv of the LiDAR branch on the LDS-staged kernel (isf_encoder_options.stage_rows; staging tables built on
     the geometry stream) == the gather kernels, bit for bit: small LDS shares (fall-back gathers inside every tile), a

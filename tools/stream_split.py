@@ -52,6 +52,26 @@ def main():
         dt = time.perf_counter() - t0
     print(f"two streams, 2 x batch 2: {4 * args.steps / dt:8.1f} frames/s  {dt / args.steps * 1e3:.3f} ms per 4 frames")
 
+    # (c) two forwards of the FULL batch in flight (consecutive batches pipelined on two streams)
+    def worker_full(stream, n, off):
+        with torch.cuda.stream(stream):
+            for s in range(n):
+                lb(sets[(s + off) % 2])
+            stream.synchronize()
+
+    for n in (5, args.steps // 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker_full, args=(streams[h], n, h)) for h in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"two streams, 2 x batch 4 in flight: {4 * 2 * (args.steps // 2) / dt:8.1f} frames/s  "
+          f"{dt / (2 * (args.steps // 2)) * 1e3:.3f} ms per batch of 4")
+
 
 if __name__ == "__main__":
     main()
