@@ -74,8 +74,8 @@ class ISFusionEncoder(nn.Module):
     def img_fv_to_bev(self, mlvl_feats, bs, **kwargs):
         """A8 Point-to-Grid: one kernel over (pillar, slot, camera) instead of B*6 grid_sample calls."""
         pm = kwargs["pts_metas"]
-        return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs["lidar2img"],
-                              kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
+        return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs.get("lidar2img"),
+                              kwargs.get("img_aug_matrix"), kwargs.get("lidar_aug_matrix"),   # unused when p2g_cam is given
                               kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views,
                               cam=kwargs.get("p2g_cam"), out=kwargs.get("p2g_out"))
 

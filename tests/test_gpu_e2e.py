@@ -179,3 +179,46 @@ def test_hip_graph_tail_reproduces_the_eager_forward(dev):
     net.enable_graph(False)
     got, _ = run(1)                  # eager again (frozen caches)
     assert all(torch.equal(got[k], eager[1][0][k]) for k in keys)
+
+
+def test_back_to_back_forwards_without_host_sync(dev):
+    """The bench loop queues forwards without ever synchronising; the host then runs ahead of the GPU (the LiDAR branch
+    of forward n + 1 is being launched while the tail of forward n executes, by a whole tail in graph mode).  Twelve
+    full-size forwards (B = 2 x 300 k points, alternating frame sets) queued back to back must reproduce the
+    synchronised results bit for bit -- eager and as HIP-graph replays (regression: the replays ended in a GPU memory
+    fault when the pillar voxelization ran on a side stream)."""
+    from isfusion_amd import synthetic
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    B = 2
+    net = ISFusionPtsPath().eval()
+    net._lidar.randomize_weights_(0).randomize_bn_(1)
+    for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250), (net.pts_bbox_head, 300)):
+        mod.load_state_dict(seeded_state_dict(mod, seed))
+    net = net.to(dev).freeze()
+    sets = []
+    for fs in range(2):
+        pts = [torch.from_numpy(synthetic.lidar_sweeps(7100 + 10 * fs + i, 300000)).to(dev) for i in range(B)]
+        inp = synthetic.fusion_inputs(90 + fs, B)
+        img_feats = tuple(torch.from_numpy(a).to(dev) for a in inp["img_feats"])
+        kw = dict(lidar2img=torch.from_numpy(inp["lidar2img"]), img_aug_matrix=torch.from_numpy(inp["img_aug_matrix"]),
+                  lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
+        sets.append((pts, img_feats, [dict(input_shape=inp["input_shape"]) for _ in range(B)], kw))
+    keys = ("center", "height", "dim", "rot", "vel", "heatmap", "dense_heatmap")
+
+    def run(i):
+        pts, img_feats, metas, kw = sets[i % 2]
+        out = net.forward_pts(pts, img_feats, metas, **kw)[0][0]
+        return {k: out[k].clone() for k in keys}
+
+    want = []
+    for i in range(2):
+        want.append(run(i))
+        torch.cuda.synchronize()
+    for graph in (False, True):
+        net.enable_graph(graph)
+        got = [run(i) for i in range(12)]          # no host sync in between
+        torch.cuda.synchronize()
+        for i, g in enumerate(got):
+            for k in keys:
+                assert torch.equal(g[k], want[i % 2][k]), (graph, i, k)

@@ -1,6 +1,7 @@
 """GPU idle time inside the steady-state steps of a rocprofv3 kernel trace: union of the kernels' [start, end) intervals
 over all streams against the wall span, the largest gaps and the kernels on either side of them.
-usage: python tools/timeline_gaps.py TRACE_DB [marker] [steps] [first]
+usage: python tools/timeline_gaps.py TRACE_DB [marker] [steps] [first] [context]
+context > 0: also list that many dispatches on either side of the three largest gaps (name, stream, start, duration)
 looks at `steps` (default 5) whole steps starting at step `first` (default: the last ones; bench.py runs warm-up + timed
 steps first and an event-instrumented pass after them -- pass first = 4 to look inside the timed region), a step = from one dispatch of the kernel whose name contains `marker`
 (default vfe_prep_kernel, the first kernel of the LiDAR branch) to the next"""
@@ -47,6 +48,14 @@ def main():
     print("# largest gaps: us, after kernel -> before kernel, at ms")
     for g in sorted(gaps, reverse=True)[:25]:
         print("%8.1f  %-70s -> %-70s @ %.2f" % (g[0] / 1e3, g[1], g[2], g[3]))
+    context = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    if context:
+        for g in sorted(gaps, reverse=True)[:3]:
+            at = g[3] * 1e6 + t0
+            idx = max(i for i, r in enumerate(rows) if r[1] <= at + 1)
+            print(f"# around the {g[0] / 1e3:.1f} us gap at {g[3]:.2f} ms:")
+            for r in rows[max(0, idx - context):idx + context + 1]:
+                print("   %9.1f us  +%7.1f us  q%-3s %s" % ((r[0] - t0) / 1e3, (r[1] - r[0]) / 1e3, r[3], short(r[2])))
     hist = {}
     for g in gaps:
         key = (g[1], g[2])
