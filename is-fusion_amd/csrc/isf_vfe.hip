@@ -245,19 +245,23 @@ __device__ __forceinline__ void vfe_layer1_mfma(const float (&f)[F], bool valid,
   }
 }
 
-// C/D-layout layer-1 sums -> relu(BN) -> fp32 tile [point][kLdsStride]
+// C/D-layout layer-1 sums -> relu(BN) -> fp32 tile [point - 32 half][kLdsStride] for the points of row groups 2 half
+// and 2 half + 1.  The tiles hold HALF a wave's points (8.3 KiB per wave instead of 16.6): LDS is what bounds the
+// occupancy of the two VFE kernels (round 2: 8 waves per CU; now 18).
+static constexpr int kHalfPts = 32;
 __device__ __forceinline__ void vfe_layer1_store_tile(const f32x4 (&acc)[4][4], const float* __restrict__ sc1,
                                                       const float* __restrict__ shift1, float* __restrict__ tile,
-                                                      int lane) {
+                                                      int lane, int half) {
   const int col = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const float sc = sc1[16 * nt + col], sh = shift1[16 * nt + col];
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
+    for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        tile[(16 * rg + 4 * kq + t) * kLdsStride + 16 * nt + col] = fmaxf(fmaf(acc[rg][nt][t], sc, sh), 0.f);
+        tile[(16 * r2 + 4 * kq + t) * kLdsStride + 16 * nt + col] =
+            fmaxf(fmaf(half ? acc[2 + r2][nt][t] : acc[r2][nt][t], sc, sh), 0.f);
   }
 }
 
@@ -268,9 +272,10 @@ __device__ __forceinline__ void vfe_layer1_store_tile(const f32x4 (&acc)[4][4], 
 // boundary -- or whose neighbour across the boundary belongs to another voxel (`vprev`, `vnext`: the voxel ids of
 // records j0-1 and j0+64) -- is written with one 256-byte row store; a run cut by the boundary uses integer
 // atomicMax on the zero-initialised destination (identical result for non-negative floats).
-template <typename ValFn>
+// fill(half) puts the points [32 half, 32 half + 32) into the wave's tile before val() reads them (val(p): p in 0..63).
+template <typename FillFn, typename ValFn>
 __device__ __forceinline__ void vfe_segmented_max(int myvox, int vprev, int vnext, int lane, float* __restrict__ dst,
-                                                  ValFn val) {
+                                                  FillFn fill, ValFn val) {
   int run = -1, first = 0;
   float m = 0.f;
   auto flush = [&](int last) {   // run covers points [first, last]
@@ -281,6 +286,11 @@ __device__ __forceinline__ void vfe_segmented_max(int myvox, int vprev, int vnex
   };
 #pragma unroll
   for (int c = 0; c < 64; c += 16) {
+    if (c % kHalfPts == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous half has been read
+      fill(c / kHalfPts);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
     float vals[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) vals[q] = val(c + q);
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
     const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
     const float4* __restrict__ mean4, VfeGeom g, const uint2* __restrict__ w1p, const float* __restrict__ sc1,
     const float* __restrict__ shift1, float* __restrict__ vmax1) {
-  __shared__ __attribute__((aligned(16))) float tile[kL1Threads * kLdsStride];
+  __shared__ __attribute__((aligned(16))) float tile[(kL1Threads / 64) * kHalfPts * kLdsStride];
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const long long wj0 = (long long)blockIdx.x * kL1Threads + wave * 64;
@@ -346,21 +356,22 @@ __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
     v = __float_as_int(rec[kRec - 1]);
     vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
   }
-  float* wt = tile + wave * 64 * kLdsStride;
+  float* wt = tile + wave * kHalfPts * kLdsStride;   // >= the 4 KiB layer-1 staging area
   f32x4 acc[4][4];
   vfe_layer1_mfma<CIN + 6>(f, v >= 0, w1p, reinterpret_cast<char*>(wt), lane, acc);
-  vfe_layer1_store_tile(acc, sc1, shift1, wt, lane);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   vfe_segmented_max(v, vfe_record_voxel(recs, wj0 - 1, nv), vfe_record_voxel(recs, wj0 + 64, nv), lane, vmax1,
-                    [&](int p) { return wt[p * kLdsStride + lane]; });
+                    [&](int half) { vfe_layer1_store_tile(acc, sc1, shift1, wt, lane, half); },
+                    [&](int p) { return wt[(p % kHalfPts) * kLdsStride + lane]; });
 }
 
 // ------------------------------------------------------------------------------------------ layer 2 (MFMA)
 // One wave = 64 sorted points = 4 MFMA row groups; K = 128 = [h1 (64) | vmax1[voxel] (64)] in two halves.
-// LDS per wave: A tile, split format [unit 8][hi|lo][point 64][8 halves] = 16 KiB (conflict free for both
-// the point-per-lane writes and the ds_read_b128 fragment reads), reused as the fp32 [64][65] output tile.
+// LDS per wave, 8.3 KiB: the A tile of ONE 32-channel chunk, split format [unit 4][hi|lo][point 64][8 halves] = 8 KiB
+// (conflict free for both the point-per-lane writes and the ds_read_b128 fragment reads; the four chunks of K = 128 go
+// through it one after the other, each with its B fragments loaded once), reused as the fp32 [32 points][65] tiles of
+// the layer-1 hand-over and of the output (two point halves each).
 static constexpr int kL2Waves = 2;
-static constexpr int kL2WaveBytes = 64 * kLdsStride * 4;  // 16640 >= 16384
+static constexpr int kL2WaveBytes = kHalfPts * kLdsStride * 4;  // 8320 >= 8192
 
 template <int CIN>
 __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
@@ -394,15 +405,20 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
       v = __float_as_int(rec[kRec - 1]);
       vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
     }
-    // layer 1 recomputed on the matrix cores (its output [P, 64] never goes to HBM), through the fp32 tile back
-    // to one-point-per-lane registers for the split-format A tile of layer 2
+    // layer 1 recomputed on the matrix cores (its output [P, 64] never goes to HBM), through the fp32 tile (32 points
+    // at a time) back to one-point-per-lane registers for the split-format A tile of layer 2
     f32x4 acc1[4][4];
     vfe_layer1_mfma<CIN + 6>(f, v >= 0, w1p, reinterpret_cast<char*>(ftile), lane, acc1);
-    vfe_layer1_store_tile(acc1, sc1, shift1, ftile, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-    for (int o = 0; o < kC; ++o) h[o] = ftile[lane * kLdsStride + o];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int half = 0; half < 2; ++half) {
+      vfe_layer1_store_tile(acc1, sc1, shift1, ftile, lane, half);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if ((lane >> 5) == half) {
+#pragma unroll
+        for (int o = 0; o < kC; ++o) h[o] = ftile[(lane & 31) * kLdsStride + o];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
   }
   vox[lane] = v;
 
@@ -412,50 +428,46 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto mfma_half = [&](int half) {  // consumes the 64 channels currently in the A tile
+  // chunk q of K = 128 (q = 2 * half + kc: 32 channels of x, this lane's point) -> A tile -> 48 MFMAs
+  auto chunk = [&](const float (&x)[kC], int half, int kc) {
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      uint4 ah[4], al[4];
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        ah[rg] = atile[((4 * kc + kg) * 2 + 0) * 64 + rg * 16 + col];
-        al[rg] = atile[((4 * kc + kg) * 2 + 1) * 64 + rg * 16 + col];
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const uint4 bhu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + lane];
-        const uint4 blu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + 64 + lane];
-        const h8 bh = *reinterpret_cast<const h8*>(&bhu);
-        const h8 bl = *reinterpret_cast<const h8*>(&blu);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const h8 a_h = *reinterpret_cast<const h8*>(&ah[rg]);
-          const h8 a_l = *reinterpret_cast<const h8*>(&al[rg]);
-          acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, bh, acc[rg][nt], 0, 0, 0);
-          acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bl, acc[rg][nt], 0, 0, 0);
-          acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bh, acc[rg][nt], 0, 0, 0);
-        }
-      }
-    }
-  };
-  auto store_units = [&](const float (&x)[kC]) {  // this lane's point -> A tile (split)
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       f32x8 vv;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) vv[q] = x[u * 8 + q];
+      for (int q = 0; q < 8; ++q) vv[q] = x[(4 * kc + u) * 8 + q];
       uint4 hi, lo;
       vfe_split8(vv, hi, lo);
       atile[(u * 2 + 0) * 64 + lane] = hi;
       atile[(u * 2 + 1) * 64 + lane] = lo;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    uint4 ah[4], al[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      ah[rg] = atile[(kg * 2 + 0) * 64 + rg * 16 + col];
+      al[rg] = atile[(kg * 2 + 1) * 64 + rg * 16 + col];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile may be overwritten by the next chunk
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const uint4 bhu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + lane];
+      const uint4 blu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + 64 + lane];
+      const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+      const h8 bl = *reinterpret_cast<const h8*>(&blu);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const h8 a_h = *reinterpret_cast<const h8*>(&ah[rg]);
+        const h8 a_l = *reinterpret_cast<const h8*>(&al[rg]);
+        acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, bh, acc[rg][nt], 0, 0, 0);
+        acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bl, acc[rg][nt], 0, 0, 0);
+        acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bh, acc[rg][nt], 0, 0, 0);
+      }
+    }
   };
 
   // half 0: h1
-  store_units(h);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  mfma_half(0);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  chunk(h, 0, 0);
+  chunk(h, 0, 1);
   // half 1: the voxel's layer-1 max (map_voxel_center_to_point gather, voxel_encoder.py:541-544)
   {
     float r[kC];
@@ -470,23 +482,24 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
 #pragma unroll
       for (int o = 0; o < kC; ++o) r[o] = 0.f;
     }
-    store_units(r);
+    chunk(r, 1, 0);
+    chunk(r, 1, 1);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  mfma_half(1);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  // accumulators (col = lane&15 -> channel, row = 4*(lane>>4)+t -> point) -> fp32 tile [pt][65]
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ftile[(rg * 16 + 4 * kg + t) * kLdsStride + nt * 16 + col] = acc[rg][nt][t];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // accumulators (col = lane&15 -> channel, row = 4*(lane>>4)+t -> point) -> fp32 tile [pt - 32 half][65], half by half
   const float sc = sc2[lane], sh = shift2[lane];
   vfe_segmented_max(vox[lane], vfe_record_voxel(recs, (long long)j0 - 1, nv),
                     vfe_record_voxel(recs, (long long)j0 + 64, nv), lane, out,
-                    [&](int p) { return fmaxf(fmaf(ftile[p * kLdsStride + lane], sc, sh), 0.f); });
+                    [&](int half) {
+#pragma unroll
+                      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                          for (int t = 0; t < 4; ++t)
+                            ftile[(r2 * 16 + 4 * kg + t) * kLdsStride + nt * 16 + col] =
+                                half ? acc[2 + r2][nt][t] : acc[r2][nt][t];
+                    },
+                    [&](int p) { return fmaxf(fmaf(ftile[(p % kHalfPts) * kLdsStride + lane], sc, sh), 0.f); });
 }
 
 // ------------------------------------------------------------------------------------------ driver
