@@ -238,6 +238,19 @@ int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, cons
                           int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
                           const float* shift, const void* residual_split, int relu, void* out_split,
                           const int32_t* order, long long* trace, int* grid_blocks, isf_stream_t stream);
+/* The same convolution for the NARROW layers (c_in, c_out in {32, 64}) with the gathered rows brought in by LDS-DMA
+ * (isf_spconv_dma.hip; mode 0 | 1 | 257, +32; order: NULL or isf_sparse_conv_tile_order's table).  A gather instruction of
+ * isf_sparse_conv_forward_f16x3 loads straight into the MFMA operand layout -- four different rows = four cache lines per
+ * lane quad: 64 address-unit cycles -- and on the narrow layers (few MFMAs per gathered row) the address unit sets the
+ * step time.  Here a quad fetches the 64 contiguous bytes of ONE row (16 cycles) into a wave-private LDS transit buffer
+ * and the MFMA layout is produced by the LDS read; no neighbour table in LDS, 5-6 workgroups per CU.  Results are
+ * BIT-IDENTICAL to isf_sparse_conv_forward_f16x3 (same products in the same order per accumulator);
+ * isf_sparse_encoder_forward / isf_lidar_branch_forward run their narrow layers on it (diagnostic +128: gather kernel).
+ * Replaces the reference's gather stage (bevfusion-ops/spconv/include/spconv/reordering.cu.h:21-97) for those layers. */
+int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                                int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                                const float* shift, const void* residual_split, int relu, void* out_split, int mode,
+                                const int32_t* order, isf_stream_t stream);
 /* The same convolution with the tile's input rows staged in LDS ("LDS staging of active-voxel tiles"; the reference's
  * gather stage: bevfusion-ops/spconv/include/spconv/reordering.cu.h:21-97 -> staging buffer -> GEMM, spconv_ops.h:300-345).
  * isf_rulebook_stage_tables derives the staging tables of a neighbour table once per rulebook: for every unit of
@@ -292,7 +305,8 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            kernels; 2 = f16 storage + single-pass f16 arithmetic (opt-in, the reference's fp16 mode: activations are
  *            f16 rows between the layers, mode 257 of isf_sparse_conv_forward_f16x3);
  * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3;
- *            +64 = tiles in launch order, no isf_sparse_conv_tile_order tables -- results bit-identical);
+ *            +64 = tiles in launch order, no isf_sparse_conv_tile_order tables; +128 = narrow layers on the gather
+ *            kernel instead of isf_sparse_conv_forward_dma -- results bit-identical either way);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

@@ -134,6 +134,8 @@ SIGNATURES = {
     "isf_sparse_conv_forward_f16x3_ordered": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                                       c_void_p, c_void_p]),
+    "isf_sparse_conv_forward_dma": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                       c_void_p]),

@@ -175,6 +175,13 @@ static inline bool conv16_order_applies(const Conv16LaunchInfo& i) {
   const int t = i.full + i.half;
   return t > i.cus_per_xcd && t <= i.wgs_per_cu * i.cus_per_xcd && t <= 255 && i.cus_per_xcd <= 64;
 }
+// isf_spconv_dma.hip: the same convolution for the narrow layers (<= 64 channels in and out) with the gathered rows
+// brought in by LDS-DMA, one cache line per lane quad; bit-identical to sparse_conv_forward_f16x3_impl
+bool sparse_conv_dma_supported(int c_in, int c_out);
+int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
+                                 int nbr_stride, int n_out, const float* scale, const float* shift,
+                                 const void* residual, int relu, void* ys, int mode, hipStream_t st,
+                                 const int32_t* order = nullptr, Conv16LaunchInfo* query = nullptr);
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st);

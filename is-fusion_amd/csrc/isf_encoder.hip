@@ -161,11 +161,15 @@ struct LevelState {
 // tile order of one conv launch over a neighbour table (conv16_tile_order_impl), built behind the table on the
 // geometry stream; *order stays nullptr when the launch is not a single resident round
 static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int32_t* nbr, int stride, int n_out,
-                            int mode, const int32_t** order, hipStream_t sg) {
+                            int mode, bool dma, const int32_t** order, hipStream_t sg) {
   *order = nullptr;
   Conv16LaunchInfo info;
-  ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, nullptr,
+  if (dma)
+    ISF_TRY(sparse_conv_forward_dma_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, nullptr,
                                          nullptr, nullptr, 0, nullptr, mode, sg, nullptr, &info));
+  else
+    ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, nullptr,
+                                           nullptr, nullptr, 0, nullptr, mode, sg, nullptr, &info));
   if (!conv16_order_applies(info)) return ISF_OK;
   const size_t n = (size_t)conv16_order_parts(info) * conv16_order_tiles(info);
   int32_t *work = nullptr, *ord = nullptr;
@@ -207,13 +211,14 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 isf_encoder_stats* stats, int time_layers, const isf_encoder_options* opt,
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64);   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128);   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
+  const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~64);
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -278,6 +283,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     StageTables stg;
     const int32_t* order = nullptr;
     const bool want_order = use16 && tile_order && srows == 0;
+    // narrow layers: LDS-DMA gathers (isf_spconv_dma.hip); the timing diagnostics and mode 16 exist on the gather kernel
+    const bool dma = use16 && dma_gather && srows == 0 && dg == 0 && sparse_conv_dma_supported(ly.c_in, ly.c_out);
     if (ly.conv_type == ISF_CONV_SUBM) {
       const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
                        L.cache_ks[2] == ly.ksize[2];
@@ -296,7 +303,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_order = nullptr;
         L.cache_order_cin = L.cache_order_cout = 0;
         if (want_order) {
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, &L.cache_order, sg));
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
         }
@@ -309,7 +316,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, &L.cache_order, sg));
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
           ISF_TRY(stream_wait_stream(a, st, sg));
@@ -338,7 +345,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
                          stride, pair_counts + i, sg));
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
-      if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, &order, sg));
+      if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_nbr = nullptr;
       Nx.cache_order = nullptr;
@@ -361,6 +368,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(sparse_conv_forward_staged_impl(x, ly.c_in, ly.packed16, K, ly.c_out, stg.slots, stride, stg.ulist,
                                               stg.ucount, n_out, ly.scale, ly.shift, res, ly.relu, y, srows, conv_mode,
                                               st));
+    else if (dma)
+      ISF_TRY(sparse_conv_forward_dma_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
+                                           res, ly.relu, y, conv_mode, st, order));
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y, conv_mode, st, order));

@@ -223,6 +223,22 @@ def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None
     return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
 
 
+def sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False,
+                            mode=0, order=None):
+    """sparse_conv_forward_f16x3 on the LDS-DMA gather kernel of the narrow layers (isf_sparse_conv_forward_dma:
+    c_in, c_out in {32, 64}); bit-identical results."""
+    _lib.require_cuda(features)
+    f16io = (mode & ~32) == 257
+    xs = to_half(features) if f16io else to_split(features)
+    rs = None if residual is None else (to_half(residual) if f16io else to_split(residual))
+    ys = torch.empty(rb.num_out * c_out * (2 if f16io else 4), dtype=torch.uint8, device=features.device)
+    _lib.check(_lib.load().isf_sparse_conv_forward_dma(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode), _lib.ptr(order),
+        _lib.stream()), "isf_sparse_conv_forward_dma")
+    return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
+
+
 def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,
                       order=None):
     """DIAGNOSTIC (isf_sparse_conv_trace): one production launch of a 128 -> 128 / 256 -> 256 layer on split rows `xs`

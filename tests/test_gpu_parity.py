@@ -562,6 +562,54 @@ def test_lidar_branch_tile_order_reproduces_launch_order_bits(dev):
         assert torch.equal(lb(pl, precision=2), lb(pl, precision=2, conv_diag=64)), n
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 32), (64, 32), (32, 64)])
+def test_dma_gather_kernel_bit_identical_to_gather_kernel(dev, cin, cout):
+    """isf_sparse_conv_forward_dma (narrow layers: the gathered rows come in by LDS-DMA, one cache line per lane quad,
+    through a wave-private transit buffer; taps outer, one 32-channel chunk per step, neighbour indices in registers) ==
+    isf_sparse_conv_forward_f16x3 bit for bit: same products, same order per accumulator.  SubM / strided / 3x1x1
+    geometry, BN + residual + ReLU epilogue, split / single-pass / f16-storage modes, uniform tiles, a level of a
+    few hundred rows (half tiles only, empty workgroups) and one of 40 k rows (several rounds of workgroups)."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin * 7 + cout)
+    B, shape = 2, [12, 64, 64]
+    for n in (300, 5000, 40000):
+        idx = _random_geometry(rng, B, shape, n)
+        x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+        for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                                 (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+            K = int(np.prod(ks))
+            rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+            w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32), dev)
+            res = T(rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32), dev)
+            sc = T(rng.random(cout, dtype=np.float32) + 0.5, dev)
+            sh = T(rng.normal(0, 0.2, cout).astype(np.float32), dev)
+            p16 = sp.pack_filters_f16x3(w)
+            for mode in (0, 1, 257, 32):
+                ref = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode)
+                got = sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode)
+                assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks, mode)
+            got = sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb)          # no epilogue terms
+            assert torch.equal(got, sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb))
+    with pytest.raises(Exception):
+        sp.sparse_conv_forward_dma(T(np.zeros((10, 128), np.float32), dev), p16, 27, 128, 128, rb)   # wide: not built
+
+
+def test_lidar_branch_dma_gather_layers_reproduce_gather_kernel_bits(dev):
+    """the encoder runs its narrow layers (levels 0 / 1) on the LDS-DMA gather kernel; diagnostic 128 keeps them on the
+    gather kernel -- same bits, in the split, single-pass f16 and f16-storage precisions"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(950 + i, n), dev) for i in range(frames)]
+        want = lb(pl, conv_diag=128)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        assert torch.equal(lb(pl), want), n
+        assert torch.equal(lb(pl, conv_diag=32), lb(pl, conv_diag=32 + 128)), n      # uniform tiles
+        for prec in (2,):
+            assert torch.equal(lb(pl, precision=prec), lb(pl, precision=prec, conv_diag=128)), (n, prec)
+
+
 def test_lidar_branch_with_lds_staged_convs_reproduces_gather_bits(dev):
     """every conv of the LiDAR branch on the LDS-staged kernel (isf_encoder_options.stage_rows; staging tables built on
     the geometry stream) == the gather kernels, bit for bit: small LDS shares (fall-back gathers inside every tile), a
