@@ -35,18 +35,18 @@ namespace isf {
 
 __device__ uint4 g_zero_line[8];   // 128 zero bytes: what a row without a neighbour reads
 
-template <int NT, int NW>
+template <int NT, int NW, int RG = 2>
 struct ConvDmaSmem {
-  static constexpr int TM = 32 * NW;
+  static constexpr int TM = 16 * RG * NW;
   static constexpr int bbuf_bytes = 2 * NT * 2048;        // double-buffered weight stage
-  static constexpr int transit_bytes = NW * 4096;         // per wave: [2 row groups][hi, lo][64 pieces of 16 B]
-  static constexpr int epi_bytes = NW * Conv16Epi<NT, 2>::wave_bytes;
+  static constexpr int transit_bytes = NW * RG * 2048;    // per wave: [RG row groups][hi, lo][64 pieces of 16 B]
+  static constexpr int epi_bytes = NW * Conv16Epi<NT, RG>::wave_bytes;
   static constexpr int main_bytes = bbuf_bytes + transit_bytes;
   static constexpr int bytes = main_bytes > epi_bytes ? main_bytes : epi_bytes;   // wave masks overlay the weight stage
 };
 
 // MODE: bit 1 = single-pass f16 (hi halves only), bit 256 (with 1) = f16 storage -- as in spconv_f16x3_kernel
-template <int CIN, int NT, int NW, int MODE>
+template <int CIN, int NT, int NW, int MODE, int RG = 2>
 __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, int cout, const float* __restrict__ scale,
@@ -54,9 +54,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     Conv16Plan plan, const int32_t* __restrict__ order) {
   constexpr bool HALF = (MODE & 1) != 0, F16IO = (MODE & 256) != 0;
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
-  constexpr int RG = 2;
-  using S = ConvDmaSmem<NT, NW>;
-  constexpr int NTHR = 64 * NW, TM = S::TM, WR = 32;
+  using S = ConvDmaSmem<NT, NW, RG>;
+  constexpr int NTHR = 64 * NW, TM = S::TM, WR = 16 * RG;
   constexpr int NCH = CIN / 32, CH8 = CIN / 8, BN = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* bbuf = reinterpret_cast<uint4*>(smem);                                   // [2][NT][2][64]
@@ -74,7 +73,9 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   const int wrows = half_tile ? WR / 2 : WR;
 
   // ---- prologue: which taps does each 16-row group of the wave use (bit k of rgm[rg]); no table is kept
-  unsigned rgm[RG] = {0u, 0u};
+  unsigned rgm[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) rgm[rg] = 0u;
   {
     int tmp[kMaxTaps];
     const int row = row0w + lane;
@@ -87,13 +88,16 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
 #pragma unroll
     for (int k = 0; k < kMaxTaps; ++k) {
       const unsigned long long m = __ballot(tmp[k] >= 0);
-      rgm[0] |= ((m & 0xffffull) ? 1u : 0u) << k;
-      rgm[1] |= ((m & 0xffff0000ull) ? 1u : 0u) << k;
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) rgm[rg] |= (((m >> (16 * rg)) & 0xffffull) ? 1u : 0u) << k;
     }
   }
-  rgm[0] = __builtin_amdgcn_readfirstlane(rgm[0]);
-  rgm[1] = __builtin_amdgcn_readfirstlane(rgm[1]);
-  const unsigned wmask = rgm[0] | rgm[1];
+  unsigned wmask = 0u;
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    rgm[rg] = __builtin_amdgcn_readfirstlane(rgm[rg]);
+    wmask |= rgm[rg];
+  }
   if (lane == 0) misc[wave] = (int)wmask;
   __syncthreads();
   unsigned wg_mask = 0;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   const int gpiece = ((lane & 3) - (grow_l >> 2)) & 3;
   const int rpos = 4 * col + ((kg + (col >> 2)) & 3);             // read side
   const unsigned bbuf_addr = __builtin_amdgcn_readfirstlane(lds_addr(bbuf));
-  const uint4* transit = reinterpret_cast<const uint4*>(smem + S::bbuf_bytes) + wave * 256;
+  const uint4* transit = reinterpret_cast<const uint4*>(smem + S::bbuf_bytes) + wave * (RG * 128);
   const unsigned transit_addr = __builtin_amdgcn_readfirstlane(lds_addr(transit));
   const uint4* zero = g_zero_line;
 
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   // step cursor: taps (set bits of wg_mask, increasing) outer, chunks inner
   unsigned rem = wg_mask;
   int tap = -1, ch = NCH - 1;
-  int idx_cur[RG] = {-1, -1}, idx_nxt[RG] = {-1, -1};
+  int idx_cur[RG], idx_nxt[RG];
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) idx_cur[rg] = idx_nxt[rg] = -1;
   auto advance = [&]() {   // -> the next step's (tap, ch); on a tap change rotates the index registers
     if (++ch == NCH) {
       ch = 0;
@@ -235,15 +241,16 @@ bool sparse_conv_dma_supported(int c_in, int c_out) {
   return (c_in == 32 || c_in == 64) && (c_out == 32 || c_out == 64);
 }
 
-// 4 waves x 32 rows per workgroup; 8 waves (one weight stage per 256 rows, 3 workgroups per CU) measured slower:
-// 64 -> 64 0.740 -> 0.768 ms per step (profiles/r03_dma_gather.txt)
-template <int CIN, int NT, int MODE, int NW = 4>
+// 4 waves x 32 rows per workgroup.  Measured slower (profiles/r03_dma_gather.txt): 8 waves (one weight stage per 256 rows,
+// 3 workgroups per CU) 64 -> 64 0.740 -> 0.768 ms per step; 4 waves x 64 rows (RG = 4: twice the MFMAs per step and
+// barrier, 3 workgroups per CU) 0.770 -> 0.865 -- the resident workgroups are what hides the loads' round trip.
+template <int CIN, int NT, int MODE, int NW = 4, int RG = 2>
 static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                       const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                       const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
                       Conv16LaunchInfo* query) {
-  using S = ConvDmaSmem<NT, NW>;
-  auto kern = spconv_dma_kernel<CIN, NT, NW, MODE>;
+  using S = ConvDmaSmem<NT, NW, RG>;
+  auto kern = spconv_dma_kernel<CIN, NT, NW, MODE, RG>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};
   if (wgs_per_cu.load(std::memory_order_acquire) == 0) {
     if (S::bytes > 48 * 1024)
