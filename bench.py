@@ -87,7 +87,8 @@ def pmc_traffic(cin, cout):
         return None
     nt = min(cout // 16, 8)
     for k, v in per.items():
-        if k.startswith(f"spconv_f16x3_kernel<{cin}, {nt},") and "fetch_bytes" in v and "write_bytes" in v:
+        if (k.startswith(f"spconv_f16x3_kernel<{cin}, {nt},") or k.startswith(f"spconv_dma_kernel<{cin}, {nt},")) and \
+                "fetch_bytes" in v and "write_bytes" in v:
             return round(v["fetch_bytes"] + v["write_bytes"])
     return None
 

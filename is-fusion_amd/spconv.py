@@ -239,6 +239,16 @@ def sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale=None, 
     return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
 
 
+def sparse_conv_forward_best(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False,
+                             mode=0):
+    """The kernel choice of isf_sparse_encoder_forward for one layer driven from Python (all choices give the same
+    bits): the LDS-DMA gather kernel for the narrow shapes, the tile-order table for launches of one resident round."""
+    if c_in <= 64 and c_out <= 64 and (mode & ~32) in (0, 1, 257):
+        return sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode)
+    order = tile_order(rb, c_in, c_out, mode) if (mode & ~32) in (0, 1, 257) else None
+    return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode, order)
+
+
 def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,
                       order=None):
     """DIAGNOSTIC (isf_sparse_conv_trace): one production launch of a 128 -> 128 / 256 -> 256 layer on split rows `xs`
@@ -346,7 +356,7 @@ class SparseConvFunction(torch.autograd.Function):
         w = weight.detach().float().contiguous()
         features = features.detach().float().contiguous()
         if _f16x3_shape(c_in, c_out):      # the inference kernel (f16x3 split MFMA): 3-4x the fp32-MFMA kernel's rate
-            out = sparse_conv_forward_f16x3(features, pack_filters_f16x3(w), K, c_in, c_out, rb)
+            out = sparse_conv_forward_best(features, pack_filters_f16x3(w), K, c_in, c_out, rb)
         else:
             out = torch.empty((rb.num_out, c_out), dtype=torch.float32, device=features.device)
             _lib.check(_lib.load().isf_sparse_conv_forward(
@@ -374,7 +384,7 @@ class SparseConvFunction(torch.autograd.Function):
                 gs, sc = _lib.pow2_rescale(g)
                 wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*ctx.wshape[:-2], c_out, c_in)
                 rbt = _TransposedRulebook(nbr_t, st, rb.num_out, rb.num_in)
-                grad_in = sparse_conv_forward_f16x3(gs, pack_filters_f16x3(wt), K, c_out, c_in, rbt) / sc
+                grad_in = sparse_conv_forward_best(gs, pack_filters_f16x3(wt), K, c_out, c_in, rbt) / sc
             else:   # fp32-MFMA kernel: no f16 halves, gradients of any magnitude are safe
                 grad_in = torch.empty((rb.num_in, c_in), dtype=torch.float32, device=g.device)
                 _lib.check(lib.isf_sparse_conv_backward_input(_lib.ptr(g), rb.num_out, c_out, _lib.ptr(w), K, c_in,

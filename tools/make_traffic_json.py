@@ -8,7 +8,7 @@ src = sys.argv[1]
 out = {}
 for line in open(src):
     m = re.match(r"^(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)", line)
-    if m and "spconv_f16x3_kernel" in m.group(1):
+    if m and ("spconv_f16x3_kernel" in m.group(1) or "spconv_dma_kernel" in m.group(1)):
         d = out.setdefault(m.group(1).strip(), {})
         kb = float(m.group(4))
         if m.group(2) == "FETCH_SIZE":
