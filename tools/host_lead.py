@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--fold-once", action="store_true", help="fold the camera matrices once (p2g_cam passed in)")
     ap.add_argument("--cfg-id", type=int, default=3, help="bench.CFG_ID: seeds of the synthetic sweeps")
+    ap.add_argument("--same-set", action="store_true", help="the same frame set every forward")
+    ap.add_argument("--sync-after", default="", help="device sync after these warm-up forwards, e.g. 0,1 (fault bisection)")
     ap.add_argument("--spin", action="store_true", help="hipSetDeviceFlags(hipDeviceScheduleSpin) before the context exists")
     args = ap.parse_args()
     if args.spin:
@@ -54,12 +56,13 @@ def main():
         if args.fold_once:
             kw = dict(p2g_cam=ops.p2g_camera_params(kw["lidar2img"], kw["img_aug_matrix"], kw["lidar_aug_matrix"]).to(dev))
         sets.append((pts, img_feats, [dict(input_shape=inp["input_shape"]) for _ in range(B)], kw))
-    if os.environ.get("HOST_LEAD_SAMESET"):
+    if args.same_set:
         sets[1] = sets[0]
+    sync_after = [int(v) for v in args.sync_after.split(",") if v != ""]
     for i in range(6):
         p, f, m, kw = sets[i % 2]
         net.forward_pts(p, f, m, **kw)
-        if os.environ.get("HOST_LEAD_DEBUG") and str(i) in os.environ["HOST_LEAD_DEBUG"].split(","):
+        if i in sync_after:
             torch.cuda.synchronize()
             print("warm-up forward", i, "done", flush=True)
     torch.cuda.synchronize()
