@@ -164,46 +164,62 @@ __global__ __launch_bounds__(256) void p2g_backward_kernel(const float* __restri
 // them.
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// One block = 1024 cells (4 per thread): the candidates of a block are appended with ONE atomicAdd on the sample's
+// counter -- with 256 cells per block the 1266 blocks of a 10 x 180 x 180 map queued behind each other on that one
+// address (32 us for a 1.3 MB read; now 317 atomics).
+static constexpr int kNmsCellsPerThread = 4;
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ hm, int K, int H, int W,
                                                              unsigned pool1_mask, unsigned long long* __restrict__ cand,
                                                              int* __restrict__ cand_count, float* __restrict__ masked) {
   const int b = blockIdx.y;
   const int n = K * H * W;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool keep = false;
-  float hv = 0.f;
-  if (i < n) {
-    const int x = i % W, y = (i / W) % H, c = i / (W * H);
-    const float* plane = hm + ((size_t)b * K + c) * H * W;
-    hv = sigmoidf_(plane[y * W + x]);
-    if ((pool1_mask >> c) & 1u) {
-      keep = true;
-    } else if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
-      float mx = hv;
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) mx = fmaxf(mx, sigmoidf_(plane[(y + dy) * W + x + dx]));
-      keep = hv == mx;
-    }
-    if (masked) masked[(size_t)b * n + i] = keep ? hv : 0.f;
-    keep = keep && hv > 0.f;
-  }
-  // block-aggregated append
-  __shared__ int wave_cnt[4], wave_base[4];
-  const unsigned long long bal = __ballot(keep);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wave_cnt[wave] = __popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    int base = tot ? atomicAdd(cand_count + b, tot) : 0;
-    for (int w = 0; w < 4; ++w) { wave_base[w] = base; base += wave_cnt[w]; }
+  __shared__ int cnt_s[kNmsCellsPerThread][4], base_s[kNmsCellsPerThread][4];
+  bool keep[kNmsCellsPerThread];
+  float hv[kNmsCellsPerThread];
+  unsigned long long bal[kNmsCellsPerThread];
+#pragma unroll
+  for (int q = 0; q < kNmsCellsPerThread; ++q) {
+    const int i = (blockIdx.x * kNmsCellsPerThread + q) * 256 + threadIdx.x;
+    keep[q] = false;
+    hv[q] = 0.f;
+    if (i < n) {
+      const int x = i % W, y = (i / W) % H, c = i / (W * H);
+      const float* plane = hm + ((size_t)b * K + c) * H * W;
+      hv[q] = sigmoidf_(plane[y * W + x]);
+      if ((pool1_mask >> c) & 1u) {
+        keep[q] = true;
+      } else if (x >= 1 && x < W - 1 && y >= 1 && y < H - 1) {
+        float mx = hv[q];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) mx = fmaxf(mx, sigmoidf_(plane[(y + dy) * W + x + dx]));
+        keep[q] = hv[q] == mx;
+      }
+      if (masked) masked[(size_t)b * n + i] = keep[q] ? hv[q] : 0.f;
+      keep[q] = keep[q] && hv[q] > 0.f;
+    }
+    bal[q] = __ballot(keep[q]);
+    if (lane == 0) cnt_s[q][wave] = __popcll(bal[q]);
   }
   __syncthreads();
-  if (keep) {
-    const int pos = wave_base[wave] + __popcll(bal & ((1ull << lane) - 1));
-    cand[(size_t)b * n + pos] = ((unsigned long long)__float_as_uint(hv) << 19) | (unsigned long long)(0x7FFFF - i);
+  if (threadIdx.x == 0) {   // block-aggregated append
+    int tot = 0;
+    for (int q = 0; q < kNmsCellsPerThread; ++q)
+      for (int w = 0; w < 4; ++w) tot += cnt_s[q][w];
+    int base = tot ? atomicAdd(cand_count + b, tot) : 0;
+    for (int q = 0; q < kNmsCellsPerThread; ++q)
+      for (int w = 0; w < 4; ++w) { base_s[q][w] = base; base += cnt_s[q][w]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kNmsCellsPerThread; ++q) {
+    if (keep[q]) {
+      const int i = (blockIdx.x * kNmsCellsPerThread + q) * 256 + threadIdx.x;
+      const int pos = base_s[q][wave] + __popcll(bal[q] & ((1ull << lane) - 1));
+      cand[(size_t)b * n + pos] = ((unsigned long long)__float_as_uint(hv[q]) << 19) | (unsigned long long)(0x7FFFF - i);
+    }
   }
 }
 
@@ -216,14 +232,40 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
 static constexpr int kTopkChunk = 4096;
 
 // the workgroup's keys c[0..slots) (zeros ignored) -> sel[0..1024) sorted descending (zeros last); returns the number of
-// real keys selected (min(k, number of non-zero keys))
+// real keys selected (min(k, number of non-zero keys)).  1024 threads.  Barrier count matters here (one workgroup per
+// chunk / sample, nothing else to overlap with): the suffix sums over the 1024 radix bins are taken inside each wave
+// with shuffles plus one pass over the 16 wave totals (2 barriers per digit instead of 20), and the bitonic sort keeps
+// one key per thread in registers -- strides below 64 exchange through shuffles, the ten strides of 64 and more through
+// two alternating LDS arrays (10 barriers instead of 55).  The keys are read from memory ONCE (up to four per thread stay
+// in registers over the count, the five digit passes and the collection; more slots than that fall back to re-reading).
+template <typename Fn>
+__device__ __forceinline__ void topk_for_each_key(const unsigned long long* __restrict__ c, int slots, bool in_regs,
+                                                  const unsigned long long (&my)[4], Fn fn) {
+  if (in_regs) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fn(my[q]);
+  } else {
+    for (int i = threadIdx.x; i < slots; i += 1024) fn(c[i]);
+  }
+}
+
 __device__ int topk_block_select(const unsigned long long* __restrict__ c, int slots, int k, unsigned long long* sel,
-                                 int* hist, int* scan, unsigned long long* s_prefix, int* s_need, int* s_cnt) {
-  const int t = threadIdx.x;
+                                 unsigned long long* sel2, int* hist, int* wave_tot, unsigned long long* s_prefix,
+                                 int* s_need, int* s_cnt) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool in_regs = slots <= 4 * 1024;   // block-uniform
+  unsigned long long my[4] = {0ull, 0ull, 0ull, 0ull};
+  if (in_regs) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = t + q * 1024;
+      if (i < slots) my[q] = c[i];
+    }
+  }
   if (t == 0) *s_cnt = 0;
   __syncthreads();
   int mine = 0;
-  for (int i = t; i < slots; i += 1024) mine += c[i] != 0ull;
+  topk_for_each_key(c, slots, in_regs, my, [&](unsigned long long key) { mine += key != 0ull; });
   if (mine) atomicAdd(s_cnt, mine);
   __syncthreads();
   const int nc = *s_cnt;
@@ -231,60 +273,75 @@ __device__ int topk_block_select(const unsigned long long* __restrict__ c, int s
   unsigned long long thr = 1;   // every real key
   if (nc > k) {
     if (t == 0) { *s_prefix = 0; *s_need = k; }
-    __syncthreads();
     // 50-bit keys, 5 digits of 10 bits from the top
     for (int shift = 40; shift >= 0; shift -= 10) {
       hist[t] = 0;
-      __syncthreads();
+      __syncthreads();   // also publishes s_prefix / s_need of the previous digit
       const unsigned long long prefix = *s_prefix;
       const int need = *s_need;
-      for (int i = t; i < slots; i += 1024) {
-        const unsigned long long key = c[i];
+      topk_for_each_key(c, slots, in_regs, my, [&](unsigned long long key) {
         if (key != 0ull && (shift == 40 || (key >> (shift + 10)) == prefix))
           atomicAdd(&hist[(int)((key >> shift) & 1023)], 1);
-      }
+      });
       __syncthreads();
-      // inclusive suffix sum over bins (bin 1023 first)
-      scan[t] = hist[t];
-      __syncthreads();
-      for (int d = 1; d < 1024; d <<= 1) {
-        const int v = t + d < 1024 ? scan[t + d] : 0;
-        __syncthreads();
-        scan[t] += v;
-        __syncthreads();
+      // inclusive suffix sum over the bins (bin 1023 first): inside the wave by shuffles, then the higher waves' totals
+      const int v = hist[t];
+      int sfx = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(sfx, d, 64);
+        if (lane + d < 64) sfx += o;
       }
-      const int incl = scan[t], excl = incl - hist[t];
+      if (lane == 0) wave_tot[wave] = sfx;
+      __syncthreads();
+      int above = 0;
+      for (int u = wave + 1; u < 16; ++u) above += wave_tot[u];
+      const int incl = sfx + above, excl = incl - v;
       if (excl < need && need <= incl) {   // exactly one bin
         *s_prefix = (prefix << 10) | (unsigned long long)t;
         *s_need = need - excl;
       }
-      __syncthreads();
+      __syncthreads();   // wave_tot / s_prefix may be rewritten by the next digit
     }
     thr = *s_prefix;   // the k-th largest key (keys are unique)
   }
   if (t == 0) *s_cnt = 0;
   sel[t] = 0;
   __syncthreads();
-  for (int i = t; i < slots; i += 1024) {
-    const unsigned long long key = c[i];
+  topk_for_each_key(c, slots, in_regs, my, [&](unsigned long long key) {
     if (key >= thr) {
       const int pos = atomicAdd(s_cnt, 1);
       if (pos < 1024) sel[pos] = key;
     }
-  }
+  });
   __syncthreads();
-  // bitonic sort, descending (unused slots hold key 0 = smallest)
+  // bitonic sort, descending (unused slots hold key 0 = smallest), one key per thread
+  unsigned long long key = sel[t];
+  unsigned long long* bufs[2] = {sel2, sel};
+  int which = 0;
   for (int size = 2; size <= 1024; size <<= 1) {
+    const bool desc = (t & size) == 0;
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int partner = t ^ stride;
-      if (partner > t) {
-        const bool desc = (t & size) == 0;
-        const unsigned long long a = sel[t], bb = sel[partner];
-        if ((a < bb) == desc) { sel[t] = bb; sel[partner] = a; }
+      unsigned long long other;
+      if (stride >= 64) {
+        unsigned long long* buf = bufs[which];
+        which ^= 1;
+        buf[t] = key;
+        __syncthreads();
+        other = buf[t ^ stride];
+      } else {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, stride, 64);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), stride, 64);
+        other = ((unsigned long long)hi << 32) | lo;
       }
-      __syncthreads();
+      const bool lower = (t & stride) == 0;
+      const bool keep_max = lower == desc;
+      key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
     }
   }
+  __syncthreads();
+  sel[t] = key;
+  __syncthreads();
   return nc < k ? nc : k;
 }
 
@@ -293,8 +350,8 @@ __global__ __launch_bounds__(1024) void topk_partial_kernel(const unsigned long 
                                                             const int* __restrict__ cand_count, int n, int k,
                                                             unsigned long long* __restrict__ partial) {
   __shared__ int hist[1024];
-  __shared__ int scan[1024];
-  __shared__ unsigned long long sel[1024];
+  __shared__ int wave_tot[16];
+  __shared__ unsigned long long sel[1024], sel2[1024];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_need, s_cnt;
   const int b = blockIdx.y, j = blockIdx.x, t = threadIdx.x;
@@ -305,21 +362,24 @@ __global__ __launch_bounds__(1024) void topk_partial_kernel(const unsigned long 
     if (t < k) partial[((size_t)b * gridDim.x + j) * k + t] = 0ull;
     return;
   }
-  (void)topk_block_select(cand + (size_t)b * n + lo, cnt, k, sel, hist, scan, &s_prefix, &s_need, &s_cnt);
+  (void)topk_block_select(cand + (size_t)b * n + lo, cnt, k, sel, sel2, hist, wave_tot, &s_prefix, &s_need, &s_cnt);
   if (t < k) partial[((size_t)b * gridDim.x + j) * k + t] = sel[t];
 }
 
 // stage 2: one workgroup per sample over the chunks' winners
-__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ partial, int slots, int n,
-                                                          int HW, int k, int32_t* __restrict__ top_mod,
+__global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ partial, int slots,
+                                                          const int* __restrict__ cand_count, int n, int HW, int k,
+                                                          int32_t* __restrict__ top_mod,
                                                           int32_t* __restrict__ top_raw) {
   __shared__ int hist[1024];
-  __shared__ int scan[1024];
-  __shared__ unsigned long long sel[1024];
+  __shared__ int wave_tot[16];
+  __shared__ unsigned long long sel[1024], sel2[1024];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_need, s_cnt;
   const int b = blockIdx.x, t = threadIdx.x;
-  const int kk = topk_block_select(partial + (size_t)b * slots, slots, k, sel, hist, scan, &s_prefix, &s_need, &s_cnt);
+  // the candidates are compacted to the front: only the first ceil(count / chunk) chunks have winners (typically 9 of 80)
+  const int live = min(slots, ((cand_count[b] + kTopkChunk - 1) / kTopkChunk) * k);
+  const int kk = topk_block_select(partial + (size_t)b * slots, live, k, sel, sel2, hist, wave_tot, &s_prefix, &s_need, &s_cnt);
   if (t < kk) {
     const int idx = 0x7FFFF - (int)(sel[t] & 0x7FFFF);
     top_raw[(size_t)b * k + t] = idx;
@@ -570,15 +630,15 @@ int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int
   ISF_TRY(a.alloc_n(&cand, (size_t)batch_size * n));
   ISF_TRY(a.alloc_n(&count, (size_t)batch_size + 16));
   ISF_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * batch_size, st));
-  hipLaunchKernelGGL(nms_candidates_kernel, dim3(ceil_div(n, 256), batch_size), dim3(256), 0, st, heatmap,
+  hipLaunchKernelGGL(nms_candidates_kernel, dim3(ceil_div(n, 256 * kNmsCellsPerThread), batch_size), dim3(256), 0, st, heatmap,
                      num_classes, height, width, pool1_class_mask, cand, count, masked_heatmap);
   ISF_LAUNCH_CHECK();
   const int chunks = ceil_div(n, kTopkChunk);   // candidates are compacted to the front: the tail chunks are empty
   unsigned long long* partial = nullptr;
   ISF_TRY(a.alloc_n(&partial, (size_t)batch_size * chunks * k));
   hipLaunchKernelGGL(topk_partial_kernel, dim3(chunks, batch_size), dim3(1024), 0, st, cand, count, (int)n, k, partial);
-  hipLaunchKernelGGL(topk_final_kernel, dim3(batch_size), dim3(1024), 0, st, partial, chunks * k, (int)n, height * width,
-                     k, top_index, top_index_raw);
+  hipLaunchKernelGGL(topk_final_kernel, dim3(batch_size), dim3(1024), 0, st, partial, chunks * k, count, (int)n,
+                     height * width, k, top_index, top_index_raw);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
