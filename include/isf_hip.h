@@ -306,7 +306,9 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            f16 rows between the layers, mode 257 of isf_sparse_conv_forward_f16x3);
  * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3;
  *            +64 = tiles in launch order, no isf_sparse_conv_tile_order tables; +128 = narrow layers on the gather
- *            kernel instead of isf_sparse_conv_forward_dma -- results bit-identical either way);
+ *            kernel instead of isf_sparse_conv_forward_dma; +256 (isf_lidar_branch_forward) = the voxel encoder writes
+ *            fp32 rows and a conversion pass makes the split rows, instead of writing them directly -- results
+ *            bit-identical either way);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

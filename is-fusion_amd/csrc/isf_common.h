@@ -135,7 +135,9 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
                      const float* shift1, int c1, const float* w2, const float* scale2,
                      const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
                      int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
-                     hipStream_t st, hipEvent_t* coords_ready = nullptr);
+                     hipStream_t st, hipEvent_t* coords_ready = nullptr,
+                     void* voxel_feats_split = nullptr /* [P, c2] rows in the split format as well (whole rows are written
+                     there INSTEAD of voxel_feats; rows cut by a wave boundary in both) */);
 // isf_rulebook.hip
 int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int32_t** perm_out,
                hipStream_t st);

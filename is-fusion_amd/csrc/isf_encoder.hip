@@ -209,16 +209,17 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 const int shape0[3], const OccIndex* occ0, const isf_conv_layer* layers,
                                 int num_layers, float* spatial_features, int out_shape[4],
                                 isf_encoder_stats* stats, int time_layers, const isf_encoder_options* opt,
-                                hipStream_t st, hipEvent_t geometry_ready = nullptr) {
+                                hipStream_t st, hipEvent_t geometry_ready = nullptr,
+                                const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128);   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -249,7 +250,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   int out_rows[32];
   const void* x = x0;
   const void* x_in0 = x0;
-  if (use16) {  // inter-layer activations live in the split (hi8|lo8 f16) format: same bytes as fp32
+  ISF_REQUIRE(!x0_split || (use16 && !f16io), ISF_ERR_ARG, "sparse_encoder: split input without the split kernels");
+  if (x0_split) {
+    x = x0_split;
+    x_in0 = x0_split;
+  } else if (use16) {  // inter-layer activations live in the split (hi8|lo8 f16) format: same bytes as fp32
     void* xs0 = nullptr;
     ISF_TRY(a.alloc(&xs0, (size_t)std::max(n0, 1) * layers[0].c_in * 4));
     if (f16io) ISF_TRY(f32_to_half_impl(x0, (size_t)n0 * layers[0].c_in, xs0, st));
@@ -480,6 +485,14 @@ int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors
                                      spatial_features, out_shape_host, stats_host, time_layers, options, st);
 }
 
+// does sparse_encoder_forward_impl run these layers on the split-format kernels (fp32-class f16x3 arithmetic)?
+static bool encoder_takes_split_input(const isf_conv_layer* layers, int num_layers, const isf_encoder_options* opt) {
+  if ((opt ? opt->precision : 0) != 0 || num_layers <= 0 || num_layers > 32) return false;
+  for (int i = 0; i < num_layers; ++i)
+    if (!layers[i].packed16 || !isf::sparse_conv_f16x3_supported(layers[i].c_in, layers[i].c_out)) return false;
+  return true;
+}
+
 int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_host, int batch_size,
                              const isf_vfe_params* vfe_host, const int sparse_shape_host[3],
                              const isf_conv_layer* layers_host, int num_layers, float* spatial_features,
@@ -511,16 +524,22 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
   int n0 = 0;
   OccIndex occ0;
   hipEvent_t coords_ready = nullptr;
+  // the voxel rows go straight into the split format the first convolution reads (whole rows from the VFE's segmented
+  // max, the rows cut by a wave boundary from a fix-up pass): no [N, 64] fp32 -> split conversion pass in between
+  void* vf_split = nullptr;
+  if (encoder_takes_split_input(layers_host, num_layers, options) && vfe_host->c2 == layers_host[0].c_in &&
+      !(options && (options->diagnostic & 256)))   // diagnostic 256: fp32 rows + the conversion pass (same bits)
+    ISF_TRY(a.alloc(&vf_split, (size_t)P * vfe_host->c2 * 4));
   ISF_TRY(dynamic_vfe_impl(a, points, coors4, P, Cin, batch_size, vfe_host->voxel_size, vfe_host->coors_range,
                            vfe_host->w1, vfe_host->scale1, vfe_host->shift1, vfe_host->c1, vfe_host->w2,
                            vfe_host->scale2, vfe_host->shift2, vfe_host->c2, vf, vc, nullptr, &n0, &occ0,
-                           sparse_shape_host[0], st, &coords_ready));
+                           sparse_shape_host[0], st, &coords_ready, vf_split));
   ISF_REQUIRE(n0 > 0, ISF_ERR_ARG, "lidar_branch_forward: no point falls inside the voxel grid");
   const bool occ_ok = occ0.D == sparse_shape_host[0] && occ0.H == sparse_shape_host[1] &&
                       occ0.W == sparse_shape_host[2];
   return sparse_encoder_forward_impl(a, vf, vc, n0, batch_size, sparse_shape_host, occ_ok ? &occ0 : nullptr,
                                      layers_host, num_layers, spatial_features, out_shape_host, stats_host,
-                                     time_layers, options, st, occ_ok ? coords_ready : nullptr);
+                                     time_layers, options, st, occ_ok ? coords_ready : nullptr, vf_split);
 }
 
 }  // extern "C"

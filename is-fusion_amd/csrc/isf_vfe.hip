@@ -273,16 +273,31 @@ __device__ __forceinline__ void vfe_layer1_store_tile(const f32x4 (&acc)[4][4], 
 // records j0-1 and j0+64) -- is written with one 256-byte row store; a run cut by the boundary uses integer
 // atomicMax on the zero-initialised destination (identical result for non-negative floats).
 // fill(half) puts the points [32 half, 32 half + 32) into the wave's tile before val() reads them (val(p): p in 0..63).
+// split_dst != nullptr: whole rows go there in the SPLIT activation format of the sparse-conv kernels (isf_common.h:
+// per 32 channels 4 x 8 f16 hi then 4 x 8 f16 lo) instead of fp32 into dst -- lane = channel stores its two halves;
+// rows cut by a wave boundary still accumulate in dst (fp32 atomicMax) and are converted by vfe_cut_rows_split_kernel.
+__device__ __forceinline__ void vfe_store_split(_Float16* __restrict__ split_dst, int row, int lane, float m) {
+  const _Float16 hi = (_Float16)m;
+  const _Float16 lo = (_Float16)(m - (float)hi);
+  _Float16* p = split_dst + (size_t)row * (2 * kC) + (lane >> 5) * 64 + (lane & 31);
+  p[0] = hi;
+  p[32] = lo;
+}
+
 template <typename FillFn, typename ValFn>
 __device__ __forceinline__ void vfe_segmented_max(int myvox, int vprev, int vnext, int lane, float* __restrict__ dst,
-                                                  FillFn fill, ValFn val) {
+                                                  FillFn fill, ValFn val, _Float16* __restrict__ split_dst = nullptr) {
   int run = -1, first = 0;
   float m = 0.f;
   auto flush = [&](int last) {   // run covers points [first, last]
     if (run < 0) return;
     const bool whole = (first > 0 || vprev != run) && (last < 63 || vnext != run);
-    if (whole) dst[(size_t)run * kC + lane] = m;
-    else if (m > 0.f) atomicMax(reinterpret_cast<int*>(dst) + (size_t)run * kC + lane, __float_as_int(m));
+    if (whole) {
+      if (split_dst) vfe_store_split(split_dst, run, lane, m);
+      else dst[(size_t)run * kC + lane] = m;
+    } else if (m > 0.f) {
+      atomicMax(reinterpret_cast<int*>(dst) + (size_t)run * kC + lane, __float_as_int(m));
+    }
   };
 #pragma unroll
   for (int c = 0; c < 64; c += 16) {
@@ -326,6 +341,23 @@ __global__ __launch_bounds__(256) void vfe_zero_cut_rows_kernel(const float* __r
   if (v0 != v1 || v0 < 0) return;
   a[(size_t)v0 * 64 + lane] = 0.f;
   b[(size_t)v0 * 64 + lane] = 0.f;
+}
+
+// split output: the rows of the voxels cut by a wave boundary are final in the fp32 buffer only when layer 2 has
+// finished; one wave per boundary converts the row of the voxel that straddles it (a voxel cut by several boundaries is
+// converted several times, to the same bits)
+__global__ __launch_bounds__(256) void vfe_cut_rows_split_kernel(const float* __restrict__ recs,
+                                                                 const int* __restrict__ n_valid,
+                                                                 const float* __restrict__ rows,
+                                                                 _Float16* __restrict__ split_dst) {
+  const int lane = threadIdx.x & 63;
+  const long long k = (long long)blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
+  const long long j = k * 64;
+  const long long nv = *n_valid;
+  if (j >= nv) return;
+  const int v0 = __float_as_int(recs[(size_t)(j - 1) * 8 + 7]), v1 = __float_as_int(recs[(size_t)j * 8 + 7]);
+  if (v0 != v1 || v0 < 0) return;
+  vfe_store_split(split_dst, v0, lane, rows[(size_t)v0 * 64 + lane]);
 }
 
 // voxel id stored in record j (wave-uniform scalar load), -1 outside [0, n)
@@ -378,7 +410,8 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
     const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
     const float4* __restrict__ mean4, VfeGeom g, const uint2* __restrict__ w1p, const float* __restrict__ sc1,
     const float* __restrict__ shift1, const float* __restrict__ vmax1, const uint4* __restrict__ w2p,
-    const float* __restrict__ sc2, const float* __restrict__ shift2, float* __restrict__ out) {
+    const float* __restrict__ sc2, const float* __restrict__ shift2, float* __restrict__ out,
+    _Float16* __restrict__ out_split) {
   __shared__ __attribute__((aligned(16))) char smem[kL2Waves * kL2WaveBytes];
   __shared__ int vox_s[kL2Waves * 64];
   const int lane = threadIdx.x & 63;
@@ -499,7 +532,7 @@ __global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
                             ftile[(r2 * 16 + 4 * kg + t) * kLdsStride + nt * 16 + col] =
                                 half ? acc[2 + r2][nt][t] : acc[r2][nt][t];
                     },
-                    [&](int p) { return fmaxf(fmaf(ftile[(p % kHalfPts) * kLdsStride + lane], sc, sh), 0.f); });
+                    [&](int p) { return fmaxf(fmaf(ftile[(p % kHalfPts) * kLdsStride + lane], sc, sh), 0.f); }, out_split);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -508,7 +541,7 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
                    VfeGeom g, const float* w1, const float* scale1, const float* shift1, const float* w2,
                    const float* scale2, const float* shift2, float* voxel_feats, int32_t* voxel_coors,
                    int32_t* pt2vox_out, int* n_host, OccIndex* occ_out, int d_alloc, hipStream_t st,
-                   hipEvent_t* coords_ready) {
+                   hipEvent_t* coords_ready, void* voxel_feats_split) {
   const int F = CIN + 6;
   OccIndex occ;
   // d_alloc > grid z lets the sparse encoder (sparse_shape[0] = grid z + 1) reuse this index for level 0
@@ -570,7 +603,11 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, recs,
                      voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1);
   hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st, recs,
-                     voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1, w2p, sc2, shift2, voxel_feats);
+                     voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1, w2p, sc2, shift2, voxel_feats,
+                     reinterpret_cast<_Float16*>(voxel_feats_split));
+  if (voxel_feats_split)
+    hipLaunchKernelGGL(vfe_cut_rows_split_kernel, dim3(ceil_div(ceil_div(P, 64), 4)), dim3(256), 0, st, recs, n_valid,
+                       voxel_feats, reinterpret_cast<_Float16*>(voxel_feats_split));
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -580,7 +617,7 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
                      const float* shift1, int c1, const float* w2, const float* scale2,
                      const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
                      int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
-                     hipStream_t st, hipEvent_t* coords_ready) {
+                     hipStream_t st, hipEvent_t* coords_ready, void* voxel_feats_split) {
   ISF_REQUIRE(c1 == kC && c2 == kC, ISF_ERR_UNSUPPORTED,
               "dynamic_vfe: feat_channels (%d,%d) not built; this build has (64,64)", c1, c2);
   ISF_REQUIRE(Cin == 4 || Cin == 5, ISF_ERR_UNSUPPORTED, "dynamic_vfe: in_channels %d not built (4|5)", Cin);
@@ -593,9 +630,10 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
   g.ox = vs[0] / 2 + range[0]; g.oy = vs[1] / 2 + range[1]; g.oz = vs[2] / 2 + range[2];
   if (Cin == 5)
     return vfe_run<5>(a, points, coors4, P, B, grid, g, w1, scale1, shift1, w2, scale2, shift2,
-                      voxel_feats, voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready);
+                      voxel_feats, voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready,
+                      voxel_feats_split);
   return vfe_run<4>(a, points, coors4, P, B, grid, g, w1, scale1, shift1, w2, scale2, shift2, voxel_feats,
-                    voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready);
+                    voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready, voxel_feats_split);
 }
 
 }  // namespace isf

@@ -606,6 +606,9 @@ def test_lidar_branch_dma_gather_layers_reproduce_gather_kernel_bits(dev):
         assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
         assert torch.equal(lb(pl), want), n
         assert torch.equal(lb(pl, conv_diag=32), lb(pl, conv_diag=32 + 128)), n      # uniform tiles
+        # the voxel encoder writes its rows straight into the split format the first convolution reads (whole rows from
+        # the segmented max, rows cut by a wave boundary from a fix-up pass); diagnostic 256 = fp32 rows + conversion pass
+        assert torch.equal(lb(pl, conv_diag=256), want), n
         for prec in (2,):
             assert torch.equal(lb(pl, precision=prec), lb(pl, precision=prec, conv_diag=128)), (n, prec)
 
