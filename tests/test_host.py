@@ -483,3 +483,36 @@ def test_freeze_ends_when_weights_can_change():
     import pickle
     pickle.dumps(net)                                               # hooks are module-level functions
 
+
+
+def test_layer_level_kernel_choice_mirrors_the_engine(monkeypatch):
+    """spconv.sparse_conv_forward_best is what SparseConvFunction (the sparse_conv_ext.indice_conv replacement) calls:
+    narrow shapes go to the LDS-DMA gather kernel, wider ones to the split kernel with the rulebook's tile-order table,
+    the timing diagnostics to the plain gather kernel -- the same choices isf_sparse_encoder_forward makes per layer."""
+    from isfusion_amd import spconv as sp
+    calls = []
+    monkeypatch.setattr(sp, "sparse_conv_forward_dma", lambda *a, **k: calls.append(("dma", a[3], a[4], a[-1])) or "dma")
+    monkeypatch.setattr(sp, "sparse_conv_forward_f16x3",
+                        lambda *a, **k: calls.append(("split", a[3], a[4], a[-2], a[-1])) or "split")
+    monkeypatch.setattr(sp, "tile_order", lambda rb, ci, co, mode=0: ("order", ci, co, mode))
+    rb = object()
+    assert sp.sparse_conv_forward_best(None, None, 27, 64, 64, rb) == "dma"
+    assert sp.sparse_conv_forward_best(None, None, 27, 32, 64, rb, mode=257) == "dma"
+    assert sp.sparse_conv_forward_best(None, None, 27, 64, 128, rb) == "split"
+    assert sp.sparse_conv_forward_best(None, None, 27, 256, 256, rb, mode=1) == "split"
+    assert sp.sparse_conv_forward_best(None, None, 27, 64, 64, rb, mode=16) == "split"     # diagnostic: gather kernel
+    assert sp.sparse_conv_forward_best(None, None, 27, 256, 256, rb, mode=2) == "split"
+    assert calls == [("dma", 64, 64, 0), ("dma", 32, 64, 257),
+                     ("split", 64, 128, 0, ("order", 64, 128, 0)), ("split", 256, 256, 1, ("order", 256, 256, 1)),
+                     ("split", 64, 64, 16, None), ("split", 256, 256, 2, None)]
+
+
+def test_h2d_async_cpu_path_and_ring_bookkeeping():
+    """fusion_ops.h2d_async: on a CPU target it is a plain copy (nothing to keep ahead of); the pinned ring is keyed by
+    (device, shape, dtype) and only ever touched for CUDA targets"""
+    from isfusion_amd import fusion_ops as ops
+    before = dict(ops._H2D_RING)
+    t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    out = ops.h2d_async(t, "cpu")
+    assert torch.equal(out, t) and out.device.type == "cpu"
+    assert ops._H2D_RING == before
