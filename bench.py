@@ -173,6 +173,52 @@ def cpu_baseline_fusion(seed):
     return time.perf_counter() - t0, P
 
 
+def main_rehearsal(args):
+    """--backend gloo: the multi-rank plumbing of this file on the CPU -- self-launch, rendezvous on 127.0.0.1, disjoint
+    frame ids per rank, barrier + max-over-ranks clock, ONE line from rank 0 -- around a stub step.  Not a measurement:
+    the line says so.  tests/test_host.py runs `python bench.py --gpus 2 --backend gloo` and checks two processes ran."""
+    import torch
+    import torch.distributed as dist
+    from isfusion_amd import launch
+    rank, world, _ = launch.world_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = frames_for_rank(rank, world, args.batch)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    x = torch.ones(64, 64)
+    for _ in range(args.warmup):
+        x = (x @ x) / 64.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = (x @ x) / 64.0       # the stub step
+    barrier()
+    dt = time.perf_counter() - t0
+    pids, frames = [os.getpid()], [mine]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        pids, frames = [None] * world, [None] * world
+        dist.all_gather_object(pids, os.getpid())
+        dist.all_gather_object(frames, mine)
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL (gloo, stub step): launch / clock / line plumbing only", "value": 0.0,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "rehearsal",
+                          "config": {"workload": "stub", "parallelism": f"dp{world}", "backend": "gloo",
+                                     "rank_pids": pids, "rank_frames": frames}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main_fusion(args):
     """--config 3: BASELINE configs[2] as the line of its own (same JSON contract as the headline)."""
     import torch
@@ -180,7 +226,7 @@ def main_fusion(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -387,9 +433,18 @@ def main():
                     help="DIAGNOSTIC ONLY: f16 storage + single-pass f16 conv kernels (isf_encoder_options.precision 2: the "
                          "reference's indice_conv_half data types, BASELINE configs[4] dtype); reduced precision, never "
                          "the headline line")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (the measurement); gloo = CPU REHEARSAL of the multi-rank launch / clock / JSON "
+                         "line with a stub step (tests/test_host.py), never a measurement")
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = BATCH_PER_GPU if args.config == 2 else 2
+    # `python bench.py --gpus N` started plainly: become N ranks (one per GPU) under torch.distributed.run; fewer than N
+    # devices is an error.  Under a launcher (WORLD_SIZE set) this is a no-op.
+    from isfusion_amd import launch
+    launch.self_launch(args.gpus, args.backend)
+    if args.backend == "gloo":
+        return main_rehearsal(args)
     if args.config == 3:
         return main_fusion(args)
 
@@ -400,7 +455,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -532,6 +587,8 @@ def main():
                                     f"branch at {args.voxel} m voxels, {args.points}-pt sweeps, batch={args.batch}/GPU, "
                                     + ("f16 storage" if args.f16 else "fp32-class")),
                        "points_per_frame": args.points, "batch_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "collectives": f"RCCL {launch.rccl_version()} over xGMI (barrier + clock reduction only: the "
+                                      f"forward has no data-path collective)" if world > 1 else "none (1 rank)",
                        "frame_sets_rotated": len(frame_sets),
                        "frozen_caches": "lb.freeze(): inference deployment, the packed-weight caches skip their per-call "
                                         "parameter-change scan"},

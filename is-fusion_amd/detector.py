@@ -82,6 +82,13 @@ class ISFusionPtsPath(nn.Module):
         ops.freeze(self, flag)
         return self
 
+    def train(self, mode=True):
+        """Entering training mode ends the freeze (optimizer steps are about to change the weights): the packed caches
+        and the captured HIP graphs below this module are dropped here, not at the next forward that happens to look."""
+        if mode and self.__dict__.get("_isf_frozen", False):
+            self.freeze(False)
+        return super().train(mode)
+
     @torch.no_grad()
     def voxelize(self, points, voxel_type="pillar"):
         """isfusion.py:148-176 (pillar branch): per-sample hard voxelization, batch index prepended."""
@@ -177,7 +184,8 @@ class ISFusionPtsPath(nn.Module):
         HIP graph per batch size (captured on the first call), so the host no longer paces those launches (the GPU was
         idle 10-14 % of a step between them).  The LiDAR branch, the pillar voxelization and Point-to-Grid (their sizes
         depend on the frame) stay eager and write straight into the graph's input buffers.  Weights must be final
-        (freeze()); a load_state_dict or train() drops the captured graphs."""
+        (freeze()); freeze() / a load_state_dict below this module / train() drop the captured graphs together with the
+        packed-weight caches their kernels point into (fusion_ops.drop_caches)."""
         self.__dict__["_graph_on"] = bool(flag)
         self.__dict__["_graphs"] = {}
         return self

@@ -79,10 +79,19 @@ def linear(x, pl, *, table=None, index=None, act=ACT_NONE, residual=None, ln=Non
 
 
 def drop_caches(module, *_):
-    """Forget every packed-weight / table cache below `module` (they are derived from the parameters)."""
+    """Forget everything below `module` that was derived from its parameters: packed-weight / table caches, the
+    SparseEncoder's C plan, the LidarBranch's folded VFE parameters and captured HIP graphs (their kernels hold
+    pointers into the packed copies)."""
     for sub in module.modules():
-        sub.__dict__.pop("_isf_cache", None)
-        sub.__dict__.pop("_isf_packed", None)
+        d = sub.__dict__
+        d.pop("_isf_cache", None)
+        d.pop("_isf_packed", None)
+        if d.get("_plan") is not None:
+            d["_plan"] = None
+        if d.get("_vfe_cache") is not None:
+            d["_vfe_cache"] = None
+        if isinstance(d.get("_graphs"), dict):
+            d["_graphs"].clear()
 
 
 def param_key(module):
@@ -101,7 +110,13 @@ def _unfreeze_on_load(module, *_):
 def freeze(module, flag=True):
     """Inference deployments: skip the per-call "did a parameter change?" scan of the caches below `module`.
     The skip ends by itself when weights can change: a load_state_dict anywhere below `module`, or a forward in
-    training mode (see frozen()), clears it -- call freeze() again once the weights are final."""
+    training mode (see frozen()), clears it -- call freeze() again once the weights are final.
+
+    Every change of the flag -- freezing, unfreezing, the load_state_dict hook -- DROPS the derived state below
+    `module` (drop_caches): a frozen cache is used without looking at the parameters, so it must have been packed after
+    the freeze; load_state_dict -> freeze() -> forward, or train() -> optimizer steps -> eval() -> freeze(), would
+    otherwise reuse copies packed from the old weights (and replay HIP graphs that point into them)."""
+    drop_caches(module)
     for sub in module.modules():
         sub.__dict__["_isf_frozen"] = bool(flag)
         if hasattr(sub, "_frozen"):          # SparseEncoder / LidarBranch keep their own flag

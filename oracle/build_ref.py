@@ -44,7 +44,8 @@ def build(verbose=False):
 
 
 def load_prebuilt():
-    """Import oracle/_ref/isf_ref_voxel_layer.so if it was built earlier (it travels to the GPU box)."""
+    """Import oracle/_ref/isf_ref_voxel_layer.so if it was built earlier (authoring container only: oracle/_ref/ is
+    listed in .gpurunignore, the GPU box never sees it -- the goldens it generated are what travels)."""
     import importlib.util
     import torch  # noqa: F401  (the extension links against libtorch)
     path = os.path.join(OUT, NAME + ".so")

@@ -176,6 +176,41 @@ def test_multiprocess_gloo_world2(tmp_path):
         assert p.returncode == 0 and "OK" in o, o
 
 
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must BECOME two ranks (the reference's
+    tools/run-nus.sh:11-13 starts its ranks itself), not print an n_gpus-1 line: the gloo rehearsal runs the same
+    self-launch / rendezvous / sharding / max-over-ranks clock / one-line path around a stub step."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                       # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["data"] == "rehearsal"
+    pids = line["config"]["rank_pids"]
+    assert len(set(pids)) == 2 and os.getpid() not in pids   # two distinct worker processes ran the step
+    fr = line["config"]["rank_frames"]
+    assert sorted(fr[0] + fr[1]) == list(range(2 * len(fr[0]))) and not set(fr[0]) & set(fr[1])
+
+
+def test_self_launch_refuses_fewer_devices_and_is_a_noop_under_a_launcher(monkeypatch):
+    from isfusion_amd import launch
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert launch.self_launch(1) is None
+    if not torch.cuda.is_available():
+        with pytest.raises(SystemExit) as e:             # no silent single-GPU run labelled N
+            launch.self_launch(2, "nccl")
+        assert "only 0 GPU" in str(e.value)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert launch.self_launch(2) is None                  # already a rank: nothing to do
+    with pytest.raises(SystemExit):
+        launch.self_launch(4)                             # launcher / flag mismatch is loud
+    cmd = launch.launch_command("bench.py", ["--gpus", "8"], 8, 29500)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+
+
 def test_detector_level_state_dict_uses_reference_names():
     """ISFusionPtsPath registers its sub-modules under the reference detector's attribute names (isfusion.py:20-51):
     a released checkpoint's pts_* / fusion_encoder.* keys load unchanged (no wrapper prefixes, no duplicates)."""
@@ -275,8 +310,8 @@ def test_parameter_changes_invalidate_packed_weight_caches():
             p.copy_(p.detach().clone())
         break
     assert "linear0" not in ops._cache(sub, dev)
-    ops._cache(sub, dev)["linear0"] = "kept"
-    ops.freeze(sub.eval())                                  # an inference-deployment switch: eval mode
+    ops.freeze(sub.eval())                                  # an inference-deployment switch: eval mode (drops the caches)
+    ops._cache(sub, dev)["linear0"] = "kept"                # packed after the freeze
     with torch.no_grad():
         next(sub.parameters()).mul_(1.0)
     assert ops._cache(sub, dev).get("linear0") == "kept"    # frozen: no scan
@@ -482,6 +517,44 @@ def test_freeze_ends_when_weights_can_change():
     assert not ops.frozen(net[0]) and not ops.frozen(net[0].eval())  # seen in training mode: stays unfrozen after eval()
     import pickle
     pickle.dumps(net)                                               # hooks are module-level functions
+
+
+def test_freeze_after_a_weight_change_never_reuses_the_old_packed_copies():
+    """load_state_dict -> freeze() -> forward with NO forward in between (and train -> step -> eval ->
+    freeze) used to leave a cache packed from the old weights in place, and a frozen cache is used without a look at
+    the parameters.  Every change of the flag now drops the derived state: caches, C plan, VFE fold, HIP graphs."""
+    import torch
+    from isfusion_amd import fusion_ops as ops
+    dev = torch.device("cpu")
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)).eval()
+    ops.freeze(net)
+    c0 = ops._cache(net[0], dev)
+    c0["packed"] = "from the old weights"
+    net.load_state_dict({k: v + 1 for k, v in net.state_dict().items()})   # unfreezes (pre-hook) ...
+    ops.freeze(net)                                                         # ... and is frozen again at once
+    c1 = ops._cache(net[0], dev)
+    assert c1 is not c0 and "packed" not in c1
+    # the other stale route: weights written in place while unfrozen, then freeze() without a forward in between
+    ops.freeze(net, False)
+    c2 = ops._cache(net[1], dev)
+    c2["packed"] = "old"
+    with torch.no_grad():
+        net[1].weight.mul_(2.0)
+    ops.freeze(net)
+    assert "packed" not in ops._cache(net[1], dev)
+    # derived state kept outside _cache(): plan / VFE fold / captured graphs are dropped with the flag change
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(2, 2)
+            self._plan, self._vfe_cache, self._frozen = "plan", "vfe", False
+            self.__dict__["_graphs"] = {("k",): "captured"}
+    h = Holder().eval()
+    ops.freeze(h)
+    assert h._plan is None and h._vfe_cache is None and h._graphs == {} and h._frozen is True
+    h._plan, h._graphs[("k",)] = "plan2", "g2"
+    h.lin.load_state_dict(h.lin.state_dict())
+    assert h._plan is None and h._graphs == {} and h._frozen is False
 
 
 

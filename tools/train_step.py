@@ -1,8 +1,13 @@
 """Data-parallel training steps of the point-cloud path under torchrun (BASELINE configs[3] shape: B frames per GPU, RCCL
 all-reduce over xGMI on the GRADIENTS only -- the forward has no collective):
 
+    python tools/train_step.py --gpus N [--batch 2] [--points 60000] [--steps 3] [--bf16] [--autocast]
+
+starts N ranks by itself (isfusion_amd.launch.self_launch: a re-exec under torch.distributed.run on 127.0.0.1; fewer
+than N visible GPUs is an error) -- the reference's tools/run-nus.sh:11-13; under a launcher it runs as the rank it is:
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29540 \
-        tools/train_step.py [--batch 2] [--points 60000] [--steps 3] [--bf16] [--autocast]
+        tools/train_step.py --gpus N [...]
 
 One process per GPU; every rank draws its own synthetic frames.  The module is wrapped in DistributedDataParallel
 (bucketed gradient all-reduce overlapped with the backward); the path's BatchNorm layers are the config's:
@@ -24,6 +29,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="ranks to start (0 = whatever the launcher started, else 1)")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--points", type=int, default=60000)
     ap.add_argument("--steps", type=int, default=3)
@@ -32,7 +38,9 @@ def main():
                     help="run forward + loss under torch.autocast(bfloat16): stock convs / linears in bf16, the HIP "
                          "autograd Functions cast their inputs to fp32")
     a = ap.parse_args()
-    from isfusion_amd import synthetic
+    from isfusion_amd import launch, synthetic
+    if a.gpus > 0:
+        launch.self_launch(a.gpus, "nccl")
     from isfusion_amd.detector import ISFusionPtsPath
     from isfusion_amd.fusion_modules import seeded_state_dict
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,7 +91,7 @@ def main():
     dist.barrier()
     dt = (time.perf_counter() - t0) / max(a.steps, 1)
     if rank == 0:
-        print(json.dumps({"world_size": world, "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16, "autocast_bf16": a.autocast,
+        print(json.dumps({"world_size": world, "n_gpus": world, "parallelism": f"dp{world}", "rccl": launch.rccl_version(), "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16, "autocast_bf16": a.autocast,
                           "ms_per_train_step": round(dt * 1e3, 2), "losses": [round(v, 5) for v in losses]}))
     dist.destroy_process_group()
 
