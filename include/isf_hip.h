@@ -251,6 +251,36 @@ int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in
                                 int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
                                 const float* shift, const void* residual_split, int relu, void* out_split, int mode,
                                 const int32_t* order, isf_stream_t stream);
+/* The same convolution for the 256-COLUMN layers (c_out = 256, c_in in {128, 256}: levels 3 / 4 of the encoder) as ONE
+ * WORKGROUP PER COMPUTE UNIT (isf_spconv_cu.hip).  A level-3 launch is 160 rows x 256 columns per CU: cut into 128 x 128
+ * tiles it ends with its busiest CU (1.4x the mean work: the density of a LiDAR sweep varies 3x) and every tile streams
+ * its own weight stage.  isf_sparse_conv_cu_plan cuts the rows of a rulebook into units of whole 16-row groups with EQUAL
+ * matrix work (taps with a neighbour per group; <= 256 rows; cus * r units) -- plan_buf holds
+ * isf_sparse_conv_cu_plan_ints(num_out) int32, the plan struct points into it, no host sync (the grid is sized by
+ * max_units) -- once per rulebook; isf_sparse_conv_forward_cu runs one 8-wave workgroup per unit over ALL 256 output columns:
+ * wave w owns columns [32 w, 32 w + 32), its weight fragments go global -> VGPR (no LDS, one stream per CU instead of one
+ * per tile), the gathered rows come in by LDS-DMA once per CU through a three-stage ring (two steps ahead).  Results are
+ * BIT-IDENTICAL to isf_sparse_conv_forward_f16x3 (mode 0).  isf_sparse_encoder_forward / isf_lidar_branch_forward run
+ * their 256-column layers on it (diagnostic +512: tile kernel).  isf_sparse_conv_cu_plan_host / _max_units: the plan
+ * arithmetic on the host (tests, tools; no device work): work [num_groups] -> units [max_units][2] = (first group, groups).
+ * Replaces the reference's per-tap gather -> GEMM -> scatter-add (spconv_ops.h:260-361) for those layers. */
+typedef struct isf_conv_cu_plan {
+  const int32_t* group_masks;   /* device [ceil(num_out / 16)] */
+  const int32_t* units;         /* device [*num_units][2] */
+  const int32_t* num_units;     /* device scalar */
+  int max_units;                /* host bound of *num_units */
+  int num_out;                  /* rows the plan was built for */
+} isf_conv_cu_plan;
+int isf_sparse_conv_cu_plan_ints(int num_out, size_t* num_ints);
+int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int32_t* plan_buf,
+                            isf_conv_cu_plan* plan, isf_stream_t stream);
+int isf_sparse_conv_forward_cu(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                               int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                               const float* shift, const void* residual_split, int relu, void* out_split,
+                               const isf_conv_cu_plan* plan, isf_stream_t stream);
+int isf_sparse_conv_cu_plan_host(const int32_t* work, int num_groups, int cus, int32_t* units, int max_units,
+                                 int* num_units);
+int isf_sparse_conv_cu_max_units(int num_groups, int cus);
 /* The same convolution with the tile's input rows staged in LDS ("LDS staging of active-voxel tiles"; the reference's
  * gather stage: bevfusion-ops/spconv/include/spconv/reordering.cu.h:21-97 -> staging buffer -> GEMM, spconv_ops.h:300-345).
  * isf_rulebook_stage_tables derives the staging tables of a neighbour table once per rulebook: for every unit of
@@ -307,8 +337,9 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  * diagnostic timing diagnostics of the conv kernels (0 = off; 2 / 4 / 6 / 8 / 16, +32: see isf_sparse_conv_forward_f16x3;
  *            +64 = tiles in launch order, no isf_sparse_conv_tile_order tables; +128 = narrow layers on the gather
  *            kernel instead of isf_sparse_conv_forward_dma; +256 (isf_lidar_branch_forward) = the voxel encoder writes
- *            fp32 rows and a conversion pass makes the split rows, instead of writing them directly -- results
- *            bit-identical either way);
+ *            fp32 rows and a conversion pass makes the split rows, instead of writing them directly; +512 = the
+ *            256-column layers on the tile kernel instead of isf_sparse_conv_forward_cu -- results bit-identical
+ *            either way);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

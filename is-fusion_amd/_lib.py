@@ -55,6 +55,12 @@ def encoder_options(precision=0, diagnostic=0, stage_rows=0, stage_mask=0):
     return ctypes.byref(EncoderOptions(int(precision), int(diagnostic), int(stage_rows), int(stage_mask)))
 
 
+class ConvCuPlan(ctypes.Structure):
+    """struct isf_conv_cu_plan: unit plan of the one-workgroup-per-CU sparse-conv kernel (pointers into plan_buf)."""
+    _fields_ = [("group_masks", c_void_p), ("units", c_void_p), ("num_units", c_void_p), ("max_units", c_int),
+                ("num_out", c_int)]
+
+
 class VfeParams(ctypes.Structure):
     """struct isf_vfe_params."""
     _fields_ = [
@@ -139,6 +145,13 @@ SIGNATURES = {
     "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                       c_void_p]),
+    "isf_sparse_conv_cu_plan_ints": (c_int, [c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    "isf_sparse_conv_cu_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.POINTER(ConvCuPlan), c_void_p]),
+    "isf_sparse_conv_forward_cu": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.POINTER(ConvCuPlan),
+                                           c_void_p]),
+    "isf_sparse_conv_cu_plan_host": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_int)]),
+    "isf_sparse_conv_cu_max_units": (c_int, [c_int, c_int]),
     "isf_stage_unit_rows": (c_int, []),
     "isf_stage_unit_cap": (c_int, []),
     "isf_rulebook_stage_tables": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

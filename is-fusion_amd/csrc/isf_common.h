@@ -187,6 +187,22 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st);
+// isf_spconv_cu.hip: the same convolution for the 256-column layers as one workgroup per compute unit over units of equal
+// matrix work (plan built once per rulebook); bit-identical to sparse_conv_forward_f16x3_impl
+struct ConvCuPlan {
+  const int32_t* group_masks = nullptr;   // [ceil(n_out / 16)] taps a 16-row group multiplies through
+  const int2* units = nullptr;            // [*num_units] (first group, groups)
+  const int32_t* num_units = nullptr;     // device scalar
+  int max_units = 0;                      // host-side bound of *num_units (sizes the grid: no host sync)
+  int n_out = 0;
+};
+bool sparse_conv_cu_supported(int c_in, int c_out);
+size_t conv_cu_plan_ints(int n_out);
+int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int32_t* buf /* conv_cu_plan_ints(n_out) */,
+                      ConvCuPlan* plan, hipStream_t st);
+int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
+                                int nbr_stride, int n_out, const float* scale, const float* shift, const void* residual,
+                                int relu, void* ys, const ConvCuPlan& plan, hipStream_t st);
 // isf_spconv_stage.hip (LDS-staged input rows; staging tables of a rulebook)
 int stage_tables_impl(const int32_t* nbr, int nbr_stride, int K, uint16_t* slots, int32_t* ulist, int32_t* ucount,
                       hipStream_t st);

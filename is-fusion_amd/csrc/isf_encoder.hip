@@ -156,7 +156,15 @@ struct LevelState {
   StageTables cache_stage;   // staging tables of cache_nbr (slots == nullptr: not built)
   const int32_t* cache_order;   // tile order of cache_nbr for a (cache_order_cin -> cache_order_cout) launch, or nullptr
   int cache_order_cin, cache_order_cout;
+  ConvCuPlan cache_cu;          // unit plan of cache_nbr for the one-workgroup-per-CU kernel (n_out == 0: not built)
 };
+
+// unit plan of one neighbour table (isf_spconv_cu.hip), built behind it on the geometry stream
+static int build_cu_plan(Arena& a, const int32_t* nbr, int stride, int K, int n_out, ConvCuPlan* plan, hipStream_t sg) {
+  int32_t* buf = nullptr;
+  ISF_TRY(a.alloc_n(&buf, conv_cu_plan_ints(n_out)));
+  return conv_cu_plan_impl(nbr, stride, K, n_out, buf, plan, sg);
+}
 
 // tile order of one conv launch over a neighbour table (conv16_tile_order_impl), built behind the table on the
 // geometry stream; *order stays nullptr when the launch is not a single resident round
@@ -212,14 +220,15 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
+  const bool cu_units = (diagnostic & 512) == 0;     // bit 512: the 256-column layers on the tile kernel as well
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -242,6 +251,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.cache_nbr = nullptr;
   L.cache_order = nullptr;
   L.cache_order_cin = L.cache_order_cout = 0;
+  L.cache_cu = ConvCuPlan();
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
   bool use16 = precision != 1;
   for (int i = 0; i < num_layers; ++i)
@@ -287,7 +297,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                              : ((stage_mask == 0 || ((stage_mask >> i) & 1u)) ? stage_opt : 0);
     StageTables stg;
     const int32_t* order = nullptr;
-    const bool want_order = use16 && tile_order && srows == 0;
+    // 256-column layers: one workgroup per CU over units of equal work (isf_spconv_cu.hip; fp32-class mode only)
+    const bool cu = use16 && cu_units && srows == 0 && conv_mode == 0 && sparse_conv_cu_supported(ly.c_in, ly.c_out);
+    ConvCuPlan cu_plan;
+    const bool want_order = use16 && tile_order && srows == 0 && !cu;
     // narrow layers: LDS-DMA gathers (isf_spconv_dma.hip); the timing diagnostics and mode 16 exist on the gather kernel
     const bool dma = use16 && dma_gather && srows == 0 && dg == 0 && sparse_conv_dma_supported(ly.c_in, ly.c_out);
     if (ly.conv_type == ISF_CONV_SUBM) {
@@ -307,11 +320,13 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
         L.cache_order = nullptr;
         L.cache_order_cin = L.cache_order_cout = 0;
+        L.cache_cu = ConvCuPlan();
         if (want_order) {
           ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
         }
+        if (cu) ISF_TRY(build_cu_plan(a, nbr, stride, K, n_out, &L.cache_cu, sg));
         ISF_TRY(stream_wait_stream(a, st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
@@ -326,7 +341,12 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           L.cache_order_cout = ly.c_out;
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
+        if (cu && L.cache_cu.n_out == 0) {   // an earlier layer of the level did not need the unit plan
+          ISF_TRY(build_cu_plan(a, nbr, stride, K, n_out, &L.cache_cu, sg));
+          ISF_TRY(stream_wait_stream(a, st, sg));
+        }
       }
+      cu_plan = L.cache_cu;
       stg = L.cache_stage;
       if (want_order) order = L.cache_order;
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
@@ -351,7 +371,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                          stride, pair_counts + i, sg));
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
       if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg));
+      if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
+      Nx.cache_cu = ConvCuPlan();
       Nx.cache_nbr = nullptr;
       Nx.cache_order = nullptr;
       Nx.cache_order_cin = Nx.cache_order_cout = 0;
@@ -373,6 +395,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(sparse_conv_forward_staged_impl(x, ly.c_in, ly.packed16, K, ly.c_out, stg.slots, stride, stg.ulist,
                                               stg.ucount, n_out, ly.scale, ly.shift, res, ly.relu, y, srows, conv_mode,
                                               st));
+    else if (cu && n_out > 0)
+      ISF_TRY(sparse_conv_forward_cu_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale, ly.shift, res,
+                                          ly.relu, y, cu_plan, st));
     else if (dma)
       ISF_TRY(sparse_conv_forward_dma_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
                                            res, ly.relu, y, conv_mode, st, order));

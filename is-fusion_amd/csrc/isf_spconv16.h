@@ -121,6 +121,46 @@ static inline Conv16Plan conv16_plan(int n_out, int TM, int ncb, int wgs_per_cu,
   return plan;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Unit plan of the one-workgroup-per-CU kernel (isf_spconv_cu.hip).  The rows of a launch are cut into UNITS of whole
+// 16-row groups, every unit carrying about the same matrix work -- work of a group = the taps through which at least one
+// of its rows has a neighbour = what it issues MFMAs for -- so that each compute unit gets one unit (or r of them) and
+// they all finish together, whatever the density of the scene under them.  Host and device walk the same arithmetic
+// (tests/test_tile_plan.py): cut u of U0 = first group whose inclusive work prefix exceeds u * total / U0; a unit longer
+// than kCuCapGroups groups (what one workgroup's accumulators hold) is split evenly.
+static constexpr int kCuCapGroups = 16;       // 256 rows x 256 columns of fp32 accumulators in 8 waves x 128 registers
+static constexpr int kCuAvgGroups = 12;       // a launch gets cus * r balanced units with n_groups / (cus * r) <= this
+
+__host__ __device__ inline int conv_cu_balanced_units(int n_groups, int cus) {
+  const int per = cus * kCuAvgGroups;
+  const int r = n_groups > per ? (n_groups + per - 1) / per : 1;
+  return cus * r;
+}
+// upper bound of the final unit count (splitting adds at most one unit per kCuCapGroups groups)
+__host__ __device__ inline int conv_cu_max_units(int n_groups, int cus) {
+  return conv_cu_balanced_units(n_groups, cus) + (n_groups + kCuCapGroups - 1) / kCuCapGroups;
+}
+// first group of balanced unit u (0 <= u <= U0): W = inclusive prefix of the per-group work
+__host__ __device__ inline int conv_cu_cut(const int32_t* W, int n_groups, int U0, int u) {
+  if (u <= 0) return 0;
+  if (u >= U0) return n_groups;
+  const long long target = (long long)u * (long long)W[n_groups - 1] / U0;
+  int lo = 0, hi = n_groups;                 // first i with W[i] > target
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((long long)W[mid] > target) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+__host__ __device__ inline int conv_cu_pieces(int len) { return len <= 0 ? 0 : (len + kCuCapGroups - 1) / kCuCapGroups; }
+// piece p of a balanced unit of `len` groups starting at group c -> (first group, groups)
+__host__ __device__ inline void conv_cu_piece(int c, int len, int p, int& g0, int& ng) {
+  const int P = conv_cu_pieces(len);
+  const int a = (int)((long long)p * len / P), b = (int)((long long)(p + 1) * len / P);
+  g0 = c + a;
+  ng = b - a;
+}
+
 // Epilogue shared by both kernels: per 16-row group, accumulator (col = lane&15, row = 4*(lane>>4)+t) -> LDS row-major
 // (wave-private transpose tile) -> one lane per (row, 8-channel unit): BN fold (incl. the weight scale), residual,
 // ReLU, split, store.  The 8 BN scales / shifts of an item are fetched with two 32-byte loads issued together (the
@@ -147,7 +187,9 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
   const int col = lane & 15, kg = lane >> 4;
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
-    if (rg >= groups) break;                           // half tiles: the upper row groups of the wave do not exist
+    if (rg >= groups) continue;                        // half tiles / short units: the upper row groups do not exist
+                                                       // (continue, not break: a break keeps hipcc from unrolling RG = 16
+                                                       // and the accumulators would be indexed through scratch memory)
 #pragma unroll
     for (int ps = 0; ps < NT / EPN; ++ps) {
       constexpr int UNITS = (16 * EPN) / 8;           // 8-channel units per row in this pass

@@ -1,0 +1,532 @@
+// isf_spconv_cu.hip -- the f16x3 sparse convolution of the 256-column layers (levels 3 / 4 of the encoder) as ONE
+// WORKGROUP PER COMPUTE UNIT over work units of equal matrix work.
+//
+// Why a different structure (profiles/r03_conv_trace.txt).  The tile kernel (isf_spconv16.hip) cuts
+// a level-3 launch -- 40 k rows x 256 columns, 160 rows per CU -- into 128-row x 128-column tiles, 2.5 per CU, whose
+// matrix work varies 3x with the density of the scene; the launch ends with its busiest CU (1.38x the mean) while every
+// workgroup streams its own 16-KiB weight stage per step through the CU's vector-memory path and the LDS.  Finer tiles
+// lose more to the weight stream than they gain in balance (measured: half tiles, equal-work tiles, tap split).  Here:
+//   * a launch is cut into UNITS of whole 16-row groups with equal work (taps with a neighbour, summed over the unit's
+//     groups -- conv_cu_plan_impl, once per rulebook on the geometry stream), one unit per CU, <= 256 rows each: the CUs
+//     finish together;
+//   * ONE workgroup of 8 waves owns the unit and ALL 256 output columns: wave w owns columns [32 w, 32 w + 32) of
+//     every row group (16 x 2 accumulator tiles = 128 registers).  A weight fragment is needed by exactly one wave, so
+//     the weights go global -> VGPR directly (1 KiB coalesced per instruction, one step ahead) and never touch LDS --
+//     per step the CU pulls one 32-KiB stage for ALL its rows instead of 16 KiB per 128-row tile;
+//   * the gathered rows come in by LDS-DMA, a lane quad fetching the 64 contiguous bytes of ONE row (the address-unit
+//     friendly pattern of isf_spconv_dma.hip), each row ONCE per CU (the tile kernel gathers it once per column block),
+//     into a three-stage ring: the gathers of step s + 2 are issued at step s, so an L2 miss has two steps to land;
+//   * one s_barrier per step hands the stage over; row groups without the tap are skipped by every wave (scalar branch).
+// Products and their order per accumulator are those of spconv_f16x3_kernel (chunk outer, taps inner, a_lo b_hi ->
+// a_hi b_lo -> a_hi b_hi; a 16-row group multiplies through a tap iff one of its rows has a neighbour there): results
+// are BIT-IDENTICAL to it.  Replaces, like it, the reference's gather -> GEMM -> scatter-add loop of
+// bevfusion-ops/spconv/include/spconv/spconv_ops.h:260-361.
+#include "isf_spconv16.h"
+
+#include <atomic>
+
+namespace isf {
+
+__device__ uint4 g_zero_line_cu[8];   // 128 zero bytes: what a row without a neighbour reads (one per translation unit: no RDC)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int kCuWaves = 8;
+static constexpr int kCuRows = 16 * kCuCapGroups;       // 256
+static constexpr int kCuStages = 3;
+static constexpr int kCuCout = 256;
+
+struct ConvCuSmem {
+  static constexpr int nbr_bytes = kMaxTaps * kCuRows * 4;            // [27][256] int32
+  static constexpr int stage_bytes = kCuCapGroups * 2048;             // [16 groups][hi, lo][64 x 16 B]
+  static constexpr int ring_bytes = kCuStages * stage_bytes;
+  static constexpr int tapm_bytes = 32 * 4;                           // per tap: bit j = group j multiplies through it
+  static constexpr int epi_bytes = kCuWaves * Conv16Epi<2, kCuCapGroups>::wave_bytes;   // overlays the ring
+  static_assert(epi_bytes <= ring_bytes, "epilogue tile must fit the ring");
+  static constexpr int bytes = ring_bytes + nbr_bytes + tapm_bytes;
+};
+
+// 16 bytes per lane, global -> VGPR, hidden from hipcc's scoreboard: the loads of the next step's weight fragments stay
+// in flight behind the gathers of the step after it, and the loop waits with a counted vmcnt (cu_wait below) instead
+// of the vmcnt(0) the compiler would place in front of the first use.
+__device__ __forceinline__ void gload16(i32x4& dst, const void* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+// wait until at most `pend` (0, 2 or 4; wave-uniform) vector-memory operations of this wave are outstanding.  ONE asm
+// statement with the choice inside it, and the fragment registers tied to it: no use of them can be scheduled above the
+// wait, and there is no join of several asm results in front of which hipcc would copy registers whose data has not
+// landed (three separate statements under an if / else did exactly that).
+#define ISF_CU_WAIT(bn, pend)                                                                                        \
+  asm volatile(                                                                                                      \
+      "s_cmp_eq_u32 %4, 0\n\t"                                                                                       \
+      "s_cbranch_scc1 1f\n\t"                                                                                        \
+      "s_cmp_eq_u32 %4, 2\n\t"                                                                                       \
+      "s_cbranch_scc1 2f\n\t"                                                                                        \
+      "s_waitcnt vmcnt(4)\n\t"                                                                                       \
+      "s_branch 3f\n"                                                                                                \
+      "2:\n\t"                                                                                                       \
+      "s_waitcnt vmcnt(2)\n\t"                                                                                       \
+      "s_branch 3f\n"                                                                                                \
+      "1:\n\t"                                                                                                       \
+      "s_waitcnt vmcnt(0)\n"                                                                                         \
+      "3:"                                                                                                           \
+      : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])                                                           \
+      : "s"(pend)                                                                                                    \
+      : "memory", "scc")
+
+struct CuCursor {
+  unsigned rem;   // taps of the current chunk not yet visited
+  int tap, ch;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
+    const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
+    const float* __restrict__ w_inv_scale, int K, const float* __restrict__ scale, const float* __restrict__ shift,
+    const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
+    const int32_t* __restrict__ group_masks, const int2* __restrict__ units, const int32_t* __restrict__ num_units) {
+  using S = ConvCuSmem;
+  constexpr int NCH = CIN / 32, CH8 = CIN / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* ring = reinterpret_cast<uint4*>(smem);
+  int* nbr_l = reinterpret_cast<int*>(smem + S::ring_bytes);                       // [27][256]
+  int* tapm_l = reinterpret_cast<int*>(smem + S::ring_bytes + S::nbr_bytes);       // [27]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kg = lane >> 4;
+
+  // workgroup -> unit: XCD x (workgroups are dealt round-robin to the 8 XCDs) takes one contiguous range of units =
+  // of rows, so its L2 holds the sliding window of y / z neighbour rows
+  const int U = *num_units;
+  const int per_xcd = (U + 7) >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int u = xcd * per_xcd + slot;
+  if (slot >= per_xcd || u >= U) return;
+  const int2 un = units[u];
+  const int g0 = un.x, n_rg = un.y;              // first 16-row group, groups (1..16)
+  const int row0 = g0 * 16;
+  const int row_end = min(row0 + n_rg * 16, n_out);
+
+  // ---- prologue: neighbour table of the unit -> LDS; per-tap group masks
+  {
+    constexpr int NB_IT = (kMaxTaps * kCuRows) / (64 * kCuWaves);   // 13.5 -> 14
+    int tmp[NB_IT + 1];
+#pragma unroll
+    for (int it = 0; it <= NB_IT; ++it) {
+      const int i = tid + it * 64 * kCuWaves;
+      const int k = i >> 8, r = i & 255;
+      tmp[it] = -1;
+      if (k < K && row0 + r < row_end) tmp[it] = nbr[(size_t)k * nbr_stride + row0 + r];
+    }
+#pragma unroll
+    for (int it = 0; it <= NB_IT; ++it) {
+      const int i = tid + it * 64 * kCuWaves;
+      if (i < kMaxTaps * kCuRows) nbr_l[i] = tmp[it];
+    }
+  }
+  unsigned unit_mask = 0;     // taps any group of the unit multiplies through
+  if (tid < kMaxTaps) {
+    unsigned m = 0;
+    for (int j = 0; j < n_rg; ++j) m |= (((unsigned)group_masks[g0 + j] >> tid) & 1u) << j;
+    tapm_l[tid] = (int)m;
+  }
+  for (int j = 0; j < n_rg; ++j) unit_mask |= (unsigned)group_masks[g0 + j];
+  unit_mask = __builtin_amdgcn_readfirstlane(unit_mask);
+  // the groups whose rows this wave gathers: wave, wave + 8
+  const unsigned dm0 = wave < n_rg ? (unsigned)__builtin_amdgcn_readfirstlane(group_masks[g0 + wave]) : 0u;
+  const unsigned dm1 = wave + 8 < n_rg ? (unsigned)__builtin_amdgcn_readfirstlane(group_masks[g0 + wave + 8]) : 0u;
+  __syncthreads();
+  const int ntaps = __popc(unit_mask);
+  const int nsteps = ntaps * NCH;
+
+  f32x4 acc[kCuCapGroups][2];
+#pragma unroll
+  for (int j = 0; j < kCuCapGroups; ++j) {
+    acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto advance = [&](CuCursor& c) {     // chunk outer, taps (set bits of unit_mask, increasing) inner
+    if (c.rem == 0) {
+      c.rem = unit_mask;
+      ++c.ch;
+    }
+    c.tap = __ffs(c.rem) - 1;
+    c.rem &= c.rem - 1;
+  };
+
+  // gather lane (isf_spconv_dma.hip): row lane >> 2 of a group, piece rotated so that the MFMA-layout read is
+  // conflict-free; the reader (row col, k-group kg) finds its piece at position 4 col + ((kg + (col >> 2)) & 3)
+  const int grow_l = lane >> 2;
+  const int gpiece = ((lane & 3) - (grow_l >> 2)) & 3;
+  const int rpos = 4 * col + ((kg + (col >> 2)) & 3);
+  const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_addr(ring));
+  const uint4* zero = g_zero_line_cu;
+
+  auto read_idx = [&](int tap, int& i0, int& i1) {     // this lane's gather rows through `tap` (groups wave, wave + 8)
+    i0 = nbr_l[tap * kCuRows + wave * 16 + grow_l];
+    i1 = nbr_l[tap * kCuRows + (wave + 8) * 16 + grow_l];
+  };
+  auto dma_count = [&](int tap) -> int { return 2 * (int)((dm0 >> tap) & 1u) + 2 * (int)((dm1 >> tap) & 1u); };
+  auto issue_A = [&](int tap, int ch, int stage, int i0, int i1) {
+    const unsigned base = ring_addr + (unsigned)stage * (unsigned)S::stage_bytes;
+    if ((dm0 >> tap) & 1u) {
+      const uint4* src = i0 >= 0 ? xs + ((size_t)i0 * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
+      glds16(src, base + (unsigned)wave * 2048u);
+      glds16(src + 4, base + (unsigned)wave * 2048u + 1024u);
+    }
+    if ((dm1 >> tap) & 1u) {
+      const uint4* src = i1 >= 0 ? xs + ((size_t)i1 * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
+      glds16(src, base + (unsigned)(wave + 8) * 2048u);
+      glds16(src + 4, base + (unsigned)(wave + 8) * 2048u + 1024u);
+    }
+  };
+  // Weight fragments of this wave, [column tile][hi, lo] -> [2 nt + h], in TWO register sets used alternately: step t
+  // multiplies with one set while the loads of step t + 1 land in the other.  (One "next" set renamed to a "current" set
+  // per step does not work with loads the compiler cannot see: it places the renaming copies in front of the counted
+  // wait and copies registers whose data has not landed.)
+  i32x4 bx[4], by[4];
+  auto load_B = [&](int tap, int ch, i32x4 (&bn)[4]) {
+    const uint4* src = wpk + (((size_t)tap * NCH + ch) * (kCuCout / 16) + 2 * wave) * 128 + lane;
+    gload16(bn[0], src);
+    gload16(bn[1], src + 64);
+    gload16(bn[2], src + 128);
+    gload16(bn[3], src + 192);
+  };
+
+  // ---- pipeline fill: A(0), B(0), A(1) (in that order: the wait at the top of step t leaves only A(t + 1) in flight)
+  CuCursor cb{0u, -1, -1}, ca{0u, -1, -1};     // cb: the step whose weights are loaded next, ca: whose rows are gathered next
+  int idx0 = -1, idx1 = -1;
+  unsigned m_cur = 0;
+  int pend = 0;                                 // A-DMA instructions of step t + 1 this wave has in flight
+  bx[0] = bx[1] = bx[2] = bx[3] = i32x4{0, 0, 0, 0};
+  by[0] = by[1] = by[2] = by[3] = i32x4{0, 0, 0, 0};
+  if (nsteps > 0) {
+    advance(ca);
+    read_idx(ca.tap, idx0, idx1);
+    issue_A(ca.tap, ca.ch, 0, idx0, idx1);
+    advance(cb);
+    m_cur = (unsigned)tapm_l[cb.tap];
+    load_B(cb.tap, cb.ch, bx);
+    if (nsteps > 1) {
+      advance(ca);
+      read_idx(ca.tap, idx0, idx1);
+      issue_A(ca.tap, ca.ch, 1, idx0, idx1);
+      pend = dma_count(ca.tap);
+    }
+    if (nsteps > 2) {                            // rows of step 2: indices now, gathers at step 0
+      advance(ca);
+      read_idx(ca.tap, idx0, idx1);
+    }
+  }
+  int stage = 0;
+  // one step: bn = the set holding B(t) (in flight until the wait), bo = the set B(t + 1) is loaded into
+  auto step = [&](int t, i32x4 (&bn)[4], i32x4 (&bo)[4]) {
+    // B(t), A(t) of this wave landed; only its A(t + 1) gathers (issued after B(t)) may still be in flight
+    ISF_CU_WAIT(bn, pend);
+    __builtin_amdgcn_s_barrier();     // A(t) complete for every wave; every wave is done reading stage (t + 2) % 3
+    asm volatile("" ::: "memory");
+    const unsigned m = __builtin_amdgcn_readfirstlane(m_cur);
+    if (t + 1 < nsteps) {
+      advance(cb);
+      load_B(cb.tap, cb.ch, bo);
+      m_cur = (unsigned)tapm_l[cb.tap];
+    }
+    pend = 0;
+    if (t + 2 < nsteps) {
+      int s2 = stage + 2;
+      if (s2 >= kCuStages) s2 -= kCuStages;
+      issue_A(ca.tap, ca.ch, s2, idx0, idx1);
+      pend = dma_count(ca.tap);       // issued AFTER B(t + 1): exactly what may stay in flight at the next wait
+      if (t + 3 < nsteps) {
+        advance(ca);
+        read_idx(ca.tap, idx0, idx1);
+      }
+    }
+    if (m) {
+      const uint4* sa = ring + stage * (S::stage_bytes / 16) + rpos;
+      const h8 bh0 = *reinterpret_cast<const h8*>(&bn[0]), bl0 = *reinterpret_cast<const h8*>(&bn[1]);
+      const h8 bh1 = *reinterpret_cast<const h8*>(&bn[2]), bl1 = *reinterpret_cast<const h8*>(&bn[3]);
+      const int jf = __ffs(m) - 1;
+      uint4 ah_n = sa[jf * 128], al_n = sa[jf * 128 + 64];
+#pragma unroll
+      for (int j = 0; j < kCuCapGroups; ++j) {
+        if ((m >> j) & 1u) {
+          const uint4 ahu = ah_n, alu = al_n;
+          const unsigned rest = j < 15 ? m >> (j + 1) : 0u;
+          if (rest) {                            // the next group's fragments are read while this one multiplies
+            const int jn = j + __ffs(rest);
+            ah_n = sa[jn * 128];
+            al_n = sa[jn * 128 + 64];
+          }
+          const h8 ah = *reinterpret_cast<const h8*>(&ahu);
+          const h8 al = *reinterpret_cast<const h8*>(&alu);
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[j][1], 0, 0, 0);
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, acc[j][1], 0, 0, 0);
+          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[j][0], 0, 0, 0);
+          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[j][1], 0, 0, 0);
+        }
+      }
+    }
+    if (++stage == kCuStages) stage = 0;
+  };
+  for (int t = 0; t < nsteps; t += 2) {
+    step(t, bx, by);
+    if (t + 1 < nsteps) step(t + 1, by, bx);
+  }
+  {
+    const int none = 0;
+    ISF_CU_WAIT(bx, none);
+  }
+  __syncthreads();   // every wave is done with the ring -> reuse as the epilogue transpose tiles
+
+  float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<2, kCuCapGroups>::wave_bytes / 4);
+  conv16_epilogue<2, kCuCapGroups, false>(acc, tile_l, lane, row0, 32 * wave, kCuCout, *w_inv_scale, scale, shift, residual,
+                                          ys, row_end, relu, n_rg);
+}
+
+// ------------------------------------------------------------------------------------------------------ unit plan
+// group_masks[g] bit k: some row of 16-row group g has a neighbour through tap k; work[g] = popcount
+__global__ __launch_bounds__(256) void cu_group_mask_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K,
+                                                            int n_out, int n_groups, int32_t* __restrict__ masks,
+                                                            int32_t* __restrict__ work) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gbase = (blockIdx.x * 4 + wv) * 4;             // this wave's four groups = 64 rows
+  if (gbase >= n_groups) return;
+  const int row = gbase * 16 + lane;
+  unsigned m[4] = {0u, 0u, 0u, 0u};
+  for (int k = 0; k < K; ++k) {
+    const bool has = row < n_out && nbr[(size_t)k * nbr_stride + row] >= 0;
+    const unsigned long long b = __ballot(has);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] |= (((b >> (16 * q)) & 0xffffull) ? 1u : 0u) << k;
+  }
+  if (lane < 4 && gbase + lane < n_groups) {
+    const unsigned mine = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+    masks[gbase + lane] = (int)mine;
+    work[gbase + lane] = __popc(mine);
+  }
+}
+
+// One workgroup: inclusive prefix of the work, the balanced cuts, the split of over-long units, the unit table.
+// scratch: W [n_groups] | cuts [U0 + 1] | offs [U0 + 1]
+__global__ __launch_bounds__(1024) void cu_plan_kernel(const int32_t* __restrict__ work, int n_groups, int U0,
+                                                       int32_t* W, int32_t* cuts, int32_t* offs,
+                                                       int2* __restrict__ units,
+                                                       int32_t* __restrict__ num_units) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto block_scan = [&](int v, int& total) -> int {   // inclusive scan over the 1024 threads
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(x, d, 64);
+      if (lane >= d) x += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int s = wsum[w];
+      if (w < wv) before += s;
+      tot += s;
+    }
+    total = tot;
+    return x + before;
+  };
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_groups; base += 1024) {
+    const int i = base + tid;
+    int tot;
+    const int inc = block_scan(i < n_groups ? work[i] : 0, tot);
+    const int carry = carry_s;
+    if (i < n_groups) W[i] = inc + carry;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int uu = tid; uu <= U0; uu += 1024) cuts[uu] = conv_cu_cut(W, n_groups, U0, uu);
+  __syncthreads();
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < U0; base += 1024) {
+    const int uu = base + tid;
+    int tot;
+    const int p = uu < U0 ? conv_cu_pieces(cuts[uu + 1] - cuts[uu]) : 0;
+    const int inc = block_scan(p, tot);
+    const int carry = carry_s;
+    if (uu < U0) offs[uu] = inc - p + carry;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (tid == 0) *num_units = carry_s;
+  for (int uu = tid; uu < U0; uu += 1024) {
+    const int c = cuts[uu], len = cuts[uu + 1] - c, P = conv_cu_pieces(len), o = offs[uu];
+    for (int p = 0; p < P; ++p) {
+      int g0, ng;
+      conv_cu_piece(c, len, p, g0, ng);
+      units[o + p] = make_int2(g0, ng);
+    }
+  }
+}
+
+static int cu_count() {
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_acquire);
+  if (c == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        c <= 0)
+      c = 256;
+    cus.store(c, std::memory_order_release);
+  }
+  return c;
+}
+
+bool sparse_conv_cu_supported(int c_in, int c_out) { return c_out == kCuCout && (c_in == 128 || c_in == 256); }
+
+size_t conv_cu_plan_ints(int n_out) {   // int32 entries a plan of n_out rows needs (masks, work, W, cuts, offs, units, count)
+  const int ng = ceil_div(n_out > 0 ? n_out : 1, 16), cus = cu_count();
+  const int U0 = conv_cu_balanced_units(ng, cus), UM = conv_cu_max_units(ng, cus);
+  return (size_t)ng * 3 + 2 * (size_t)(U0 + 1) + 2 * (size_t)UM + 64;
+}
+
+int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int32_t* buf, ConvCuPlan* plan,
+                      hipStream_t st) {
+  ISF_REQUIRE(nbr && buf && plan && n_out > 0 && K >= 1 && K <= kMaxTaps && nbr_stride >= n_out, ISF_ERR_ARG,
+              "sparse_conv_cu_plan: bad arguments");
+  const int ng = ceil_div(n_out, 16), cus = cu_count();
+  const int U0 = conv_cu_balanced_units(ng, cus), UM = conv_cu_max_units(ng, cus);
+  int32_t* masks = buf;
+  int32_t* work = masks + ng;
+  int32_t* W = work + ng;
+  int32_t* cuts = W + ng;
+  int32_t* offs = cuts + (U0 + 1);
+  int32_t* cnt = offs + (U0 + 1);
+  int2* units = reinterpret_cast<int2*>(cnt + 2 + ((cnt + 2 - buf) & 1));   // 8-byte aligned behind the count
+  hipLaunchKernelGGL(cu_group_mask_kernel, dim3(ceil_div(ng, 16)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, ng, masks,
+                     work);
+  hipLaunchKernelGGL(cu_plan_kernel, dim3(1), dim3(1024), 0, st, work, ng, U0, W, cuts, offs, units, cnt);
+  ISF_LAUNCH_CHECK();
+  plan->group_masks = masks;
+  plan->units = units;
+  plan->num_units = cnt;
+  plan->max_units = UM;
+  plan->n_out = n_out;
+  return ISF_OK;
+}
+
+int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
+                                int nbr_stride, int n_out, const float* scale, const float* shift, const void* residual,
+                                int relu, void* ys, const ConvCuPlan& plan, hipStream_t st) {
+  if (n_out <= 0) return ISF_OK;
+  ISF_REQUIRE(sparse_conv_cu_supported(c_in, c_out), ISF_ERR_UNSUPPORTED, "sparse_conv_cu: (Cin,Cout)=(%d,%d) not built",
+              c_in, c_out);
+  ISF_REQUIRE(K >= 1 && K <= kMaxTaps && nbr_stride >= n_out, ISF_ERR_ARG, "sparse_conv_cu: bad rulebook");
+  ISF_REQUIRE(plan.group_masks && plan.units && plan.num_units && plan.n_out == n_out && plan.max_units > 0, ISF_ERR_ARG,
+              "sparse_conv_cu: the unit plan was built for %d rows, the launch has %d", plan.n_out, n_out);
+  const uint4* w = reinterpret_cast<const uint4*>(packed16);
+  const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
+  static std::atomic<int> attr_set{0};
+  if (attr_set.load(std::memory_order_acquire) == 0) {
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_cu_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ConvCuSmem::bytes));
+    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_cu_kernel<256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, ConvCuSmem::bytes));
+    attr_set.store(1, std::memory_order_release);
+  }
+  const dim3 grid(8 * ceil_div(plan.max_units, 8)), block(64 * kCuWaves);
+#define ISF_CU_ARGS                                                                                                 \
+  reinterpret_cast<const uint4*>(xs), nbr, nbr_stride, w, winv, K, scale, shift, reinterpret_cast<const uint4*>(residual), \
+      reinterpret_cast<uint4*>(ys), n_out, relu, plan.group_masks, plan.units, plan.num_units
+  if (c_in == 128) hipLaunchKernelGGL(spconv_cu_kernel<128>, grid, block, ConvCuSmem::bytes, st, ISF_CU_ARGS);
+  else hipLaunchKernelGGL(spconv_cu_kernel<256>, grid, block, ConvCuSmem::bytes, st, ISF_CU_ARGS);
+#undef ISF_CU_ARGS
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+}  // namespace isf
+
+extern "C" {
+
+int isf_sparse_conv_cu_plan_ints(int num_out, size_t* num_ints) {
+  ISF_REQUIRE(num_ints && num_out >= 0, ISF_ERR_ARG, "sparse_conv_cu_plan_ints: bad arguments");
+  *num_ints = isf::conv_cu_plan_ints(num_out);
+  return ISF_OK;
+}
+
+int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int32_t* plan_buf,
+                            isf_conv_cu_plan* plan, isf_stream_t stream) {
+  ISF_REQUIRE(plan, ISF_ERR_ARG, "sparse_conv_cu_plan: null plan");
+  isf::ConvCuPlan p;
+  ISF_TRY(isf::conv_cu_plan_impl(nbr, nbr_stride, num_taps, num_out, plan_buf, &p, isf::as_stream(stream)));
+  plan->group_masks = p.group_masks;
+  plan->units = reinterpret_cast<const int32_t*>(p.units);
+  plan->num_units = p.num_units;
+  plan->max_units = p.max_units;
+  plan->num_out = p.n_out;
+  return ISF_OK;
+}
+
+int isf_sparse_conv_forward_cu(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                               int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                               const float* shift, const void* residual_split, int relu, void* out_split,
+                               const isf_conv_cu_plan* plan, isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0 && plan, ISF_ERR_ARG,
+              "sparse_conv_forward_cu: bad arguments");
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)), ISF_ERR_ARG,
+              "sparse_conv_forward_cu: null pointer");
+  isf::ConvCuPlan p;
+  p.group_masks = plan->group_masks;
+  p.units = reinterpret_cast<const int2*>(plan->units);
+  p.num_units = plan->num_units;
+  p.max_units = plan->max_units;
+  p.n_out = plan->num_out;
+  return isf::sparse_conv_forward_cu_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
+                                          shift, residual_split, relu, out_split, p, isf::as_stream(stream));
+}
+
+// the plan arithmetic on the host (tests / tools: no device work): work [num_groups] -> units [max_units][2]
+int isf_sparse_conv_cu_plan_host(const int32_t* work, int num_groups, int cus, int32_t* units, int max_units,
+                                 int* num_units) {
+  ISF_REQUIRE(work && units && num_units && num_groups > 0 && cus > 0, ISF_ERR_ARG, "sparse_conv_cu_plan_host: bad arguments");
+  ISF_REQUIRE(max_units >= isf::conv_cu_max_units(num_groups, cus), ISF_ERR_ARG,
+              "sparse_conv_cu_plan_host: units holds %d entries, %d needed", max_units, isf::conv_cu_max_units(num_groups, cus));
+  std::vector<int32_t> W((size_t)num_groups);
+  long long s = 0;
+  for (int i = 0; i < num_groups; ++i) {
+    s += work[i];
+    W[(size_t)i] = (int32_t)s;
+  }
+  const int U0 = isf::conv_cu_balanced_units(num_groups, cus);
+  int n = 0;
+  for (int uu = 0; uu < U0; ++uu) {
+    const int c = isf::conv_cu_cut(W.data(), num_groups, U0, uu), e = isf::conv_cu_cut(W.data(), num_groups, U0, uu + 1);
+    const int P = isf::conv_cu_pieces(e - c);
+    for (int p = 0; p < P; ++p) {
+      int g0, ng;
+      isf::conv_cu_piece(c, e - c, p, g0, ng);
+      units[2 * n] = g0;
+      units[2 * n + 1] = ng;
+      ++n;
+    }
+  }
+  *num_units = n;
+  return ISF_OK;
+}
+
+int isf_sparse_conv_cu_max_units(int num_groups, int cus) { return isf::conv_cu_max_units(num_groups, cus); }
+
+}  // extern "C"

@@ -239,12 +239,74 @@ def sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale=None, 
     return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
 
 
+def cu_plan(rb):
+    """Unit plan of the one-workgroup-per-CU kernel for a Rulebook (isf_sparse_conv_cu_plan), cached on it:
+    (isf_conv_cu_plan struct, the int32 buffer it points into).  One plan serves every 256-column layer on the rulebook."""
+    if getattr(rb, "_cu_plan", None) is None:
+        lib = _lib.load()
+        K = rb.nbr.numel() // rb.stride
+        n = ctypes.c_size_t(0)
+        _lib.check(lib.isf_sparse_conv_cu_plan_ints(rb.num_out, ctypes.byref(n)), "isf_sparse_conv_cu_plan_ints")
+        buf = torch.zeros((n.value,), dtype=torch.int32, device=rb.nbr.device)
+        plan = _lib.ConvCuPlan()
+        _lib.check(lib.isf_sparse_conv_cu_plan(_lib.ptr(rb.nbr), rb.stride, K, rb.num_out, _lib.ptr(buf),
+                                               ctypes.byref(plan), _lib.stream()), "isf_sparse_conv_cu_plan")
+        rb._cu_plan = (plan, buf)
+    return rb._cu_plan
+
+
+def cu_plan_units(rb):
+    """The plan's unit table as a CPU tensor [num_units, 2] = (first 16-row group, groups) and the group masks [groups]."""
+    plan, buf = cu_plan(rb)
+    base = buf.data_ptr()
+    n = int(buf[(plan.num_units - base) // 4].item())
+    uo = (plan.units - base) // 4
+    ng = (rb.num_out + 15) // 16
+    return buf[uo:uo + 2 * n].view(n, 2).cpu(), buf[:ng].cpu()
+
+
+def cu_plan_host(work, cus=256):
+    """isf_sparse_conv_cu_plan_host: the plan arithmetic on the CPU (no device work): work [groups] int32 -> units
+    [num_units, 2]."""
+    import numpy as np
+    lib = _lib.load()
+    work = np.ascontiguousarray(work, dtype=np.int32)
+    cap = lib.isf_sparse_conv_cu_max_units(len(work), cus)
+    units = np.zeros((cap, 2), dtype=np.int32)
+    n = ctypes.c_int(0)
+    _lib.check(lib.isf_sparse_conv_cu_plan_host(work.ctypes.data, len(work), cus, units.ctypes.data, cap, ctypes.byref(n)),
+               "isf_sparse_conv_cu_plan_host")
+    return units[:n.value]
+
+
+def sparse_conv_cu_supported(c_in, c_out):
+    return c_out == 256 and c_in in (128, 256)
+
+
+def sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False):
+    """sparse_conv_forward_f16x3 (mode 0) on the one-workgroup-per-CU kernel of the 256-column layers
+    (isf_sparse_conv_forward_cu; c_out = 256, c_in in {128, 256}); bit-identical results."""
+    _lib.require_cuda(features)
+    xs = to_split(features)
+    rs = None if residual is None else to_split(residual)
+    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)
+    plan, _buf = cu_plan(rb)
+    _lib.check(_lib.load().isf_sparse_conv_forward_cu(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), ctypes.byref(plan),
+        _lib.stream()), "isf_sparse_conv_forward_cu")
+    return from_split(ys, (rb.num_out, c_out))
+
+
 def sparse_conv_forward_best(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False,
                              mode=0):
     """The kernel choice of isf_sparse_encoder_forward for one layer driven from Python (all choices give the same
-    bits): the LDS-DMA gather kernel for the narrow shapes, the tile-order table for launches of one resident round."""
+    bits): the LDS-DMA gather kernel for the narrow shapes, the one-workgroup-per-CU kernel for the 256-column shapes,
+    the tile-order table for launches of one resident round."""
     if c_in <= 64 and c_out <= 64 and (mode & ~32) in (0, 1, 257):
         return sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode)
+    if sparse_conv_cu_supported(c_in, c_out) and (mode & ~32) == 0:
+        return sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu)
     order = tile_order(rb, c_in, c_out, mode) if (mode & ~32) in (0, 1, 257) else None
     return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode, order)
 

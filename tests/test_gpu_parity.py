@@ -594,6 +594,70 @@ def test_dma_gather_kernel_bit_identical_to_gather_kernel(dev, cin, cout):
         sp.sparse_conv_forward_dma(T(np.zeros((10, 128), np.float32), dev), p16, 27, 128, 128, rb)   # wide: not built
 
 
+@pytest.mark.parametrize("cin", [128, 256])
+def test_cu_unit_kernel_bit_identical_to_tile_kernel(dev, cin):
+    """isf_sparse_conv_forward_cu (256-column layers: one 8-wave workgroup per compute unit over units of equal matrix
+    work, weight fragments global -> VGPR, gathered rows by LDS-DMA through a three-stage ring) ==
+    isf_sparse_conv_forward_f16x3 bit for bit: same products, same order per accumulator.  SubM / strided / 3x1x1
+    geometry, BN + residual + ReLU epilogue and none, from a level of 5 rows (one unit, one group) over a few hundred
+    (fewer units than CUs) to 40 k rows (one unit per CU) and 120 k (several per CU); the device plan equals the host
+    walk of the same arithmetic and covers every 16-row group exactly once."""
+    from isfusion_amd import spconv as sp
+    cout = 256
+    rng = np.random.default_rng(cin)
+    B, shape = 2, [12, 96, 96]
+    for n in (5, 300, 5000, 40000, 120000):
+        idx = _random_geometry(rng, B, shape, n)
+        x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+        for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                                 (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+            if n == 120000 and not subm:
+                continue
+            K = int(np.prod(ks))
+            rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+            w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32), dev)
+            res = T(rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32), dev)
+            sc = T(rng.random(cout, dtype=np.float32) + 0.5, dev)
+            sh = T(rng.normal(0, 0.2, cout).astype(np.float32), dev)
+            p16 = sp.pack_filters_f16x3(w)
+            ref = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True)
+            got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb, sc, sh, res, relu=True)
+            assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks)
+            got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb)          # no epilogue terms
+            assert torch.equal(got, sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb)), (n, subm, ks)
+            assert torch.equal(sp.sparse_conv_forward_best(x, p16, K, cin, cout, rb, sc, sh, res, relu=True), ref)
+            # the plan: device == host walk; groups covered once; masks = taps with a neighbour per 16-row group
+            units, masks = sp.cu_plan_units(rb)
+            nbr = rb.nbr.view(K, rb.stride)[:, :rb.num_out].cpu().numpy()
+            ng = (rb.num_out + 15) // 16
+            pad = np.full((K, ng * 16), -1, np.int32)
+            pad[:, :rb.num_out] = nbr
+            want_masks = ((pad.reshape(K, ng, 16) >= 0).any(2) * (1 << np.arange(K))[:, None]).sum(0)
+            assert np.array_equal(masks.numpy().astype(np.int64), want_masks)
+            work = np.array([bin(int(v)).count("1") for v in want_masks], np.int32)
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            assert np.array_equal(units.numpy(), sp.cu_plan_host(work, cus)), (n, subm, ks)
+    with pytest.raises(Exception):
+        sp.sparse_conv_forward_cu(T(np.zeros((10, 64), np.float32), dev), p16, 27, 64, 64, rb)   # narrow: not built
+
+
+def test_lidar_branch_cu_unit_layers_reproduce_tile_kernel_bits(dev):
+    """the encoder runs its 256-column layers (levels 3 / 4: 128 -> 256 strided, 4 x 256 -> 256 SubM, the 3-tap conv_out)
+    on the one-workgroup-per-CU kernel, unit plans built per rulebook on the geometry stream; diagnostic 512 keeps them on
+    the tile kernel -- same bits, from a 3 k-point frame to the bench size, and repeated calls give the same bits"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(970 + i, n), dev) for i in range(frames)]
+        want = lb(pl, conv_diag=512)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        got = lb(pl)
+        assert torch.equal(got, want), n
+        assert torch.equal(lb(pl), got), n
+        assert torch.equal(lb(pl, conv_diag=512 + 64 + 128), want), n       # every switchable variant off
+
+
 def test_lidar_branch_dma_gather_layers_reproduce_gather_kernel_bits(dev):
     """the encoder runs its narrow layers (levels 0 / 1) on the LDS-DMA gather kernel; diagnostic 128 keeps them on the
     gather kernel -- same bits, in the split, single-pass f16 and f16-storage precisions"""

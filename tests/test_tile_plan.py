@@ -85,3 +85,59 @@ def test_one_round_launches_are_dealt_evenly(plan_exe):
     # a frame set whose need rounds up to 6 keeps uniform tiles
     plan6, _ = tiles_of(plan_exe, 44704, 128, 2)
     assert plan6[1] == 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Unit plan of the one-workgroup-per-CU kernel (csrc/isf_spconv16.h: conv_cu_cut / conv_cu_piece, walked on the host by
+# isf_sparse_conv_cu_plan_host -- the same functions the device planner calls; no GPU work).
+def _cu_units(work, cus=256):
+    from isfusion_amd import spconv as sp
+    return sp.cu_plan_host(work, cus)
+
+
+@pytest.mark.parametrize("case", ["level3", "dense", "sparse", "one", "tiny", "zeros", "big", "spiky", "cus32"])
+def test_cu_unit_plan_covers_every_group_once_and_balances(case):
+    import numpy as np
+    from isfusion_amd import _lib
+    rng = np.random.default_rng(sum(map(ord, case)))
+    cus = 256
+    if case == "level3":      # 40.7 k rows, 9..27 taps per group (profiles/r03_conv_trace.txt: mean 16)
+        work = np.clip(rng.normal(16, 5, 2544), 9, 27).astype(np.int32)
+    elif case == "dense":
+        work = np.full(2544, 27, np.int32)
+    elif case == "sparse":    # 3-tap conv_out: the cap, not the work, sizes the units
+        work = rng.integers(1, 4, 2258).astype(np.int32)
+    elif case == "one":
+        work = np.array([5], np.int32)
+    elif case == "tiny":
+        work = rng.integers(1, 28, 7).astype(np.int32)
+    elif case == "zeros":     # rows without any neighbour still belong to exactly one unit
+        work = np.zeros(300, np.int32); work[::17] = 9
+    elif case == "big":       # several units per CU
+        work = rng.integers(1, 28, 20000).astype(np.int32)
+    elif case == "spiky":
+        work = np.ones(5000, np.int32); work[2000:2100] = 27
+    else:
+        work = rng.integers(1, 28, 1000).astype(np.int32); cus = 32
+    units = _cu_units(work, cus)
+    n = len(work)
+    assert len(units) <= _lib.load().isf_sparse_conv_cu_max_units(n, cus)
+    # contiguous, ascending, every group exactly once, 1..16 groups per unit
+    assert units[0, 0] == 0 and units[-1, 0] + units[-1, 1] == n
+    assert (units[1:, 0] == units[:-1, 0] + units[:-1, 1]).all()
+    assert units[:, 1].min() >= 1 and units[:, 1].max() <= 16
+    # balance: no unit carries more than the balanced share + one group's worth of rounding (the cap may only cut work)
+    w = np.array([work[a:a + k].sum() for a, k in units])
+    r = max(1, -(-n // (cus * 12)))
+    share = work.sum() / (cus * r)
+    assert w.max() <= share + 27 + 1e-9, (w.max(), share)
+    if case in ("level3", "dense"):
+        assert len(units) == cus and w.min() >= share - 27          # one unit per CU, all within a group of the mean
+
+
+def test_cu_unit_plan_is_deterministic_and_monotone_in_cuts():
+    import numpy as np
+    rng = np.random.default_rng(5)
+    work = rng.integers(0, 28, 3333).astype(np.int32)
+    a, b = _cu_units(work), _cu_units(work.copy())
+    assert np.array_equal(a, b)

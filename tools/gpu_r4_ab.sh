@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 4: parity of the one-workgroup-per-CU conv kernel, then an interleaved same-box A/B of the headline bench
+# (default = 256-column layers on isf_sparse_conv_forward_cu; --conv-diag 512 = tile kernel).  Usage (GPU box):
+#   bash tools/gpu_r4_ab.sh <tag> [pytest -k expression]
+set -u
+TAG=${1:-r04_ab}
+KEXPR=${2:-cu_unit}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export ISF_BENCH_FRAME_CACHE=/tmp/isf_frames
+( timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "$KEXPR" 2>&1 | tail -15 ) > $OUT/pytest.txt
+cat $OUT/pytest.txt | tail -5
+for rep in 1 2 3; do
+  for v in 0 512; do
+    timeout 300 python bench.py --steps 40 --warmup 8 --no-cfg3 --no-cpu-baseline --conv-diag $v > $OUT/bench_diag${v}_$rep.json 2> $OUT/bench_diag${v}_$rep.err
+    python - <<PY
+import json
+try:
+    l = json.loads(open("$OUT/bench_diag${v}_$rep.json").read().strip().splitlines()[-1])
+    pk = l["roofline"]["per_kernel"]
+    print("diag", $v, "rep", $rep, l["value"], "frames/s", l["ms_per_step"], "ms; conv", l["roofline"]["conv_ms_per_step"],
+          {k.replace("spconv_mfma", ""): v["ms"] for k, v in pk.items() if "256" in k or "128" in k})
+except Exception as e:
+    print("diag", $v, "rep", $rep, "FAILED", e)
+PY
+  done
+done 2>&1 | tee $OUT/ab_summary.txt
