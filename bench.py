@@ -394,6 +394,133 @@ def fusion_leg(args, rank, world, dev, B, steps, warmup, with_cpu_baseline):
     return None
 
 
+# ------------------------------------------------------------------------------ BASELINE configs[4] / configs[3] legs
+def f16_stress_leg(args, rank, world, dev, steps=16, warmup=4, B=4, points=500000, voxel=0.05):
+    """BASELINE configs[4] on one GPU, attached to the headline line as "cfg5_f16": the LiDAR branch at 0.05 m voxels
+    (sparse shape [41, 2160, 2160], BEV 270 x 270) on 500 k-point sweeps in the f16 STORAGE mode (isf_encoder_options
+    .precision = 2: f16 rows between the layers, f16 operands, fp32 accumulate -- the reference's indice_conv_half data
+    types): frames/s and, per conv kernel, the algorithmic HBM rate (SURVEY 8d bytes with 2-byte elements) as a fraction
+    of the 8 TB/s peak -- the "HBM-bound sparse-conv roofline run"."""
+    import numpy as np
+    import torch
+    import isfusion_amd as m
+    me = dict(m.ISFUSION_0075["pts_middle_encoder"])
+    side = int(round(108.0 / voxel))
+    me["sparse_shape"] = [41, side, side]
+    lb = m.LidarBranch(voxel_size=[voxel, voxel, 0.2], pts_middle_encoder=me)
+    lb = lb.randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
+    sets = [[torch.from_numpy(q).to(dev) for q in make_frames(rank, world, B, points, 20 + fs)] for fs in range(2)]
+    for i in range(warmup):
+        out = lb(sets[i % 2], precision=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = lb(sets[i % 2], precision=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    tab = lb.conv_layer_table()
+    groups, tot_ms, tot_by = {}, 0.0, 0.0
+    ns = 4
+    for i in range(ns):                                   # per-layer HIP events: separate passes, both frame sets
+        lb(sets[i % 2], precision=2, time_layers=True)
+        st = lb.last_stats
+        for j, (kind, cin, cout, K) in enumerate(tab):
+            by, fl = conv_layer_bytes_flops(kind, cin, cout, K, st.num_in[j], st.num_out[j], st.pairs[j], 2)
+            g = groups.setdefault(f"spconv<cin={cin},cout={cout}>", dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+            g["ms"] += float(st.ms[j]) / ns; g["bytes"] += by / ns; g["flops"] += fl / ns; g["launches"] += 1
+            tot_ms += float(st.ms[j]) / ns; tot_by += by / ns
+    for g in groups.values():
+        g["launches"] //= ns
+    per = {k: dict(ms=round(v["ms"], 4), launches=v["launches"], algorithmic_gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                   hbm_frac=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                   mfma_frac=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)) for k, v in groups.items()
+           if v["ms"] > 0}
+    return {"metric": "nuScenes-shaped frames/sec forward, LiDAR branch at 0.05 m voxels (BASELINE configs[4] on 1 GPU)",
+            "value": round(B * steps / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3),
+            "dtype": "f16 storage, f16 operands, fp32 accumulate (isf_encoder_options.precision = 2)",
+            "config": {"workload": f"BASELINE configs[4] shape on one GPU: voxel {voxel} m, sparse shape [41, {side}, {side}], "
+                                   f"{points}-pt synthetic sweeps, batch={B}, LiDAR branch only (cameras are out of scope); "
+                                   "the 8-GPU leg is N replicas (bench.py --gpus 8)", "batch_per_gpu": B,
+                       "points_per_frame": points},
+            "conv_ms_per_step": round(tot_ms, 3), "all_conv_algorithmic_gbs": round(tot_by / (tot_ms * 1e-3) / 1e9, 1),
+            "all_conv_hbm_frac": round(tot_by / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "voxels_level0": int(st.num_in[0]), "per_kernel": per}
+
+
+def train_leg(args, rank, world, dev, steps=3, B=2, points=60000):
+    """BASELINE configs[3] on one GPU, attached as "cfg4_train": the full point-cloud path's training step (forward with
+    gradients through LiDAR branch, fusion encoder, SECONDV2 stages and neck + stand-in loss + backward + SGD step) under
+    torch.autocast(bfloat16), B frames per GPU.  ms per step from the wall clock around `steps` synchronised steps;
+    launches and the device-time share from one further step under torch.profiler (None when the profiler is not
+    usable on the box).  The 8-GPU leg wraps the same module in DDP (tools/train_step.py --gpus 8: RCCL all-reduce of the
+    gradients only)."""
+    import torch
+    from isfusion_amd import synthetic
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    net = ISFusionPtsPath().train()
+    net._lidar.randomize_weights_(0).randomize_bn_(1)
+    for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250)):
+        mod.load_state_dict(seeded_state_dict(mod, seed))
+    for q in net.pts_bbox_head.parameters():
+        q.requires_grad_(False)                       # head losses / target assignment: training control plane
+    net = net.to(dev)
+    opt = torch.optim.SGD([q for q in net.parameters() if q.requires_grad], lr=1e-4, momentum=0.9)
+    pts = [torch.from_numpy(synthetic.lidar_sweeps(9000 + 100 * rank + i, points)).to(dev) for i in range(B)]
+    inp = synthetic.fusion_inputs(7 + rank, B)
+    img = tuple(torch.from_numpy(x).to(dev) for x in inp["img_feats"])
+    kw = dict(lidar2img=torch.from_numpy(inp["lidar2img"]), img_aug_matrix=torch.from_numpy(inp["img_aug_matrix"]),
+              lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
+    metas = [dict(input_shape=inp["input_shape"]) for _ in range(B)]
+    losses = []
+
+    def one():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out, hm = net.forward_train_pts(pts, img, metas, **kw)
+            loss = (out[0].float() ** 2).mean() + hm.float().sigmoid().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        losses.append(float(one()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(float(one()))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    launches = kernel_ms = None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            one()
+            torch.cuda.synchronize()
+        evs = [e for e in prof.events() if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower()]
+        if evs:
+            launches = len(evs)
+            kernel_ms = sum(float(getattr(e, "device_time", 0.0) or getattr(e, "cuda_time", 0.0)) for e in evs) / 1e3
+    except Exception as e:                             # the measurement above stands without the profile
+        launches, kernel_ms = None, None
+        sys.stderr.write(f"train_leg: profiler unavailable ({e})\n")
+    assert all(v == v and abs(v) < 1e30 for v in losses), losses
+    return {"metric": "training step of the full point-cloud path (BASELINE configs[3] on 1 GPU)", "value": round(ms, 2),
+            "unit": "ms per step", "higher_is_better": False, "steps": steps, "warmup": 2,
+            "dtype": "torch.autocast(bfloat16): stock convs / linears in bf16, the HIP autograd Functions compute in "
+                     "fp32-class f16x3 arithmetic",
+            "config": {"workload": f"forward_train_pts + stand-in loss + backward + SGD step, batch={B}/GPU, {points}-pt "
+                                   "synthetic sweeps, 6-camera feature maps precomputed (random); detection losses / target "
+                                   "assignment are the reference's control plane (out of scope)", "batch_per_gpu": B,
+                       "points_per_frame": points, "parallelism": "dp1 (8-GPU: tools/train_step.py --gpus 8, DDP over RCCL)"},
+            "launches_per_step": launches, "device_kernel_ms_per_step": None if kernel_ms is None else round(kernel_ms, 2),
+            "kernel_time_share": None if kernel_ms is None else round(kernel_ms / ms, 3),
+            "losses": [round(v, 5) for v in losses]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -414,11 +541,15 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true",
                     help="skip the BASELINE configs[2] leg the default run appends to the headline line as \"cfg3\"")
     ap.add_argument("--cfg3-steps", type=int, default=30)
+    ap.add_argument("--no-cfg4", action="store_true",
+                    help="skip the BASELINE configs[3] leg (1-GPU bf16-autocast training step) appended as \"cfg4_train\"")
+    ap.add_argument("--no-cfg5", action="store_true",
+                    help="skip the BASELINE configs[4] leg (0.05 m voxels, 500 k points, f16 storage) appended as \"cfg5_f16\"")
     ap.add_argument("--graph", action="store_true",
                     help="config 3: replay the shape-static tail (conv_fusion .. head) as one HIP graph instead of ~330 "
                          "eager launches")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
-    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256],
+    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in (1, 2, 3, 4, 8, 12)],
                     help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_encoder_options.diagnostic; "
                          "results are garbage, the line is labelled)")
     ap.add_argument("--stage-rows", type=int, default=0,
@@ -513,7 +644,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    diag = (args.conv_diag & 15) != 0   # timing diagnostics: results are garbage (16 = sharing off, 32 = uniform tiles: valid)
+    diag = (args.conv_diag & 15) != 0 or ((args.conv_diag >> 10) & 3) != 0   # timing diagnostics: results are garbage (16 = sharing off, 32 = uniform tiles: valid)
     assert diag or torch.isfinite(out).all()
 
     if rank == 0:
@@ -617,6 +748,14 @@ def main():
                                                 "config")}
             line["cfg3"]["stages_ms"] = c3["roofline"].pop("stages_ms")
             line["cfg3"]["roofline"] = c3["roofline"]
+        if world == 1 and not args.no_cfg5:
+            # BASELINE configs[4] (0.05 m voxels, 500 k points, f16 storage) and configs[3] (bf16-autocast training step)
+            # on this GPU, same process, after the headline: driver-observed numbers for the two remaining configurations
+            torch.cuda.empty_cache()
+            line["cfg5_f16"] = f16_stress_leg(args, rank, world, dev)
+        if world == 1 and not args.no_cfg4:
+            torch.cuda.empty_cache()
+            line["cfg4_train"] = train_leg(args, rank, world, dev)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -270,6 +270,8 @@ typedef struct isf_conv_cu_plan {
   const int32_t* num_units;     /* device scalar */
   int max_units;                /* host bound of *num_units */
   int num_out;                  /* rows the plan was built for */
+  int variant;                  /* 0 = production.  DIAGNOSTICS: 1 / 2 / 3 = no gathers / no weight loads / neither (TIMING
+                                   ONLY, results garbage); 4 / 12 / 8 = prefetch depth 1 / 2 / 3 steps (results valid) */
 } isf_conv_cu_plan;
 int isf_sparse_conv_cu_plan_ints(int num_out, size_t* num_ints);
 int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int32_t* plan_buf,
@@ -339,7 +341,7 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            kernel instead of isf_sparse_conv_forward_dma; +256 (isf_lidar_branch_forward) = the voxel encoder writes
  *            fp32 rows and a conversion pass makes the split rows, instead of writing them directly; +512 = the
  *            256-column layers on the tile kernel instead of isf_sparse_conv_forward_cu -- results bit-identical
- *            either way);
+ *            either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

@@ -195,6 +195,7 @@ struct ConvCuPlan {
   const int32_t* num_units = nullptr;     // device scalar
   int max_units = 0;                      // host-side bound of *num_units (sizes the grid: no host sync)
   int n_out = 0;
+  int variant = 0;                        // 0 = production; timing diagnostics / pipeline depths: isf_spconv_cu.hip
 };
 bool sparse_conv_cu_supported(int c_in, int c_out);
 size_t conv_cu_plan_ints(int n_out);

@@ -33,17 +33,19 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int kCuWaves = 8;
 static constexpr int kCuRows = 16 * kCuCapGroups;       // 256
-static constexpr int kCuStages = 3;
 static constexpr int kCuCout = 256;
+static constexpr int kCuDepth = 2;                      // production prefetch depth (steps)
 
+template <int D>   // D = prefetch depth in steps; D + 1 stages of gathered rows
 struct ConvCuSmem {
   static constexpr int nbr_bytes = kMaxTaps * kCuRows * 4;            // [27][256] int32
   static constexpr int stage_bytes = kCuCapGroups * 2048;             // [16 groups][hi, lo][64 x 16 B]
-  static constexpr int ring_bytes = kCuStages * stage_bytes;
+  static constexpr int ring_bytes = (D + 1) * stage_bytes;
   static constexpr int tapm_bytes = 32 * 4;                           // per tap: bit j = group j multiplies through it
   static constexpr int epi_bytes = kCuWaves * Conv16Epi<2, kCuCapGroups>::wave_bytes;   // overlays the ring
   static_assert(epi_bytes <= ring_bytes, "epilogue tile must fit the ring");
   static constexpr int bytes = ring_bytes + nbr_bytes + tapm_bytes;
+  static_assert(bytes <= 160 * 1024, "LDS of one compute unit");
 };
 
 // 16 bytes per lane, global -> VGPR, hidden from hipcc's scoreboard: the loads of the next step's weight fragments stay
@@ -52,41 +54,36 @@ struct ConvCuSmem {
 __device__ __forceinline__ void gload16(i32x4& dst, const void* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
 }
-// wait until at most `pend` (0, 2 or 4; wave-uniform) vector-memory operations of this wave are outstanding.  ONE asm
-// statement with the choice inside it, and the fragment registers tied to it: no use of them can be scheduled above the
-// wait, and there is no join of several asm results in front of which hipcc would copy registers whose data has not
-// landed (three separate statements under an if / else did exactly that).
-#define ISF_CU_WAIT(bn, pend)                                                                                        \
-  asm volatile(                                                                                                      \
-      "s_cmp_eq_u32 %4, 0\n\t"                                                                                       \
-      "s_cbranch_scc1 1f\n\t"                                                                                        \
-      "s_cmp_eq_u32 %4, 2\n\t"                                                                                       \
-      "s_cbranch_scc1 2f\n\t"                                                                                        \
-      "s_waitcnt vmcnt(4)\n\t"                                                                                       \
-      "s_branch 3f\n"                                                                                                \
-      "2:\n\t"                                                                                                       \
-      "s_waitcnt vmcnt(2)\n\t"                                                                                       \
-      "s_branch 3f\n"                                                                                                \
-      "1:\n\t"                                                                                                       \
-      "s_waitcnt vmcnt(0)\n"                                                                                         \
-      "3:"                                                                                                           \
-      : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])                                                           \
-      : "s"(pend)                                                                                                    \
-      : "memory", "scc")
+// wait until at most `allowed` (wave-uniform, >= 0) vector-memory operations of this wave are outstanding -- rounded down
+// to an even immediate <= 16 (waiting for more than necessary is safe).  ONE asm statement with the choice inside it, and
+// the fragment registers tied to it: no use of them can be scheduled above the wait, and there is no join of several asm
+// results in front of which hipcc would copy registers whose data has not landed (separate statements under an
+// if / else did exactly that).
+#define ISF_CU_W1(N) "s_cmp_ge_u32 %4, " #N "\n\ts_cbranch_scc0 " #N "0f\n\ts_waitcnt vmcnt(" #N ")\n\ts_branch 99f\n" #N "0:\n\t"
+#define ISF_CU_WAIT(bn, allowed)                                                                                     \
+  asm volatile(ISF_CU_W1(16) ISF_CU_W1(14) ISF_CU_W1(12) ISF_CU_W1(10) ISF_CU_W1(8) ISF_CU_W1(6) ISF_CU_W1(4)        \
+                   ISF_CU_W1(2) "s_waitcnt vmcnt(0)\n"                                                               \
+                                "99:"                                                                                \
+               : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])                                                  \
+               : "s"(allowed)                                                                                        \
+               : "memory", "scc")
 
 struct CuCursor {
   unsigned rem;   // taps of the current chunk not yet visited
   int tap, ch;
 };
 
-template <int CIN>
+// D: prefetch depth in steps (weights: D + 1 register sets, gathered rows: D + 1 LDS stages).  KNOCK: TIMING DIAGNOSTICS
+// (results garbage): bit 1 = no gathers, bit 2 = no weight loads.
+template <int CIN, int D, int KNOCK>
 __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     const int32_t* __restrict__ group_masks, const int2* __restrict__ units, const int32_t* __restrict__ num_units) {
-  using S = ConvCuSmem;
-  constexpr int NCH = CIN / 32, CH8 = CIN / 8;
+  using S = ConvCuSmem<D>;
+  constexpr int NCH = CIN / 32, CH8 = CIN / 8, NS = D + 1;
+  constexpr bool NOGATHER = (KNOCK & 1) != 0, NOWEIGHT = (KNOCK & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ring = reinterpret_cast<uint4*>(smem);
   int* nbr_l = reinterpret_cast<int*>(smem + S::ring_bytes);                       // [27][256]
@@ -168,8 +165,11 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
     i0 = nbr_l[tap * kCuRows + wave * 16 + grow_l];
     i1 = nbr_l[tap * kCuRows + (wave + 8) * 16 + grow_l];
   };
-  auto dma_count = [&](int tap) -> int { return 2 * (int)((dm0 >> tap) & 1u) + 2 * (int)((dm1 >> tap) & 1u); };
+  auto dma_count = [&](int tap) -> int {
+    return NOGATHER ? 0 : 2 * (int)((dm0 >> tap) & 1u) + 2 * (int)((dm1 >> tap) & 1u);
+  };
   auto issue_A = [&](int tap, int ch, int stage, int i0, int i1) {
+    if (NOGATHER) return;
     const unsigned base = ring_addr + (unsigned)stage * (unsigned)S::stage_bytes;
     if ((dm0 >> tap) & 1u) {
       const uint4* src = i0 >= 0 ? xs + ((size_t)i0 * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
@@ -182,68 +182,82 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
       glds16(src + 4, base + (unsigned)(wave + 8) * 2048u + 1024u);
     }
   };
-  // Weight fragments of this wave, [column tile][hi, lo] -> [2 nt + h], in TWO register sets used alternately: step t
-  // multiplies with one set while the loads of step t + 1 land in the other.  (One "next" set renamed to a "current" set
-  // per step does not work with loads the compiler cannot see: it places the renaming copies in front of the counted
-  // wait and copies registers whose data has not landed.)
-  i32x4 bx[4], by[4];
-  auto load_B = [&](int tap, int ch, i32x4 (&bn)[4]) {
+  // Weight fragments of this wave, [column tile][hi, lo] -> [2 nt + h], in D + 1 register sets used in rotation: step t
+  // multiplies with set t % (D + 1) while the loads of steps t + 1 .. t + D land in the others.  (One "next" set renamed
+  // to a "current" set per step does not work with loads the compiler cannot see: it places the renaming copies in front
+  // of the counted wait and copies registers whose data has not landed.)
+  i32x4 bs[NS][4];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) bs[k][0] = bs[k][1] = bs[k][2] = bs[k][3] = i32x4{0, 0, 0, 0};
+  auto load_B = [&](int tap, int ch, i32x4 (&bn)[4]) -> int {
+    if (NOWEIGHT) return 0;
     const uint4* src = wpk + (((size_t)tap * NCH + ch) * (kCuCout / 16) + 2 * wave) * 128 + lane;
     gload16(bn[0], src);
     gload16(bn[1], src + 64);
     gload16(bn[2], src + 128);
     gload16(bn[3], src + 192);
+    return 4;
   };
 
-  // ---- pipeline fill: A(0), B(0), A(1) (in that order: the wait at the top of step t leaves only A(t + 1) in flight)
-  CuCursor cb{0u, -1, -1}, ca{0u, -1, -1};     // cb: the step whose weights are loaded next, ca: whose rows are gathered next
+  // ---- the pipeline.  Group G(s) = {weights of step s + D, gathers of step s + D}, issued in that order at step s (the
+  // fill issues G(-D) .. G(-1)); at the top of step t everything up to G(t - D) must have landed and the D - 1 younger
+  // groups may stay in flight: the wait allows exactly their operation count (inq[]).
+  CuCursor cg{0u, -1, -1};     // the step whose group is issued next
+  CuCursor ci{0u, -1, -1};     // the step whose gather indices are read next (one ahead of cg)
+  CuCursor cm{0u, -1, -1};     // the step whose group mask is read next (one ahead of the multiply)
   int idx0 = -1, idx1 = -1;
   unsigned m_cur = 0;
-  int pend = 0;                                 // A-DMA instructions of step t + 1 this wave has in flight
-  bx[0] = bx[1] = bx[2] = bx[3] = i32x4{0, 0, 0, 0};
-  by[0] = by[1] = by[2] = by[3] = i32x4{0, 0, 0, 0};
-  if (nsteps > 0) {
-    advance(ca);
-    read_idx(ca.tap, idx0, idx1);
-    issue_A(ca.tap, ca.ch, 0, idx0, idx1);
-    advance(cb);
-    m_cur = (unsigned)tapm_l[cb.tap];
-    load_B(cb.tap, cb.ch, bx);
-    if (nsteps > 1) {
-      advance(ca);
-      read_idx(ca.tap, idx0, idx1);
-      issue_A(ca.tap, ca.ch, 1, idx0, idx1);
-      pend = dma_count(ca.tap);
+  int inq[D > 1 ? D - 1 : 1];   // operations of the D - 1 youngest groups, oldest first
+#pragma unroll
+  for (int i = 0; i < (D > 1 ? D - 1 : 1); ++i) inq[i] = 0;
+  int issued_steps = 0;         // steps whose group has been issued
+  auto issue_group = [&](i32x4 (&bn)[4], int stage) -> int {   // the group of step `issued_steps`
+    advance(cg);
+    int n = load_B(cg.tap, cg.ch, bn);
+    issue_A(cg.tap, cg.ch, stage, idx0, idx1);
+    n += dma_count(cg.tap);
+    ++issued_steps;
+    if (issued_steps < nsteps) {          // indices of the next group's rows
+      advance(ci);
+      read_idx(ci.tap, idx0, idx1);
     }
-    if (nsteps > 2) {                            // rows of step 2: indices now, gathers at step 0
-      advance(ca);
-      read_idx(ca.tap, idx0, idx1);
+    return n;
+  };
+  if (nsteps > 0) {
+    advance(ci);
+    read_idx(ci.tap, idx0, idx1);
+    advance(cm);
+    m_cur = (unsigned)tapm_l[cm.tap];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {         // G(k - D): step k
+      int n = 0;
+      if (k < nsteps) n = issue_group(bs[k], k);
+      if (k >= 1) inq[k - 1] = n;         // G(-D) is the one the first wait drains
     }
   }
   int stage = 0;
-  // one step: bn = the set holding B(t) (in flight until the wait), bo = the set B(t + 1) is loaded into
+  // one step: bn = the set holding B(t), bo = the set B(t + D) is loaded into, s_new = the stage A(t + D) lands in
   auto step = [&](int t, i32x4 (&bn)[4], i32x4 (&bo)[4]) {
-    // B(t), A(t) of this wave landed; only its A(t + 1) gathers (issued after B(t)) may still be in flight
-    ISF_CU_WAIT(bn, pend);
-    __builtin_amdgcn_s_barrier();     // A(t) complete for every wave; every wave is done reading stage (t + 2) % 3
+    int allowed = 0;
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) allowed += inq[i];
+    ISF_CU_WAIT(bn, allowed);
+    __builtin_amdgcn_s_barrier();     // A(t) complete for every wave; every wave is done reading the stage of step t - 1
     asm volatile("" ::: "memory");
     const unsigned m = __builtin_amdgcn_readfirstlane(m_cur);
     if (t + 1 < nsteps) {
-      advance(cb);
-      load_B(cb.tap, cb.ch, bo);
-      m_cur = (unsigned)tapm_l[cb.tap];
+      advance(cm);
+      m_cur = (unsigned)tapm_l[cm.tap];
     }
-    pend = 0;
-    if (t + 2 < nsteps) {
-      int s2 = stage + 2;
-      if (s2 >= kCuStages) s2 -= kCuStages;
-      issue_A(ca.tap, ca.ch, s2, idx0, idx1);
-      pend = dma_count(ca.tap);       // issued AFTER B(t + 1): exactly what may stay in flight at the next wait
-      if (t + 3 < nsteps) {
-        advance(ca);
-        read_idx(ca.tap, idx0, idx1);
-      }
+    int n = 0;
+    if (issued_steps < nsteps) {
+      int s_new = stage + D;
+      if (s_new >= NS) s_new -= NS;
+      n = issue_group(bo, s_new);
     }
+#pragma unroll
+    for (int i = 0; i + 1 < D - 1; ++i) inq[i] = inq[i + 1];
+    if (D > 1) inq[D - 2] = n;
     if (m) {
       const uint4* sa = ring + stage * (S::stage_bytes / 16) + rpos;
       const h8 bh0 = *reinterpret_cast<const h8*>(&bn[0]), bl0 = *reinterpret_cast<const h8*>(&bn[1]);
@@ -271,15 +285,16 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
         }
       }
     }
-    if (++stage == kCuStages) stage = 0;
+    if (++stage == NS) stage = 0;
   };
-  for (int t = 0; t < nsteps; t += 2) {
-    step(t, bx, by);
-    if (t + 1 < nsteps) step(t + 1, by, bx);
+  for (int t = 0; t < nsteps; t += NS) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      if (t + k < nsteps) step(t + k, bs[k], bs[(k + D) % NS]);
   }
   {
     const int none = 0;
-    ISF_CU_WAIT(bx, none);
+    ISF_CU_WAIT(bs[0], none);
   }
   __syncthreads();   // every wave is done with the ring -> reuse as the epilogue transpose tiles
 
@@ -423,6 +438,7 @@ int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int3
   plan->num_units = cnt;
   plan->max_units = UM;
   plan->n_out = n_out;
+  plan->variant = 0;
   return ISF_OK;
 }
 
@@ -437,21 +453,36 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
               "sparse_conv_cu: the unit plan was built for %d rows, the launch has %d", plan.n_out, n_out);
   const uint4* w = reinterpret_cast<const uint4*>(packed16);
   const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
-  static std::atomic<int> attr_set{0};
-  if (attr_set.load(std::memory_order_acquire) == 0) {
-    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_cu_kernel<128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, ConvCuSmem::bytes));
-    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(spconv_cu_kernel<256>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, ConvCuSmem::bytes));
-    attr_set.store(1, std::memory_order_release);
-  }
   const dim3 grid(8 * ceil_div(plan.max_units, 8)), block(64 * kCuWaves);
-#define ISF_CU_ARGS                                                                                                 \
-  reinterpret_cast<const uint4*>(xs), nbr, nbr_stride, w, winv, K, scale, shift, reinterpret_cast<const uint4*>(residual), \
-      reinterpret_cast<uint4*>(ys), n_out, relu, plan.group_masks, plan.units, plan.num_units
-  if (c_in == 128) hipLaunchKernelGGL(spconv_cu_kernel<128>, grid, block, ConvCuSmem::bytes, st, ISF_CU_ARGS);
-  else hipLaunchKernelGGL(spconv_cu_kernel<256>, grid, block, ConvCuSmem::bytes, st, ISF_CU_ARGS);
-#undef ISF_CU_ARGS
+  // variant (DIAGNOSTIC; 0 = production): 1 / 2 / 3 = no gathers / no weight loads / neither (results garbage, timing
+  // only); 4 = prefetch depth 1, 8 = depth 3 (results valid)
+#define ISF_CU_LAUNCH(CI, DD, KK)                                                                                       \
+  do {                                                                                                                  \
+    auto kern = spconv_cu_kernel<CI, DD, KK>;                                                                           \
+    static std::atomic<int> attr_set{0};                                                                                \
+    if (attr_set.load(std::memory_order_acquire) == 0) {                                                                \
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      ConvCuSmem<DD>::bytes));                                                          \
+      attr_set.store(1, std::memory_order_release);                                                                     \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(kern, grid, block, ConvCuSmem<DD>::bytes, st, reinterpret_cast<const uint4*>(xs), nbr,           \
+                       nbr_stride, w, winv, K, scale, shift, reinterpret_cast<const uint4*>(residual),                  \
+                       reinterpret_cast<uint4*>(ys), n_out, relu, plan.group_masks, plan.units, plan.num_units);        \
+  } while (0)
+#define ISF_CU_VARIANTS(CI)                                                                                             \
+  switch (plan.variant) {                                                                                               \
+    case 0: ISF_CU_LAUNCH(CI, kCuDepth, 0); break;                                                                      \
+    case 1: ISF_CU_LAUNCH(CI, kCuDepth, 1); break;                                                                      \
+    case 2: ISF_CU_LAUNCH(CI, kCuDepth, 2); break;                                                                      \
+    case 3: ISF_CU_LAUNCH(CI, kCuDepth, 3); break;                                                                      \
+    case 4: ISF_CU_LAUNCH(CI, 1, 0); break;                                                                             \
+    case 8: ISF_CU_LAUNCH(CI, 3, 0); break;                                                                             \
+    case 12: ISF_CU_LAUNCH(CI, 2, 0); break;                                                                            \
+    default: ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_cu: variant %d", plan.variant);                               \
+  }
+  if (c_in == 128) { ISF_CU_VARIANTS(128) } else { ISF_CU_VARIANTS(256) }
+#undef ISF_CU_VARIANTS
+#undef ISF_CU_LAUNCH
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -476,6 +507,7 @@ int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, in
   plan->num_units = p.num_units;
   plan->max_units = p.max_units;
   plan->num_out = p.n_out;
+  plan->variant = 0;
   return ISF_OK;
 }
 
@@ -494,6 +526,7 @@ int isf_sparse_conv_forward_cu(const void* features_split, int num_in, int c_in,
   p.num_units = plan->num_units;
   p.max_units = plan->max_units;
   p.n_out = plan->num_out;
+  p.variant = plan->variant;
   return isf::sparse_conv_forward_cu_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
                                           shift, residual_split, relu, out_split, p, isf::as_stream(stream));
 }

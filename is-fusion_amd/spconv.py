@@ -283,14 +283,17 @@ def sparse_conv_cu_supported(c_in, c_out):
     return c_out == 256 and c_in in (128, 256)
 
 
-def sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False):
+def sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False,
+                           variant=0):
     """sparse_conv_forward_f16x3 (mode 0) on the one-workgroup-per-CU kernel of the 256-column layers
-    (isf_sparse_conv_forward_cu; c_out = 256, c_in in {128, 256}); bit-identical results."""
+    (isf_sparse_conv_forward_cu; c_out = 256, c_in in {128, 256}); bit-identical results.  variant: isf_conv_cu_plan
+    .variant (0 production; 4 / 12 / 8 = prefetch depth 1 / 2 / 3, valid results; 1 / 2 / 3 timing knock-outs)."""
     _lib.require_cuda(features)
     xs = to_split(features)
     rs = None if residual is None else to_split(residual)
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)
     plan, _buf = cu_plan(rb)
+    plan = _lib.ConvCuPlan(plan.group_masks, plan.units, plan.num_units, plan.max_units, plan.num_out, int(variant))
     _lib.check(_lib.load().isf_sparse_conv_forward_cu(
         _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
         _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), ctypes.byref(plan),

@@ -626,6 +626,9 @@ def test_cu_unit_kernel_bit_identical_to_tile_kernel(dev, cin):
             got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb)          # no epilogue terms
             assert torch.equal(got, sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb)), (n, subm, ks)
             assert torch.equal(sp.sparse_conv_forward_best(x, p16, K, cin, cout, rb, sc, sh, res, relu=True), ref)
+            for variant in (4, 12, 8):                                        # prefetch depths 1 / 2 / 3 steps
+                got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, variant=variant)
+                assert torch.equal(got, ref), (n, subm, ks, variant)
             # the plan: device == host walk; groups covered once; masks = taps with a neighbour per 16-row group
             units, masks = sp.cu_plan_units(rb)
             nbr = rb.nbr.view(K, rb.stride)[:, :rb.num_out].cpu().numpy()

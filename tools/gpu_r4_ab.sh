@@ -10,8 +10,10 @@ mkdir -p $OUT
 export ISF_BENCH_FRAME_CACHE=/tmp/isf_frames
 ( timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "$KEXPR" 2>&1 | tail -15 ) > $OUT/pytest.txt
 cat $OUT/pytest.txt | tail -5
-for rep in 1 2 3; do
-  for v in 0 512; do
+VARIANTS=${3:-"0 512"}
+REPS=${4:-"1 2 3"}
+for rep in $REPS; do
+  for v in $VARIANTS; do
     timeout 300 python bench.py --steps 40 --warmup 8 --no-cfg3 --no-cpu-baseline --conv-diag $v > $OUT/bench_diag${v}_$rep.json 2> $OUT/bench_diag${v}_$rep.err
     python - <<PY
 import json
