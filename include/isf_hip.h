@@ -260,8 +260,9 @@ int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in
  * max_units) -- once per rulebook; isf_sparse_conv_forward_cu runs one 8-wave workgroup per unit over ALL 256 output columns:
  * wave w owns columns [32 w, 32 w + 32), its weight fragments go global -> VGPR (no LDS, one stream per CU instead of one
  * per tile), the gathered rows come in by LDS-DMA once per CU through a three-stage ring (two steps ahead).  Results are
- * BIT-IDENTICAL to isf_sparse_conv_forward_f16x3 (mode 0).  isf_sparse_encoder_forward / isf_lidar_branch_forward run
- * their 256-column layers on it (diagnostic +512: tile kernel).  isf_sparse_conv_cu_plan_host / _max_units: the plan
+ * BIT-IDENTICAL to isf_sparse_conv_forward_f16x3 (mode 0).  MEASURED SLOWER than the tile kernel on the MI355X (256 -> 256:
+ * 1.39 .. 1.50 ms per step against 1.26; profiles/r04_cu_kernel_ab.txt), so it is an OPT-IN:
+ * isf_sparse_encoder_forward / isf_lidar_branch_forward run their 256-column layers on it with diagnostic +512.  isf_sparse_conv_cu_plan_host / _max_units: the plan
  * arithmetic on the host (tests, tools; no device work): work [num_groups] -> units [max_units][2] = (first group, groups).
  * Replaces the reference's per-tap gather -> GEMM -> scatter-add (spconv_ops.h:260-361) for those layers. */
 typedef struct isf_conv_cu_plan {
@@ -271,7 +272,8 @@ typedef struct isf_conv_cu_plan {
   int max_units;                /* host bound of *num_units */
   int num_out;                  /* rows the plan was built for */
   int variant;                  /* 0 = production.  DIAGNOSTICS: 1 / 2 / 3 = no gathers / no weight loads / neither (TIMING
-                                   ONLY, results garbage); 4 / 12 / 8 = prefetch depth 1 / 2 / 3 steps (results valid) */
+                                   ONLY, results garbage); 4 / 5 = 4-wave workgroups at prefetch depth 1 / 2 steps, 6 / 7 =
+                                   8-wave workgroups at depth 1 / 2 (results valid) */
 } isf_conv_cu_plan;
 int isf_sparse_conv_cu_plan_ints(int num_out, size_t* num_ints);
 int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int32_t* plan_buf,
@@ -340,8 +342,8 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            +64 = tiles in launch order, no isf_sparse_conv_tile_order tables; +128 = narrow layers on the gather
  *            kernel instead of isf_sparse_conv_forward_dma; +256 (isf_lidar_branch_forward) = the voxel encoder writes
  *            fp32 rows and a conversion pass makes the split rows, instead of writing them directly; +512 = the
- *            256-column layers on the tile kernel instead of isf_sparse_conv_forward_cu -- results bit-identical
- *            either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
+ *            256-column layers on isf_sparse_conv_forward_cu (one workgroup per CU; opt-in: measured slower than
+ *            the tile kernel) -- results bit-identical either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

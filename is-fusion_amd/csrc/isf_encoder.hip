@@ -223,7 +223,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10));   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
-  const bool cu_units = (diagnostic & 512) == 0;     // bit 512: the 256-column layers on the tile kernel as well
+  const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
+                                                     // layers on the one-workgroup-per-CU kernel
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);

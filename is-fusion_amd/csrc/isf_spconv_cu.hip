@@ -31,18 +31,18 @@ __device__ uint4 g_zero_line_cu[8];   // 128 zero bytes: what a row without a ne
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int kCuWaves = 8;
 static constexpr int kCuRows = 16 * kCuCapGroups;       // 256
 static constexpr int kCuCout = 256;
-static constexpr int kCuDepth = 2;                      // production prefetch depth (steps)
+static constexpr int kCuDepth = 1;                      // production prefetch depth (steps)
+static constexpr int kCuWavesProd = 4;                  // production workgroup: 4 waves x 64 columns
 
-template <int D>   // D = prefetch depth in steps; D + 1 stages of gathered rows
+template <int D, int NW>   // D = prefetch depth in steps; D + 1 stages of gathered rows
 struct ConvCuSmem {
   static constexpr int nbr_bytes = kMaxTaps * kCuRows * 4;            // [27][256] int32
   static constexpr int stage_bytes = kCuCapGroups * 2048;             // [16 groups][hi, lo][64 x 16 B]
   static constexpr int ring_bytes = (D + 1) * stage_bytes;
   static constexpr int tapm_bytes = 32 * 4;                           // per tap: bit j = group j multiplies through it
-  static constexpr int epi_bytes = kCuWaves * Conv16Epi<2, kCuCapGroups>::wave_bytes;   // overlays the ring
+  static constexpr int epi_bytes = NW * Conv16Epi<16 / NW, kCuCapGroups>::wave_bytes;   // overlays the ring
   static_assert(epi_bytes <= ring_bytes, "epilogue tile must fit the ring");
   static constexpr int bytes = ring_bytes + nbr_bytes + tapm_bytes;
   static_assert(bytes <= 160 * 1024, "LDS of one compute unit");
@@ -59,13 +59,23 @@ __device__ __forceinline__ void gload16(i32x4& dst, const void* src) {
 // the fragment registers tied to it: no use of them can be scheduled above the wait, and there is no join of several asm
 // results in front of which hipcc would copy registers whose data has not landed (separate statements under an
 // if / else did exactly that).
-#define ISF_CU_W1(N) "s_cmp_ge_u32 %4, " #N "\n\ts_cbranch_scc0 " #N "0f\n\ts_waitcnt vmcnt(" #N ")\n\ts_branch 99f\n" #N "0:\n\t"
-#define ISF_CU_WAIT(bn, allowed)                                                                                     \
-  asm volatile(ISF_CU_W1(16) ISF_CU_W1(14) ISF_CU_W1(12) ISF_CU_W1(10) ISF_CU_W1(8) ISF_CU_W1(6) ISF_CU_W1(4)        \
-                   ISF_CU_W1(2) "s_waitcnt vmcnt(0)\n"                                                               \
-                                "99:"                                                                                \
-               : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])                                                  \
-               : "s"(allowed)                                                                                        \
+#define ISF_CU_W1(N) "s_cmp_ge_u32 %[al], " #N "\n\ts_cbranch_scc0 " #N "0f\n\ts_waitcnt vmcnt(" #N ")\n\ts_branch 99f\n" #N "0:\n\t"
+#define ISF_CU_WCHAIN                                                                                                 \
+  ISF_CU_W1(24) ISF_CU_W1(20) ISF_CU_W1(16) ISF_CU_W1(14) ISF_CU_W1(12) ISF_CU_W1(10) ISF_CU_W1(8) ISF_CU_W1(6)       \
+      ISF_CU_W1(4) ISF_CU_W1(2) "s_waitcnt vmcnt(0)\n"                                                                \
+                                "99:"
+#define ISF_CU_WAIT4_ALL(bn) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])::"memory")
+#define ISF_CU_WAIT8_ALL(bn)                                                                                         \
+  asm volatile("s_waitcnt vmcnt(0)"                                                                                  \
+               : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]), "+v"(bn[6]), "+v"(bn[7]) \
+               :                                                                                                     \
+               : "memory")
+#define ISF_CU_WAIT4(bn, allowed)                                                                                    \
+  asm volatile(ISF_CU_WCHAIN : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]) : [al] "s"(allowed) : "memory", "scc")
+#define ISF_CU_WAIT8(bn, allowed)                                                                                    \
+  asm volatile(ISF_CU_WCHAIN                                                                                         \
+               : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]), "+v"(bn[6]), "+v"(bn[7])  \
+               : [al] "s"(allowed)                                                                                   \
                : "memory", "scc")
 
 struct CuCursor {
@@ -73,16 +83,22 @@ struct CuCursor {
   int tap, ch;
 };
 
+// NW: waves per workgroup (8: wave = 16 row groups x 32 columns, 128 accumulator registers, two waves per SIMD; 4: wave =
+// 16 row groups x 64 columns, 256 accumulator registers (the AGPR half of the register file), one wave per SIMD: every A
+// fragment is read from LDS by 4 waves instead of 8 and a row-group block is 12 MFMAs instead of 6 per fragment read).
 // D: prefetch depth in steps (weights: D + 1 register sets, gathered rows: D + 1 LDS stages).  KNOCK: TIMING DIAGNOSTICS
 // (results garbage): bit 1 = no gathers, bit 2 = no weight loads.
-template <int CIN, int D, int KNOCK>
-__global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
+template <int CIN, int NW, int D, int KNOCK>
+__global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     const int32_t* __restrict__ group_masks, const int2* __restrict__ units, const int32_t* __restrict__ num_units) {
-  using S = ConvCuSmem<D>;
+  using S = ConvCuSmem<D, NW>;
   constexpr int NCH = CIN / 32, CH8 = CIN / 8, NS = D + 1;
+  constexpr int NTW = 16 / NW;          // 16-column tiles per wave
+  constexpr int NF = 2 * NTW;           // weight fragments per wave and step: [column tile][hi, lo]
+  constexpr int GQ = kCuCapGroups / NW; // row groups whose rows a wave gathers: wave + NW q
   constexpr bool NOGATHER = (KNOCK & 1) != 0, NOWEIGHT = (KNOCK & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ring = reinterpret_cast<uint4*>(smem);
@@ -107,18 +123,19 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
 
   // ---- prologue: neighbour table of the unit -> LDS; per-tap group masks
   {
-    constexpr int NB_IT = (kMaxTaps * kCuRows) / (64 * kCuWaves);   // 13.5 -> 14
-    int tmp[NB_IT + 1];
+    constexpr int NTHR = 64 * NW;
+    constexpr int NB_IT = (kMaxTaps * kCuRows + NTHR - 1) / NTHR;
+    int tmp[NB_IT];
 #pragma unroll
-    for (int it = 0; it <= NB_IT; ++it) {
-      const int i = tid + it * 64 * kCuWaves;
+    for (int it = 0; it < NB_IT; ++it) {
+      const int i = tid + it * NTHR;
       const int k = i >> 8, r = i & 255;
       tmp[it] = -1;
       if (k < K && row0 + r < row_end) tmp[it] = nbr[(size_t)k * nbr_stride + row0 + r];
     }
 #pragma unroll
-    for (int it = 0; it <= NB_IT; ++it) {
-      const int i = tid + it * 64 * kCuWaves;
+    for (int it = 0; it < NB_IT; ++it) {
+      const int i = tid + it * NTHR;
       if (i < kMaxTaps * kCuRows) nbr_l[i] = tmp[it];
     }
   }
@@ -130,19 +147,21 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
   }
   for (int j = 0; j < n_rg; ++j) unit_mask |= (unsigned)group_masks[g0 + j];
   unit_mask = __builtin_amdgcn_readfirstlane(unit_mask);
-  // the groups whose rows this wave gathers: wave, wave + 8
-  const unsigned dm0 = wave < n_rg ? (unsigned)__builtin_amdgcn_readfirstlane(group_masks[g0 + wave]) : 0u;
-  const unsigned dm1 = wave + 8 < n_rg ? (unsigned)__builtin_amdgcn_readfirstlane(group_masks[g0 + wave + 8]) : 0u;
+  unsigned dm[GQ];            // tap masks of the groups whose rows this wave gathers
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) {
+    const int j = wave + NW * q;
+    dm[q] = j < n_rg ? (unsigned)__builtin_amdgcn_readfirstlane(group_masks[g0 + j]) : 0u;
+  }
   __syncthreads();
   const int ntaps = __popc(unit_mask);
   const int nsteps = ntaps * NCH;
 
-  f32x4 acc[kCuCapGroups][2];
+  f32x4 acc[kCuCapGroups][NTW];
 #pragma unroll
-  for (int j = 0; j < kCuCapGroups; ++j) {
-    acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int j = 0; j < kCuCapGroups; ++j)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto advance = [&](CuCursor& c) {     // chunk outer, taps (set bits of unit_mask, increasing) inner
     if (c.rem == 0) {
@@ -161,42 +180,45 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_addr(ring));
   const uint4* zero = g_zero_line_cu;
 
-  auto read_idx = [&](int tap, int& i0, int& i1) {     // this lane's gather rows through `tap` (groups wave, wave + 8)
-    i0 = nbr_l[tap * kCuRows + wave * 16 + grow_l];
-    i1 = nbr_l[tap * kCuRows + (wave + 8) * 16 + grow_l];
+  auto read_idx = [&](int tap, int (&ix)[GQ]) {     // this lane's gather rows through `tap` (groups wave + NW q)
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) ix[q] = nbr_l[tap * kCuRows + (wave + NW * q) * 16 + grow_l];
   };
   auto dma_count = [&](int tap) -> int {
-    return NOGATHER ? 0 : 2 * (int)((dm0 >> tap) & 1u) + 2 * (int)((dm1 >> tap) & 1u);
+    int n = 0;
+    if (!NOGATHER) {
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) n += 2 * (int)((dm[q] >> tap) & 1u);
+    }
+    return n;
   };
-  auto issue_A = [&](int tap, int ch, int stage, int i0, int i1) {
+  auto issue_A = [&](int tap, int ch, int stage, const int (&ix)[GQ]) {
     if (NOGATHER) return;
     const unsigned base = ring_addr + (unsigned)stage * (unsigned)S::stage_bytes;
-    if ((dm0 >> tap) & 1u) {
-      const uint4* src = i0 >= 0 ? xs + ((size_t)i0 * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
-      glds16(src, base + (unsigned)wave * 2048u);
-      glds16(src + 4, base + (unsigned)wave * 2048u + 1024u);
-    }
-    if ((dm1 >> tap) & 1u) {
-      const uint4* src = i1 >= 0 ? xs + ((size_t)i1 * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
-      glds16(src, base + (unsigned)(wave + 8) * 2048u);
-      glds16(src + 4, base + (unsigned)(wave + 8) * 2048u + 1024u);
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) {
+      if ((dm[q] >> tap) & 1u) {
+        const uint4* src = ix[q] >= 0 ? xs + ((size_t)ix[q] * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
+        glds16(src, base + (unsigned)(wave + NW * q) * 2048u);
+        glds16(src + 4, base + (unsigned)(wave + NW * q) * 2048u + 1024u);
+      }
     }
   };
   // Weight fragments of this wave, [column tile][hi, lo] -> [2 nt + h], in D + 1 register sets used in rotation: step t
   // multiplies with set t % (D + 1) while the loads of steps t + 1 .. t + D land in the others.  (One "next" set renamed
   // to a "current" set per step does not work with loads the compiler cannot see: it places the renaming copies in front
   // of the counted wait and copies registers whose data has not landed.)
-  i32x4 bs[NS][4];
+  i32x4 bs[NS][NF];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) bs[k][0] = bs[k][1] = bs[k][2] = bs[k][3] = i32x4{0, 0, 0, 0};
-  auto load_B = [&](int tap, int ch, i32x4 (&bn)[4]) -> int {
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) bs[k][f] = i32x4{0, 0, 0, 0};
+  auto load_B = [&](int tap, int ch, i32x4 (&bn)[NF]) -> int {
     if (NOWEIGHT) return 0;
-    const uint4* src = wpk + (((size_t)tap * NCH + ch) * (kCuCout / 16) + 2 * wave) * 128 + lane;
-    gload16(bn[0], src);
-    gload16(bn[1], src + 64);
-    gload16(bn[2], src + 128);
-    gload16(bn[3], src + 192);
-    return 4;
+    const uint4* src = wpk + (((size_t)tap * NCH + ch) * (kCuCout / 16) + NTW * wave) * 128 + lane;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) gload16(bn[f], src + 64 * f);
+    return NF;
   };
 
   // ---- the pipeline.  Group G(s) = {weights of step s + D, gathers of step s + D}, issued in that order at step s (the
@@ -205,27 +227,29 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
   CuCursor cg{0u, -1, -1};     // the step whose group is issued next
   CuCursor ci{0u, -1, -1};     // the step whose gather indices are read next (one ahead of cg)
   CuCursor cm{0u, -1, -1};     // the step whose group mask is read next (one ahead of the multiply)
-  int idx0 = -1, idx1 = -1;
+  int idx[GQ];
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) idx[q] = -1;
   unsigned m_cur = 0;
   int inq[D > 1 ? D - 1 : 1];   // operations of the D - 1 youngest groups, oldest first
 #pragma unroll
   for (int i = 0; i < (D > 1 ? D - 1 : 1); ++i) inq[i] = 0;
   int issued_steps = 0;         // steps whose group has been issued
-  auto issue_group = [&](i32x4 (&bn)[4], int stage) -> int {   // the group of step `issued_steps`
+  auto issue_group = [&](i32x4 (&bn)[NF], int stage) -> int {   // the group of step `issued_steps`
     advance(cg);
     int n = load_B(cg.tap, cg.ch, bn);
-    issue_A(cg.tap, cg.ch, stage, idx0, idx1);
+    issue_A(cg.tap, cg.ch, stage, idx);
     n += dma_count(cg.tap);
     ++issued_steps;
     if (issued_steps < nsteps) {          // indices of the next group's rows
       advance(ci);
-      read_idx(ci.tap, idx0, idx1);
+      read_idx(ci.tap, idx);
     }
     return n;
   };
   if (nsteps > 0) {
     advance(ci);
-    read_idx(ci.tap, idx0, idx1);
+    read_idx(ci.tap, idx);
     advance(cm);
     m_cur = (unsigned)tapm_l[cm.tap];
 #pragma unroll
@@ -236,12 +260,18 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
     }
   }
   int stage = 0;
-  // one step: bn = the set holding B(t), bo = the set B(t + D) is loaded into, s_new = the stage A(t + D) lands in
-  auto step = [&](int t, i32x4 (&bn)[4], i32x4 (&bo)[4]) {
+  // one step: bn = the set holding B(t), bo = the set B(t + D) is loaded into
+  auto step = [&](int t, i32x4 (&bn)[NF], i32x4 (&bo)[NF]) {
     int allowed = 0;
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) allowed += inq[i];
-    ISF_CU_WAIT(bn, allowed);
+    if constexpr (D == 1) {                 // nothing younger than G(t - 1) exists: drain
+      if constexpr (NF == 4) ISF_CU_WAIT4_ALL(bn);
+      else ISF_CU_WAIT8_ALL(bn);
+    } else {
+      if constexpr (NF == 4) ISF_CU_WAIT4(bn, allowed);
+      else ISF_CU_WAIT8(bn, allowed);
+    }
     __builtin_amdgcn_s_barrier();     // A(t) complete for every wave; every wave is done reading the stage of step t - 1
     asm volatile("" ::: "memory");
     const unsigned m = __builtin_amdgcn_readfirstlane(m_cur);
@@ -257,11 +287,15 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
     }
 #pragma unroll
     for (int i = 0; i + 1 < D - 1; ++i) inq[i] = inq[i + 1];
-    if (D > 1) inq[D - 2] = n;
+    if (D > 1) inq[D > 1 ? D - 2 : 0] = n;
     if (m) {
       const uint4* sa = ring + stage * (S::stage_bytes / 16) + rpos;
-      const h8 bh0 = *reinterpret_cast<const h8*>(&bn[0]), bl0 = *reinterpret_cast<const h8*>(&bn[1]);
-      const h8 bh1 = *reinterpret_cast<const h8*>(&bn[2]), bl1 = *reinterpret_cast<const h8*>(&bn[3]);
+      h8 bh[NTW], bl[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        bh[nt] = *reinterpret_cast<const h8*>(&bn[2 * nt]);
+        bl[nt] = *reinterpret_cast<const h8*>(&bn[2 * nt + 1]);
+      }
       const int jf = __ffs(m) - 1;
       uint4 ah_n = sa[jf * 128], al_n = sa[jf * 128 + 64];
 #pragma unroll
@@ -276,12 +310,14 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
           }
           const h8 ah = *reinterpret_cast<const h8*>(&ahu);
           const h8 al = *reinterpret_cast<const h8*>(&alu);
-          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[j][0], 0, 0, 0);
-          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[j][1], 0, 0, 0);
-          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[j][0], 0, 0, 0);
-          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, acc[j][1], 0, 0, 0);
-          acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[j][0], 0, 0, 0);
-          acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[j][1], 0, 0, 0);
+          // per accumulator: a_lo b_hi -> a_hi b_lo -> a_hi b_hi (the order of spconv_f16x3_kernel), the column tiles
+          // interleaved so that consecutive MFMAs are independent
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[j][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[j][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[j][nt], 0, 0, 0);
         }
       }
     }
@@ -293,14 +329,14 @@ __global__ __launch_bounds__(64 * kCuWaves, 1) void spconv_cu_kernel(
       if (t + k < nsteps) step(t + k, bs[k], bs[(k + D) % NS]);
   }
   {
-    const int none = 0;
-    ISF_CU_WAIT(bs[0], none);
+    if constexpr (NF == 4) ISF_CU_WAIT4_ALL(bs[0]);
+    else ISF_CU_WAIT8_ALL(bs[0]);
   }
   __syncthreads();   // every wave is done with the ring -> reuse as the epilogue transpose tiles
 
-  float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<2, kCuCapGroups>::wave_bytes / 4);
-  conv16_epilogue<2, kCuCapGroups, false>(acc, tile_l, lane, row0, 32 * wave, kCuCout, *w_inv_scale, scale, shift, residual,
-                                          ys, row_end, relu, n_rg);
+  float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NTW, kCuCapGroups>::wave_bytes / 4);
+  conv16_epilogue<NTW, kCuCapGroups, false>(acc, tile_l, lane, row0, 16 * NTW * wave, kCuCout, *w_inv_scale, scale, shift,
+                                            residual, ys, row_end, relu, n_rg);
 }
 
 // ------------------------------------------------------------------------------------------------------ unit plan
@@ -453,31 +489,33 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
               "sparse_conv_cu: the unit plan was built for %d rows, the launch has %d", plan.n_out, n_out);
   const uint4* w = reinterpret_cast<const uint4*>(packed16);
   const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
-  const dim3 grid(8 * ceil_div(plan.max_units, 8)), block(64 * kCuWaves);
+  const dim3 grid(8 * ceil_div(plan.max_units, 8));
   // variant (DIAGNOSTIC; 0 = production): 1 / 2 / 3 = no gathers / no weight loads / neither (results garbage, timing
-  // only); 4 = prefetch depth 1, 8 = depth 3 (results valid)
-#define ISF_CU_LAUNCH(CI, DD, KK)                                                                                       \
+  // only); 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2 (results valid)
+#define ISF_CU_LAUNCH(CI, WW, DD, KK)                                                                                   \
   do {                                                                                                                  \
-    auto kern = spconv_cu_kernel<CI, DD, KK>;                                                                           \
+    constexpr int smem_bytes = ConvCuSmem<DD, WW>::bytes;                                                               \
+    auto kern = spconv_cu_kernel<CI, WW, DD, KK>;                                                                         \
     static std::atomic<int> attr_set{0};                                                                                \
     if (attr_set.load(std::memory_order_acquire) == 0) {                                                                \
       ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                      ConvCuSmem<DD>::bytes));                                                          \
+                                      smem_bytes));                                                                     \
       attr_set.store(1, std::memory_order_release);                                                                     \
     }                                                                                                                   \
-    hipLaunchKernelGGL(kern, grid, block, ConvCuSmem<DD>::bytes, st, reinterpret_cast<const uint4*>(xs), nbr,           \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WW), smem_bytes, st, reinterpret_cast<const uint4*>(xs), nbr,           \
                        nbr_stride, w, winv, K, scale, shift, reinterpret_cast<const uint4*>(residual),                  \
                        reinterpret_cast<uint4*>(ys), n_out, relu, plan.group_masks, plan.units, plan.num_units);        \
   } while (0)
 #define ISF_CU_VARIANTS(CI)                                                                                             \
   switch (plan.variant) {                                                                                               \
-    case 0: ISF_CU_LAUNCH(CI, kCuDepth, 0); break;                                                                      \
-    case 1: ISF_CU_LAUNCH(CI, kCuDepth, 1); break;                                                                      \
-    case 2: ISF_CU_LAUNCH(CI, kCuDepth, 2); break;                                                                      \
-    case 3: ISF_CU_LAUNCH(CI, kCuDepth, 3); break;                                                                      \
-    case 4: ISF_CU_LAUNCH(CI, 1, 0); break;                                                                             \
-    case 8: ISF_CU_LAUNCH(CI, 3, 0); break;                                                                             \
-    case 12: ISF_CU_LAUNCH(CI, 2, 0); break;                                                                            \
+    case 0: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 0); break;                                                        \
+    case 1: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 1); break;                                                        \
+    case 2: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 2); break;                                                        \
+    case 3: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 3); break;                                                        \
+    case 4: ISF_CU_LAUNCH(CI, 4, 1, 0); break;                                                                          \
+    case 5: ISF_CU_LAUNCH(CI, 4, 2, 0); break;                                                                          \
+    case 6: ISF_CU_LAUNCH(CI, 8, 1, 0); break;                                                                          \
+    case 7: ISF_CU_LAUNCH(CI, 8, 2, 0); break;                                                                          \
     default: ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_cu: variant %d", plan.variant);                               \
   }
   if (c_in == 128) { ISF_CU_VARIANTS(128) } else { ISF_CU_VARIANTS(256) }

@@ -287,7 +287,8 @@ def sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale=None, s
                            variant=0):
     """sparse_conv_forward_f16x3 (mode 0) on the one-workgroup-per-CU kernel of the 256-column layers
     (isf_sparse_conv_forward_cu; c_out = 256, c_in in {128, 256}); bit-identical results.  variant: isf_conv_cu_plan
-    .variant (0 production; 4 / 12 / 8 = prefetch depth 1 / 2 / 3, valid results; 1 / 2 / 3 timing knock-outs)."""
+    .variant (0 production; 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2: valid results;
+    1 / 2 / 3 timing knock-outs)."""
     _lib.require_cuda(features)
     xs = to_split(features)
     rs = None if residual is None else to_split(residual)
@@ -304,12 +305,10 @@ def sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale=None, s
 def sparse_conv_forward_best(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None, relu=False,
                              mode=0):
     """The kernel choice of isf_sparse_encoder_forward for one layer driven from Python (all choices give the same
-    bits): the LDS-DMA gather kernel for the narrow shapes, the one-workgroup-per-CU kernel for the 256-column shapes,
-    the tile-order table for launches of one resident round."""
+    bits): the LDS-DMA gather kernel for the narrow shapes, the tile-order table for launches of one resident round
+    (the one-workgroup-per-CU kernel of the 256-column shapes is an opt-in: measured slower)."""
     if c_in <= 64 and c_out <= 64 and (mode & ~32) in (0, 1, 257):
         return sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode)
-    if sparse_conv_cu_supported(c_in, c_out) and (mode & ~32) == 0:
-        return sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu)
     order = tile_order(rb, c_in, c_out, mode) if (mode & ~32) in (0, 1, 257) else None
     return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode, order)
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: parity of the one-workgroup-per-CU conv kernel, then an interleaved same-box A/B of the headline bench
-# (default = 256-column layers on isf_sparse_conv_forward_cu; --conv-diag 512 = tile kernel).  Usage (GPU box):
+# (--conv-diag 512 = 256-column layers on isf_sparse_conv_forward_cu, + 1024 v = its variant v).  Usage (GPU box):
 #   bash tools/gpu_r4_ab.sh <tag> [pytest -k expression]
 set -u
 TAG=${1:-r04_ab}
