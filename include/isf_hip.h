@@ -50,6 +50,10 @@ const char* isf_last_error(void);      /* message of the last failure on this th
 int isf_device_count(int* count_host); /* number of visible HIP devices (0 on a CPU-only host) */
 int isf_release_workspace(void);       /* free every (device, stream) workspace */
 int isf_workspace_bytes(size_t* bytes_host); /* current arena size on the current device */
+/* DIAGNOSTIC: every device allocation behind the workspaces of the current device: stream_base_bytes [max_triples][3] =
+ * (stream handle, base address, bytes) -- per workspace its blocks, then its two persistent byte maps; *num_triples = how
+ * many exist.  tools/graph_fault.py maps a GPU memory-fault address onto them. */
+int isf_debug_workspace_blocks(unsigned long long* stream_base_bytes, int max_triples, int* num_triples);
 
 /* A1  dynamic voxelization ------------------------------------------------------------------------
  * replaces voxel_layer.dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3)

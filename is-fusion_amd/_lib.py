@@ -99,6 +99,7 @@ SIGNATURES = {
     "isf_device_count": (c_int, [c_int_p]),
     "isf_release_workspace": (c_int, []),
     "isf_workspace_bytes": (c_int, [ctypes.POINTER(ctypes.c_size_t)]),
+    "isf_debug_workspace_blocks": (c_int, [ctypes.POINTER(ctypes.c_ulonglong), c_int, c_int_p]),
     "isf_dynamic_voxelize": (c_int, [c_void_p, c_int, c_int, _F3, _F6, c_void_p, c_void_p]),
     "isf_dynamic_voxelize_batched": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), c_int, c_int, _F3,
                                              _F6, c_void_p, c_void_p]),

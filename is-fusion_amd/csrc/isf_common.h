@@ -61,6 +61,7 @@ class Arena {
   int alloc_n(T** out, size_t n) { return alloc(reinterpret_cast<void**>(out), n * sizeof(T)); }
   int release();                            // frees blocks, byte maps, side stream, events
   size_t capacity() const;
+  int list_blocks(unsigned long long* base_cap, int max_pairs, int* num_pairs) const;   // diagnostic
   // helper objects owned by the workspace
   hipStream_t side = nullptr;               // geometry / rulebook work of the sparse encoder overlaps the convolutions
   std::vector<hipEvent_t> events;           // recycled hipEventDisableTiming events

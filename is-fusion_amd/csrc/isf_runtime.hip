@@ -80,6 +80,22 @@ int Arena::release() {
   return ISF_OK;
 }
 
+int Arena::list_blocks(unsigned long long* base_cap, int max_pairs, int* num_pairs) const {
+  int n = 0;
+  for (auto& b : blocks_) {
+    if (n < max_pairs) { base_cap[2 * n] = (unsigned long long)(size_t)b.base; base_cap[2 * n + 1] = b.cap; }
+    ++n;
+  }
+  if (bytemaps.fine) {
+    if (n < max_pairs) { base_cap[2 * n] = (unsigned long long)(size_t)bytemaps.fine; base_cap[2 * n + 1] = bytemaps.words * 64; }
+    ++n;
+    if (n < max_pairs) { base_cap[2 * n] = (unsigned long long)(size_t)bytemaps.coarse; base_cap[2 * n + 1] = bytemaps.words; }
+    ++n;
+  }
+  *num_pairs = n;
+  return ISF_OK;
+}
+
 size_t Arena::capacity() const {
   size_t t = 0;
   for (auto& b : blocks_) t += b.cap;
@@ -470,6 +486,32 @@ int isf_release_workspace(void) {
   isf::g_arenas.clear();
   ISF_HIP_TRY(hipSetDevice(cur));
   return rc;
+}
+
+// DIAGNOSTIC: every device allocation behind the workspaces of the current device: (stream handle, base, bytes) triples,
+// per workspace its blocks, then its two byte maps -- tools/graph_fault.py maps a GPU fault address onto them
+int isf_debug_workspace_blocks(unsigned long long* stream_base_bytes, int max_triples, int* num_triples) {
+  if (!stream_base_bytes || !num_triples || max_triples < 0) return ISF_ERR_ARG;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  std::lock_guard<std::mutex> lock(isf::g_mu);
+  int n = 0;
+  for (auto& kv : isf::g_arenas) {
+    if (kv.first.first != cur) continue;
+    unsigned long long tmp[64];
+    int k = 0;
+    (void)kv.second->list_blocks(tmp, 32, &k);
+    for (int i = 0; i < k && i < 32; ++i) {
+      if (n < max_triples) {
+        stream_base_bytes[3 * n] = (unsigned long long)(size_t)kv.first.second;
+        stream_base_bytes[3 * n + 1] = tmp[2 * i];
+        stream_base_bytes[3 * n + 2] = tmp[2 * i + 1];
+      }
+      ++n;
+    }
+  }
+  *num_triples = n;
+  return ISF_OK;
 }
 
 int isf_workspace_bytes(size_t* bytes_host) {

@@ -142,7 +142,30 @@ class ISFusionPtsPath(nn.Module):
 
     def _forward_pts_graph(self, pts, img_feats, img_metas, **kwargs):
         """extract_pts_feat's eager head (LiDAR branch || pillar voxelization -> Point-to-Grid) writing into the input
-        buffers of the captured tail, then one graph launch"""
+        buffers of the captured tail, then one graph launch.
+
+        Never on the legacy NULL stream.  With torch's default stream (HIP's legacy NULL stream) as the launch stream,
+        pillar tensors produced on a side stream and read by the Point-to-Grid launch that precedes hipGraphLaunch ended
+        4 of 5 runs in a GPU memory fault at the fourth unsynchronised forward -- at addresses gigabytes away from every
+        allocation of the library, of torch and of the graph, not reproducible with serialised launches
+        (AMD_SERIALIZE_KERNEL=3), with a copy of the tensors in between, or -- 0 of 6 runs -- with ANY non-NULL stream as
+        the launch stream (tools/graph_fault.py, profiles/r04_graph_fault.txt).  So a caller on the
+        NULL stream is moved onto a private launch stream for the duration of the forward (both directions ordered by
+        events); callers on their own streams run where they are."""
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != 0 or self.__dict__.get("_graph_on_null_stream", False):
+            return self._forward_pts_graph_on_stream(pts, img_feats, img_metas, **kwargs)
+        dev = pts[0].device
+        ls = self.__dict__.setdefault("_launch_streams", {}).get(dev)
+        if ls is None:
+            ls = self._launch_streams[dev] = torch.cuda.Stream(device=dev)
+        ls.wait_stream(cur)          # the inputs, and the previous forward's consumers of the graph's output buffers
+        with torch.cuda.stream(ls):
+            out = self._forward_pts_graph_on_stream(pts, img_feats, img_metas, **kwargs)
+        cur.wait_stream(ls)
+        return out
+
+    def _forward_pts_graph_on_stream(self, pts, img_feats, img_metas, **kwargs):
         from . import fusion_ops as ops
         assert not self.training, "inference path (eval mode)"
         self._lidar.train(False)
@@ -153,12 +176,23 @@ class ISFusionPtsPath(nn.Module):
         if cam is None:
             cam = ops.h2d_async(ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
                                                       kwargs["lidar_aug_matrix"]), dev)
-        self._lidar(pts, out=x)
-        # the pillar voxelization stays on the launch stream here: on extract_pts_feat's side stream, back-to-back
-        # replays (no host sync for >= 5 forwards) end in a GPU memory fault that neither the eager forward nor a
-        # synchronised replay shows (tools/host_lead.py --graph, profiles/r03_host_lead.txt; not understood -- the side
-        # stream waits for the launch stream, i.e. for the previous replay, before it starts)
-        pil = self.voxelize(pts, voxel_type="pillar")
+        main = torch.cuda.current_stream()
+        if self.__dict__.get("_graph_pillar_side", True):
+            # as in extract_pts_feat: the pillar voxelization's per-sample host round trips wait for the pillar kernels
+            # only, on a side stream, while the LiDAR branch keeps the GPU busy on the launch stream
+            side = self.__dict__.setdefault("_side_streams", {}).setdefault(dev, None)
+            if side is None:
+                side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            self._lidar(pts, out=x)
+            with torch.cuda.stream(side):
+                pil = self.voxelize(pts, voxel_type="pillar")
+            main.wait_stream(side)
+            for t in pil:
+                t.record_stream(main)
+        else:
+            self._lidar(pts, out=x)
+            pil = self.voxelize(pts, voxel_type="pillar")
         ops.p2g_sample(pil[0], pil[2], img_feats[1], None, None, None, img_metas[0]["input_shape"], B,
                        self.fusion_encoder.bev_size, self.fusion_encoder.num_views, cam=cam, out=img_bev)
         g.replay()
@@ -178,7 +212,7 @@ class ISFusionPtsPath(nn.Module):
         return self.pts_neck(feats), ins_heatmap
 
     # ------------------------------------------------------------------------------------------- HIP graph
-    def enable_graph(self, flag=True):
+    def enable_graph(self, flag=True, pillar_side_stream=True, on_null_stream=False):
         """Inference deployment: `forward_pts` replays everything behind Point-to-Grid -- conv_fusion, Grid-to-Region,
         instance fusion, SECONDV2 stages, neck, head: ~330 launches whose shapes depend on the batch size only -- as ONE
         HIP graph per batch size (captured on the first call), so the host no longer paces those launches (the GPU was
@@ -187,6 +221,10 @@ class ISFusionPtsPath(nn.Module):
         (freeze()); freeze() / a load_state_dict below this module / train() drop the captured graphs together with the
         packed-weight caches their kernels point into (fusion_ops.drop_caches)."""
         self.__dict__["_graph_on"] = bool(flag)
+        # diagnostics of tools/graph_fault.py (DESIGN.md section 7): pillar_side_stream=False keeps the pillar voxelization
+        # on the launch stream; on_null_stream=True lets the forward run on the legacy NULL stream (the faulting set-up)
+        self.__dict__["_graph_pillar_side"] = bool(pillar_side_stream)
+        self.__dict__["_graph_on_null_stream"] = bool(on_null_stream)
         self.__dict__["_graphs"] = {}
         return self
 

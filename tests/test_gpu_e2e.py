@@ -185,8 +185,11 @@ def test_back_to_back_forwards_without_host_sync(dev):
     """The bench loop queues forwards without ever synchronising; the host then runs ahead of the GPU (the LiDAR branch
     of forward n + 1 is being launched while the tail of forward n executes, by a whole tail in graph mode).  Twelve
     full-size forwards (B = 2 x 300 k points, alternating frame sets) queued back to back must reproduce the
-    synchronised results bit for bit -- eager and as HIP-graph replays (regression: the replays ended in a GPU memory
-    fault when the pillar voxelization ran on a side stream)."""
+    synchronised results bit for bit -- eager and as HIP-graph replays.  Regression (tools/graph_fault.py,
+    profiles/r04_graph_fault.txt): with the legacy NULL stream as the launch stream the replays ended in a GPU memory
+    fault at the fourth unsynchronised forward when the pillar voxelization ran on a side stream; graph mode now moves a
+    caller on the NULL stream onto a private launch stream (side-stream voxelization restored), and a caller on its own
+    stream runs where it is."""
     from isfusion_amd import synthetic
     from isfusion_amd.detector import ISFusionPtsPath
     from isfusion_amd.fusion_modules import seeded_state_dict
@@ -215,10 +218,14 @@ def test_back_to_back_forwards_without_host_sync(dev):
     for i in range(2):
         want.append(run(i))
         torch.cuda.synchronize()
-    for graph in (False, True):
+    own = torch.cuda.Stream(device=dev)
+    for graph, stream in ((False, None), (True, None), (True, own)):
         net.enable_graph(graph)
-        got = [run(i) for i in range(12)]          # no host sync in between
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+            got = [run(i) for i in range(12)]          # no host sync in between
         torch.cuda.synchronize()
         for i, g in enumerate(got):
             for k in keys:
-                assert torch.equal(g[k], want[i % 2][k]), (graph, i, k)
+                assert torch.equal(g[k], want[i % 2][k]), (graph, stream is not None, i, k)
