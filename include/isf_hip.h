@@ -255,6 +255,28 @@ int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in
                                 int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
                                 const float* shift, const void* residual_split, int relu, void* out_split, int mode,
                                 const int32_t* order, isf_stream_t stream);
+/* LINE-COMPRESSED neighbour table (narrow layers).  The taps of one (kz, ky) line of a 3-wide kernel probe x-adjacent cells
+ * and rows are sorted by (b, z, y, x), so the neighbours a row has through a line are CONSECUTIVE rows: one int32 per line
+ * (the row of the first present neighbour, -1 if none) + one bit per tap say everything the dense table says --
+ *   lines [num_taps / taps_per_line][nbr_stride] int32, mask [nbr_stride] uint32 (bit k: tap k present),
+ *   nbr[k][o] = mask[o] bit k ? lines[k / tpl][o] + popcount(mask[o] bits of that line below k) : -1
+ * -- in 40 bytes per row (3 x 3 x 3) instead of 108: the dense table of a narrow layer is as many bytes per row as a
+ * 32-channel activation row, read twice per convolution (tap masks, then indices).  Only tables in rank order qualify
+ * (what isf_build_rulebook produces for sorted inputs; isf_rulebook_to_lines sets *not_consecutive_flag (device int, may be
+ * NULL) to 1 for any other table).  isf_rulebook_to_lines / isf_lines_to_rulebook convert; isf_sparse_conv_forward_dma_lines
+ * = isf_sparse_conv_forward_dma reading the compressed table (a lane keeps its rows' masks in registers and loads one
+ * index per LINE): results BIT-IDENTICAL.  isf_sparse_encoder_forward / isf_lidar_branch_forward build the tables of their
+ * narrow levels directly in this form (diagnostic +16384: dense tables).  taps_per_line = kernel width (1 or 3).
+ * Replaces nothing in the reference (its rulebook is pair lists, indice.cu.h:22-203); measured in DESIGN.md section 5.3. */
+int isf_rulebook_to_lines(const int32_t* nbr, int nbr_stride, int num_taps, int taps_per_line, int num_out,
+                          int32_t* lines, uint32_t* mask, int* not_consecutive_flag, isf_stream_t stream);
+int isf_lines_to_rulebook(const int32_t* lines, const uint32_t* mask, int nbr_stride, int num_taps, int taps_per_line,
+                          int32_t* nbr, isf_stream_t stream);
+int isf_sparse_conv_forward_dma_lines(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                                      int taps_per_line, int c_out, const int32_t* lines, const uint32_t* mask,
+                                      int nbr_stride, int num_out, const float* scale, const float* shift,
+                                      const void* residual_split, int relu, void* out_split, int mode,
+                                      isf_stream_t stream);
 /* The same convolution for the 256-COLUMN layers (c_out = 256, c_in in {128, 256}: levels 3 / 4 of the encoder) as ONE
  * WORKGROUP PER COMPUTE UNIT (isf_spconv_cu.hip).  A level-3 launch is 160 rows x 256 columns per CU: cut into 128 x 128
  * tiles it ends with its busiest CU (1.4x the mean work: the density of a LiDAR sweep varies 3x) and every tile streams
@@ -348,6 +370,7 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            fp32 rows and a conversion pass makes the split rows, instead of writing them directly; +512 = the
  *            256-column layers on isf_sparse_conv_forward_cu (one workgroup per CU; opt-in: measured slower than
  *            the tile kernel) -- results bit-identical either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
+ *            +16384 = dense neighbour tables for the narrow layers instead of the line-compressed ones -- bit-identical;
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

@@ -146,6 +146,11 @@ SIGNATURES = {
     "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                       c_void_p]),
+    "isf_rulebook_to_lines": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isf_lines_to_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_sparse_conv_forward_dma_lines": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                                  c_void_p]),
     "isf_sparse_conv_cu_plan_ints": (c_int, [c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "isf_sparse_conv_cu_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, ctypes.POINTER(ConvCuPlan), c_void_p]),
     "isf_sparse_conv_forward_cu": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,

@@ -145,6 +145,10 @@ int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int3
 int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
                const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, const int32_t* perm,
                int32_t* nbr, int nbr_stride, unsigned long long* pair_count, hipStream_t st_);
+// line-compressed table (isf_rulebook.hip): lines [ks0 * ks1][stride] + mask [stride], rank order only
+int launch_nbr_lines(Arena& a, const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
+                     const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, int32_t* lines, uint32_t* mask,
+                     int stride, unsigned long long* pair_count, hipStream_t st_);
 int launch_mark_out(const int32_t* in_coors4, int n_in, const int in_shape[3], const int ks[3],
                     const int st[3], const int pd[3], const OccIndex& out_occ, hipStream_t st_);
 // isf_spconv.hip
@@ -184,10 +188,11 @@ bool sparse_conv_dma_supported(int c_in, int c_out);
 int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
                                  int nbr_stride, int n_out, const float* scale, const float* shift,
                                  const void* residual, int relu, void* ys, int mode, hipStream_t st,
-                                 const int32_t* order = nullptr, Conv16LaunchInfo* query = nullptr);
+                                 const int32_t* order = nullptr, Conv16LaunchInfo* query = nullptr,
+                                 const uint32_t* lmask = nullptr /* line-compressed table: nbr = lines */, int nx = 0);
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
-                           hipStream_t st);
+                           hipStream_t st, const uint32_t* lmask = nullptr /* line-compressed table's masks instead of nbr */);
 // isf_spconv_cu.hip: the same convolution for the 256-column layers as one workgroup per compute unit over units of equal
 // matrix work (plan built once per rulebook); bit-identical to sparse_conv_forward_f16x3_impl
 struct ConvCuPlan {

@@ -156,6 +156,7 @@ struct LevelState {
   StageTables cache_stage;   // staging tables of cache_nbr (slots == nullptr: not built)
   const int32_t* cache_order;   // tile order of cache_nbr for a (cache_order_cin -> cache_order_cout) launch, or nullptr
   int cache_order_cin, cache_order_cout;
+  const uint32_t* cache_lmask;  // non-null: cache_nbr is LINE-COMPRESSED (lines [ks0 * ks1][stride]) with these tap masks
   ConvCuPlan cache_cu;          // unit plan of cache_nbr for the one-workgroup-per-CU kernel (n_out == 0: not built)
 };
 
@@ -169,7 +170,7 @@ static int build_cu_plan(Arena& a, const int32_t* nbr, int stride, int K, int n_
 // tile order of one conv launch over a neighbour table (conv16_tile_order_impl), built behind the table on the
 // geometry stream; *order stays nullptr when the launch is not a single resident round
 static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int32_t* nbr, int stride, int n_out,
-                            int mode, bool dma, const int32_t** order, hipStream_t sg) {
+                            int mode, bool dma, const int32_t** order, hipStream_t sg, const uint32_t* lmask = nullptr) {
   *order = nullptr;
   Conv16LaunchInfo info;
   if (dma)
@@ -183,7 +184,7 @@ static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int
   int32_t *work = nullptr, *ord = nullptr;
   ISF_TRY(a.alloc_n(&work, n));
   ISF_TRY(a.alloc_n(&ord, n));
-  ISF_TRY(conv16_tile_order_impl(nbr, stride, K, n_out, info, work, ord, sg));
+  ISF_TRY(conv16_tile_order_impl(nbr, stride, K, n_out, info, work, ord, sg, lmask));
   *order = ord;
   return ISF_OK;
 }
@@ -220,16 +221,17 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10));   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
+  const bool line_tables = (diagnostic & 256 * 64) == 0;   // bit 16384: full neighbour tables for the narrow layers too
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10)));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -253,6 +255,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.cache_order = nullptr;
   L.cache_order_cin = L.cache_order_cout = 0;
   L.cache_cu = ConvCuPlan();
+  L.cache_lmask = nullptr;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
   bool use16 = precision != 1;
   for (int i = 0; i < num_layers; ++i)
@@ -304,15 +307,42 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     const bool want_order = use16 && tile_order && srows == 0 && !cu;
     // narrow layers: LDS-DMA gathers (isf_spconv_dma.hip); the timing diagnostics and mode 16 exist on the gather kernel
     const bool dma = use16 && dma_gather && srows == 0 && dg == 0 && sparse_conv_dma_supported(ly.c_in, ly.c_out);
+    const uint32_t* lmask = nullptr;   // non-null: `nbr` is the line-compressed table of this layer
+    const int nx = ly.ksize[2];
+    // a rulebook may be line-compressed when every layer that reads it runs the LDS-DMA kernel: for a SubM table, all the
+    // SubM layers of this level with the same kernel (up to the next strided conv); for a strided conv, itself
+    auto lines_ok = [&](int first) -> bool {
+      if (!use16 || !dma_gather || !line_tables || dg != 0 || stage_opt > 0 || (nx != 1 && nx != 3) ||
+          ly.ksize[0] * ly.ksize[1] > 9)
+        return false;
+      for (int j = first; j < num_layers; ++j) {
+        const isf_conv_layer& q = layers[j];
+        if (q.conv_type != ISF_CONV_SUBM) break;
+        if (q.ksize[0] != ly.ksize[0] || q.ksize[1] != ly.ksize[1] || q.ksize[2] != ly.ksize[2]) continue;
+        if (!sparse_conv_dma_supported(q.c_in, q.c_out)) return false;
+      }
+      return true;
+    };
     if (ly.conv_type == ISF_CONV_SUBM) {
       const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
                        L.cache_ks[2] == ly.ksize[2];
       if (!hit) {
         ISF_TRY(ensure_occ(a, L, B, sg));
         stride = isf_nbr_stride(L.n);
-        ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
-        ISF_TRY(launch_nbr(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
-                           stride, pair_counts + i, sg));
+        L.cache_lmask = nullptr;
+        if (sparse_conv_dma_supported(ly.c_in, ly.c_out) && lines_ok(i)) {
+          const int nl = ly.ksize[0] * ly.ksize[1];
+          uint32_t* lm = nullptr;
+          ISF_TRY(a.alloc_n(&nbr, (size_t)nl * stride));
+          ISF_TRY(a.alloc_n(&lm, (size_t)stride));
+          ISF_TRY(launch_nbr_lines(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nbr, lm, stride,
+                                   pair_counts + i, sg));
+          L.cache_lmask = lm;
+        } else {
+          ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
+          ISF_TRY(launch_nbr(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
+                             stride, pair_counts + i, sg));
+        }
         L.cache_nbr = nbr;
         L.cache_stride = stride;
         for (int j = 0; j < 3; ++j) L.cache_ks[j] = ly.ksize[j];
@@ -323,7 +353,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_order_cin = L.cache_order_cout = 0;
         L.cache_cu = ConvCuPlan();
         if (want_order) {
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg));
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
         }
@@ -337,7 +367,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg));
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
           ISF_TRY(stream_wait_stream(a, st, sg));
@@ -348,6 +378,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         }
       }
       cu_plan = L.cache_cu;
+      lmask = L.cache_lmask;
+      ISF_REQUIRE(!lmask || dma, ISF_ERR_UNSUPPORTED, "sparse_encoder: layer %d cannot read a line-compressed table", i);
       stg = L.cache_stage;
       if (want_order) order = L.cache_order;
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
@@ -367,14 +399,24 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       if (Nx.n > 0) ISF_TRY(occ_compact_coords4(Nx.occ, nc, sg));
       Nx.coors = nc;
       stride = isf_nbr_stride(Nx.n);
-      ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
-      ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
-                         stride, pair_counts + i, sg));
+      if (dma && lines_ok(num_layers)) {     // a strided conv's table has one reader
+        uint32_t* lm = nullptr;
+        ISF_TRY(a.alloc_n(&nbr, (size_t)ly.ksize[0] * ly.ksize[1] * stride));
+        ISF_TRY(a.alloc_n(&lm, (size_t)stride));
+        ISF_TRY(launch_nbr_lines(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nbr, lm, stride,
+                                 pair_counts + i, sg));
+        lmask = lm;
+      } else {
+        ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
+        ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
+                           stride, pair_counts + i, sg));
+      }
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
-      if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg));
+      if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask));
       if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_cu = ConvCuPlan();
+      Nx.cache_lmask = nullptr;
       Nx.cache_nbr = nullptr;
       Nx.cache_order = nullptr;
       Nx.cache_order_cin = Nx.cache_order_cout = 0;
@@ -401,7 +443,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                           ly.relu, y, cu_plan, st));
     else if (dma)
       ISF_TRY(sparse_conv_forward_dma_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
-                                           res, ly.relu, y, conv_mode, st, order));
+                                           res, ly.relu, y, conv_mode, st, order, nullptr, lmask, nx));
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y, conv_mode, st, order));

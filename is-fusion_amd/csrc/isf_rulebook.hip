@@ -145,6 +145,110 @@ __global__ __launch_bounds__(256) void rb_mark_out_kernel(const int32_t* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LINE-COMPRESSED neighbour table.  The ks[2] taps of a (kz, ky) line probe x-adjacent cells, and rows are sorted by
+// (b, z, y, x): the neighbours a row has through the taps of one line are CONSECUTIVE rows.  So a row needs one int32
+// per line -- the row of its first present neighbour -- and one bit per tap: lines [ks0 * ks1][stride] + mask [stride]
+// = 40 bytes per row for a 3 x 3 x 3 kernel instead of 108, and nbr[k][o] = mask bit k ? lines[k / nx][o] +
+// popcount(mask bits of the line below k) : -1.  The narrow layers (levels 0 / 1, isf_spconv_dma.hip) read their table
+// in this form: their table bytes were as many as a 32-channel row's.  One thread per output row (the nine lines share
+// the coordinate load).  Only for tables in rank order (no permutation).
+__global__ __launch_bounds__(256) void rb_lines_kernel(const int32_t* __restrict__ out_coors4, int n_out, RbGeom g,
+                                                       const unsigned long long* __restrict__ in_bits,
+                                                       const uint32_t* __restrict__ in_prefix,
+                                                       int32_t* __restrict__ lines, uint32_t* __restrict__ mask,
+                                                       int stride, uint32_t* __restrict__ block_pairs) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nl = g.ks[0] * g.ks[1], nx = g.ks[2];
+  unsigned m = 0;
+  int4 c = make_int4(-1, 0, 0, 0);
+  if (o < n_out) c = reinterpret_cast<const int4*>(out_coors4)[o];
+  const bool live = o < n_out && c.x >= 0 && c.x < g.batch;
+  const int ix0 = c.w * g.st[2] - g.pd[2];
+#pragma unroll
+  for (int line = 0; line < 9; ++line) {
+    if (line >= nl) continue;
+    const int ky = line % g.ks[1], kz = line / g.ks[1];
+    const int iz = c.y * g.st[0] - g.pd[0] + kz;
+    const int iy = c.z * g.st[1] - g.pd[1] + ky;
+    int first = -1;
+    if (live && iz >= 0 && iz < g.in_shape[0] && iy >= 0 && iy < g.in_shape[1]) {
+      const long long base = (((long long)c.x * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2];
+      long long wcur = -1;
+      unsigned long long word = 0;
+      uint32_t pre = 0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ix0 + kx;
+        if (kx < nx && ix >= 0 && ix < g.in_shape[2]) {
+          const long long cell = base + ix;
+          if ((cell >> 6) != wcur) {
+            wcur = cell >> 6;
+            word = in_bits[wcur];
+            pre = in_prefix[wcur];
+          }
+          const unsigned long long bit = 1ull << (cell & 63);
+          if (word & bit) {
+            if (first < 0) first = (int)(pre + (uint32_t)__popcll(word & (bit - 1)));
+            m |= 1u << (line * nx + kx);
+          }
+        }
+      }
+    }
+    if (o < stride) lines[(size_t)line * stride + o] = first;
+  }
+  if (o < stride) mask[o] = m;
+  if (block_pairs) {
+    __shared__ int wsum[4];
+    int found = __popc(m);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = found;
+    __syncthreads();
+    if (threadIdx.x == 0) block_pairs[blockIdx.x] = (uint32_t)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  }
+}
+
+// full table -> line-compressed (rows >= n_out: no neighbours).  flag (optional): set to 1 when a line's neighbours are
+// NOT consecutive rows (a permuted or hand-made table): the compressed form cannot express it.
+__global__ __launch_bounds__(256) void rb_to_lines_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K, int nx,
+                                                          int n_out, int32_t* __restrict__ lines,
+                                                          uint32_t* __restrict__ mask, int* __restrict__ flag) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nbr_stride) return;
+  unsigned m = 0;
+  const int nl = K / nx;
+  for (int line = 0; line < nl; ++line) {
+    int first = -1, cnt = 0;
+    for (int kx = 0; kx < nx; ++kx) {
+      const int k = line * nx + kx;
+      const int v = o < n_out ? nbr[(size_t)k * nbr_stride + o] : -1;
+      if (v >= 0) {
+        if (first < 0) first = v;
+        else if (v != first + cnt && flag) *flag = 1;
+        ++cnt;
+        m |= 1u << k;
+      }
+    }
+    lines[(size_t)line * nbr_stride + o] = first;
+  }
+  mask[o] = m;
+}
+
+__global__ __launch_bounds__(256) void rb_from_lines_kernel(const int32_t* __restrict__ lines,
+                                                            const uint32_t* __restrict__ mask, int nbr_stride, int K,
+                                                            int nx, int32_t* __restrict__ nbr) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nbr_stride) return;
+  const unsigned m = mask[o];
+  for (int k = 0; k < K; ++k) {
+    const int line = k / nx, first = line * nx;
+    const unsigned below = m & ((1u << k) - 1u) & ~((1u << first) - 1u);
+    nbr[(size_t)k * nbr_stride + o] = ((m >> k) & 1u) ? lines[(size_t)line * nbr_stride + o] + __popc(below) : -1;
+  }
+}
+
 static RbGeom make_rb_geom(const int in_shape[3], const int ks[3], const int st[3], const int pd[3],
                            bool subm, int batch) {
   RbGeom g;
@@ -171,6 +275,22 @@ int launch_nbr(Arena& a, const int32_t* out_coors4, int n_out, const int in_shap
                      in_occ.prefix, perm, nbr, nbr_stride, block_pairs);
   if (pair_count)
     hipLaunchKernelGGL(rb_sum_pairs_kernel, dim3(1), dim3(1024), 0, st_, block_pairs, lines * nbx, pair_count);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int launch_nbr_lines(Arena& a, const int32_t* out_coors4, int n_out, const int in_shape[3], const int ks[3],
+                     const int st[3], const int pd[3], bool subm, const OccIndex& in_occ, int32_t* lines, uint32_t* mask,
+                     int stride, unsigned long long* pair_count, hipStream_t st_) {
+  const RbGeom g = make_rb_geom(in_shape, ks, st, pd, subm, in_occ.B);
+  const int nbx = ceil_div(stride, 256);
+  ISF_REQUIRE(ks[2] >= 1 && ks[2] <= 3 && ks[0] * ks[1] <= 9 && ks[0] * ks[1] * ks[2] <= 27, ISF_ERR_UNSUPPORTED,
+              "rulebook lines: kernel %d x %d x %d", ks[0], ks[1], ks[2]);
+  uint32_t* block_pairs = nullptr;
+  if (pair_count) ISF_TRY(a.alloc_n(&block_pairs, (size_t)nbx));
+  hipLaunchKernelGGL(rb_lines_kernel, dim3(nbx), dim3(256), 0, st_, out_coors4, n_out, g, in_occ.bits, in_occ.prefix, lines,
+                     mask, stride, block_pairs);
+  if (pair_count) hipLaunchKernelGGL(rb_sum_pairs_kernel, dim3(1), dim3(1024), 0, st_, block_pairs, nbx, pair_count);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -344,6 +464,29 @@ int isf_indice_pairs_to_rulebook(const int32_t* indice_pairs, const int32_t* ind
   if (num_in == 0) return ISF_OK;
   hipLaunchKernelGGL(isf::rb_from_pairs_kernel, dim3(isf::ceil_div((long long)num_taps * num_in, 256)),
                      dim3(256), 0, st, indice_pairs, indice_num, num_taps, num_in, num_out, nbr, nbr_stride);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_rulebook_to_lines(const int32_t* nbr, int nbr_stride, int num_taps, int taps_per_line, int num_out,
+                          int32_t* lines, uint32_t* mask, int* not_consecutive_flag, isf_stream_t stream) {
+  ISF_REQUIRE(nbr && lines && mask && nbr_stride > 0 && num_out >= 0 && num_out <= nbr_stride && num_taps >= 1 &&
+                  num_taps <= 27 && (taps_per_line == 1 || taps_per_line == 3) && num_taps % taps_per_line == 0 &&
+                  num_taps / taps_per_line <= 9,
+              ISF_ERR_ARG, "rulebook_to_lines: bad arguments");
+  hipLaunchKernelGGL(isf::rb_to_lines_kernel, dim3(isf::ceil_div(nbr_stride, 256)), dim3(256), 0, isf::as_stream(stream),
+                     nbr, nbr_stride, num_taps, taps_per_line, num_out, lines, mask, not_consecutive_flag);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+int isf_lines_to_rulebook(const int32_t* lines, const uint32_t* mask, int nbr_stride, int num_taps, int taps_per_line,
+                          int32_t* nbr, isf_stream_t stream) {
+  ISF_REQUIRE(nbr && lines && mask && nbr_stride > 0 && num_taps >= 1 && num_taps <= 27 &&
+                  (taps_per_line == 1 || taps_per_line == 3) && num_taps % taps_per_line == 0,
+              ISF_ERR_ARG, "lines_to_rulebook: bad arguments");
+  hipLaunchKernelGGL(isf::rb_from_lines_kernel, dim3(isf::ceil_div(nbr_stride, 256)), dim3(256), 0, isf::as_stream(stream),
+                     lines, mask, nbr_stride, num_taps, taps_per_line, nbr);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

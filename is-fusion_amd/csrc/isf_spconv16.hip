@@ -583,6 +583,32 @@ __global__ __launch_bounds__(256) void conv16_tile_work_kernel(const int32_t* __
   if (threadIdx.x == 0) work[blockIdx.x] = total;
 }
 
+// the same count from a line-compressed table's tap masks (isf_rulebook.hip): a group's taps = the OR of its rows' masks
+__global__ __launch_bounds__(256) void conv16_tile_work_mask_kernel(const uint32_t* __restrict__ lmask, int n_out,
+                                                                    Conv16Plan plan, int TM, int32_t* __restrict__ work) {
+  const int tiles = plan.full + plan.half;
+  const int part = blockIdx.x / tiles, t = blockIdx.x - part * tiles;
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  int row0 = 0, row_end = 0;
+  bool half = false;
+  if (conv16_tile_rows(plan, TM, n_out, part, t, row0, row_end, half)) {
+    const int rows = half ? TM / 2 : TM;
+    int mine = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) {      // 16 consecutive lanes = one 16-row group
+      const int row = row0 + r;
+      unsigned m = row < row_end ? lmask[row] : 0u;
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) m |= (unsigned)__shfl_xor((int)m, d, 64);
+      if ((threadIdx.x & 15) == 0) mine += __popc(m);
+    }
+    if (mine) atomicAdd(&total, mine);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) work[blockIdx.x] = total;
+}
+
 // one wave per part: longest tile first, to the CU with the least work among those with a free slot
 __global__ __launch_bounds__(64) void conv16_tile_order_kernel(const int32_t* __restrict__ work, int tiles, int cus,
                                                                int32_t* __restrict__ order) {
@@ -628,13 +654,16 @@ __global__ __launch_bounds__(64) void conv16_tile_order_kernel(const int32_t* __
 }
 
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
-                           int32_t* work, int32_t* order, hipStream_t st) {
+                           int32_t* work, int32_t* order, hipStream_t st, const uint32_t* lmask) {
   ISF_REQUIRE(conv16_order_applies(info), ISF_ERR_ARG, "tile order: launch of %d + %d tiles per part on %d x %d slots",
               info.full, info.half, info.wgs_per_cu, info.cus_per_xcd);
   const int parts = conv16_order_parts(info), tiles = conv16_order_tiles(info);
   const Conv16Plan plan{info.full, info.half, info.part_rows};
-  hipLaunchKernelGGL(conv16_tile_work_kernel, dim3(parts * tiles), dim3(256), 0, st, nbr, nbr_stride, K, n_out, plan,
-                     info.TM, work);
+  if (lmask)
+    hipLaunchKernelGGL(conv16_tile_work_mask_kernel, dim3(parts * tiles), dim3(256), 0, st, lmask, n_out, plan, info.TM, work);
+  else
+    hipLaunchKernelGGL(conv16_tile_work_kernel, dim3(parts * tiles), dim3(256), 0, st, nbr, nbr_stride, K, n_out, plan,
+                       info.TM, work);
   hipLaunchKernelGGL(conv16_tile_order_kernel, dim3(parts), dim3(64), 0, st, work, tiles, info.cus_per_xcd, order);
   ISF_LAUNCH_CHECK();
   return ISF_OK;

@@ -46,9 +46,14 @@ struct ConvDmaSmem {
 };
 
 // MODE: bit 1 = single-pass f16 (hi halves only), bit 256 (with 1) = f16 storage -- as in spconv_f16x3_kernel
-template <int CIN, int NT, int NW, int MODE, int RG = 2>
+// LINES: the neighbour table comes LINE-COMPRESSED (isf_rulebook.hip): `nbr` = lines [K / nx][nbr_stride] (row of the
+// first present neighbour of a (kz, ky) line), `lmask` [nbr_stride] (bit k: tap k present); a lane keeps its rows' masks
+// in registers and loads one int32 per LINE (one line ahead) instead of one per tap; the prologue reads one word per row
+// instead of 27.  Same indices, same products: bit-identical.
+template <int CIN, int NT, int NW, int MODE, int RG = 2, bool LINES = false>
 __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
-    const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
+    const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, const uint32_t* __restrict__ lmask, int nx,
+    int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, int cout, const float* __restrict__ scale,
     const float* __restrict__ shift, const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     Conv16Plan plan, const int32_t* __restrict__ order) {
@@ -76,7 +81,16 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   unsigned rgm[RG];
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) rgm[rg] = 0u;
-  {
+  if constexpr (LINES) {
+    const int row = row0w + lane;
+    const unsigned mrow = (lane < wrows && row < row_end) ? lmask[row] : 0u;
+#pragma unroll
+    for (int k = 0; k < kMaxTaps; ++k) {
+      const unsigned long long m = __ballot((mrow >> k) & 1u);
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) rgm[rg] |= (((m >> (16 * rg)) & 0xffffull) ? 1u : 0u) << k;
+    }
+  } else {
     int tmp[kMaxTaps];
     const int row = row0w + lane;
     const bool live = lane < wrows && row < row_end;
@@ -133,6 +147,36 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       if (((rgm[rg] >> tap) & 1u) && row < row_end) idx[rg] = nbr[(size_t)tap * nbr_stride + row];
     }
   };
+  // LINES: this lane's gather rows' tap masks, the first-neighbour row of the current / the next needed line
+  unsigned mg[RG];
+  int base_cur[RG], base_nxt[RG];
+  int line_cur = -1;
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) {
+    mg[rg] = 0u;
+    base_cur[rg] = base_nxt[rg] = -1;
+    if constexpr (LINES) {
+      const int row = row0w + rg * 16 + grow_l;
+      if (rgm[rg] && row < row_end) mg[rg] = lmask[row];
+    }
+  }
+  auto line_of = [&](int tap) -> int { return nx == 3 ? (tap * 43) >> 7 : tap; };   // tap / 3 for tap < 27
+  auto load_line = [&](int line, int (&base)[RG]) {
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) {
+      const int row = row0w + rg * 16 + grow_l;
+      const unsigned lbits = ((nx == 3 ? 7u : 1u) << (line * nx));
+      base[rg] = -1;
+      if ((mg[rg] & lbits) && row < row_end) base[rg] = nbr[(size_t)line * nbr_stride + row];
+    }
+  };
+  auto line_idx = [&](int tap, int (&idx)[RG]) {     // indices through `tap` from base_cur (its line) and the masks
+    const unsigned first = (unsigned)(line_of(tap) * nx);
+    const unsigned below = ((1u << tap) - 1u) & ~((1u << first) - 1u);
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+      idx[rg] = ((mg[rg] >> tap) & 1u) ? base_cur[rg] + __popc(mg[rg] & below) : -1;
+  };
   auto issue_A = [&](int tap, int ch, const int (&idx)[RG]) {
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
@@ -167,13 +211,26 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       ch = 0;
       tap = __ffs(rem) - 1;
       rem &= rem - 1;
+      if constexpr (LINES) {
+        const int line = line_of(tap);
+        if (line != line_cur) {              // a new line: its bases were requested one line ago
+          line_cur = line;
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) idx_cur[rg] = idx_nxt[rg];
-      if (rem) load_idx(__ffs(rem) - 1, idx_nxt);
+          for (int rg = 0; rg < RG; ++rg) base_cur[rg] = base_nxt[rg];
+          const unsigned later = (line + 1) * nx < 32 ? rem & ~((1u << ((line + 1) * nx)) - 1u) : 0u;
+          if (later) load_line(line_of(__ffs(later) - 1), base_nxt);
+        }
+        line_idx(tap, idx_cur);
+      } else {
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) idx_cur[rg] = idx_nxt[rg];
+        if (rem) load_idx(__ffs(rem) - 1, idx_nxt);
+      }
     }
   };
   if (nsteps > 0) {
-    load_idx(__ffs(rem) - 1, idx_nxt);
+    if constexpr (LINES) load_line(line_of(__ffs(rem) - 1), base_nxt);
+    else load_idx(__ffs(rem) - 1, idx_nxt);
     advance();
     issue_A(tap, ch, idx_cur);
     stage_B(tap, ch, 0);
@@ -244,13 +301,13 @@ bool sparse_conv_dma_supported(int c_in, int c_out) {
 // 4 waves x 32 rows per workgroup.  Measured slower (profiles/r03_dma_gather.txt): 8 waves (one weight stage per 256 rows,
 // 3 workgroups per CU) 64 -> 64 0.740 -> 0.768 ms per step; 4 waves x 64 rows (RG = 4: twice the MFMAs per step and
 // barrier, 3 workgroups per CU) 0.770 -> 0.865 -- the resident workgroups are what hides the loads' round trip.
-template <int CIN, int NT, int MODE, int NW = 4, int RG = 2>
+template <int CIN, int NT, int MODE, bool LINES, int NW = 4, int RG = 2>
 static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
-                      const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
-                      const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
-                      Conv16LaunchInfo* query) {
+                      const int32_t* nbr, const uint32_t* lmask, int nx, int nbr_stride, int n_out, const float* scale,
+                      const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
+                      const int32_t* order, Conv16LaunchInfo* query) {
   using S = ConvDmaSmem<NT, NW, RG>;
-  auto kern = spconv_dma_kernel<CIN, NT, NW, MODE, RG>;
+  auto kern = spconv_dma_kernel<CIN, NT, NW, MODE, RG, LINES>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};
   if (wgs_per_cu.load(std::memory_order_acquire) == 0) {
     if (S::bytes > 48 * 1024)
@@ -271,23 +328,31 @@ static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const flo
                               cus_per_xcd.load(std::memory_order_relaxed)};
     return ISF_OK;
   }
-  hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K,
-                     cout, scale, shift, residual, ys, n_out, relu, plan, order);
+  hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, lmask, nx, nbr_stride, wpk,
+                     winv, K, cout, scale, shift, residual, ys, n_out, relu, plan, order);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
 
 template <int CIN, int NT>
 static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
-                        const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
-                        const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
-                        Conv16LaunchInfo* query) {
+                        const int32_t* nbr, const uint32_t* lmask, int nx, int nbr_stride, int n_out, const float* scale,
+                        const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
+                        const int32_t* order, Conv16LaunchInfo* query) {
   const bool balance = (mode & 32) == 0;
-#define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
-  switch (mode & ~32) {
-    case 0: return launch_dma<CIN, NT, 0>(ISF_ARGS_DMA);
-    case 1: return launch_dma<CIN, NT, 1>(ISF_ARGS_DMA);
-    case 257: return launch_dma<CIN, NT, 257>(ISF_ARGS_DMA);
+#define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, lmask, nx, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
+  if (lmask) {
+    switch (mode & ~32) {
+      case 0: return launch_dma<CIN, NT, 0, true>(ISF_ARGS_DMA);
+      case 1: return launch_dma<CIN, NT, 1, true>(ISF_ARGS_DMA);
+      case 257: return launch_dma<CIN, NT, 257, true>(ISF_ARGS_DMA);
+    }
+  } else {
+    switch (mode & ~32) {
+      case 0: return launch_dma<CIN, NT, 0, false>(ISF_ARGS_DMA);
+      case 1: return launch_dma<CIN, NT, 1, false>(ISF_ARGS_DMA);
+      case 257: return launch_dma<CIN, NT, 257, false>(ISF_ARGS_DMA);
+    }
   }
 #undef ISF_ARGS_DMA
   ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_dma: mode %d (0, 1, 257, +32)", mode);
@@ -296,7 +361,7 @@ static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float
 int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
                                  int nbr_stride, int n_out, const float* scale, const float* shift,
                                  const void* residual, int relu, void* ys, int mode, hipStream_t st,
-                                 const int32_t* order, Conv16LaunchInfo* query) {
+                                 const int32_t* order, Conv16LaunchInfo* query, const uint32_t* lmask, int nx) {
   if (n_out <= 0) {
     if (query) *query = Conv16LaunchInfo{0, 0, 0, 0, 0, 0, 0};
     return ISF_OK;
@@ -305,12 +370,13 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
   ISF_REQUIRE(sparse_conv_dma_supported(c_in, c_out), ISF_ERR_UNSUPPORTED, "sparse_conv_dma: (Cin,Cout)=(%d,%d) not built",
               c_in, c_out);
   ISF_REQUIRE(nbr_stride % 128 == 0 && nbr_stride >= n_out, ISF_ERR_ARG, "sparse_conv_dma: bad nbr_stride");
+  ISF_REQUIRE(!lmask || ((nx == 1 || nx == 3) && K % nx == 0), ISF_ERR_ARG, "sparse_conv_dma: %d taps in lines of %d", K, nx);
   const uint4* w = reinterpret_cast<const uint4*>(packed16);
   const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
   const uint4* x = reinterpret_cast<const uint4*>(xs);
   const uint4* r = reinterpret_cast<const uint4*>(residual);
   uint4* y = reinterpret_cast<uint4*>(ys);
-#define ISF_CALL_DMA(CI, NTT) dispatch_dma<CI, NTT>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query)
+#define ISF_CALL_DMA(CI, NTT) dispatch_dma<CI, NTT>(mode, x, w, winv, K, c_out, nbr, lmask, nx, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query)
   if (c_in == 32) return c_out == 32 ? ISF_CALL_DMA(32, 2) : ISF_CALL_DMA(32, 4);
   return c_out == 32 ? ISF_CALL_DMA(64, 2) : ISF_CALL_DMA(64, 4);
 #undef ISF_CALL_DMA
@@ -332,6 +398,21 @@ int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in
   return isf::sparse_conv_forward_dma_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out,
                                            scale, shift, residual_split, relu, out_split, mode, isf::as_stream(stream),
                                            order, nullptr);
+}
+
+int isf_sparse_conv_forward_dma_lines(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                                      int taps_per_line, int c_out, const int32_t* lines, const uint32_t* mask,
+                                      int nbr_stride, int num_out, const float* scale, const float* shift,
+                                      const void* residual_split, int relu, void* out_split, int mode,
+                                      isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0, ISF_ERR_ARG,
+              "sparse_conv_forward_dma_lines: bad arguments");
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(features_split && packed16 && lines && mask && out_split && ((scale == nullptr) == (shift == nullptr)),
+              ISF_ERR_ARG, "sparse_conv_forward_dma_lines: null pointer");
+  return isf::sparse_conv_forward_dma_impl(features_split, c_in, packed16, num_taps, c_out, lines, nbr_stride, num_out,
+                                           scale, shift, residual_split, relu, out_split, mode, isf::as_stream(stream),
+                                           nullptr, nullptr, mask, taps_per_line);
 }
 
 }  // extern "C"

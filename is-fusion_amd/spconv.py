@@ -239,6 +239,47 @@ def sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale=None, 
     return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
 
 
+def rulebook_lines(rb, taps_per_line=3):
+    """(lines int32 [K / tpl, stride], mask int32 [stride], flag int32 [1]) -- the LINE-COMPRESSED form of a Rulebook's
+    neighbour table (isf_rulebook_to_lines), cached on it; flag != 0: the table is not in rank order and has no such form."""
+    if getattr(rb, "_lines", None) is None:
+        K = rb.nbr.numel() // rb.stride
+        dev = rb.nbr.device
+        lines = torch.empty((K // taps_per_line, rb.stride), dtype=torch.int32, device=dev)
+        mask = torch.empty((rb.stride,), dtype=torch.int32, device=dev)
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().isf_rulebook_to_lines(_lib.ptr(rb.nbr), rb.stride, K, taps_per_line, rb.num_out,
+                                                     _lib.ptr(lines), _lib.ptr(mask), _lib.ptr(flag), _lib.stream()),
+                   "isf_rulebook_to_lines")
+        rb._lines = (lines, mask, flag)
+    return rb._lines
+
+
+def lines_to_nbr(lines, mask, K, taps_per_line=3):
+    """isf_lines_to_rulebook: the dense table [K, stride] a line-compressed one stands for."""
+    stride = mask.numel()
+    nbr = torch.empty((K, stride), dtype=torch.int32, device=mask.device)
+    _lib.check(_lib.load().isf_lines_to_rulebook(_lib.ptr(lines), _lib.ptr(mask), stride, K, taps_per_line, _lib.ptr(nbr),
+                                                 _lib.stream()), "isf_lines_to_rulebook")
+    return nbr
+
+
+def sparse_conv_forward_dma_lines(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
+                                  relu=False, mode=0, taps_per_line=3):
+    """sparse_conv_forward_dma reading the line-compressed table (isf_sparse_conv_forward_dma_lines); bit-identical."""
+    _lib.require_cuda(features)
+    f16io = (mode & ~32) == 257
+    xs = to_half(features) if f16io else to_split(features)
+    rs = None if residual is None else (to_half(residual) if f16io else to_split(residual))
+    ys = torch.empty(rb.num_out * c_out * (2 if f16io else 4), dtype=torch.uint8, device=features.device)
+    lines, mask, _flag = rulebook_lines(rb, taps_per_line)
+    _lib.check(_lib.load().isf_sparse_conv_forward_dma_lines(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, taps_per_line, c_out, _lib.ptr(lines), _lib.ptr(mask),
+        rb.stride, rb.num_out, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode),
+        _lib.stream()), "isf_sparse_conv_forward_dma_lines")
+    return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
+
+
 def cu_plan(rb):
     """Unit plan of the one-workgroup-per-CU kernel for a Rulebook (isf_sparse_conv_cu_plan), cached on it:
     (isf_conv_cu_plan struct, the int32 buffer it points into).  One plan serves every 256-column layer on the rulebook."""

@@ -660,6 +660,71 @@ def test_lidar_branch_cu_unit_layers_reproduce_tile_kernel_bits(dev):
         assert torch.equal(lb(pl, conv_diag=512 + 64 + 128), want), n       # CU kernel on, tile order / DMA gathers off
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (32, 32), (64, 32), (32, 64)])
+def test_line_compressed_table_conv_bit_identical_and_round_trips(dev, cin, cout):
+    """LINE-COMPRESSED neighbour table (9 line bases + a 27-bit tap mask per row instead of 27 indices): the dense table
+    -> lines -> dense round trip is exact for rank-order tables (SubM / strided / 3x1x1), a permuted table raises the
+    flag, and isf_sparse_conv_forward_dma_lines == isf_sparse_conv_forward_dma bit for bit in the split, single-pass and
+    f16-storage modes, from a few hundred rows (half tiles) to several rounds of workgroups."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin * 5 + cout)
+    B, shape = 2, [12, 64, 64]
+    for n in (300, 5000, 40000):
+        idx = _random_geometry(rng, B, shape, n)
+        x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+        for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                                 (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+            K, tpl = int(np.prod(ks)), ks[2]
+            rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+            lines, mask, flag = sp.rulebook_lines(rb, tpl)
+            assert int(flag.item()) == 0
+            back = sp.lines_to_nbr(lines, mask, K, tpl)
+            want = rb.nbr.view(K, rb.stride).clone()
+            want[:, rb.num_out:] = -1
+            assert torch.equal(back, want), (n, subm, ks)
+            m = mask.cpu().numpy().astype(np.int64)[:rb.num_out]
+            assert np.array_equal(np.array([bin(v).count("1") for v in m]), (want[:, :rb.num_out] >= 0).sum(0).cpu().numpy())
+            w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32), dev)
+            res = T(rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32), dev)
+            sc = T(rng.random(cout, dtype=np.float32) + 0.5, dev)
+            sh = T(rng.normal(0, 0.2, cout).astype(np.float32), dev)
+            p16 = sp.pack_filters_f16x3(w)
+            for mode in (0, 1, 257, 32):
+                ref = sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode)
+                got = sp.sparse_conv_forward_dma_lines(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode,
+                                                       taps_per_line=tpl)
+                assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks, mode)
+            got = sp.sparse_conv_forward_dma_lines(x, p16, K, cin, cout, rb, taps_per_line=tpl)
+            assert torch.equal(got, sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb)), (n, subm, ks)
+    # a table whose rows are not in rank order has no line form: the converter says so
+    rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    perm = torch.randperm(rb.num_out, device=dev, dtype=torch.int64)
+    nb = rb.nbr.view(27, rb.stride).clone()
+    live = nb[:, :rb.num_out] >= 0
+    nb[:, :rb.num_out][live] = perm[nb[:, :rb.num_out][live].long()].int()
+    rb2 = sp.Rulebook(nb.contiguous(), rb.stride, rb.num_in, rb.num_out, rb.out_indices, rb.out_shape)
+    assert int(sp.rulebook_lines(rb2)[2].item()) == 1
+
+
+def test_lidar_branch_line_tables_reproduce_dense_table_bits(dev):
+    """the encoder builds the neighbour tables of its narrow levels (0 / 1: every reader runs the LDS-DMA kernel) directly
+    in the line-compressed form; diagnostic 16384 keeps dense tables -- same bits from a 3 k-point frame to the bench size,
+    in the fp32-class and f16-storage precisions, with and without the tile-order tables"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(990 + i, n), dev) for i in range(frames)]
+        want = lb(pl, conv_diag=16384)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        assert torch.equal(lb(pl), want), n
+        assert torch.equal(lb(pl, conv_diag=64), lb(pl, conv_diag=64 + 16384)), n
+        assert torch.equal(lb(pl, precision=2), lb(pl, precision=2, conv_diag=16384)), n
+        st0 = lb(pl, want_stats=True) is not None and lb.last_stats
+        st1 = lb(pl, want_stats=True, conv_diag=16384) is not None and lb.last_stats
+        assert [st0.pairs[i] for i in range(21)] == [st1.pairs[i] for i in range(21)]      # same pair counts either way
+
+
 def test_lidar_branch_dma_gather_layers_reproduce_gather_kernel_bits(dev):
     """the encoder runs its narrow layers (levels 0 / 1) on the LDS-DMA gather kernel; diagnostic 128 keeps them on the
     gather kernel -- same bits, in the split, single-pass f16 and f16-storage precisions"""
