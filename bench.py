@@ -93,10 +93,15 @@ def pmc_traffic(cin, cout):
     return None
 
 
-def conv_layer_bytes_flops(kind, cin, cout, K, n_in, n_out, pairs, s=4):
-    """SURVEY.md section 8d algorithmic (compulsory) traffic of one sparse-conv layer; s = bytes per element (4: fp32 /
-    split rows, 2: the f16 storage mode)."""
-    by = n_in * cin * s + n_out * cout * s + pairs * 8 + K * cin * cout * s
+def conv_layer_bytes_flops(kind, cin, cout, K, n_in, n_out, pairs, s=4, dense_tables=False):
+    """Compulsory traffic of one sparse-conv layer; s = bytes per element (4: fp32 / split rows,
+    2: the f16 storage mode).  The rulebook term is the table the kernel actually has to read, per output row: 4 K bytes
+    for the dense neighbour table (108 for 27 taps), 4 (K / 3) + 4 for the line-compressed table of the narrow layers
+    (40) -- for the benchmark geometry within a few bytes per row of SURVEY's pairs * 8 (8.7 pairs per row at level 0,
+    15.5 at level 3), and never less than what is read (the dense table was under-charged on the narrow layers)."""
+    lines = cin <= 64 and cout <= 64 and not dense_tables and K % 3 == 0
+    table = n_out * (4 * (K // 3) + 4 if lines else 4 * K)
+    by = n_in * cin * s + n_out * cout * s + table + K * cin * cout * s
     fl = 2.0 * pairs * cin * cout
     return by, fl
 
@@ -656,7 +661,8 @@ def main():
         tot_bytes = tot_flops = 0.0
         for ms, n_in, n_out, pairs in samples:                               # per-step figures: averaged over the samples
             for i, (kind, cin, cout, K) in enumerate(tab):
-                by, fl = conv_layer_bytes_flops(kind, cin, cout, K, n_in[i], n_out[i], pairs[i], 2 if args.f16 else 4)
+                by, fl = conv_layer_bytes_flops(kind, cin, cout, K, n_in[i], n_out[i], pairs[i], 2 if args.f16 else 4,
+                                                bool(args.conv_diag & (16384 | 128)))
                 tot_bytes += by / ns
                 tot_flops += fl / ns
                 g = groups.setdefault(f"spconv_mfma<cin={cin},cout={cout}>", dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
