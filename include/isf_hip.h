@@ -238,6 +238,24 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
                                           int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                           const float* scale, const float* shift, const void* residual_split, int relu,
                                           void* out_split, int mode, const int32_t* order, isf_stream_t stream);
+/* TILE TABLE of a launch that is resident in one round of workgroups (levels 3 / 4: 2.5 tiles per compute unit).  Uniform
+ * tiles carry 3x different matrix work (scene density), so the launch ends with its densest CU.  isf_sparse_conv_tile_table
+ * deals the 16-row groups of every XCD's row range to that XCD's compute units as contiguous runs of about EQUAL WORK
+ * (taps with a neighbour per group) and cuts a CU's run into full tiles plus one remainder tile, slot = where the
+ * dispatcher places it: table [parts][workgroups per CU * CUs per XCD][2] = (first group, groups); scratch holds
+ * 2 * ceil(num_out / 16) ints; *num_ints = ints written (0: the launch is not one round -- use the plain entry).
+ * isf_sparse_conv_forward_f16x3_tiled runs the convolution over it: BIT-IDENTICAL results (a row's products and their
+ * order do not depend on the tile it falls into).  isf_sparse_encoder_forward builds one table per deep level behind the
+ * neighbour table (diagnostic +32768: uniform tiles + isf_sparse_conv_tile_order).  isf_sparse_conv_tile_table_host: the
+ * same arithmetic on the host (tests).  Measured in DESIGN.md section 5.4. */
+int isf_sparse_conv_tile_table(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
+                               int32_t* scratch, int32_t* table, int* num_ints, isf_stream_t stream);
+int isf_sparse_conv_forward_f16x3_tiled(const void* features_split, int num_in, int c_in, const void* packed16,
+                                        int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                                        const float* scale, const float* shift, const void* residual_split, int relu,
+                                        void* out_split, int mode, const int32_t* table, isf_stream_t stream);
+int isf_sparse_conv_tile_table_host(const int32_t* work, int num_groups, int part_groups, int parts, int cus, int wgs_per_cu,
+                                    int groups_per_tile, int32_t* tiles, int* fits);
 int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
                           int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
                           const float* shift, const void* residual_split, int relu, void* out_split,
@@ -371,6 +389,7 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            256-column layers on isf_sparse_conv_forward_cu (one workgroup per CU; opt-in: measured slower than
  *            the tile kernel) -- results bit-identical either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
  *            +16384 = dense neighbour tables for the narrow layers instead of the line-compressed ones -- bit-identical;
+ *            +32768 = uniform tiles + tile order for the deep levels instead of equal-work tile tables -- bit-identical;
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

@@ -143,6 +143,13 @@ SIGNATURES = {
                                                       c_void_p, c_void_p]),
     "isf_sparse_conv_forward_dma": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "isf_sparse_conv_tile_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                           ctypes.POINTER(c_int), c_void_p]),
+    "isf_sparse_conv_forward_f16x3_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                                    c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                                    c_void_p, c_void_p]),
+    "isf_sparse_conv_tile_table_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                ctypes.POINTER(c_int)]),
     "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                       c_void_p]),

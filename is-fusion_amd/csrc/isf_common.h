@@ -182,6 +182,18 @@ static inline bool conv16_order_applies(const Conv16LaunchInfo& i) {
   const int t = i.full + i.half;
   return t > i.cus_per_xcd && t <= i.wgs_per_cu * i.cus_per_xcd && t <= 255 && i.cus_per_xcd <= 64;
 }
+// a tile table needs the whole part resident in one round: groups per part <= CUs x workgroups per CU x groups per tile
+static inline bool conv16_table_applies(const Conv16LaunchInfo& i) {
+  return i.TM > 0 && i.cus_per_xcd > 0 && i.part_rows / 16 <= i.cus_per_xcd * i.wgs_per_cu * (i.TM / 16);
+}
+static inline int conv16_table_ints(const Conv16LaunchInfo& i) {
+  return conv16_order_parts(i) * 2 * i.wgs_per_cu * i.cus_per_xcd;
+}
+int conv16_tile_table_impl(const int32_t* group_work, int n_out, const Conv16LaunchInfo& info, int32_t* table,
+                           hipStream_t st);
+// isf_spconv_cu.hip: per 16-row group the taps through which one of its rows has a neighbour (masks) and their count (work)
+int conv_group_masks_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int32_t* masks, int32_t* work,
+                          hipStream_t st);
 // isf_spconv_dma.hip: the same convolution for the narrow layers (<= 64 channels in and out) with the gathered rows
 // brought in by LDS-DMA, one cache line per lane quad; bit-identical to sparse_conv_forward_f16x3_impl
 bool sparse_conv_dma_supported(int c_in, int c_out);

@@ -154,8 +154,9 @@ struct LevelState {
   int cache_stride;
   long long cache_pairs;
   StageTables cache_stage;   // staging tables of cache_nbr (slots == nullptr: not built)
-  const int32_t* cache_order;   // tile order of cache_nbr for a (cache_order_cin -> cache_order_cout) launch, or nullptr
+  const int32_t* cache_order;   // tile order / table of cache_nbr for a (cache_order_cin -> cache_order_cout) launch, or nullptr
   int cache_order_cin, cache_order_cout;
+  bool cache_order_is_table;
   const uint32_t* cache_lmask;  // non-null: cache_nbr is LINE-COMPRESSED (lines [ks0 * ks1][stride]) with these tap masks
   ConvCuPlan cache_cu;          // unit plan of cache_nbr for the one-workgroup-per-CU kernel (n_out == 0: not built)
 };
@@ -167,11 +168,15 @@ static int build_cu_plan(Arena& a, const int32_t* nbr, int stride, int K, int n_
   return conv_cu_plan_impl(nbr, stride, K, n_out, buf, plan, sg);
 }
 
-// tile order of one conv launch over a neighbour table (conv16_tile_order_impl), built behind the table on the
-// geometry stream; *order stays nullptr when the launch is not a single resident round
+// tile order / tile table of one conv launch over a neighbour table, built behind the table on the geometry stream.  A
+// launch of the tile kernel that is resident in one round gets a TILE TABLE (conv16_table_part: the groups dealt to the
+// compute units by equal work; *is_table = true, run the conv with mode | 1024); the LDS-DMA kernel's launches keep the
+// permutation of uniform tiles (conv16_tile_order_impl); *order stays nullptr when neither applies.
 static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int32_t* nbr, int stride, int n_out,
-                            int mode, bool dma, const int32_t** order, hipStream_t sg, const uint32_t* lmask = nullptr) {
+                            int mode, bool dma, const int32_t** order, hipStream_t sg, const uint32_t* lmask = nullptr,
+                            bool* is_table = nullptr, bool tables = true) {
   *order = nullptr;
+  if (is_table) *is_table = false;
   Conv16LaunchInfo info;
   if (dma)
     ISF_TRY(sparse_conv_forward_dma_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, nullptr,
@@ -179,6 +184,18 @@ static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int
   else
     ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, nullptr,
                                            nullptr, nullptr, 0, nullptr, mode, sg, nullptr, &info));
+  if (!dma && is_table && tables && !lmask && conv16_table_applies(info) && n_out >= 16 * info.cus_per_xcd) {
+    const int ng = ceil_div(n_out, 16);
+    int32_t *masks = nullptr, *work = nullptr, *table = nullptr;
+    ISF_TRY(a.alloc_n(&masks, (size_t)ng));
+    ISF_TRY(a.alloc_n(&work, (size_t)ng));
+    ISF_TRY(a.alloc_n(&table, (size_t)conv16_table_ints(info)));
+    ISF_TRY(conv_group_masks_impl(nbr, stride, K, n_out, masks, work, sg));
+    ISF_TRY(conv16_tile_table_impl(work, n_out, info, table, sg));
+    *order = table;
+    *is_table = true;
+    return ISF_OK;
+  }
   if (!conv16_order_applies(info)) return ISF_OK;
   const size_t n = (size_t)conv16_order_parts(info) * conv16_order_tiles(info);
   int32_t *work = nullptr, *ord = nullptr;
@@ -221,9 +238,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
+  const bool tile_tables = (diagnostic & 32768) == 0;      // bit 32768: uniform tiles + LPT order instead of equal-work tables
   const bool line_tables = (diagnostic & 256 * 64) == 0;   // bit 16384: full neighbour tables for the narrow layers too
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
@@ -231,7 +249,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -254,6 +272,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.cache_nbr = nullptr;
   L.cache_order = nullptr;
   L.cache_order_cin = L.cache_order_cout = 0;
+  L.cache_order_is_table = false;
   L.cache_cu = ConvCuPlan();
   L.cache_lmask = nullptr;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
@@ -301,6 +320,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                              : ((stage_mask == 0 || ((stage_mask >> i) & 1u)) ? stage_opt : 0);
     StageTables stg;
     const int32_t* order = nullptr;
+    bool order_is_table = false;
     // 256-column layers: one workgroup per CU over units of equal work (isf_spconv_cu.hip; fp32-class mode only)
     const bool cu = use16 && cu_units && srows == 0 && conv_mode == 0 && sparse_conv_cu_supported(ly.c_in, ly.c_out);
     ConvCuPlan cu_plan;
@@ -351,9 +371,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
         L.cache_order = nullptr;
         L.cache_order_cin = L.cache_order_cout = 0;
+        L.cache_order_is_table = false;
         L.cache_cu = ConvCuPlan();
         if (want_order) {
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask));
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask,
+                                   &L.cache_order_is_table, tile_tables));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
         }
@@ -367,7 +389,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask));
+          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask,
+                                   &L.cache_order_is_table, tile_tables));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
           ISF_TRY(stream_wait_stream(a, st, sg));
@@ -381,7 +404,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       lmask = L.cache_lmask;
       ISF_REQUIRE(!lmask || dma, ISF_ERR_UNSUPPORTED, "sparse_encoder: layer %d cannot read a line-compressed table", i);
       stg = L.cache_stage;
-      if (want_order) order = L.cache_order;
+      if (want_order) {
+        order = L.cache_order;
+        order_is_table = L.cache_order_is_table;
+      }
       if (stats) stats->pairs[i] = hit ? L.cache_pairs : -(long long)i - 1;
     } else {
       ISF_TRY(ensure_occ(a, L, B, sg));
@@ -412,7 +438,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                            stride, pair_counts + i, sg));
       }
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
-      if (want_order) ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask));
+      if (want_order)
+        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask, &order_is_table, tile_tables));
       if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_cu = ConvCuPlan();
@@ -420,6 +447,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       Nx.cache_nbr = nullptr;
       Nx.cache_order = nullptr;
       Nx.cache_order_cin = Nx.cache_order_cout = 0;
+      Nx.cache_order_is_table = false;
       n_out = Nx.n;
       L = Nx;
       ISF_TRY(stream_wait_stream(a, st, sg));
@@ -446,7 +474,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                            res, ly.relu, y, conv_mode, st, order, nullptr, lmask, nx));
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
-                                             ly.shift, res, ly.relu, y, conv_mode, st, order));
+                                             ly.shift, res, ly.relu, y, conv_mode | (order_is_table ? 1024 : 0), st, order));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
       ISF_TRY(sparse_conv_forward_packed_impl(reinterpret_cast<const float*>(x), n_in, ly.c_in, ly.packed, K,
                                               ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,

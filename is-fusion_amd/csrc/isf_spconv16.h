@@ -63,7 +63,8 @@ __device__ __forceinline__ f32x8 join8(const uint4 hi, const uint4 lo) {
 // tiles of TM / 2 rows (every wave of a half tile owns ONE 16-row group instead of two) -- see conv16_plan.
 // -> false when this workgroup has no tile.
 struct Conv16Plan {
-  int full, half;   // tiles per part
+  int full, half;   // tiles per part.  half < 0: TABLE mode -- `full` slots per part, slot j of a part works on the tile
+                    // (first 16-row group, groups) the launch's tile table names (conv16_table_part)
   int part_rows;    // rows per part (a multiple of 16; the parts split the rows evenly whatever the tile mix)
 };
 
@@ -90,10 +91,59 @@ __device__ __forceinline__ bool conv16_tile_of_block(int ncb, Conv16Plan plan, i
   int j = blockIdx.x >> 3;
   cb = ncb == 2 ? xcd & 1 : 0;
   const int part = ncb == 2 ? xcd >> 1 : xcd;
+  if (plan.half < 0) {   // tile table: (first group, groups) per slot; a tile of <= TM / 32 groups runs as a half tile
+    const int g0 = order[2 * (part * plan.full + j)], ng = order[2 * (part * plan.full + j) + 1];
+    row0 = g0 * 16;
+    row_end = row0 + ng * 16 < n_out ? row0 + ng * 16 : n_out;
+    half = ng * 32 <= TM;
+    return ng > 0 && row0 < n_out;
+  }
   if (order) j = order[part * (plan.full + plan.half) + j];
   return conv16_tile_rows(plan, TM, n_out, part, j, row0, row_end, half);
 }
-static inline int conv16_grid_blocks(Conv16Plan plan) { return 8 * (plan.full + plan.half); }
+static inline int conv16_grid_blocks(Conv16Plan plan) { return 8 * (plan.half < 0 ? plan.full : plan.full + plan.half); }
+
+// TILE TABLE of a launch that is resident in one round of workgroups: instead of cutting a part's rows into equal tiles
+// (whose matrix work varies 3x with the density of the scene, so that the launch ends with its densest compute unit),
+// the part's 16-row groups are dealt to the XCD's compute units as contiguous runs of about EQUAL WORK (work of a group =
+// taps through which one of its rows has a neighbour, + a constant for its fixed cost), at most wgs_per_cu * gt groups
+// per CU, and a CU's run is cut into full tiles of gt groups plus one tile with the remainder; tile k of CU c goes to
+// workgroup slot c + cus * k, which is where the dispatcher puts it (round-robin over the XCD's CUs,
+// tools/probes/wg_placement.hip).  Dense CUs get fewer rows, sparse ones more.  Host and device walk the same code
+// (tests/test_tile_plan.py).  -> false when the part does not fit one round (the caller keeps the uniform plan).
+static constexpr int kTableGroupBias = 2;
+__host__ __device__ inline bool conv16_table_part(const int32_t* work, int G0, int G1, int cus, int wgs_per_cu, int gt,
+                                                  int32_t* tiles /* [wgs_per_cu * cus][2] */) {
+  const int slots = wgs_per_cu * cus, cap = wgs_per_cu * gt;
+  for (int j = 0; j < 2 * slots; ++j) tiles[j] = 0;
+  if (G1 - G0 > cus * cap) return false;
+  long long rem = 0;
+  for (int g = G0; g < G1; ++g) rem += work[g] + kTableGroupBias;
+  int g = G0;
+  for (int c = 0; c < cus && g < G1; ++c) {
+    const int left_cus = cus - c, left_groups = G1 - g;
+    const long long target = (rem + left_cus - 1) / left_cus;
+    int must = left_groups - (left_cus - 1) * cap;     // what the others cannot hold
+    if (must < 0) must = 0;
+    int take = 0;
+    long long acc = 0;
+    while (g + take < G1 && take < cap) {
+      const long long w = work[g + take] + kTableGroupBias;
+      if (take >= must && (acc >= target || (take > 0 && acc + w - target > target - acc))) break;
+      acc += w;
+      ++take;
+    }
+    for (int k = 0, off = 0; off < take; ++k) {
+      const int ng = take - off < gt ? take - off : gt;
+      tiles[2 * (c + cus * k)] = g + off;
+      tiles[2 * (c + cus * k) + 1] = ng;
+      off += ng;
+    }
+    g += take;
+    rem -= acc;
+  }
+  return g == G1;
+}
 
 // How a launch is cut into tiles.  The matrix pipe is per SIMD and a workgroup puts one wave (NW = 4) on each SIMD of
 // its CU, so what bounds a launch that fits the chip in ONE round of workgroups is the largest number of 16-row groups

@@ -405,7 +405,7 @@ bool sparse_conv_f16x3_supported(int c_in, int c_out) {
 }
 
 template <int CIN, int NT, int RG, int NW, int MODE = 0>
-static int launch16(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
+static int launch16(bool balance, bool table /* `order` is a tile table (conv16_table_part), not a permutation */, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                     const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                     const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
                     Conv16LaunchInfo* query, long long* trace = nullptr) {
@@ -425,8 +425,10 @@ static int launch16(bool balance, const uint4* xs, const uint4* wpk, const float
   }
   const int ncb = cout / (16 * NT);
   ISF_REQUIRE(ncb == 1 || ncb == 2, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d column blocks", ncb);
-  const Conv16Plan plan = conv16_plan(n_out, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
-                                      cus_per_xcd.load(std::memory_order_relaxed), balance);
+  Conv16Plan plan = conv16_plan(n_out, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
+                                cus_per_xcd.load(std::memory_order_relaxed), balance);
+  if (table && !query) plan = Conv16Plan{wgs_per_cu.load(std::memory_order_relaxed) * cus_per_xcd.load(std::memory_order_relaxed),
+                                         -1, plan.part_rows};
   if (query) {   // what this launch would look like (conv16_tile_order_impl works on exactly these tiles)
     *query = Conv16LaunchInfo{plan.full, plan.half, plan.part_rows, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
                               cus_per_xcd.load(std::memory_order_relaxed)};
@@ -449,8 +451,8 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                          const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
                          Conv16LaunchInfo* query) {
-#define ISF_ARGS16 (mode & 32) == 0, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
-  switch (mode & ~32) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
+#define ISF_ARGS16 (mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
+  switch (mode & ~(32 | 1024)) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
     case 0: break;
     case 1: return launch16<CIN, NT, 2, 4, 1>(ISF_ARGS16);
     case 2: return launch16<CIN, NT, 2, 4, 2>(ISF_ARGS16);
@@ -535,9 +537,9 @@ int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K
   for (int pass = 0; pass < 2; ++pass) {   // pass 0: the launch shape (grid size), pass 1: launch
     Conv16LaunchInfo* q = pass == 0 ? &info : nullptr;
     int rc;
-    if (c_in == 256) rc = launch16<256, 8, 2, 4, 512>(true, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
-    else if (wide) rc = launch16<128, 8, 2, 8, 512>(true, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
-    else rc = launch16<128, 8, 2, 4, 512>(true, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    if (c_in == 256) rc = launch16<256, 8, 2, 4, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    else if (wide) rc = launch16<128, 8, 2, 8, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    else rc = launch16<128, 8, 2, 4, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
     ISF_TRY(rc);
   }
   *grid_blocks = 8 * (info.full + info.half);
@@ -651,6 +653,28 @@ __global__ __launch_bounds__(64) void conv16_tile_order_kernel(const int32_t* __
       load += w;
     }
   }
+}
+
+// one thread per part walks conv16_table_part (<= a few thousand groups: ~20 us, on the geometry stream)
+__global__ void conv16_tile_table_kernel(const int32_t* __restrict__ work, int n_groups, int part_groups, int cus,
+                                         int wgs_per_cu, int gt, int32_t* __restrict__ tiles) {
+  const int part = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  const int G0 = part * part_groups < n_groups ? part * part_groups : n_groups;
+  const int G1 = (part + 1) * part_groups < n_groups ? (part + 1) * part_groups : n_groups;
+  (void)conv16_table_part(work, G0, G1, cus, wgs_per_cu, gt, tiles + (size_t)part * 2 * wgs_per_cu * cus);   // fits: checked
+}                                                                                                               // on the host
+
+// tile table of a launch (info from the launch query); group_work [ceil(n_out / 16)] from conv_group_masks_impl;
+// table: conv16_table_ints(info) int32.  Only for launches conv16_table_applies() accepts.
+int conv16_tile_table_impl(const int32_t* group_work, int n_out, const Conv16LaunchInfo& info, int32_t* table,
+                           hipStream_t st) {
+  ISF_REQUIRE(conv16_table_applies(info), ISF_ERR_ARG, "tile table: the launch is not one resident round");
+  const int parts = conv16_order_parts(info);
+  hipLaunchKernelGGL(conv16_tile_table_kernel, dim3(parts), dim3(64), 0, st, group_work, ceil_div(n_out, 16),
+                     info.part_rows / 16, info.cus_per_xcd, info.wgs_per_cu, info.TM / 16, table);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
 }
 
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
@@ -806,6 +830,55 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
                                              num_out, scale, shift, residual_split, relu, out_split, mode,
                                              isf::as_stream(stream), order);
+}
+
+int isf_sparse_conv_tile_table(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
+                               int32_t* scratch, int32_t* table, int* num_ints, isf_stream_t stream) {
+  ISF_REQUIRE(nbr && scratch && table && num_ints && num_out >= 0, ISF_ERR_ARG, "sparse_conv_tile_table: bad arguments");
+  *num_ints = 0;
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
+              "sparse_conv_tile_table: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
+  isf::Conv16LaunchInfo info;
+  ISF_TRY(isf::sparse_conv_forward_f16x3_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
+                                              nullptr, nullptr, 0, nullptr, 0, isf::as_stream(stream), nullptr, &info));
+  if (!isf::conv16_table_applies(info)) return ISF_OK;
+  const int ng = isf::ceil_div(num_out, 16);
+  ISF_TRY(isf::conv_group_masks_impl(nbr, nbr_stride, num_taps, num_out, scratch, scratch + ng, isf::as_stream(stream)));
+  ISF_TRY(isf::conv16_tile_table_impl(scratch + ng, num_out, info, table, isf::as_stream(stream)));
+  *num_ints = isf::conv16_table_ints(info);
+  return ISF_OK;
+}
+
+int isf_sparse_conv_forward_f16x3_tiled(const void* features_split, int num_in, int c_in, const void* packed16,
+                                        int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
+                                        const float* scale, const float* shift, const void* residual_split, int relu,
+                                        void* out_split, int mode, const int32_t* table, isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && c_in > 0 && c_out > 0 && num_taps > 0 && table, ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3_tiled: bad arguments");
+  if (num_out == 0) return ISF_OK;
+  ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
+              ISF_ERR_ARG, "sparse_conv_forward_f16x3_tiled: null pointer");
+  ISF_REQUIRE(mode == 0 || mode == 1 || mode == 16 || mode == 257, ISF_ERR_ARG,
+              "sparse_conv_forward_f16x3_tiled: mode %d (0, 1, 16, 257)", mode);
+  return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out,
+                                             scale, shift, residual_split, relu, out_split, mode | 1024,
+                                             isf::as_stream(stream), table);
+}
+
+// conv16_table_part walked on the host (tests, tools; no device work): work [num_groups] -> tiles [parts][wgs * cus][2]
+int isf_sparse_conv_tile_table_host(const int32_t* work, int num_groups, int part_groups, int parts, int cus, int wgs_per_cu,
+                                    int groups_per_tile, int32_t* tiles, int* fits) {
+  ISF_REQUIRE(work && tiles && fits && num_groups > 0 && part_groups > 0 && parts > 0 && cus > 0 && wgs_per_cu > 0 &&
+                  groups_per_tile > 0, ISF_ERR_ARG, "sparse_conv_tile_table_host: bad arguments");
+  *fits = 1;
+  for (int p = 0; p < parts; ++p) {
+    const int G0 = p * part_groups < num_groups ? p * part_groups : num_groups;
+    const int G1 = (p + 1) * part_groups < num_groups ? (p + 1) * part_groups : num_groups;
+    if (!isf::conv16_table_part(work, G0, G1, cus, wgs_per_cu, groups_per_tile, tiles + (size_t)p * 2 * wgs_per_cu * cus))
+      *fits = 0;
+  }
+  return ISF_OK;
 }
 
 int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,

@@ -431,6 +431,14 @@ __global__ __launch_bounds__(1024) void cu_plan_kernel(const int32_t* __restrict
   }
 }
 
+int conv_group_masks_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int32_t* masks, int32_t* work,
+                          hipStream_t st) {
+  const int ng = ceil_div(n_out, 16);
+  hipLaunchKernelGGL(cu_group_mask_kernel, dim3(ceil_div(ng, 16)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, ng, masks, work);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 static int cu_count() {
   static std::atomic<int> cus{0};
   int c = cus.load(std::memory_order_acquire);

@@ -203,8 +203,39 @@ def tile_order(rb, c_in, c_out, mode=0):
     return cache[key][0] if cache[key] is not None else None
 
 
+def tile_table(rb, c_in, c_out):
+    """Equal-work tile table of the launch isf_sparse_conv_forward_f16x3 would make on this Rulebook
+    (isf_sparse_conv_tile_table), cached per channel shape; None when the launch is not one resident round."""
+    cache = rb.__dict__.setdefault("_tile_tables", {})
+    key = (c_in, c_out)
+    if key not in cache:
+        lib = _lib.load()
+        K = rb.nbr.numel() // rb.stride
+        dev = rb.nbr.device
+        ng = (rb.num_out + 15) // 16
+        scratch = torch.empty((2 * ng + 2,), dtype=torch.int32, device=dev)
+        table = torch.zeros((8 * 2 * 3 * 64,), dtype=torch.int32, device=dev)     # parts x slots x 2 at most
+        n = ctypes.c_int(0)
+        _lib.check(lib.isf_sparse_conv_tile_table(_lib.ptr(rb.nbr), rb.stride, K, rb.num_out, c_in, c_out,
+                                                  _lib.ptr(scratch), _lib.ptr(table), ctypes.byref(n), _lib.stream()),
+                   "isf_sparse_conv_tile_table")
+        cache[key] = table[:n.value] if n.value else None
+    return cache[key]
+
+
+def tile_table_host(work, part_groups, parts, cus=32, wgs_per_cu=3, groups_per_tile=8):
+    """isf_sparse_conv_tile_table_host: conv16_table_part on the CPU -> (tiles [parts, wgs * cus, 2], fits)."""
+    work = np.ascontiguousarray(work, dtype=np.int32)
+    tiles = np.zeros((parts, wgs_per_cu * cus, 2), dtype=np.int32)
+    fits = ctypes.c_int(0)
+    _lib.check(_lib.load().isf_sparse_conv_tile_table_host(work.ctypes.data, len(work), part_groups, parts, cus, wgs_per_cu,
+                                                           groups_per_tile, tiles.ctypes.data, ctypes.byref(fits)),
+               "isf_sparse_conv_tile_table_host")
+    return tiles, bool(fits.value)
+
+
 def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
-                              relu=False, mode=0, order=None):
+                              relu=False, mode=0, order=None, table=None):
     """fp32 in / fp32 out convenience wrapper around the split-precision kernel (converts at both ends); mode 257 (f16
     storage) converts through f16 rows instead of split rows.  order: tile_order(rb, c_in, c_out, mode) or None."""
     _lib.require_cuda(features)
@@ -215,7 +246,10 @@ def sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale=None
     lib = _lib.load()
     args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
             _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), int(mode))
-    if order is None:
+    if table is not None:
+        _lib.check(lib.isf_sparse_conv_forward_f16x3_tiled(*args, _lib.ptr(table), _lib.stream()),
+                   "isf_sparse_conv_forward_f16x3_tiled")
+    elif order is None:
         _lib.check(lib.isf_sparse_conv_forward_f16x3(*args, _lib.stream()), "isf_sparse_conv_forward_f16x3")
     else:
         _lib.check(lib.isf_sparse_conv_forward_f16x3_ordered(*args, _lib.ptr(order), _lib.stream()),
@@ -350,6 +384,10 @@ def sparse_conv_forward_best(features, packed16, K, c_in, c_out, rb, scale=None,
     (the one-workgroup-per-CU kernel of the 256-column shapes is an opt-in: measured slower)."""
     if c_in <= 64 and c_out <= 64 and (mode & ~32) in (0, 1, 257):
         return sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode)
+    table = tile_table(rb, c_in, c_out) if mode in (0, 1, 257) else None
+    if table is not None:
+        return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode,
+                                         table=table)
     order = tile_order(rb, c_in, c_out, mode) if (mode & ~32) in (0, 1, 257) else None
     return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode, order)
 

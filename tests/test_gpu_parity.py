@@ -725,6 +725,64 @@ def test_lidar_branch_line_tables_reproduce_dense_table_bits(dev):
         assert [st0.pairs[i] for i in range(21)] == [st1.pairs[i] for i in range(21)]      # same pair counts either way
 
 
+@pytest.mark.parametrize("cin,cout", [(128, 128), (256, 256), (128, 256), (64, 128), (64, 64)])
+def test_tile_table_conv_bit_identical_and_covers_every_group(dev, cin, cout):
+    """equal-work TILE TABLE of a one-round launch (isf_sparse_conv_tile_table: the 16-row groups of an XCD's row range
+    dealt to its compute units by equal work, a CU's run cut into full tiles + a remainder tile): every group of the
+    launch appears in exactly one tile, tiles have 1..TM/16 groups, and isf_sparse_conv_forward_f16x3_tiled ==
+    isf_sparse_conv_forward_f16x3 bit for bit (split, single-pass and f16-storage modes; SubM / strided / 3x1x1); launches
+    of several rounds have no table."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin + 3 * cout)
+    B, shape = 2, [12, 96, 96]
+    for n in (200, 5000, 40000):
+        idx = _random_geometry(rng, B, shape, n)
+        x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+        for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1]),
+                                 (False, [3, 1, 1], [2, 1, 1], [0, 0, 0])):
+            K = int(np.prod(ks))
+            rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+            table = sp.tile_table(rb, cin, cout)
+            if table is None:
+                continue
+            t = table.view(-1, 2).cpu().numpy()
+            ng = (rb.num_out + 15) // 16
+            seen = np.zeros(ng + 64, np.int32)
+            for g0, k in t:
+                assert 0 <= k <= 16
+                seen[g0:g0 + k] += 1
+            assert (seen[:ng] == 1).all() and (seen[ng:] == 0).all(), (n, subm, ks)
+            w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32), dev)
+            res = T(rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32), dev)
+            sc = T(rng.random(cout, dtype=np.float32) + 0.5, dev)
+            sh = T(rng.normal(0, 0.2, cout).astype(np.float32), dev)
+            p16 = sp.pack_filters_f16x3(w)
+            for mode in (0, 1, 257):
+                ref = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode)
+                got = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode, table=table)
+                assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks, mode)
+    big = _random_geometry(rng, 4, [12, 128, 128], 200000)
+    rb = sp.build_rulebook(T(big, dev), 4, [12, 128, 128], [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    assert sp.tile_table(rb, cin, cout) is None                      # several rounds of workgroups: no table
+
+
+def test_lidar_branch_tile_tables_reproduce_uniform_tile_bits(dev):
+    """the encoder gives every one-round launch of the tile kernel (levels 3 / 4; level 2 at small batch) an equal-work tile
+    table built behind the neighbour table on the geometry stream; diagnostic 32768 keeps uniform tiles + the tile-order
+    permutation -- same bits from a 3 k-point frame to the bench size, in the fp32-class and f16-storage precisions"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(930 + i, n), dev) for i in range(frames)]
+        want = lb(pl, conv_diag=32768)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        assert torch.equal(lb(pl), want), n
+        assert torch.equal(lb(pl), want), n
+        assert torch.equal(lb(pl, conv_diag=32768 + 64), want), n            # neither tables nor the permutation
+        assert torch.equal(lb(pl, precision=2), lb(pl, precision=2, conv_diag=32768)), n
+
+
 def test_lidar_branch_dma_gather_layers_reproduce_gather_kernel_bits(dev):
     """the encoder runs its narrow layers (levels 0 / 1) on the LDS-DMA gather kernel; diagnostic 128 keeps them on the
     gather kernel -- same bits, in the split, single-pass f16 and f16-storage precisions"""

@@ -141,3 +141,56 @@ def test_cu_unit_plan_is_deterministic_and_monotone_in_cuts():
     work = rng.integers(0, 28, 3333).astype(np.int32)
     a, b = _cu_units(work), _cu_units(work.copy())
     assert np.array_equal(a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Equal-work TILE TABLE of the tile kernel's one-round launches (csrc/isf_spconv16.h: conv16_table_part, walked on the host
+# by isf_sparse_conv_tile_table_host -- the function the device planner calls)
+@pytest.mark.parametrize("case", ["level3", "dense", "sparse_cap", "tiny", "nofit", "level2_8wave"])
+def test_tile_table_covers_every_group_once_and_balances_the_compute_units(case):
+    import numpy as np
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(sum(map(ord, case)))
+    cus, wgs, gt, parts = 32, 3, 8, 4
+    if case == "level3":          # 40.7 k rows -> 2544 groups, 636 per part, work 9..27
+        part_groups, work = 636, np.clip(rng.normal(16, 5, 2544), 9, 27).astype(np.int32)
+        dense = np.zeros(2544, bool); dense[300:700] = True; work[dense] = 27          # a dense region
+    elif case == "dense":
+        part_groups, work = 636, np.full(2544, 27, np.int32)
+    elif case == "sparse_cap":    # 760 groups per part on 32 x 24 = 768 slots of capacity: the cap binds
+        part_groups, work = 760, rng.integers(1, 28, 3040).astype(np.int32)
+    elif case == "tiny":
+        part_groups, work = 2, rng.integers(1, 28, 7).astype(np.int32)
+    elif case == "nofit":
+        part_groups, work = 800, rng.integers(1, 28, 3200).astype(np.int32)
+    else:                         # 8-wave 128-column shape: 2 workgroups per CU, 16 groups per tile, 8 parts
+        cus, wgs, gt, parts = 32, 2, 16, 8
+        part_groups, work = 933, rng.integers(5, 28, 7458).astype(np.int32)
+    tiles, fits = sp.tile_table_host(work, part_groups, parts, cus, wgs, gt)
+    if case == "nofit":
+        assert not fits
+        return
+    assert fits
+    n = len(work)
+    seen = np.zeros(n, np.int32)
+    for p in range(parts):
+        G0, G1 = min(p * part_groups, n), min((p + 1) * part_groups, n)
+        cu_work = np.zeros(cus)
+        cu_groups = np.zeros(cus, np.int32)
+        nxt = G0
+        for c in range(cus):
+            for k in range(wgs):
+                g0, ng = tiles[p, c + cus * k]
+                if ng == 0:
+                    continue
+                assert 1 <= ng <= gt and g0 == nxt and g0 + ng <= G1, (p, c, k, g0, ng)     # contiguous, in CU order
+                assert k == 0 or tiles[p, c + cus * (k - 1), 1] == gt                       # full tiles first, remainder last
+                seen[g0:g0 + ng] += 1
+                cu_work[c] += work[g0:g0 + ng].sum() + 2 * ng
+                cu_groups[c] += ng
+                nxt = g0 + ng
+        assert nxt == G1 and cu_groups.max() <= wgs * gt
+        if G1 - G0 >= 4 * cus and case != "sparse_cap":
+            tot = cu_work.sum()
+            assert cu_work.max() <= tot / cus + 2 * 29 + 1e-9, (case, p, cu_work.max(), tot / cus)   # within ~2 groups of the mean
+    assert (seen == 1).all()
