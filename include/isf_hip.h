@@ -245,11 +245,13 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
  * dispatcher places it: table [parts][workgroups per CU * CUs per XCD][2] = (first group, groups); scratch holds
  * 2 * ceil(num_out / 16) ints; *num_ints = ints written (0: the launch is not one round -- use the plain entry).
  * isf_sparse_conv_forward_f16x3_tiled runs the convolution over it: BIT-IDENTICAL results (a row's products and their
- * order do not depend on the tile it falls into).  isf_sparse_encoder_forward builds one table per deep level behind the
- * neighbour table (diagnostic +32768: uniform tiles + isf_sparse_conv_tile_order).  isf_sparse_conv_tile_table_host: the
- * same arithmetic on the host (tests).  Measured in DESIGN.md section 5.4. */
+ * order do not depend on the tile it falls into); the table belongs to one (c_in, c_out, mode): the workgroup shape depends
+ * on all three.  MEASURED SLOWER than uniform tiles + isf_sparse_conv_tile_order on the MI355X (256 -> 256: 1.32 vs 1.265 ms
+ * per step; profiles/r04_tile_tables.txt, DESIGN.md section 5.4: a tile's time follows its STEP count, not its matrix
+ * work), so it is an OPT-IN: isf_sparse_encoder_forward builds the tables with diagnostic +32768.
+ * isf_sparse_conv_tile_table_host: the same arithmetic on the host (tests). */
 int isf_sparse_conv_tile_table(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
-                               int32_t* scratch, int32_t* table, int* num_ints, isf_stream_t stream);
+                               int mode, int32_t* scratch, int32_t* table, int* num_ints, isf_stream_t stream);
 int isf_sparse_conv_forward_f16x3_tiled(const void* features_split, int num_in, int c_in, const void* packed16,
                                         int num_taps, int c_out, const int32_t* nbr, int nbr_stride, int num_out,
                                         const float* scale, const float* shift, const void* residual_split, int relu,
@@ -389,7 +391,8 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            256-column layers on isf_sparse_conv_forward_cu (one workgroup per CU; opt-in: measured slower than
  *            the tile kernel) -- results bit-identical either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
  *            +16384 = dense neighbour tables for the narrow layers instead of the line-compressed ones -- bit-identical;
- *            +32768 = uniform tiles + tile order for the deep levels instead of equal-work tile tables -- bit-identical;
+ *            +32768 = equal-work tile tables for the deep levels instead of uniform tiles + tile order (opt-in:
+ *            measured slower) -- bit-identical;
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
 typedef struct isf_encoder_options {
   int precision;

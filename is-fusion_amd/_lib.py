@@ -143,7 +143,7 @@ SIGNATURES = {
                                                       c_void_p, c_void_p]),
     "isf_sparse_conv_forward_dma": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-    "isf_sparse_conv_tile_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+    "isf_sparse_conv_tile_table": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                            ctypes.POINTER(c_int), c_void_p]),
     "isf_sparse_conv_forward_f16x3_tiled": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                     c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,

@@ -833,15 +833,16 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
 }
 
 int isf_sparse_conv_tile_table(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
-                               int32_t* scratch, int32_t* table, int* num_ints, isf_stream_t stream) {
+                               int mode, int32_t* scratch, int32_t* table, int* num_ints, isf_stream_t stream) {
   ISF_REQUIRE(nbr && scratch && table && num_ints && num_out >= 0, ISF_ERR_ARG, "sparse_conv_tile_table: bad arguments");
   *num_ints = 0;
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "sparse_conv_tile_table: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
-  isf::Conv16LaunchInfo info;
+  ISF_REQUIRE(mode == 0 || mode == 1 || mode == 16 || mode == 257, ISF_ERR_ARG, "sparse_conv_tile_table: mode %d", mode);
+  isf::Conv16LaunchInfo info;   // the workgroup shape, and with it the table, depends on the mode
   ISF_TRY(isf::sparse_conv_forward_f16x3_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
-                                              nullptr, nullptr, 0, nullptr, 0, isf::as_stream(stream), nullptr, &info));
+                                              nullptr, nullptr, 0, nullptr, mode, isf::as_stream(stream), nullptr, &info));
   if (!isf::conv16_table_applies(info)) return ISF_OK;
   const int ng = isf::ceil_div(num_out, 16);
   ISF_TRY(isf::conv_group_masks_impl(nbr, nbr_stride, num_taps, num_out, scratch, scratch + ng, isf::as_stream(stream)));

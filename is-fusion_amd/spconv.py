@@ -203,11 +203,12 @@ def tile_order(rb, c_in, c_out, mode=0):
     return cache[key][0] if cache[key] is not None else None
 
 
-def tile_table(rb, c_in, c_out):
-    """Equal-work tile table of the launch isf_sparse_conv_forward_f16x3 would make on this Rulebook
-    (isf_sparse_conv_tile_table), cached per channel shape; None when the launch is not one resident round."""
+def tile_table(rb, c_in, c_out, mode=0):
+    """Equal-work tile table of the launch isf_sparse_conv_forward_f16x3 would make on this Rulebook for (c_in, c_out,
+    mode) (isf_sparse_conv_tile_table), cached; None when the launch is not one resident round.  Opt-in: measured slower
+    than uniform tiles + tile_order."""
     cache = rb.__dict__.setdefault("_tile_tables", {})
-    key = (c_in, c_out)
+    key = (c_in, c_out, mode)
     if key not in cache:
         lib = _lib.load()
         K = rb.nbr.numel() // rb.stride
@@ -216,7 +217,7 @@ def tile_table(rb, c_in, c_out):
         scratch = torch.empty((2 * ng + 2,), dtype=torch.int32, device=dev)
         table = torch.zeros((8 * 2 * 3 * 64,), dtype=torch.int32, device=dev)     # parts x slots x 2 at most
         n = ctypes.c_int(0)
-        _lib.check(lib.isf_sparse_conv_tile_table(_lib.ptr(rb.nbr), rb.stride, K, rb.num_out, c_in, c_out,
+        _lib.check(lib.isf_sparse_conv_tile_table(_lib.ptr(rb.nbr), rb.stride, K, rb.num_out, c_in, c_out, int(mode),
                                                   _lib.ptr(scratch), _lib.ptr(table), ctypes.byref(n), _lib.stream()),
                    "isf_sparse_conv_tile_table")
         cache[key] = table[:n.value] if n.value else None
@@ -384,10 +385,6 @@ def sparse_conv_forward_best(features, packed16, K, c_in, c_out, rb, scale=None,
     (the one-workgroup-per-CU kernel of the 256-column shapes is an opt-in: measured slower)."""
     if c_in <= 64 and c_out <= 64 and (mode & ~32) in (0, 1, 257):
         return sparse_conv_forward_dma(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode)
-    table = tile_table(rb, c_in, c_out) if mode in (0, 1, 257) else None
-    if table is not None:
-        return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode,
-                                         table=table)
     order = tile_order(rb, c_in, c_out, mode) if (mode & ~32) in (0, 1, 257) else None
     return sparse_conv_forward_f16x3(features, packed16, K, c_in, c_out, rb, scale, shift, residual, relu, mode, order)
 

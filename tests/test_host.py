@@ -560,9 +560,8 @@ def test_freeze_after_a_weight_change_never_reuses_the_old_packed_copies():
 
 def test_layer_level_kernel_choice_mirrors_the_engine(monkeypatch):
     """spconv.sparse_conv_forward_best is what SparseConvFunction (the sparse_conv_ext.indice_conv replacement) calls:
-    narrow shapes go to the LDS-DMA gather kernel, wider ones to the split kernel with the rulebook's equal-work tile
-    table (the tile-order permutation when the launch has no table), the timing diagnostics to the plain gather kernel --
-    the same choices isf_sparse_encoder_forward makes per layer."""
+    narrow shapes go to the LDS-DMA gather kernel, wider ones to the split kernel with the rulebook's tile-order table,
+    the timing diagnostics to the plain gather kernel -- the same choices isf_sparse_encoder_forward makes per layer."""
     from isfusion_amd import spconv as sp
     calls = []
     monkeypatch.setattr(sp, "sparse_conv_forward_dma", lambda *a, **k: calls.append(("dma", a[3], a[4], a[-1])) or "dma")
@@ -570,7 +569,6 @@ def test_layer_level_kernel_choice_mirrors_the_engine(monkeypatch):
                         lambda *a, **k: calls.append(("split", a[3], a[4], a[10] if len(a) > 10 else 0,
                                                       k.get("table", a[11] if len(a) > 11 else None))) or "split")
     monkeypatch.setattr(sp, "tile_order", lambda rb, ci, co, mode=0: ("order", ci, co, mode))
-    monkeypatch.setattr(sp, "tile_table", lambda rb, ci, co: ("table", ci, co) if ci == 256 else None)
     rb = object()
     assert sp.sparse_conv_forward_best(None, None, 27, 64, 64, rb) == "dma"
     assert sp.sparse_conv_forward_best(None, None, 27, 32, 64, rb, mode=257) == "dma"
@@ -579,8 +577,7 @@ def test_layer_level_kernel_choice_mirrors_the_engine(monkeypatch):
     assert sp.sparse_conv_forward_best(None, None, 27, 64, 64, rb, mode=16) == "split"     # diagnostic: gather kernel
     assert sp.sparse_conv_forward_best(None, None, 27, 256, 256, rb, mode=2) == "split"
     assert calls == [("dma", 64, 64, 0), ("dma", 32, 64, 257),
-                     ("split", 64, 128, 0, ("order", 64, 128, 0)),          # no table for this launch: the permutation
-                     ("split", 256, 256, 1, ("table", 256, 256)),           # one resident round: the equal-work table
+                     ("split", 64, 128, 0, ("order", 64, 128, 0)), ("split", 256, 256, 1, ("order", 256, 256, 1)),
                      ("split", 64, 64, 16, None), ("split", 256, 256, 2, None)]
 
 
