@@ -2,88 +2,22 @@
 //
 //  window_attention   36-token (win x win) windows of a DENSE S x S token grid; membership is arithmetic
 //                     (reference: get_window_coors + flat2window/window2flat gathers, sst_ops.py:219-268,
-//                     sst_basic_block_v2.py:41-75).  One wave per (window, head).
+//                     sst_basic_block_v2.py:41-75).  One wave per (window, head) on the matrix cores.
 //  small_key_attention  Lk <= 256 keys resident in LDS, one thread per query, online softmax: the 200 x 200
 //                     instance self-attention (fusion_encoder.py:664) and the 32400 x 200 instance-to-scene
 //                     cross attention (fusion_encoder.py:489-494).
 //  (the per-channel map attention of A14 lives in isf_channel_attn.hip)
-// head_dim 16 (every use on the IS-Fusion path) runs attention_mfma16_kernel on the matrix cores; the fp32 VALU kernels
-// serve head_dim 32 and the window attention of the d = 256 level.
+// head_dim 16 (every use on the IS-Fusion path) runs attention_mfma16_kernel on the matrix cores, the window attention of
+// both levels window_attention_mfma_kernel; the fp32 VALU kernels serve head_dim 32 of the generic entry point.
 #include "isf_common.h"
 
 namespace isf {
 
 // ----------------------------------------------------------------------------------------------------------------
-// qkv [B*S*S, 3d] (q | k | v, head h at columns h*HD); token row = (b*S + y)*S + x.
+// window attention: qkv [B*S*S, 3d] (q | k | v, head h at columns h*HD); token row = (b*S + y)*S + x.
 // window (wy, wx) covers y in [wy*win - off, +win), off = win (shift 0: aligned) or win/2 (shift 1) minus the
-// first window index; out [B*S*S, d].
-template <int HD, int WIN>
-__global__ __launch_bounds__(512) void window_attention_kernel(const float* __restrict__ qkv, int S, int d,
-                                                              int y_off, float scale, float* __restrict__ out) {
-  constexpr int T = WIN * WIN;
-  static_assert(T <= 64, "window must fit one wave");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float (*kv)[2][T][HD] = reinterpret_cast<float (*)[2][T][HD]>(smem);   // [8 heads][k|v][T][HD]
-  const int lane = threadIdx.x & 63;
-  const int head = threadIdx.x >> 6;
-  const int b = blockIdx.z;
-  const int y0 = (int)blockIdx.y * WIN - y_off, x0 = (int)blockIdx.x * WIN - y_off;
-  const int iy = lane / WIN, ix = lane % WIN;
-  const int y = y0 + iy, x = x0 + ix;
-  const bool valid = lane < T && y >= 0 && y < S && x >= 0 && x < S;
-  float q[HD];
-  const size_t row = ((size_t)b * S + (valid ? y : 0)) * S + (valid ? x : 0);
-  const float* base = qkv + row * (size_t)(3 * d) + head * HD;
-  if (lane < T) {
-#pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      float4 qq = valid ? *reinterpret_cast<const float4*>(base + c) : make_float4(0, 0, 0, 0);
-      float4 kk = valid ? *reinterpret_cast<const float4*>(base + d + c) : make_float4(0, 0, 0, 0);
-      float4 vv = valid ? *reinterpret_cast<const float4*>(base + 2 * d + c) : make_float4(0, 0, 0, 0);
-      q[c] = qq.x * scale; q[c + 1] = qq.y * scale; q[c + 2] = qq.z * scale; q[c + 3] = qq.w * scale;
-      *reinterpret_cast<float4*>(&kv[head][0][lane][c]) = kk;
-      *reinterpret_cast<float4*>(&kv[head][1][lane][c]) = vv;
-    }
-  }
-  __syncthreads();
-  if (!valid) return;
-  float s[T];
-  float m = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < T; ++j) {
-    const int yy = y0 + j / WIN, xx = x0 + j % WIN;
-    const bool ok = yy >= 0 && yy < S && xx >= 0 && xx < S;   // wave-uniform
-    float a = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      const float4 kk = *reinterpret_cast<const float4*>(&kv[head][0][j][c]);
-      a = fmaf(q[c], kk.x, a); a = fmaf(q[c + 1], kk.y, a); a = fmaf(q[c + 2], kk.z, a); a = fmaf(q[c + 3], kk.w, a);
-    }
-    s[j] = ok ? a : -INFINITY;
-    m = fmaxf(m, s[j]);
-  }
-  float sum = 0.f;
-  float o[HD];
-#pragma unroll
-  for (int c = 0; c < HD; ++c) o[c] = 0.f;
-#pragma unroll
-  for (int j = 0; j < T; ++j) {
-    const float p = __expf(s[j] - m);   // masked: exp(-inf) = 0
-    sum += p;
-#pragma unroll
-    for (int c = 0; c < HD; c += 4) {
-      const float4 vv = *reinterpret_cast<const float4*>(&kv[head][1][j][c]);
-      o[c] = fmaf(p, vv.x, o[c]); o[c + 1] = fmaf(p, vv.y, o[c + 1]);
-      o[c + 2] = fmaf(p, vv.z, o[c + 2]); o[c + 3] = fmaf(p, vv.w, o[c + 3]);
-    }
-  }
-  const float inv = 1.f / sum;
-  float* orow = out + row * (size_t)d + head * HD;
-#pragma unroll
-  for (int c = 0; c < HD; c += 4)
-    *reinterpret_cast<float4*>(orow + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
-}
-
+// first window index; out [B*S*S, d].  Kernel: window_attention_mfma_kernel below (the one-lane-per-token VALU kernel of
+// rounds 1-3 is gone: 52 us per d = 256 launch at B = 2).
 // ----------------------------------------------------------------------------------------------------------------
 // q [B*Lq, ldq], k/v [B*Lk, ldk] (column offsets applied by the host), head h at columns h*HD; out [B*Lq, ldo]
 template <int HD>
@@ -230,6 +164,122 @@ static constexpr float kAttnNegBig = -3.0e38f;   // finite "-inf": exp(kAttnNegB
 
 // grid (ceil(Lq / 256), heads, B * nsplit); workgroup = 4 waves x 4 query tiles; keys [k0, k0 + kn) of split sp.
 // PARTIAL: write (max, sum, unnormalised O) for merge_key_splits_kernel instead of the normalised output.
+// ----------------------------------------------------------------------------------------------------------------
+// Window attention on the matrix cores (both head dims of the path: 16 at d = 128, 32 at d = 256).  One WAVE per
+// (window, head), no LDS, no workgroup barrier: the 36 tokens of a 6 x 6 window are three 16-row MFMA tiles (12 padding
+// rows masked);  S^T = K Q^T (v_mfma_f32_16x16x16_f16 in the f16x3 split, HD / 16 k-steps: K = head_dim exactly for
+// head_dim 16, two steps for 32), the 3 x 3 score tiles of the window stay in registers, softmax of a query = its
+// registers + two cross-lane steps, O^T = V^T P^T with the score registers as the B operand and V^T read transposed
+// straight from the qkv rows (16 lanes = 64 contiguous bytes of one token).  Lane (q = lane & 15, g = lane >> 4) ends with
+// O[q][4g .. 4g + 3] of each 16-wide slice of the head: one 16-byte store per slice.  Replaces the VALU kernel above for
+// the d = 256 level (52 us per launch at B = 2: one lane per token, 36 x 32 FMAs twice) -- "windowed BEV attention on
+// MFMA" for both levels; the d = 128 level's inference path is the fused window block (isf_window_block.hip).
+// Reference: sst_basic_block_v2.py:41-75 (nn.MultiheadAttention over the padded window batch).
+template <int HD>
+__global__ __launch_bounds__(256) void window_attention_mfma_kernel(const float* __restrict__ qkv, int S, int d, int nwin,
+                                                                   int y_off, int total_waves, float scale,
+                                                                   float* __restrict__ out) {
+  constexpr int WIN = 6, T = 36, NT = 3, KS = HD / 16;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= total_waves) return;                    // wave-uniform
+  const int head = wid & 7;
+  int w = wid >> 3;
+  const int wx = w % nwin;
+  w /= nwin;
+  const int wy = w % nwin, b = w / nwin;
+  const int y0 = wy * WIN - y_off, x0 = wx * WIN - y_off;
+  const int col = lane & 15, g = lane >> 4;
+  // token of tile row (tile, r): index tile * 16 + r inside the window; -1 when padding or outside the grid
+  auto token_row = [&](int j) -> long long {
+    if (j >= T) return -1;
+    const int y = y0 + j / WIN, x = x0 + j % WIN;
+    if (y < 0 || y >= S || x < 0 || x >= S) return -1;
+    return ((long long)b * S + y) * S + x;
+  };
+  long long row_c[NT];                               // the token this lane's column index names, per tile
+#pragma unroll
+  for (int t = 0; t < NT; ++t) row_c[t] = token_row(t * 16 + col);
+  // Q (B operand) and K (A operand) fragments: [tile][k-step], element (row = col, dims 16 ks + 4 g ..)
+  ah4 qh[NT][KS], ql[NT][KS], kh[NT][KS], kl[NT][KS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      af4 qv = {0.f, 0.f, 0.f, 0.f}, kv = {0.f, 0.f, 0.f, 0.f};
+      if (row_c[t] >= 0) {
+        const float* base = qkv + (size_t)row_c[t] * (size_t)(3 * d) + head * HD + 16 * ks + 4 * g;
+        const float4 a = *reinterpret_cast<const float4*>(base);
+        const float4 c = *reinterpret_cast<const float4*>(base + d);
+        qv = af4{a.x * scale, a.y * scale, a.z * scale, a.w * scale};
+        kv = af4{c.x, c.y, c.z, c.w};
+      }
+      attn_split4(qv, qh[t][ks], ql[t][ks]);
+      attn_split4(kv, kh[t][ks], kl[t][ks]);
+    }
+  // key validity of this lane's score registers: keys kt * 16 + 4 g + t
+  bool kvalid[NT][4];
+  long long krow[NT][4];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      krow[kt][t] = token_row(kt * 16 + 4 * g + t);
+      kvalid[kt][t] = krow[kt][t] >= 0;
+    }
+#pragma unroll
+  for (int qt = 0; qt < NT; ++qt) {
+    af4 sc[NT];
+    float m = kAttnNegBig;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      af4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a = attn_mma3(kh[kt][ks], kl[kt][ks], qh[qt][ks], ql[qt][ks], a);   // S^T[key][q]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (!kvalid[kt][t]) a[t] = kAttnNegBig;
+        m = fmaxf(m, a[t]);
+      }
+      sc[kt] = a;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        sc[kt][t] = __expf(sc[kt][t] - m);
+        l += sc[kt][t];
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    ah4 ph[NT], pl[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) attn_split4(sc[kt], ph[kt], pl[kt]);
+#pragma unroll
+    for (int dt = 0; dt < KS; ++dt) {
+      af4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        af4 vv = {0.f, 0.f, 0.f, 0.f};     // A: V^T[dim = 16 dt + col][key 4 g + t]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (kvalid[kt][t]) vv[t] = qkv[(size_t)krow[kt][t] * (size_t)(3 * d) + 2 * d + head * HD + 16 * dt + col];
+        ah4 vh, vl;
+        attn_split4(vv, vh, vl);
+        acc = attn_mma3(vh, vl, ph[kt], pl[kt], acc);                 // O^T[dim 4 g + t][q = col]
+      }
+      if (row_c[qt] >= 0)
+        *reinterpret_cast<float4*>(out + (size_t)row_c[qt] * d + head * HD + 16 * dt + 4 * g) =
+            make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    }
+  }
+}
+
+// grid (ceil(Lq / 256), heads, B * nsplit) ...
 template <bool PARTIAL>
 __global__ __launch_bounds__(256) void attention_mfma16_kernel(const float* __restrict__ q, int ldq,
                                                                const float* __restrict__ k, const float* __restrict__ v,
@@ -354,21 +404,17 @@ int isf_window_attention_forward(const float* qkv, int batch_size, int grid_size
   // window index 0 of this launch is the first window that holds a grid cell.
   const int y_off = shift ? window / 2 : 0;
   const int nwin = shift ? (grid_size - 1 + window / 2) / window + 1 : (grid_size + window - 1) / window;
-  const dim3 grid(nwin, nwin, batch_size), block(512);
   const int hd = embed_dims / num_heads;
   const float scale = 1.0f / sqrtf((float)hd);
   hipStream_t st = as_stream(stream);
-  const size_t lds = (size_t)8 * 2 * 36 * hd * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_kernel<32, 6>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
-  }
+  // one wave per (window, head) on the matrix cores (window_attention_mfma_kernel)
+  const int total = batch_size * nwin * nwin * 8;
   if (hd == 16)
-    hipLaunchKernelGGL((window_attention_kernel<16, 6>), grid, block, lds, st, qkv, grid_size, embed_dims, y_off, scale, out);
+    hipLaunchKernelGGL((window_attention_mfma_kernel<16>), dim3(ceil_div(total, 4)), dim3(256), 0, st, qkv, grid_size,
+                       embed_dims, nwin, y_off, total, scale, out);
   else
-    hipLaunchKernelGGL((window_attention_kernel<32, 6>), grid, block, lds, st, qkv, grid_size, embed_dims, y_off, scale, out);
+    hipLaunchKernelGGL((window_attention_mfma_kernel<32>), dim3(ceil_div(total, 4)), dim3(256), 0, st, qkv, grid_size,
+                       embed_dims, nwin, y_off, total, scale, out);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

@@ -78,6 +78,30 @@ def test_linear_rejects_bad_shapes(dev):
 
 
 # --------------------------------------------------------------------------------------- window attention
+@pytest.mark.parametrize("S,B", [(90, 2), (45, 1), (36, 2), (31, 1), (20, 2), (13, 1), (7, 2), (6, 1), (5, 1), (96, 1), (3, 2),
+                                  (54, 1)])
+@pytest.mark.parametrize("shift", [0, 1])
+def test_window_attention_d256_on_the_matrix_cores_matches_fp64(dev, S, B, shift):
+    """the d = 256 level (head_dim 32, 8 heads) of HSF Grid-to-Region: window_attention_mfma_kernel (one wave per (window,
+    head), f16x3 split MFMA, K = two 16-wide steps) against float64 per-window softmax attention on EVERY window of twelve
+    grids -- whole, partial (edge), shifted and single-window grids, grids smaller than a window"""
+    from isfusion_amd import fusion_ops as ops
+    from oracle import fusion_ops as orc
+    d, hd = 256, 32
+    qkv = rnd((B * S * S, 3 * d), 40 + shift + S)
+    out = ops.window_attention(qkv.to(dev), B, S, d, 8, 6, shift).cpu().double()
+    wid, _, _ = orc.window_geometry(S, 6, shift)
+    wid = wid.reshape(-1)
+    q, k, v = (qkv[:, i * d:(i + 1) * d].double().view(B, S * S, 8, hd) for i in range(3))
+    worst = 0.0
+    for w in torch.unique(wid):
+        sel = torch.nonzero(wid == w).squeeze(1)
+        a = torch.einsum("bihd,bjhd->bhij", q[:, sel], k[:, sel]) * hd ** -0.5
+        ref = torch.einsum("bhij,bjhd->bihd", a.softmax(-1), v[:, sel])
+        worst = max(worst, (out.view(B, S * S, 8, hd)[:, sel] - ref).abs().max().item())
+    assert worst < 2e-6, worst
+
+
 @pytest.mark.parametrize("S,d,B", [(36, 128, 2), (18, 256, 2), (180, 128, 1), (90, 256, 1), (20, 128, 1)])
 @pytest.mark.parametrize("shift", [0, 1])
 def test_window_attention_matches_restatement(dev, S, d, B, shift):
