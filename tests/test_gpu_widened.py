@@ -207,6 +207,36 @@ def test_baseline_config4_stress_005_voxels(dev, oracle_mod):
     assert torch.equal(lb([big[1]])[0], o1[1]), "frames are not independent"
 
 
+def test_baseline_config4_stress_005_voxels_f16_storage(dev):
+    """BASELINE configs[4] in ITS OWN data type at ITS OWN size: 0.05 m voxels, 500 k points per frame, f16 storage
+    (isf_encoder_options.precision = 2: f16 rows between the layers, f16 operands, fp32 accumulate -- the reference's
+    indice_conv_half).  Size-independent properties at full size: determinism, frame independence (a frame alone == the
+    same frame in a batch, bit for bit), the same occupied BEV cells as the fp32-class run, and agreement with it to f16
+    tolerance after 21 layers (one f16 ulp per layer op on O(1) features: a few 1e-3 of the feature scale)."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    vs = [0.05, 0.05, 0.2]
+    me = dict(m.ISFUSION_0075["pts_middle_encoder"])
+    me["sparse_shape"] = [41, 2160, 2160]
+    lb = m.LidarBranch(voxel_size=vs, pts_middle_encoder=me).randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    B, P = 2, 500000
+    big = [_T(synthetic.lidar_sweeps(7100 + i, P), dev) for i in range(B)]
+    h1 = lb(big, precision=2, want_stats=True)
+    assert lb.last_stats.num_in[0] > 400000                       # the 0.05 m grid really is the stress case
+    assert torch.isfinite(h1).all() and tuple(h1.shape) == (B, 512, 270, 270)
+    assert torch.equal(h1, lb(big, precision=2)), "f16 storage: not deterministic"
+    assert torch.equal(lb([big[1]], precision=2)[0], h1[1]), "f16 storage: frames are not independent"
+    f1 = lb(big)                                                  # fp32-class arithmetic on the same frames
+    scale = f1.abs().max().item()
+    assert scale > 0.1
+    # the occupied cells are geometry, not arithmetic: identical up to ReLU flips of values that are ~0 on both sides
+    differ = (h1 != 0) != (f1 != 0)
+    assert (torch.maximum(h1.abs(), f1.abs())[differ] < 3e-2 * scale).all()
+    err = (h1 - f1).abs().max().item()
+    assert err < 3e-2 * scale, (err, scale)                       # f16 tolerance after 21 layers (as the small-size test)
+    assert (h1 - f1).abs().mean().item() < 3e-3 * scale
+
+
 @pytest.mark.parametrize("name,seed,P,nf", [("nf4", 31, 3000, 4), ("nf5", 32, 2500, 5)])
 def test_hard_simple_vfe_matches_reference_golden(dev, golden, oracle_mod, name, seed, P, nf):
     import isfusion_amd as m
