@@ -222,7 +222,7 @@ def test_baseline_config4_stress_005_voxels_f16_storage(dev):
     B, P = 2, 500000
     big = [_T(synthetic.lidar_sweeps(7100 + i, P), dev) for i in range(B)]
     h1 = lb(big, precision=2, want_stats=True)
-    assert lb.last_stats.num_in[0] > 400000                       # the 0.05 m grid really is the stress case
+    assert lb.last_stats.num_in[0] > 300000                       # 2 x ~170 k voxels: the 0.05 m grid is the stress case
     assert torch.isfinite(h1).all() and tuple(h1.shape) == (B, 512, 270, 270)
     assert torch.equal(h1, lb(big, precision=2)), "f16 storage: not deterministic"
     assert torch.equal(lb([big[1]], precision=2)[0], h1[1]), "f16 storage: frames are not independent"
