@@ -125,6 +125,49 @@ __host__ __device__ inline size_t split_hi_index(size_t row, int c_units, int u)
   return (row * (size_t)c_units + (size_t)(u & ~3)) * 2 + (size_t)(u & 3);
 }
 
+// ----------------------------------------------------------------------------- voxel geometry (isf_voxelize.hip, isf_runtime.hip)
+__device__ __forceinline__ bool voxel_of_point(const float* __restrict__ p, float vx, float vy, float vz,
+                                               float x0, float y0, float z0, int gx, int gy, int gz,
+                                               int& cx, int& cy, int& cz) {
+  // fp32 subtract, fp32 IEEE divide, floor -- exactly voxelization_cpu.cpp:24 / voxelization_cuda.cu:37
+  const float fx = floorf(__fdiv_rn(__fsub_rn(p[0], x0), vx));
+  const float fy = floorf(__fdiv_rn(__fsub_rn(p[1], y0), vy));
+  const float fz = floorf(__fdiv_rn(__fsub_rn(p[2], z0), vz));
+  // float -> int: everything outside [0, grid) (incl. NaN / huge) is invalid
+  if (!(fx >= 0.f && fx < (float)gx && fy >= 0.f && fy < (float)gy && fz >= 0.f && fz < (float)gz))
+    return false;
+  cx = (int)fx; cy = (int)fy; cz = (int)fz;
+  return true;
+}
+
+struct VoxGeom {
+  float vx, vy, vz, x0, y0, z0;
+  int gx, gy, gz;
+};
+
+static inline VoxGeom make_geom(const float vs[3], const float range[6]) {
+  VoxGeom g;
+  g.vx = vs[0]; g.vy = vs[1]; g.vz = vs[2];
+  g.x0 = range[0]; g.y0 = range[1]; g.z0 = range[2];
+  // grid = round((max-min)/vs) in fp32 (voxelization_cpu.cpp:120-123)
+  g.gx = (int)roundf((range[3] - range[0]) / vs[0]);
+  g.gy = (int)roundf((range[4] - range[1]) / vs[1]);
+  g.gz = (int)roundf((range[5] - range[2]) / vs[2]);
+  return g;
+}
+
+
+// B <= kVoxMaxBatch frames of one launch: frame b owns points [off[b], off[b + 1])
+static constexpr int kVoxMaxBatch = 8;
+struct VoxBatch {
+  long long off[kVoxMaxBatch + 1];
+  int B;
+};
+// dynamic voxelization of ALL frames + byte-map marking of the level-0 occupancy index in ONE launch (the LiDAR branch ran
+// one voxelize launch per frame and re-read the coordinates in a separate mark launch); coors4 [P, 4] is written here.
+int occ_voxelize_mark_bytemap(Arena& a, const OccIndex& occ, const float* points, int P, int C, const VoxGeom& g,
+                              const VoxBatch& vb, int32_t* coors4, hipStream_t st);
+
 // ----------------------------------------------------------------------------- internal ops (arena-aware)
 // isf_voxelize.hip
 int dynamic_voxelize_impl(const float* points, int P, int C, const float vs[3], const float range[6],
@@ -138,7 +181,9 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
                      int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
                      hipStream_t st, hipEvent_t* coords_ready = nullptr,
                      void* voxel_feats_split = nullptr /* [P, c2] rows in the split format as well (whole rows are written
-                     there INSTEAD of voxel_feats; rows cut by a wave boundary in both) */);
+                     there INSTEAD of voxel_feats; rows cut by a wave boundary in both) */,
+                     const VoxBatch* voxelize = nullptr /* non-null: coors4 is an OUTPUT -- the frames are voxelized (vs,
+                     range) inside the byte-map marking launch (occ_voxelize_mark_bytemap) */);
 // isf_rulebook.hip
 int build_perm(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, int32_t** perm_out,
                hipStream_t st);

@@ -238,7 +238,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
@@ -250,7 +250,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -608,11 +608,21 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
   const int Cin = vfe_host->in_channels;
   int32_t* coors4 = nullptr;
   ISF_TRY(a.alloc_n(&coors4, (size_t)P * 4));
+  // batches of up to 8 frames: voxelized inside the byte-map marking launch of the VFE (one launch instead of B + 1 and
+  // one pass over the coordinates less); diagnostic 65536 and larger batches: one dynamic_voxelize launch per frame
+  VoxBatch vb;
+  vb.B = batch_size;
+  const bool fused_vox = batch_size <= kVoxMaxBatch && !(options && (options->diagnostic & 65536));
   for (int b = 0; b < batch_size; ++b) {
     const int64_t lo = point_offsets_host[b], hi = point_offsets_host[b + 1];
     ISF_REQUIRE(hi >= lo, ISF_ERR_ARG, "lidar_branch_forward: bad offsets");
-    ISF_TRY(dynamic_voxelize_impl(points + lo * Cin, (int)(hi - lo), Cin, vfe_host->voxel_size,
-                                  vfe_host->coors_range, coors4 + lo * 4, 4, 1, b, st));
+    if (fused_vox) {
+      vb.off[b] = lo;
+      vb.off[b + 1] = hi;
+    } else {
+      ISF_TRY(dynamic_voxelize_impl(points + lo * Cin, (int)(hi - lo), Cin, vfe_host->voxel_size,
+                                    vfe_host->coors_range, coors4 + lo * 4, 4, 1, b, st));
+    }
   }
   float* vf = nullptr;
   int32_t* vc = nullptr;
@@ -630,7 +640,7 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
   ISF_TRY(dynamic_vfe_impl(a, points, coors4, P, Cin, batch_size, vfe_host->voxel_size, vfe_host->coors_range,
                            vfe_host->w1, vfe_host->scale1, vfe_host->shift1, vfe_host->c1, vfe_host->w2,
                            vfe_host->scale2, vfe_host->shift2, vfe_host->c2, vf, vc, nullptr, &n0, &occ0,
-                           sparse_shape_host[0], st, &coords_ready, vf_split));
+                           sparse_shape_host[0], st, &coords_ready, vf_split, fused_vox ? &vb : nullptr));
   ISF_REQUIRE(n0 > 0, ISF_ERR_ARG, "lidar_branch_forward: no point falls inside the voxel grid");
   const bool occ_ok = occ0.D == sparse_shape_host[0] && occ0.H == sparse_shape_host[1] &&
                       occ0.W == sparse_shape_host[2];

@@ -312,6 +312,63 @@ __global__ __launch_bounds__(256) void occ_bytemap_pack_kernel(unsigned char* __
   reinterpret_cast<ulonglong2*>(bits + w0)[1] = make_ulonglong2(out[2], out[3]);
 }
 
+// voxelize + mark: thread -> point; the frame of a point by a walk over <= 8 offsets; coordinates exactly as
+// dynamic_voxelize_kernel computes them (voxel_of_point), (b, z, y, x) or (b, -1, -1, -1)
+__global__ __launch_bounds__(256) void occ_voxelize_mark_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+                                                                VoxBatch vb, int D, int32_t* __restrict__ coors4,
+                                                                unsigned char* __restrict__ fine,
+                                                                unsigned char* __restrict__ coarse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  int b = 0;
+#pragma unroll
+  for (int k = 1; k < kVoxMaxBatch; ++k) b += (k < vb.B && (long long)i >= vb.off[k]) ? 1 : 0;
+  int cx, cy, cz;
+  const bool ok = voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx, cy, cz);
+  reinterpret_cast<int4*>(coors4)[i] = ok ? make_int4(b, cz, cy, cx) : make_int4(b, -1, -1, -1);
+  if (ok && cz < D) {
+    const unsigned long long cell = (((unsigned long long)b * D + cz) * g.gy + cy) * g.gx + cx;
+    fine[cell] = 1;
+    coarse[cell >> 6] = 1;
+  }
+}
+
+static int occ_bytemaps_ensure(Arena& a, const OccIndex& occ, hipStream_t st, size_t* alloc_words_out) {
+  ByteMaps& bm = a.bytemaps;
+  const size_t alloc_words = round_up(occ.nwords, kWordsPerBlock);
+  *alloc_words_out = alloc_words;
+  if (bm.words < alloc_words) {  // (re)allocate the persistent maps; zeroed once, kept zero by the pack pass
+    ISF_HIP_TRY(hipStreamSynchronize(st));
+    if (bm.fine) { ISF_HIP_TRY(hipFree(bm.fine)); ISF_HIP_TRY(hipFree(bm.coarse)); bm = ByteMaps(); }
+    if (hipMalloc(&bm.fine, alloc_words * 64) != hipSuccess || hipMalloc(&bm.coarse, alloc_words) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("occupancy byte maps: hipMalloc(%zu) failed", alloc_words * 65);
+      return ISF_ERR_NOMEM;
+    }
+    ISF_HIP_TRY(hipMemsetAsync(bm.fine, 0, alloc_words * 64, st));
+    ISF_HIP_TRY(hipMemsetAsync(bm.coarse, 0, alloc_words, st));
+    bm.words = alloc_words;
+  }
+  return ISF_OK;
+}
+
+int occ_voxelize_mark_bytemap(Arena& a, const OccIndex& occ, const float* points, int P, int C, const VoxGeom& g,
+                              const VoxBatch& vb, int32_t* coors4, hipStream_t st) {
+  ISF_REQUIRE(vb.B >= 1 && vb.B <= kVoxMaxBatch && vb.B == occ.B && g.gy == occ.H && g.gx == occ.W && g.gz <= occ.D,
+              ISF_ERR_ARG, "voxelize + mark: %d frames, grid %d x %d x %d vs index %d x %d x %d", vb.B, g.gz, g.gy, g.gx,
+              occ.D, occ.H, occ.W);
+  size_t alloc_words = 0;
+  ISF_TRY(occ_bytemaps_ensure(a, occ, st, &alloc_words));
+  ByteMaps& bm = a.bytemaps;
+  if (P > 0)
+    hipLaunchKernelGGL(occ_voxelize_mark_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, vb, occ.D, coors4,
+                       bm.fine, bm.coarse);
+  hipLaunchKernelGGL(occ_bytemap_pack_kernel, dim3(ceil_div((long long)(alloc_words / 4), 256)), dim3(256), 0, st,
+                     bm.fine, bm.coarse, alloc_words, occ.bits);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 int occ_mark_coords4_bytemap(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st) {
   ByteMaps& bm = a.bytemaps;
   const size_t alloc_words = round_up(occ.nwords, kWordsPerBlock);

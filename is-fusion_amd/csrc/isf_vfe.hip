@@ -541,12 +541,15 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
                    VfeGeom g, const float* w1, const float* scale1, const float* shift1, const float* w2,
                    const float* scale2, const float* shift2, float* voxel_feats, int32_t* voxel_coors,
                    int32_t* pt2vox_out, int* n_host, OccIndex* occ_out, int d_alloc, hipStream_t st,
-                   hipEvent_t* coords_ready, void* voxel_feats_split) {
+                   hipEvent_t* coords_ready, void* voxel_feats_split, const VoxBatch* voxelize, const VoxGeom* vgeom) {
   const int F = CIN + 6;
   OccIndex occ;
   // d_alloc > grid z lets the sparse encoder (sparse_shape[0] = grid z + 1) reuse this index for level 0
   ISF_TRY(occ_create(a, &occ, B, d_alloc > grid[2] ? d_alloc : grid[2], grid[1], grid[0], st, false));
-  ISF_TRY(occ_mark_coords4_bytemap(a, occ, coors4, P, st));
+  if (voxelize)   // the frames are voxelized inside the marking launch; coors4 is written there
+    ISF_TRY(occ_voxelize_mark_bytemap(a, occ, points, P, CIN, *vgeom, *voxelize, const_cast<int32_t*>(coors4), st));
+  else
+    ISF_TRY(occ_mark_coords4_bytemap(a, occ, coors4, P, st));
   ISF_TRY(occ_scan(a, occ, st));
   float *sc1, *sc2;
   uint2* w1p;
@@ -617,7 +620,7 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
                      const float* shift1, int c1, const float* w2, const float* scale2,
                      const float* shift2, int c2, float* voxel_feats, int32_t* voxel_coors,
                      int32_t* pt2vox, int* num_voxels_host, OccIndex* occ_out, int grid_d_alloc,
-                     hipStream_t st, hipEvent_t* coords_ready, void* voxel_feats_split) {
+                     hipStream_t st, hipEvent_t* coords_ready, void* voxel_feats_split, const VoxBatch* voxelize) {
   ISF_REQUIRE(c1 == kC && c2 == kC, ISF_ERR_UNSUPPORTED,
               "dynamic_vfe: feat_channels (%d,%d) not built; this build has (64,64)", c1, c2);
   ISF_REQUIRE(Cin == 4 || Cin == 5, ISF_ERR_UNSUPPORTED, "dynamic_vfe: in_channels %d not built (4|5)", Cin);
@@ -628,12 +631,14 @@ int dynamic_vfe_impl(Arena& a, const float* points, const int32_t* coors4, int P
   VfeGeom g;
   g.vx = vs[0]; g.vy = vs[1]; g.vz = vs[2];
   g.ox = vs[0] / 2 + range[0]; g.oy = vs[1] / 2 + range[1]; g.oz = vs[2] / 2 + range[2];
+  const VoxGeom vg = make_geom(vs, range);
   if (Cin == 5)
     return vfe_run<5>(a, points, coors4, P, B, grid, g, w1, scale1, shift1, w2, scale2, shift2,
                       voxel_feats, voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready,
-                      voxel_feats_split);
+                      voxel_feats_split, voxelize, &vg);
   return vfe_run<4>(a, points, coors4, P, B, grid, g, w1, scale1, shift1, w2, scale2, shift2, voxel_feats,
-                    voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready, voxel_feats_split);
+                    voxel_coors, pt2vox, num_voxels_host, occ_out, grid_d_alloc, st, coords_ready, voxel_feats_split,
+                    voxelize, &vg);
 }
 
 }  // namespace isf

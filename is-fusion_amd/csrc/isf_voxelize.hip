@@ -16,36 +16,6 @@
 
 namespace isf {
 
-__device__ __forceinline__ bool voxel_of_point(const float* __restrict__ p, float vx, float vy, float vz,
-                                               float x0, float y0, float z0, int gx, int gy, int gz,
-                                               int& cx, int& cy, int& cz) {
-  // fp32 subtract, fp32 IEEE divide, floor -- exactly voxelization_cpu.cpp:24 / voxelization_cuda.cu:37
-  const float fx = floorf(__fdiv_rn(__fsub_rn(p[0], x0), vx));
-  const float fy = floorf(__fdiv_rn(__fsub_rn(p[1], y0), vy));
-  const float fz = floorf(__fdiv_rn(__fsub_rn(p[2], z0), vz));
-  // float -> int: everything outside [0, grid) (incl. NaN / huge) is invalid
-  if (!(fx >= 0.f && fx < (float)gx && fy >= 0.f && fy < (float)gy && fz >= 0.f && fz < (float)gz))
-    return false;
-  cx = (int)fx; cy = (int)fy; cz = (int)fz;
-  return true;
-}
-
-struct VoxGeom {
-  float vx, vy, vz, x0, y0, z0;
-  int gx, gy, gz;
-};
-
-static VoxGeom make_geom(const float vs[3], const float range[6]) {
-  VoxGeom g;
-  g.vx = vs[0]; g.vy = vs[1]; g.vz = vs[2];
-  g.x0 = range[0]; g.y0 = range[1]; g.z0 = range[2];
-  // grid = round((max-min)/vs) in fp32 (voxelization_cpu.cpp:120-123)
-  g.gx = (int)roundf((range[3] - range[0]) / vs[0]);
-  g.gy = (int)roundf((range[4] - range[1]) / vs[1]);
-  g.gz = (int)roundf((range[5] - range[2]) / vs[2]);
-  return g;
-}
-
 __global__ void dynamic_voxelize_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
                                         int32_t* __restrict__ coors, int stride, int col0,
                                         int batch_idx) {

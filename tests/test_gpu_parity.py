@@ -713,13 +713,16 @@ def test_lidar_branch_line_tables_reproduce_dense_table_bits(dev):
     import isfusion_amd as m
     from isfusion_amd import synthetic
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
-    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4), (2000, 9)):     # 9 frames: more than one fused launch holds
         pl = [T(synthetic.lidar_sweeps(990 + i, n), dev) for i in range(frames)]
         want = lb(pl, conv_diag=16384)
         assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
         assert torch.equal(lb(pl), want), n
         assert torch.equal(lb(pl, conv_diag=64), lb(pl, conv_diag=64 + 16384)), n
         assert torch.equal(lb(pl, precision=2), lb(pl, precision=2, conv_diag=16384)), n
+        # the frames are voxelized inside the VFE's byte-map marking launch (one launch for the whole batch); diagnostic
+        # 65536 = one dynamic-voxelize launch per frame + a separate marking pass
+        assert torch.equal(lb(pl, conv_diag=65536), want), n
         st0 = lb(pl, want_stats=True) is not None and lb.last_stats
         st1 = lb(pl, want_stats=True, conv_diag=16384) is not None and lb.last_stats
         assert [st0.pairs[i] for i in range(21)] == [st1.pairs[i] for i in range(21)]      # same pair counts either way
