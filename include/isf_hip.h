@@ -391,6 +391,8 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            256-column layers on isf_sparse_conv_forward_cu (one workgroup per CU; opt-in: measured slower than
  *            the tile kernel) -- results bit-identical either way; +1024 * v = isf_conv_cu_plan.variant v of those layers (timing diagnostics, v < 16);
  *            +16384 = dense neighbour tables for the narrow layers instead of the line-compressed ones -- bit-identical;
+ *            +131072 = the encoder's per-level row counts reach the host through hipMemcpyAsync + synchronise instead of
+ *            the pinned-memory mailbox (post_int / wait_int) -- bit-identical;
  *            +65536 (isf_lidar_branch_forward) = one dynamic-voxelize launch per frame + a separate byte-map marking pass
  *            instead of the fused voxelize + mark launch -- bit-identical;
  *            +32768 = equal-work tile tables for the deep levels instead of uniform tiles + tile order (opt-in:

@@ -67,6 +67,10 @@ class Arena {
   std::vector<hipEvent_t> events;           // recycled hipEventDisableTiming events
   size_t next_event = 0;
   ByteMaps bytemaps;
+  // host mailbox (post_int / wait_int): a ring of (value, ticket) pairs in pinned, device-mapped host memory
+  int* mailbox_host = nullptr;
+  int* mailbox_dev = nullptr;
+  unsigned mailbox_seq = 0;
  private:
   struct Block { char* base; size_t cap; size_t off; };
   std::vector<Block> blocks_;
@@ -100,6 +104,13 @@ int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStrea
 // coords of all set bits in rank order -> out [total,4]
 int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st);
 int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream sync
+// A device int -> the host WITHOUT a copy command: a one-thread kernel writes (value, ticket) into pinned host memory
+// behind the producer on `st` and the host spins on the ticket.  hipMemcpyAsync D2H + synchronise costs a copy-engine
+// command with 20-40 us of GPU idle around it every time a data-dependent count sizes the next launches
+// (profiles/r04_v1_timeline_gaps.txt: every large gap of a step sits behind a copyBuffer).  post_int returns at once;
+// work queued between post_int and wait_int runs while the host waits.
+int post_int(Arena& a, const int* dev, hipStream_t st, unsigned* ticket);
+int wait_int(Arena& a, unsigned ticket, hipStream_t st, int* value);
 int side_stream(Arena& a, hipStream_t* out);               // the workspace's non-blocking helper stream
 int stream_wait_stream(Arena& a, hipStream_t waiter, hipStream_t producer);  // event from the workspace's pool
 int pooled_event(Arena& a, hipEvent_t* out);               // recycled hipEventDisableTiming events

@@ -238,19 +238,20 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
                                                            // tile tables instead of uniform tiles + LPT order
   const bool line_tables = (diagnostic & 256 * 64) == 0;   // bit 16384: full neighbour tables for the narrow layers too
+  const bool mailbox = (diagnostic & 131072) == 0;         // bit 131072: data-dependent counts through hipMemcpyAsync + sync
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -419,7 +420,13 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       ISF_TRY(occ_create(a, &Nx.occ, B, Nx.shape[0], Nx.shape[1], Nx.shape[2], sg));
       ISF_TRY(launch_mark_out(L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, Nx.occ, sg));
       ISF_TRY(occ_scan(a, Nx.occ, sg));
-      ISF_TRY(read_int(Nx.occ.total, &Nx.n, sg));  // host sync: sizes the next level's buffers / grids
+      if (mailbox) {                               // host wait without a copy command (post_int / wait_int)
+        unsigned ticket = 0;
+        ISF_TRY(post_int(a, Nx.occ.total, sg, &ticket));
+        ISF_TRY(wait_int(a, ticket, sg, &Nx.n));
+      } else {
+        ISF_TRY(read_int(Nx.occ.total, &Nx.n, sg));  // host sync: sizes the next level's buffers / grids
+      }
       Nx.has_occ = true;
       int32_t* nc = nullptr;
       ISF_TRY(a.alloc_n(&nc, (size_t)std::max(Nx.n, 1) * 4));

@@ -62,7 +62,7 @@ int Arena::alloc(void** out, size_t bytes) {
 }
 
 int Arena::release() {
-  if (!blocks_.empty() || bytemaps.fine || side) ISF_HIP_TRY(hipDeviceSynchronize());
+  if (!blocks_.empty() || bytemaps.fine || side || mailbox_host) ISF_HIP_TRY(hipDeviceSynchronize());
   for (auto& b : blocks_) ISF_HIP_TRY(hipFree(b.base));
   blocks_.clear();
   if (bytemaps.fine) {
@@ -76,6 +76,10 @@ int Arena::release() {
   if (side) {
     (void)hipStreamDestroy(side);
     side = nullptr;
+  }
+  if (mailbox_host) {
+    (void)hipHostFree(mailbox_host);
+    mailbox_host = mailbox_dev = nullptr;
   }
   return ISF_OK;
 }
@@ -142,6 +146,62 @@ int stream_wait_stream(Arena& a, hipStream_t waiter, hipStream_t producer) {
   ISF_TRY(pooled_event(a, &e));
   ISF_HIP_TRY(hipEventRecord(e, producer));
   ISF_HIP_TRY(hipStreamWaitEvent(waiter, e, 0));
+  return ISF_OK;
+}
+
+static constexpr unsigned kMailboxSlots = 64;
+
+__global__ void publish_int_kernel(const int* __restrict__ src, volatile int* box, int ticket) {
+  box[0] = *src;
+  __threadfence_system();
+  box[1] = ticket;
+  __threadfence_system();
+}
+
+int post_int(Arena& a, const int* dev, hipStream_t st, unsigned* ticket) {
+  if (!a.mailbox_host) {
+    void* h = nullptr;
+    ISF_HIP_TRY(hipHostMalloc(&h, kMailboxSlots * 2 * sizeof(int), hipHostMallocMapped));
+    memset(h, 0, kMailboxSlots * 2 * sizeof(int));
+    void* d = nullptr;
+    ISF_HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+    a.mailbox_host = reinterpret_cast<int*>(h);
+    a.mailbox_dev = reinterpret_cast<int*>(d);
+    a.mailbox_seq = 0;
+  }
+  const unsigned t = ++a.mailbox_seq;          // tickets start at 1: a zeroed slot never matches
+  const unsigned slot = t % kMailboxSlots;
+  hipLaunchKernelGGL(publish_int_kernel, dim3(1), dim3(1), 0, st, dev, a.mailbox_dev + 2 * slot, (int)t);
+  ISF_LAUNCH_CHECK();
+  *ticket = t;
+  return ISF_OK;
+}
+
+int wait_int(Arena& a, unsigned ticket, hipStream_t st, int* value) {
+  ISF_REQUIRE(a.mailbox_host && ticket != 0 && a.mailbox_seq - ticket < kMailboxSlots, ISF_ERR_ARG,
+              "wait_int: ticket %u is not in flight", ticket);
+  volatile int* box = a.mailbox_host + 2 * (ticket % kMailboxSlots);
+  unsigned spins = 0;
+  while ((unsigned)box[1] != ticket) {
+    if ((++spins & 0x3fff) == 0) {             // every 16 k polls: has the stream died or drained without our kernel?
+      const hipError_t q = hipStreamQuery(st);
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        set_error("wait_int: stream error while waiting for a device count: %s", hipGetErrorString(q));
+        return ISF_ERR_HIP;
+      }
+      if (q == hipSuccess && (unsigned)box[1] != ticket) {   // drained: the write must be visible by now
+        ISF_HIP_TRY(hipStreamSynchronize(st));
+        if ((unsigned)box[1] != ticket) {
+          set_error("wait_int: ticket %u never arrived", ticket);
+          return ISF_ERR_HIP;
+        }
+      }
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  *value = box[0];
   return ISF_OK;
 }
 

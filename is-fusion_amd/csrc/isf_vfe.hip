@@ -565,10 +565,8 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   // waits, so the GPU keeps working while the host wakes up and launches the rest (the plain hipStreamSynchronize left
   // it idle for ~50 us per forward: profiles/r02_call22_timeline_gaps.txt).
   int N = 0;
-  hipEvent_t n_ready;
-  ISF_HIP_TRY(hipMemcpyAsync(&N, occ.total, sizeof(int), hipMemcpyDeviceToHost, st));
-  ISF_TRY(pooled_event(a, &n_ready));
-  ISF_HIP_TRY(hipEventRecord(n_ready, st));
+  unsigned n_ticket = 0;
+  ISF_TRY(post_int(a, occ.total, st, &n_ticket));   // (value, ticket) into pinned host memory: no copy command
   int32_t* pt2vox = pt2vox_out;
   if (!pt2vox) ISF_TRY(a.alloc_n(&pt2vox, (size_t)P));
   int32_t* slot;
@@ -587,7 +585,7 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
     ISF_TRY(pooled_event(a, coords_ready));
     ISF_HIP_TRY(hipEventRecord(*coords_ready, st));
   }
-  ISF_HIP_TRY(hipEventSynchronize(n_ready));
+  ISF_TRY(wait_int(a, n_ticket, st, &N));
   *n_host = N;
   if (occ_out) *occ_out = occ;
   if (N == 0) return ISF_OK;   // vfe_count_kernel has marked every point -1

@@ -723,6 +723,9 @@ def test_lidar_branch_line_tables_reproduce_dense_table_bits(dev):
         # the frames are voxelized inside the VFE's byte-map marking launch (one launch for the whole batch); diagnostic
         # 65536 = one dynamic-voxelize launch per frame + a separate marking pass
         assert torch.equal(lb(pl, conv_diag=65536), want), n
+        # the per-level row counts reach the host through a pinned-memory mailbox (a one-thread kernel + a host spin on
+        # the ticket); diagnostic 131072 = hipMemcpyAsync + synchronise
+        assert torch.equal(lb(pl, conv_diag=131072), want), n
         st0 = lb(pl, want_stats=True) is not None and lb.last_stats
         st1 = lb(pl, want_stats=True, conv_diag=16384) is not None and lb.last_stats
         assert [st0.pairs[i] for i in range(21)] == [st1.pairs[i] for i in range(21)]      # same pair counts either way
