@@ -224,13 +224,16 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
  * (16-row group, tap) pairs that have a neighbour -- varies ~3x across a LiDAR sweep.  isf_sparse_conv_tile_order counts
  * that work per tile of the launch isf_sparse_conv_forward_f16x3 would make for (c_in, c_out, mode, num_out) and hands
  * the tiles out longest-first to the least-loaded CU with a free slot; `order` (and the scratch `work`) hold at most
- * 8 * 255 ints, *num_entries = how many were written (0: the launch is not a single round -- pass order = NULL).
+ * 8 * 255 ints, *num_entries = how many were written (0: the launch is not a single round -- pass order = NULL).  A
+ * table belongs to ONE kernel's launch plan: mode + 2048 builds it for isf_sparse_conv_forward_dma (whose workgroups per
+ * CU, and with them the tiles, differ from isf_sparse_conv_forward_f16x3's on the same shape).
  * One table serves every layer of that channel shape on the rulebook (isf_sparse_encoder_forward builds it per level
  * behind the neighbour table).  isf_sparse_conv_forward_f16x3_ordered = the same convolution with workgroup slot j
  * working on tile order[j]: results bit-identical to isf_sparse_conv_forward_f16x3 (the same tiles compute the same
  * rows).  Replaces nothing in the reference (its gather -> GEMM -> scatter has no tiles); measured in DESIGN.md
  * section 5.1.  isf_sparse_conv_trace: DIAGNOSTIC -- the production launch of a 128 -> 128 or 256 -> 256 layer that also
- * writes 8 int64 per workgroup (trace [grid_blocks * 8], zero it first: 100 MHz time stamps at entry / after the
+ * writes 8 int64 per workgroup (trace [trace_capacity_blocks * 8], zero it first; a launch of more workgroups than the
+ * buffer holds is refused: 100 MHz time stamps at entry / after the
  * prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half tile << 32); tools/conv_trace.py. */
 int isf_sparse_conv_tile_order(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
                                int mode, int32_t* work, int32_t* order, int* num_entries, isf_stream_t stream);
@@ -261,7 +264,8 @@ int isf_sparse_conv_tile_table_host(const int32_t* work, int num_groups, int par
 int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
                           int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
                           const float* shift, const void* residual_split, int relu, void* out_split,
-                          const int32_t* order, long long* trace, int* grid_blocks, isf_stream_t stream);
+                          const int32_t* order, long long* trace, int trace_capacity_blocks, int* grid_blocks,
+                          isf_stream_t stream);
 /* The same convolution for the NARROW layers (c_in, c_out in {32, 64}) with the gathered rows brought in by LDS-DMA
  * (isf_spconv_dma.hip; mode 0 | 1 | 257, +32; order: NULL or isf_sparse_conv_tile_order's table).  A gather instruction of
  * isf_sparse_conv_forward_f16x3 loads straight into the MFMA operand layout -- four different rows = four cache lines per

@@ -151,8 +151,8 @@ SIGNATURES = {
     "isf_sparse_conv_tile_table_host": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                 ctypes.POINTER(c_int)]),
     "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
-                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int),
-                                      c_void_p]),
+                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                      ctypes.POINTER(c_int), c_void_p]),
     "isf_rulebook_to_lines": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isf_lines_to_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_dma_lines": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -521,8 +521,8 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
 // launch goes -- tools/conv_trace.py
 int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
                            int nbr_stride, int n_out, const float* scale, const float* shift, const void* residual,
-                           int relu, void* ys, const int32_t* order, long long* trace, int* grid_blocks,
-                           hipStream_t st) {
+                           int relu, void* ys, const int32_t* order, long long* trace, int trace_capacity_blocks,
+                           int* grid_blocks, hipStream_t st) {
   ISF_REQUIRE((c_in == 256 && c_out == 256) || (c_in == 128 && c_out == 128), ISF_ERR_UNSUPPORTED,
               "sparse_conv_trace: built for 128 -> 128 and 256 -> 256, got %d -> %d", c_in, c_out);
   ISF_REQUIRE(K >= 1 && K <= kMaxTaps && n_out > 0 && nbr_stride % 128 == 0 && nbr_stride >= n_out, ISF_ERR_ARG,
@@ -536,6 +536,10 @@ int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K
   const bool wide = c_out == 128 && n_out >= 8 * 256;
   for (int pass = 0; pass < 2; ++pass) {   // pass 0: the launch shape (grid size), pass 1: launch
     Conv16LaunchInfo* q = pass == 0 ? &info : nullptr;
+    if (pass == 1)   // the kernel writes trace + 8 * blockIdx.x for every workgroup of the grid (unchecked before)
+      ISF_REQUIRE(8 * (info.full + info.half) <= trace_capacity_blocks, ISF_ERR_ARG,
+                  "sparse_conv_trace: the launch has %d workgroups, the trace buffer holds %d", 8 * (info.full + info.half),
+                  trace_capacity_blocks);
     int rc;
     if (c_in == 256) rc = launch16<256, 8, 2, 4, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
     else if (wide) rc = launch16<128, 8, 2, 8, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
@@ -808,8 +812,16 @@ int isf_sparse_conv_tile_order(const int32_t* nbr, int nbr_stride, int num_taps,
   ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "sparse_conv_tile_order: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
   isf::Conv16LaunchInfo info;
-  ISF_TRY(isf::sparse_conv_forward_f16x3_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
-                                              nullptr, nullptr, 0, nullptr, mode, isf::as_stream(stream), nullptr, &info));
+  if (mode & 2048) {   // the table is for isf_sparse_conv_forward_dma: its launch plan differs (workgroups per CU)
+    ISF_REQUIRE(isf::sparse_conv_dma_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
+                "sparse_conv_tile_order: (Cin,Cout)=(%d,%d) has no LDS-DMA kernel", c_in, c_out);
+    ISF_TRY(isf::sparse_conv_forward_dma_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
+                                              nullptr, nullptr, 0, nullptr, mode & ~2048, isf::as_stream(stream), nullptr,
+                                              &info));
+  } else {
+    ISF_TRY(isf::sparse_conv_forward_f16x3_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
+                                                nullptr, nullptr, 0, nullptr, mode, isf::as_stream(stream), nullptr, &info));
+  }
   if (!isf::conv16_order_applies(info)) return ISF_OK;
   *num_entries = isf::conv16_order_parts(info) * isf::conv16_order_tiles(info);
   return isf::conv16_tile_order_impl(nbr, nbr_stride, num_taps, num_out, info, work, order, isf::as_stream(stream));
@@ -885,12 +897,14 @@ int isf_sparse_conv_tile_table_host(const int32_t* work, int num_groups, int par
 int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
                           int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
                           const float* shift, const void* residual_split, int relu, void* out_split,
-                          const int32_t* order, long long* trace, int* grid_blocks, isf_stream_t stream) {
+                          const int32_t* order, long long* trace, int trace_capacity_blocks, int* grid_blocks,
+                          isf_stream_t stream) {
   ISF_REQUIRE(num_in >= 0 && features_split && packed16 && nbr && out_split && trace && grid_blocks &&
+                  trace_capacity_blocks > 0 &&
                   ((scale == nullptr) == (shift == nullptr)), ISF_ERR_ARG, "sparse_conv_trace: bad arguments");
   return isf::sparse_conv_trace_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
-                                     shift, residual_split, relu, out_split, order, trace, grid_blocks,
-                                     isf::as_stream(stream));
+                                     shift, residual_split, relu, out_split, order, trace, trace_capacity_blocks,
+                                     grid_blocks, isf::as_stream(stream));
 }
 
 }  // extern "C"

@@ -184,11 +184,13 @@ def from_half(xh, shape):
     return out
 
 
-def tile_order(rb, c_in, c_out, mode=0):
-    """int32 tile order of the launch sparse_conv_forward_f16x3 makes for this rulebook and channel shape
-    (isf_sparse_conv_tile_order), or None when the launch is not a single resident round.  Cached on the rulebook."""
+def tile_order(rb, c_in, c_out, mode=0, dma=False):
+    """int32 tile order of the launch sparse_conv_forward_f16x3 (dma=True: sparse_conv_forward_dma -- its launch plan
+    differs) makes for this rulebook and channel shape (isf_sparse_conv_tile_order), or None when the launch is not a
+    single resident round.  Cached on the rulebook per (shape, mode, kernel)."""
     cache = rb.__dict__.setdefault("_tile_order", {})
-    key = (int(c_in), int(c_out), int(mode))
+    mode = int(mode) | (2048 if dma else 0)
+    key = (int(c_in), int(c_out), mode)
     if key not in cache:
         lib = _lib.load()
         K = rb.nbr.numel() // rb.stride
@@ -397,12 +399,13 @@ def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, 
     _lib.require_cuda(xs)
     lib = _lib.load()
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
-    trace = torch.zeros((8 * 255 * 8,), dtype=torch.int64, device=xs.device)
+    cap = 8 * 255
+    trace = torch.zeros((cap * 8,), dtype=torch.int64, device=xs.device)
     n = ctypes.c_int(0)
     _lib.check(lib.isf_sparse_conv_trace(_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr),
                                          rb.stride, rb.num_out, _lib.ptr(scale), _lib.ptr(shift),
                                          _lib.ptr(residual_split), int(bool(relu)), _lib.ptr(ys), _lib.ptr(order),
-                                         _lib.ptr(trace), ctypes.byref(n), _lib.stream()), "isf_sparse_conv_trace")
+                                         _lib.ptr(trace), cap, ctypes.byref(n), _lib.stream()), "isf_sparse_conv_trace")
     return ys, trace[:n.value * 8].view(n.value, 8)
 
 

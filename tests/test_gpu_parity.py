@@ -588,6 +588,11 @@ def test_dma_gather_kernel_bit_identical_to_gather_kernel(dev, cin, cout):
                 ref = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode)
                 got = sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode)
                 assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks, mode)
+                if mode != 32:       # the tile order of the DMA kernel's OWN launch plan (not the f16x3 plan's)
+                    od = sp.tile_order(rb, cin, cout, mode, dma=True)
+                    if od is not None:
+                        got = sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode, order=od)
+                        assert torch.equal(got, ref), (n, subm, ks, mode, "ordered")
             got = sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb)          # no epilogue terms
             assert torch.equal(got, sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb))
     with pytest.raises(Exception):
