@@ -59,21 +59,41 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict_
     for (int t = 0; t < 4; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int r_begin = chunk * rows_per_chunk, r_end = min(n_out, r_begin + rows_per_chunk);
   const int32_t* nk = nbr + (size_t)k * nbr_stride;
-  for (int r0 = r_begin; r0 < r_end; r0 += 4) {
+  // Software pipeline (round 4): the neighbour index of a 4-row group is fetched TWO groups ahead and its x / dy rows ONE
+  // group ahead, so the 16 MFMAs of a group run while the next group's 32 bytes per lane are in flight (the plain loop
+  // paid index latency + row latency in front of every 16 MFMAs: 3.6 % of the fp32 matrix rate over a training step).
+  // Same products in the same order per accumulator: results are bit-identical.
+  auto idx_of = [&](int r0) -> int {
     const int row = r0 + kslot;
-    const int in = row < r_end ? nk[row] : -1;
-    if (__ballot(in >= 0) == 0ull) continue;
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
+    return (r0 < r_end && row < r_end) ? nk[row] : -1;
+  };
+  auto load_rows = [&](int r0, int in, f32x4& a, f32x4& b) {
+    a = f32x4{0.f, 0.f, 0.f, 0.f};
+    b = f32x4{0.f, 0.f, 0.f, 0.f};
     if (in >= 0) {
       if (a_ok) a = *reinterpret_cast<const f32x4*>(x + (size_t)in * cin + ci_base + 4 * sub);
-      if (b_ok) b = *reinterpret_cast<const f32x4*>(dy + (size_t)row * cout + co_base + 4 * sub);
+      if (b_ok) b = *reinterpret_cast<const f32x4*>(dy + (size_t)(r0 + kslot) * cout + co_base + 4 * sub);
     }
-    // A[m = sub][k = kslot] of M tile s = x[in(row kslot)][ci_base + 4*sub + s]; B[k = kslot][n = sub] of N tile t =
-    // dy[row kslot][co_base + 4*sub + t]
+  };
+  int in_cur = idx_of(r_begin), in_nxt = idx_of(r_begin + 4);
+  f32x4 a_cur, b_cur, a_nxt, b_nxt;
+  load_rows(r_begin, in_cur, a_cur, b_cur);
+  for (int r0 = r_begin; r0 < r_end; r0 += 4) {
+    const int in_nn = idx_of(r0 + 8);                       // index two groups ahead
+    load_rows(r0 + 4, in_nxt, a_nxt, b_nxt);                // rows one group ahead (in_nxt arrived a group ago)
+    if (__ballot(in_cur >= 0) != 0ull) {
+      // A[m = sub][k = kslot] of M tile s = x[in(row kslot)][ci_base + 4*sub + s]; B[k = kslot][n = sub] of N tile t =
+      // dy[row kslot][co_base + 4*sub + t]
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t], acc[s][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[t], acc[s][t], 0, 0, 0);
+    }
+    in_cur = in_nxt;
+    in_nxt = in_nn;
+    a_cur = a_nxt;
+    b_cur = b_nxt;
   }
   // C/D layout: acc[s][t][r] = C[m = 4*kslot + r][n = sub]  ->  dW[ci_base + 4*m + s][co_base + 4*n + t]
   float* out = partial + ((size_t)chunk * K + k) * cin * cout;
