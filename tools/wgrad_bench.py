@@ -19,8 +19,11 @@ def main():
     ap.add_argument("--rows", type=int, default=40000)
     ap.add_argument("--cin", type=int, default=256)
     ap.add_argument("--cout", type=int, default=256)
+    ap.add_argument("--lib", default="", help="A/B: load this build of libisf_hip.so instead of the in-tree one")
     a = ap.parse_args()
     from isfusion_amd import _lib, spconv as sp
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
     B, shape = 2, [12, 96, 96]
