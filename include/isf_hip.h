@@ -291,9 +291,6 @@ int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in
  * = isf_sparse_conv_forward_dma reading the compressed table (a lane keeps its rows' masks in registers and loads one
  * index per LINE): results BIT-IDENTICAL.  isf_sparse_encoder_forward / isf_lidar_branch_forward build the tables of their
  * narrow levels directly in this form (diagnostic +16384: dense tables).  taps_per_line = kernel width (1 or 3).
- * mode as isf_sparse_conv_forward_dma, plus 512 (with mode 0 / 32 only): every step ends with throw-away loads of the
- * rows of the tap after next, left in flight across the step's wait so that the rows' DMA two steps later finds them
- * in the L2 -- same bits (encoder diagnostic +262144; measured in DESIGN.md section 5.5).
  * Replaces nothing in the reference (its rulebook is pair lists, indice.cu.h:22-203); measured in DESIGN.md section 5.3. */
 int isf_rulebook_to_lines(const int32_t* nbr, int nbr_stride, int num_taps, int taps_per_line, int num_out,
                           int32_t* lines, uint32_t* mask, int* not_consecutive_flag, isf_stream_t stream);
@@ -402,8 +399,6 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            the pinned-memory mailbox (post_int / wait_int) -- bit-identical;
  *            +65536 (isf_lidar_branch_forward) = one dynamic-voxelize launch per frame + a separate byte-map marking pass
  *            instead of the fused voxelize + mark launch -- bit-identical;
- *            +262144 = the narrow layers' kernel warms the L2 with the rows of the tap after next (mode 512 of
- *            isf_sparse_conv_forward_dma_lines) -- bit-identical;
  *            +32768 = equal-work tile tables for the deep levels instead of uniform tiles + tile order (opt-in:
  *            measured slower) -- bit-identical;
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */

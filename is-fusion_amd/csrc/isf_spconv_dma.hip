@@ -27,7 +27,6 @@
 //     5 / 6 workgroups per CU instead of 3;
 //   * rows without a neighbour read a zero line instead of being masked (the DMA writes every lane's 16 bytes); no
 //     neighbour sharing (every row is fetched, at a quarter of the cost).
-#include <type_traits>
 #include "isf_spconv16.h"
 
 #include <atomic>
@@ -51,35 +50,15 @@ struct ConvDmaSmem {
 // first present neighbour of a (kz, ky) line), `lmask` [nbr_stride] (bit k: tap k present); a lane keeps its rows' masks
 // in registers and loads one int32 per LINE (one line ahead) instead of one per tap; the prologue reads one word per row
 // instead of 27.  Same indices, same products: bit-identical.
-// WARM register plan.  The loop of the warming variant keeps loads in flight ACROSS its per-step wait (s_waitcnt
-// vmcnt(2)), which only works if no load the compiler knows about is pending there -- it would drain the queue
-// (vmcnt(0)) before the first use -- and if nothing the compiler does can move a register whose load has not landed
-// (a "+v" operand does not prevent that: hipcc splits such live ranges at will).  So the variant's table words and its
-// throw-away loads are issued from inline asm into three NAMED registers at the top of the kernel's budget: the
-// warming kernels are built for 5 waves per SIMD = 96 registers, the compiler allocates from v0 upwards (86 at most
-// today, accumulators included), and the asm names
-//   v93 / v94 = the next line's first-neighbour row of row groups 0 / 1, v95 = the warm-up loads' destination.
-// A value is copied out (v_mov, also asm) only after a wait has covered its load.  The clobber lists make the three
-// part of the kernel's allocation but do not stop the compiler from using them between the statements, so
-// tools/check_reserved_regs.py (run by `make`) disassembles the kernels and FAILS THE BUILD if any instruction the
-// compiler generated names v93..v95: more register pressure shows up there, never as a wrong result.
-#define ISF_WARM_LOAD(REG, PTR) asm volatile("global_load_dword " REG ", %0, off" ::"v"(PTR) : REG, "memory")
-#define ISF_WARM_TAKE(DST, REG) asm volatile("v_mov_b32 %0, " REG : "=v"(DST))
-#define ISF_WARM_BASE0 "v93"
-#define ISF_WARM_BASE1 "v94"
-#define ISF_WARM_JUNK "v95"
-
-template <int CIN, int NT, int NW, int MODE, int RG, bool LINES>
-__device__ __forceinline__ void spconv_dma_body(
+template <int CIN, int NT, int NW, int MODE, int RG = 2, bool LINES = false>
+__global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, const uint32_t* __restrict__ lmask, int nx,
     int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, int cout, const float* __restrict__ scale,
     const float* __restrict__ shift, const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     Conv16Plan plan, const int32_t* __restrict__ order) {
   constexpr bool HALF = (MODE & 1) != 0, F16IO = (MODE & 256) != 0;
-  constexpr bool WARM = LINES && (MODE & 512) != 0;   // warm the L2 with the rows of the tap after next
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
-  static_assert(!WARM || RG == 2, "the warming variant names one accumulation register per row group");
   using S = ConvDmaSmem<NT, NW, RG>;
   constexpr int NTHR = 64 * NW, TM = S::TM, WR = 16 * RG;
   constexpr int NCH = CIN / 32, CH8 = CIN / 8, BN = 16 * NT;
@@ -171,7 +150,7 @@ __device__ __forceinline__ void spconv_dma_body(
   // LINES: this lane's gather rows' tap masks, the first-neighbour row of the current / the next needed line
   unsigned mg[RG];
   int base_cur[RG], base_nxt[RG];
-  int line_cur = -1, line_nxt = -1;
+  int line_cur = -1;
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
     mg[rg] = 0u;
@@ -190,28 +169,6 @@ __device__ __forceinline__ void spconv_dma_body(
       base[rg] = -1;
       if ((mg[rg] & lbits) && row < row_end) base[rg] = nbr[(size_t)line * nbr_stride + row];
     }
-  };
-  // WARM: the same words, requested into a0 / a1 and taken out once a wait has covered them
-  auto line_live = [&](int line, int rg) -> bool {
-    const unsigned lbits = ((nx == 3 ? 7u : 1u) << (line * nx));
-    return (mg[rg] & lbits) && row0w + rg * 16 + grow_l < row_end;
-  };
-  auto request_line = [&](int line) {
-    if (line_live(line, 0)) {
-      const int32_t* p = nbr + (size_t)line * nbr_stride + row0w + grow_l;
-      ISF_WARM_LOAD(ISF_WARM_BASE0, p);
-    }
-    if (line_live(line, 1)) {
-      const int32_t* p = nbr + (size_t)line * nbr_stride + row0w + 16 + grow_l;
-      ISF_WARM_LOAD(ISF_WARM_BASE1, p);
-    }
-  };
-  auto take_line = [&](int line, int (&base)[RG]) {
-    int b0, b1;
-    ISF_WARM_TAKE(b0, ISF_WARM_BASE0);
-    ISF_WARM_TAKE(b1, ISF_WARM_BASE1);
-    base[0] = line_live(line, 0) ? b0 : -1;
-    base[RG - 1] = line_live(line, RG - 1) ? b1 : -1;
   };
   auto line_idx = [&](int tap, int (&idx)[RG]) {     // indices through `tap` from base_cur (its line) and the masks
     const unsigned first = (unsigned)(line_of(tap) * nx);
@@ -258,18 +215,10 @@ __device__ __forceinline__ void spconv_dma_body(
         const int line = line_of(tap);
         if (line != line_cur) {              // a new line: its bases were requested one line ago
           line_cur = line;
-          if constexpr (WARM) {
-            take_line(line, base_cur);       // line == line_nxt: the words a0 / a1 were requested for
-          } else {
 #pragma unroll
-            for (int rg = 0; rg < RG; ++rg) base_cur[rg] = base_nxt[rg];
-          }
+          for (int rg = 0; rg < RG; ++rg) base_cur[rg] = base_nxt[rg];
           const unsigned later = (line + 1) * nx < 32 ? rem & ~((1u << ((line + 1) * nx)) - 1u) : 0u;
-          if (later) {
-            line_nxt = line_of(__ffs(later) - 1);
-            if constexpr (WARM) request_line(line_nxt);
-            else load_line(line_nxt, base_nxt);
-          }
+          if (later) load_line(line_of(__ffs(later) - 1), base_nxt);
         }
         line_idx(tap, idx_cur);
       } else {
@@ -280,49 +229,15 @@ __device__ __forceinline__ void spconv_dma_body(
     }
   };
   if (nsteps > 0) {
-    if constexpr (WARM) {
-      line_nxt = line_of(__ffs(rem) - 1);
-      request_line(line_nxt);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else if constexpr (LINES) {
-      line_nxt = line_of(__ffs(rem) - 1);
-      load_line(line_nxt, base_nxt);
-    } else {
-      load_idx(__ffs(rem) - 1, idx_nxt);
-    }
+    if constexpr (LINES) load_line(line_of(__ffs(rem) - 1), base_nxt);
+    else load_idx(__ffs(rem) - 1, idx_nxt);
     advance();
     issue_A(tap, ch, idx_cur);
     stage_B(tap, ch, 0);
   }
-  // WARM: every step ends with exactly RG throw-away loads (of the rows of the tap after next, or of the zero line), so
-  // the step's wait is vmcnt(RG): everything older -- A(s), B(s), the table words -- has landed, the warm-up loads stay
-  // in flight for another step and pull their lines into the L2 meanwhile.
-  auto warm_rows = [&](bool warm, const int (&idx)[RG]) {
-    constexpr int kRowBytes = F16IO ? CIN * 2 : CIN * 4;
-    constexpr int kRowLines = kRowBytes / 128 > 0 ? kRowBytes / 128 : 1;
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-      const char* p = reinterpret_cast<const char*>(zero);
-      if (warm && idx[rg] >= 0 && (lane & 3) < kRowLines)
-        p = reinterpret_cast<const char*>(xs) + (size_t)idx[rg] * kRowBytes + (lane & 3) * 128;
-      ISF_WARM_LOAD(ISF_WARM_JUNK, p);     // unconditional: the wait counts instructions
-    }
-  };
-  if constexpr (WARM) {
-    // everything the compiler itself loaded (the rows' tap masks) has landed -- said in a form its wait-count pass
-    // understands, or it protects the first use of those registers inside the loop with a vmcnt(0) of its own
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" : "+v"(mg[0]), "+v"(mg[1]));
-    int none[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) none[rg] = -1;
-    warm_rows(false, none);               // as if by a step -1: the first wait is vmcnt(RG) too
-  }
   for (int s = 0; s < nsteps; ++s) {
     const int tap_s = tap;
-    // this wave's A(s) rows and its share of B(s) have landed
-    if constexpr (WARM) __builtin_amdgcn_s_waitcnt(0x0F70 | RG);
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's A(s) rows and its share of B(s) have landed
     __syncthreads();                      // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
     uint4 a_cur[RG][2];
 #pragma unroll
@@ -338,54 +253,19 @@ __device__ __forceinline__ void spconv_dma_body(
     uint4 bhu_n = b[0], blu_n = make_uint4(0, 0, 0, 0);
     if (!HALF) blu_n = b[64];
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transit has been read, the next rows may overwrite it
-    int warm_idx[RG];
-    bool warm = false;
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) warm_idx[rg] = -1;
-    if constexpr (WARM) {
-      // the tap AFTER the one the coming advance() selects: its rows are asked for with a throw-away load now, two
-      // steps (one when CIN == 32) before their DMA, so that the DMA finds them in the L2.  Indices come from bases that
-      // have landed (base_cur, or base_nxt requested at least a step ago); a tap two lines ahead is not warmed.
-      const unsigned rem2 = rem & (rem - 1u);
-      if (ch == NCH - 1 && rem2) {
-        const int tap2 = __ffs(rem2) - 1, line2 = line_of(tap2);
-        const bool from_cur = line2 == line_cur, from_nxt = line2 == line_nxt && line_nxt != line_cur;
-        if (from_cur || from_nxt) {
-          warm = true;
-          const unsigned first = (unsigned)(line2 * nx);
-          const unsigned below = ((1u << tap2) - 1u) & ~((1u << first) - 1u);
-          int base2[RG];
-          if (from_cur) {
-#pragma unroll
-            for (int rg = 0; rg < RG; ++rg) base2[rg] = base_cur[rg];
-          } else {
-            take_line(line_nxt, base2);
-          }
-#pragma unroll
-          for (int rg = 0; rg < RG; ++rg)
-            warm_idx[rg] = ((mg[rg] >> tap2) & 1u) ? base2[rg] + __popc(mg[rg] & below) : -1;
-        }
-      }
-    }
     if (s + 1 < nsteps) {
       advance();
       issue_A(tap, ch, idx_cur);
       stage_B(tap, ch, (s + 1) & 1);
     }
-    if constexpr (WARM) warm_rows(warm, warm_idx);
     if ((wmask >> tap_s) & 1u) {
       bool need[RG];
 #pragma unroll
       for (int rg = 0; rg < RG; ++rg) need[rg] = (rgm[rg] >> tap_s) & 1u;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        uint4 bhu = bhu_n, blu = blu_n;
-        if constexpr (WARM) {                 // no read-ahead of the next weight fragment: the registers are needed
-          if (nt > 0) {
-            bhu = b[(nt * 2 + 0) * 64];
-            if (!HALF) blu = b[(nt * 2 + 1) * 64];
-          }
-        } else if (nt + 1 < NT) {
+        const uint4 bhu = bhu_n, blu = blu_n;
+        if (nt + 1 < NT) {
           bhu_n = b[((nt + 1) * 2 + 0) * 64];
           if (!HALF) blu_n = b[((nt + 1) * 2 + 1) * 64];
         }
@@ -414,28 +294,6 @@ __device__ __forceinline__ void spconv_dma_body(
                                  row_end, relu, half_tile ? RG / 2 : RG);
 }
 
-#define ISF_DMA_PARAMS                                                                                              \
-  const uint4 *__restrict__ xs, const int32_t *__restrict__ nbr, const uint32_t *__restrict__ lmask, int nx,            \
-      int nbr_stride, const uint4 *__restrict__ wpk, const float *__restrict__ w_inv_scale, int K, int cout,            \
-      const float *__restrict__ scale, const float *__restrict__ shift, const uint4 *__restrict__ residual,             \
-      uint4 *__restrict__ ys, int n_out, int relu, Conv16Plan plan, const int32_t *__restrict__ order
-#define ISF_DMA_ARGS xs, nbr, lmask, nx, nbr_stride, wpk, w_inv_scale, K, cout, scale, shift, residual, ys, n_out, relu, plan, order
-
-template <int CIN, int NT, int NW, int MODE, int RG = 2, bool LINES = false>
-__global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(ISF_DMA_PARAMS) {
-  static_assert((MODE & 512) == 0, "the warming variant has its own entry (register limits)");
-  spconv_dma_body<CIN, NT, NW, MODE, RG, LINES>(ISF_DMA_ARGS);
-}
-
-// the warming variant: 5 waves per SIMD = 96 registers, v93..v95 named by its asm (see the plan above)
-template <int CIN, int NT, int NW, int MODE, int RG = 2>
-__global__ __launch_bounds__(64 * NW, 5) void spconv_dma_warm_kernel(ISF_DMA_PARAMS) {
-  static_assert((MODE & 512) != 0, "MODE bit 512");
-  spconv_dma_body<CIN, NT, NW, MODE, RG, true>(ISF_DMA_ARGS);
-}
-#undef ISF_DMA_PARAMS
-#undef ISF_DMA_ARGS
-
 bool sparse_conv_dma_supported(int c_in, int c_out) {
   return (c_in == 32 || c_in == 64) && (c_out == 32 || c_out == 64);
 }
@@ -449,10 +307,7 @@ static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const flo
                       const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
                       const int32_t* order, Conv16LaunchInfo* query) {
   using S = ConvDmaSmem<NT, NW, RG>;
-  auto kern = [] {
-    if constexpr ((MODE & 512) != 0) return spconv_dma_warm_kernel<CIN, NT, NW, MODE, RG>;
-    else return spconv_dma_kernel<CIN, NT, NW, MODE, RG, LINES>;
-  }();
+  auto kern = spconv_dma_kernel<CIN, NT, NW, MODE, RG, LINES>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};
   if (wgs_per_cu.load(std::memory_order_acquire) == 0) {
     if (S::bytes > 48 * 1024)
@@ -485,14 +340,12 @@ static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float
                         const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
                         const int32_t* order, Conv16LaunchInfo* query) {
   const bool balance = (mode & 32) == 0;
-  if (!lmask) mode &= ~512;   // the warming variant exists for line tables only (a plan query passes none: same plan)
 #define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, lmask, nx, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
   if (lmask) {
     switch (mode & ~32) {
       case 0: return launch_dma<CIN, NT, 0, true>(ISF_ARGS_DMA);
       case 1: return launch_dma<CIN, NT, 1, true>(ISF_ARGS_DMA);
       case 257: return launch_dma<CIN, NT, 257, true>(ISF_ARGS_DMA);
-      case 512: return launch_dma<CIN, NT, 512, true>(ISF_ARGS_DMA);
     }
   } else {
     switch (mode & ~32) {
@@ -502,7 +355,7 @@ static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float
     }
   }
 #undef ISF_ARGS_DMA
-  ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_dma: mode %d (0, 1, 257, +32; 512 with line tables)", mode);
+  ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_dma: mode %d (0, 1, 257, +32)", mode);
 }
 
 int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,

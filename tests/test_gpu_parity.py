@@ -699,12 +699,6 @@ def test_line_compressed_table_conv_bit_identical_and_round_trips(dev, cin, cout
                 got = sp.sparse_conv_forward_dma_lines(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=mode,
                                                        taps_per_line=tpl)
                 assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks, mode)
-                if mode in (0, 32):   # +512: the variant that warms the L2 two taps ahead (loads left in flight
-                    # across the step's wait, three named registers): the same bits, run after run
-                    for rep in range(3):
-                        got = sp.sparse_conv_forward_dma_lines(x, p16, K, cin, cout, rb, sc, sh, res, relu=True,
-                                                               mode=mode | 512, taps_per_line=tpl)
-                        assert torch.equal(got, ref), (n, subm, ks, mode, rep)
             got = sp.sparse_conv_forward_dma_lines(x, p16, K, cin, cout, rb, taps_per_line=tpl)
             assert torch.equal(got, sp.sparse_conv_forward_dma(x, p16, K, cin, cout, rb)), (n, subm, ks)
     # a table whose rows are not in rank order has no line form: the converter says so
@@ -737,10 +731,6 @@ def test_lidar_branch_line_tables_reproduce_dense_table_bits(dev):
         # the per-level row counts reach the host through a pinned-memory mailbox (a one-thread kernel + a host spin on
         # the ticket); diagnostic 131072 = hipMemcpyAsync + synchronise
         assert torch.equal(lb(pl, conv_diag=131072), want), n
-        # diagnostic 262144: the narrow layers warm the L2 with the rows of the tap after next (mode 512 of the LDS-DMA
-        # kernel: loads left in flight across the step's wait)
-        for rep in range(2):
-            assert torch.equal(lb(pl, conv_diag=262144), want), (n, rep)
         st0 = lb(pl, want_stats=True) is not None and lb.last_stats
         st1 = lb(pl, want_stats=True, conv_diag=16384) is not None and lb.last_stats
         assert [st0.pairs[i] for i in range(21)] == [st1.pairs[i] for i in range(21)]      # same pair counts either way
