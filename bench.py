@@ -554,7 +554,7 @@ def main():
                     help="config 3: replay the shape-static tail (conv_fusion .. head) as one HIP graph instead of ~330 "
                          "eager launches")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
-    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in range(1, 8)] + [16384, 32768, 49152, 65536, 131072, 262144] + [512 + 1024 * v for v in range(1, 8)],
+    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in range(1, 8)] + [16384, 32768, 49152, 65536, 131072] + [512 + 1024 * v for v in range(1, 8)],
                     help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_encoder_options.diagnostic; "
                          "results are garbage, the line is labelled)")
     ap.add_argument("--stage-rows", type=int, default=0,

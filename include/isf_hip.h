@@ -291,14 +291,6 @@ int isf_sparse_conv_forward_dma(const void* features_split, int num_in, int c_in
  * = isf_sparse_conv_forward_dma reading the compressed table (a lane keeps its rows' masks in registers and loads one
  * index per LINE): results BIT-IDENTICAL.  isf_sparse_encoder_forward / isf_lidar_branch_forward build the tables of their
  * narrow levels directly in this form (diagnostic +16384: dense tables).  taps_per_line = kernel width (1 or 3).
- * With the masks in registers the kernel requests PRESENT rows only (an absent row's fragment is zero; the dense-table
- * kernel reads a zero line for it).  mode as isf_sparse_conv_forward_dma, plus
- *   2048 = the caller states that the table is a SubM 3 x 3 x 3 table in rank order whose output row r is input row r
- *          (what isf_build_rulebook gives for a submanifold layer on sorted coordinates): with one 32-channel chunk per row,
- *          a row whose right-hand neighbour in x is the next row takes its fragment for tap k from the lane that held it
- *          for tap k - 1 (DPP) instead of requesting it -- the same fragment, the same bits;
- *   4096 = every row of an active 16-row group is requested, absent ones from the zero line (timing diagnostics).
- * Requests per output row on a 300 k-point frame: 11.4 -> 6.4 -> 3.3 at level 0.
  * Replaces nothing in the reference (its rulebook is pair lists, indice.cu.h:22-203); measured in DESIGN.md section 5.3. */
 int isf_rulebook_to_lines(const int32_t* nbr, int nbr_stride, int num_taps, int taps_per_line, int num_out,
                           int32_t* lines, uint32_t* mask, int* not_consecutive_flag, isf_stream_t stream);
@@ -407,8 +399,6 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            the pinned-memory mailbox (post_int / wait_int) -- bit-identical;
  *            +65536 (isf_lidar_branch_forward) = one dynamic-voxelize launch per frame + a separate byte-map marking pass
  *            instead of the fused voxelize + mark launch -- bit-identical;
- *            +262144 = the narrow layers request every row of an active group (mode 4096 of
- *            isf_sparse_conv_forward_dma_lines) instead of the present, unshared ones -- bit-identical;
  *            +32768 = equal-work tile tables for the deep levels instead of uniform tiles + tile order (opt-in:
  *            measured slower) -- bit-identical;
  *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */

@@ -238,22 +238,20 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
                                                            // tile tables instead of uniform tiles + LPT order
   const bool line_tables = (diagnostic & 256 * 64) == 0;   // bit 16384: full neighbour tables for the narrow layers too
   const bool mailbox = (diagnostic & 131072) == 0;         // bit 131072: data-dependent counts through hipMemcpyAsync + sync
-  const bool ask_all_rows = (diagnostic & 262144) != 0;   // bit 262144: the narrow layers request every row of an active
-                                                          // group (absent ones from the zero line, none shared between lanes)
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072));
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
   const unsigned stage_mask = opt ? (unsigned)opt->stage_mask : 0u;
@@ -471,10 +469,6 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   "sparse_encoder: layer %d residual source %d incompatible", i, ly.residual_from);
       res = outputs[ly.residual_from];
     }
-    // line tables: absent rows are not requested; a SubM 3 x 3 x 3 layer also shares rows between lanes (mode bit 2048 of
-    // isf_sparse_conv_forward_dma_lines; its table is in rank order and its output rows are its input rows)
-    const bool subm333 = ly.conv_type == ISF_CONV_SUBM && ly.ksize[0] == 3 && ly.ksize[1] == 3 && ly.ksize[2] == 3;
-    const int dma_rows = !lmask ? 0 : ask_all_rows ? 4096 : subm333 ? 2048 : 0;
     if (!ev.empty()) ISF_HIP_TRY(hipEventRecord(ev[2 * i], st));
     if (use16 && srows > 0)
       ISF_TRY(sparse_conv_forward_staged_impl(x, ly.c_in, ly.packed16, K, ly.c_out, stg.slots, stride, stg.ulist,
@@ -485,7 +479,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                           ly.relu, y, cu_plan, st));
     else if (dma)
       ISF_TRY(sparse_conv_forward_dma_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
-                                           res, ly.relu, y, conv_mode | dma_rows, st, order, nullptr, lmask, nx));
+                                           res, ly.relu, y, conv_mode, st, order, nullptr, lmask, nx));
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y, conv_mode | (order_is_table ? 1024 : 0), st, order));

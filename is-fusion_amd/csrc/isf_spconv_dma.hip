@@ -58,12 +58,6 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     const float* __restrict__ shift, const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     Conv16Plan plan, const int32_t* __restrict__ order) {
   constexpr bool HALF = (MODE & 1) != 0, F16IO = (MODE & 256) != 0;
-  // nx: taps per line of the compressed table (low byte); +256 = the table is a SubM 3 x 3 x 3 table in rank order (output
-  // row r IS input row r): rows take their fragment from the right-hand lane where the index arithmetic says it is the
-  // same row (see "x-neighbour sharing" below); +512 = request every row of an active group, absent ones from the zero
-  // line (the kernel before round 4 call 9: timing diagnostics)
-  const int nxf = nx;
-  nx &= 255;
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   using S = ConvDmaSmem<NT, NW, RG>;
   constexpr int NTHR = 64 * NW, TM = S::TM, WR = 16 * RG;
@@ -166,29 +160,6 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       if (rgm[rg] && row < row_end) mg[rg] = lmask[row];
     }
   }
-  // LINES: the tap mask of the row this lane MULTIPLIES (row col of each group; mg is the row it GATHERS).  Both sides
-  // derive "present" and "shared" from the same row's mask, so a lane that skips its DMA and the lanes that would have
-  // read it from the transit buffer always agree.
-  unsigned mm[RG];
-#pragma unroll
-  for (int rg = 0; rg < RG; ++rg) {
-    mm[rg] = 0u;
-    if constexpr (LINES) {
-      const int row = row0w + rg * 16 + col;
-      if (rgm[rg] && row < row_end) mm[rg] = lmask[row];
-    }
-  }
-  // x-neighbour sharing (SubM 3 x 3 x 3 in rank order, one chunk per row): taps k-1 and k of a line differ by one cell in
-  // x, and if output row r + 1 is the +x neighbour of row r (bit 14 of r's mask: tap (0, 0, +1) -- in rank order that
-  // neighbour, when present, IS row r + 1) then row r's neighbour through tap k is row r + 1's neighbour through tap
-  // k - 1: the same input row, whose fragment lane col + 1 holds from the previous step.  Such a row is not requested
-  // (its gather lanes sit the DMA out) and its fragment comes over by DPP row_shl:1 -- the fragment the DMA would have
-  // delivered, so no bit changes.  Absent rows (mask bit clear) are not requested either: their fragment is zero.
-  const bool skip_absent = LINES && !(nxf & 512);
-  const bool xshare = LINES && NCH == 1 && (nxf & 256) && !(nxf & 512) && nx == 3 && K == 27;
-  auto shares = [&](int rg, int tap_new, int tap_old) -> bool {   // wave-uniform part of "row takes tap_new from the right"
-    return xshare && tap_new == tap_old + 1 && tap_new % 3 != 0 && ((rgm[rg] >> tap_old) & 1u);
-  };
   auto line_of = [&](int tap) -> int { return nx == 3 ? (tap * 43) >> 7 : tap; };   // tap / 3 for tap < 27
   auto load_line = [&](int line, int (&base)[RG]) {
 #pragma unroll
@@ -206,7 +177,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     for (int rg = 0; rg < RG; ++rg)
       idx[rg] = ((mg[rg] >> tap) & 1u) ? base_cur[rg] + __popc(mg[rg] & below) : -1;
   };
-  auto issue_A = [&](int tap, int ch, const int (&idx)[RG], int tap_old) {   // tap_old: the tap of the step before (-2: none)
+  auto issue_A = [&](int tap, int ch, const int (&idx)[RG]) {
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
       if ((rgm[rg] >> tap) & 1u) {                                  // wave-uniform
@@ -214,29 +185,10 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
         if (idx[rg] >= 0)
           src = F16IO ? xs + (size_t)idx[rg] * CH8 + ch * 4 + gpiece
                       : xs + ((size_t)idx[rg] * CH8 + ch * 4) * 2 + gpiece;
-        bool ask = true;
-        if constexpr (LINES) {
-          if (skip_absent) ask = idx[rg] >= 0;
-          if (shares(rg, tap, tap_old))
-            ask = ask && !(((mg[rg] >> 14) & 1u) && grow_l < 15 && row0w + rg * 16 + grow_l + 1 < row_end);
-        }
-        if (ask) {                                                  // the others' transit slots keep what they had
-          glds16(src, transit_addr + (unsigned)(rg * 2) * 1024u);
-          if (!HALF) glds16(src + 4, transit_addr + (unsigned)(rg * 2 + 1) * 1024u);   // zero line: 8 pieces long
-        }
+        glds16(src, transit_addr + (unsigned)(rg * 2) * 1024u);
+        if (!HALF) glds16(src + 4, transit_addr + (unsigned)(rg * 2 + 1) * 1024u);   // zero line: 8 pieces long
       }
     }
-  };
-  auto pick = [](bool c, const uint4 a, const uint4 b) {   // per component: a ?: on the struct goes through scratch
-    return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
-  };
-  auto shl1 = [](const uint4 v) {   // lane (k-group, col) <- lane (k-group, col + 1): a DPP row is one k-group's 16 rows
-    uint4 r;
-    r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x101, 0xf, 0xf, true);
-    r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x101, 0xf, 0xf, true);
-    r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x101, 0xf, 0xf, true);
-    r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x101, 0xf, 0xf, true);
-    return r;
   };
   auto stage_B = [&](int tap, int ch, int buf) {
     const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
@@ -280,37 +232,21 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     if constexpr (LINES) load_line(line_of(__ffs(rem) - 1), base_nxt);
     else load_idx(__ffs(rem) - 1, idx_nxt);
     advance();
-    issue_A(tap, ch, idx_cur, -2);
+    issue_A(tap, ch, idx_cur);
     stage_B(tap, ch, 0);
   }
-  uint4 a_cur[RG][2];                     // outlives the step: the next tap's shared rows come out of it
-#pragma unroll
-  for (int rg = 0; rg < RG; ++rg) a_cur[rg][0] = a_cur[rg][1] = make_uint4(0, 0, 0, 0);
-  int tap_before = -2;                    // the tap of step s - 1 (NCH == 1 wherever it matters)
   for (int s = 0; s < nsteps; ++s) {
     const int tap_s = tap;
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's A(s) rows and its share of B(s) have landed
     __syncthreads();                      // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
+    uint4 a_cur[RG][2];
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
+      a_cur[rg][0] = make_uint4(0, 0, 0, 0);
+      a_cur[rg][1] = make_uint4(0, 0, 0, 0);
       if ((rgm[rg] >> tap_s) & 1u) {
-        uint4 t0 = transit[(rg * 2) * 64 + rpos], t1 = make_uint4(0, 0, 0, 0);
-        if (!HALF) t1 = transit[(rg * 2 + 1) * 64 + rpos];
-        if constexpr (LINES) {
-          const uint4 nil = make_uint4(0, 0, 0, 0);
-          const bool present = !skip_absent || ((mm[rg] >> tap_s) & 1u);
-          if (shares(rg, tap_s, tap_before)) {                      // wave-uniform
-            const uint4 s0 = shl1(a_cur[rg][0]), s1 = shl1(a_cur[rg][1]);
-            const bool shared = ((mm[rg] >> tap_s) & 1u) && ((mm[rg] >> 14) & 1u) && col < 15 &&
-                                row0w + rg * 16 + col + 1 < row_end;   // the right-hand row is this tile's
-            t0 = pick(shared, s0, t0);
-            t1 = pick(shared, s1, t1);
-          }
-          t0 = pick(present, t0, nil);
-          t1 = pick(present, t1, nil);
-        }
-        a_cur[rg][0] = t0;
-        a_cur[rg][1] = t1;
+        a_cur[rg][0] = transit[(rg * 2) * 64 + rpos];
+        if (!HALF) a_cur[rg][1] = transit[(rg * 2 + 1) * 64 + rpos];
       }
     }
     const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
@@ -319,10 +255,9 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transit has been read, the next rows may overwrite it
     if (s + 1 < nsteps) {
       advance();
-      issue_A(tap, ch, idx_cur, tap_s);
+      issue_A(tap, ch, idx_cur);
       stage_B(tap, ch, (s + 1) & 1);
     }
-    tap_before = tap_s;
     if ((wmask >> tap_s) & 1u) {
       bool need[RG];
 #pragma unroll
@@ -436,9 +371,6 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
               c_in, c_out);
   ISF_REQUIRE(nbr_stride % 128 == 0 && nbr_stride >= n_out, ISF_ERR_ARG, "sparse_conv_dma: bad nbr_stride");
   ISF_REQUIRE(!lmask || ((nx == 1 || nx == 3) && K % nx == 0), ISF_ERR_ARG, "sparse_conv_dma: %d taps in lines of %d", K, nx);
-  if (lmask && (mode & 2048)) nx |= 256;   // SubM 3 x 3 x 3 in rank order: rows shared between lanes
-  if (lmask && (mode & 4096)) nx |= 512;   // every row of an active group requested (timing diagnostics)
-  mode &= ~(2048 | 4096);
   const uint4* w = reinterpret_cast<const uint4*>(packed16);
   const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
   const uint4* x = reinterpret_cast<const uint4*>(xs);

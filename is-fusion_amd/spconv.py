@@ -303,11 +303,9 @@ def lines_to_nbr(lines, mask, K, taps_per_line=3):
 
 def sparse_conv_forward_dma_lines(features, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual=None,
                                   relu=False, mode=0, taps_per_line=3):
-    """sparse_conv_forward_dma reading the line-compressed table (isf_sparse_conv_forward_dma_lines); bit-identical.
-    mode + 2048: the table is a SubM 3 x 3 x 3 table in rank order (rb.num_in == rb.num_out, row r is row r): rows
-    shared between lanes; + 4096: every row of an active group requested (the kernel of before; timing diagnostics)."""
+    """sparse_conv_forward_dma reading the line-compressed table (isf_sparse_conv_forward_dma_lines); bit-identical."""
     _lib.require_cuda(features)
-    f16io = (mode & ~(32 | 2048 | 4096)) == 257
+    f16io = (mode & ~32) == 257
     xs = to_half(features) if f16io else to_split(features)
     rs = None if residual is None else (to_half(residual) if f16io else to_split(residual))
     ys = torch.empty(rb.num_out * c_out * (2 if f16io else 4), dtype=torch.uint8, device=features.device)
