@@ -229,3 +229,29 @@ def test_back_to_back_forwards_without_host_sync(dev):
         for i, g in enumerate(got):
             for k in keys:
                 assert torch.equal(g[k], want[i % 2][k]), (graph, stream is not None, i, k)
+
+
+def test_lidar_branch_batches_in_flight_on_two_streams_reproduce_serial_bits(dev):
+    """bench.py's "pipelined" leg: consecutive LiDAR-branch calls alternate between two HIP streams (workspaces, count
+    mailboxes and geometry side streams are per (device, stream)), so that one batch's voxelization / VFE / geometry runs
+    beside the previous batch's convolutions.  Nothing is synchronised between the calls; every output equals the serial
+    call's bit for bit, for batches of different sizes following each other on the same stream (workspace reuse)."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev).freeze()
+    sets = [[torch.from_numpy(synthetic.lidar_sweeps(700 + 10 * s + i, n)).to(dev) for i in range(b)]
+            for s, (n, b) in enumerate(((60000, 2), (20000, 3), (120000, 2), (3000, 1)))]
+    want = [lb(p).clone() for p in sets]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    got = []
+    for k in range(12):
+        with torch.cuda.stream(streams[k % 2]):
+            got.append((k % len(sets), lb(sets[k % len(sets)])))
+        if k % 3 == 2:                      # three in a row on alternating streams, then a different pairing
+            streams.reverse()
+    torch.cuda.synchronize()
+    for k, (s, out) in enumerate(got):
+        assert torch.equal(out, want[s]), (k, s)

@@ -14,7 +14,7 @@ VARIANTS=${3:-"0 512"}
 REPS=${4:-"1 2 3"}
 for rep in $REPS; do
   for v in $VARIANTS; do
-    timeout 300 python bench.py --steps 40 --warmup 8 --no-cfg3 --no-cfg4 --no-cfg5 --no-cpu-baseline --conv-diag $v > $OUT/bench_diag${v}_$rep.json 2> $OUT/bench_diag${v}_$rep.err
+    timeout 300 python bench.py --steps 40 --warmup 8 --no-cfg3 --no-cfg4 --no-cfg5 --no-pipelined --no-cpu-baseline --conv-diag $v > $OUT/bench_diag${v}_$rep.json 2> $OUT/bench_diag${v}_$rep.err
     python - <<PY
 import json
 try:

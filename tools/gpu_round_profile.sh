@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export ISF_BENCH_FRAME_CACHE=/tmp/isf_bench_frames
 python $R/bench.py 2>/dev/null | tail -1 > $R/gpurun_out/bench_line.json
-CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cfg3 --no-cfg4 --no-cfg5"
+CMD="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-cfg3 --no-cfg4 --no-cfg5 --no-pipelined"
 export MIOPEN_FIND_MODE=FAST   # keeps the naive_conv_* find-mode kernels of the warm-up out of the cfg-3 trace
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof/trace -o bench -- $CMD > /dev/null 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof/fetch -o bench -- $CMD > /dev/null 2>&1
