@@ -407,6 +407,7 @@ def pipelined_leg(lb, frame_sets, steps, warmup, in_flight=2, **kw):
     convolutions of batch k.  Same kernels, same launches, same bits (checked against a serial call below); nothing
     is synchronised between the steps, all of them start and end inside the timed region.  Reported BESIDE the
     headline, whose per-kernel figures (roofline, rocprof summary) are only meaningful for serial launches."""
+    import torch
     streams = [torch.cuda.Stream() for _ in range(in_flight)]
     cur = torch.cuda.current_stream()
     for st in streams:
