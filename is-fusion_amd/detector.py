@@ -116,6 +116,11 @@ class ISFusionPtsPath(nn.Module):
         voxelization, ISFusionEncoder with the SECONDV2 stages."""
         assert not self.training, "inference path (eval mode)"
         self._lidar.train(False)
+        if "p2g_cam" not in kwargs and all(k in kwargs for k in ("lidar2img", "img_aug_matrix", "lidar_aug_matrix")):
+            # host-side fold of the camera matrices BEFORE anything is queued: it overlaps nothing otherwise
+            from . import fusion_ops as ops
+            kwargs["p2g_cam"] = ops.h2d_async(ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
+                                                                    kwargs["lidar_aug_matrix"]), pts[0].device)
         # The pillar voxelization has a host round trip per sample (the voxel count sizes its outputs).  Issued after the
         # LiDAR branch on the same stream, each of them waits for the whole branch and then leaves the GPU idle until
         # the host has launched the next piece (tools/timeline_gaps.py: ~0.25 ms per forward).  On a side stream --
@@ -127,14 +132,6 @@ class ISFusionPtsPath(nn.Module):
             side = self._side_streams[pts[0].device] = torch.cuda.Stream(device=pts[0].device)
         side.wait_stream(main)                       # the points are ready on the main stream
         x = self._lidar(pts)
-        if "p2g_cam" not in kwargs and all(k in kwargs for k in ("lidar2img", "img_aug_matrix", "lidar_aug_matrix")):
-            # host-side fold of the camera matrices (a dozen small float64 ops, ~0.2 ms) HERE: the LiDAR branch has just
-            # queued its convolutions, so the GPU is a millisecond or more behind the host.  At the top of the forward
-            # -- where it was -- the GPU had caught up with the host (the head's small kernels are launch-bound) and sat
-            # idle for the duration (tools/timeline_gaps.py: a 0.3-ms gap in front of every forward)
-            from . import fusion_ops as ops
-            kwargs["p2g_cam"] = ops.h2d_async(ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
-                                                                    kwargs["lidar_aug_matrix"]), pts[0].device)
         with torch.cuda.stream(side):
             pil = self.voxelize(pts, voxel_type="pillar")
         main.wait_stream(side)
