@@ -592,6 +592,9 @@ def main():
                     help="config 3: replay the shape-static tail (conv_fusion .. head) as one HIP graph instead of ~330 "
                          "eager launches")
     ap.add_argument("--fp32", action="store_true", help="force the fp32 MFMA conv kernels")
+    ap.add_argument("--lib", default="",
+                    help="A/B and probe builds: load this build of libisf_hip.so instead of the in-tree one (results are "
+                         "not checked for finiteness: knock-out builds produce garbage)")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the two-batches-in-flight leg appended as \"pipelined\"")
     ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in range(1, 8)] + [16384, 32768, 49152, 65536, 131072] + [512 + 1024 * v for v in range(1, 8)],
@@ -627,6 +630,9 @@ def main():
     import torch
     import torch.distributed as dist
     import isfusion_amd as m
+    if args.lib:
+        from isfusion_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -690,11 +696,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pipelined = None
-    if world == 1 and not args.no_pipelined:
+    if world == 1 and not args.no_pipelined and not args.lib:
         pipelined = pipelined_leg(lb, frame_sets, args.steps, max(2, args.warmup // 2), 2, precision=precision,
                                   conv_diag=args.conv_diag, **stage_kw)
     diag = (args.conv_diag & 15) != 0 or ((args.conv_diag >> 10) & 3) != 0   # timing diagnostics: results are garbage (16 = sharing off, 32 = uniform tiles: valid)
-    assert diag or torch.isfinite(out).all()
+    assert diag or args.lib or torch.isfinite(out).all()
 
     if rank == 0:
         import numpy as np

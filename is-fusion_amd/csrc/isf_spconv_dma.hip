@@ -33,6 +33,13 @@
 
 namespace isf {
 
+// Probe builds only (tools/probes/build_dma_knockouts.sh compiles this file with -DISF_DMA_KNOCKOUT=<bits> into side
+// libraries; the shipped library is built with 0 and contains none of it): leave a part of the step out to see what the
+// step's time is made of.  1 = no row gathers, 2 = no weight staging, 4 = no MFMAs (nor their LDS reads), 8 = no
+// per-step barrier.  Results are garbage.
+#ifndef ISF_DMA_KNOCKOUT
+#define ISF_DMA_KNOCKOUT 0
+#endif
 __device__ uint4 g_zero_line[8];   // 128 zero bytes: what a row without a neighbour reads
 
 template <int NT, int NW, int RG = 2>
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       idx[rg] = ((mg[rg] >> tap) & 1u) ? base_cur[rg] + __popc(mg[rg] & below) : -1;
   };
   auto issue_A = [&](int tap, int ch, const int (&idx)[RG]) {
+    if constexpr ((ISF_DMA_KNOCKOUT & 1) != 0) return;
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
       if ((rgm[rg] >> tap) & 1u) {                                  // wave-uniform
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     }
   };
   auto stage_B = [&](int tap, int ch, int buf) {
+    if constexpr ((ISF_DMA_KNOCKOUT & 2) != 0) return;
     const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
     const unsigned dst = bbuf_addr + (unsigned)(buf * (NT * 128)) * 16u;
 #pragma unroll
@@ -238,7 +247,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   for (int s = 0; s < nsteps; ++s) {
     const int tap_s = tap;
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's A(s) rows and its share of B(s) have landed
-    __syncthreads();                      // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
+    if constexpr ((ISF_DMA_KNOCKOUT & 8) == 0)
+      __syncthreads();                    // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
     uint4 a_cur[RG][2];
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       issue_A(tap, ch, idx_cur);
       stage_B(tap, ch, (s + 1) & 1);
     }
-    if ((wmask >> tap_s) & 1u) {
+    if (((wmask >> tap_s) & 1u) && (ISF_DMA_KNOCKOUT & 4) == 0) {
       bool need[RG];
 #pragma unroll
       for (int rg = 0; rg < RG; ++rg) need[rg] = (rgm[rg] >> tap_s) & 1u;
