@@ -4,7 +4,8 @@ set -u
 OUT=gpurun_out/${1:-r04_dma_knockouts}
 mkdir -p $OUT
 export ISF_BENCH_FRAME_CACHE=/tmp/isf_frames
-for ko in 0 ${2:-"1 2 3 4 8 7 15"}; do
+KOS=${2:-"1 2 3 4 8 7 15"}
+for ko in 0 $KOS; do
   LIB=""
   [ "$ko" != "0" ] && LIB="--lib tools/probes/_build/libisf_hip_ko$ko.so"
   timeout 120 python bench.py $LIB --steps 20 --warmup 5 --no-cfg3 --no-cfg4 --no-cfg5 --no-pipelined --no-cpu-baseline \
