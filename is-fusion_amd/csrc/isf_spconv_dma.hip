@@ -25,9 +25,8 @@
 //     gather kernel's two-chunk steps: results are BIT-IDENTICAL), a lane's neighbour index lives in a register and is
 //     fetched one tap ahead: no neighbour table in LDS, 32 KiB (64 output columns) / 24 KiB (32) per workgroup =
 //     5 / 6 workgroups per CU instead of 3;
-//   * rows without a neighbour are not requested: their gather lanes zero their own transit slots (once -- the slots
-//     stay zero until a DMA lands in them again); no neighbour sharing (every present row is fetched, at a quarter of
-//     the cost).
+//   * rows without a neighbour read a zero line instead of being masked (the DMA writes every lane's 16 bytes); no
+//     neighbour sharing (every row is fetched, at a quarter of the cost).
 #include "isf_spconv16.h"
 
 #include <atomic>
@@ -41,6 +40,7 @@ namespace isf {
 #ifndef ISF_DMA_KNOCKOUT
 #define ISF_DMA_KNOCKOUT 0
 #endif
+__device__ uint4 g_zero_line[8];   // 128 zero bytes: what a row without a neighbour reads
 
 template <int NT, int NW, int RG = 2>
 struct ConvDmaSmem {
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   const unsigned bbuf_addr = __builtin_amdgcn_readfirstlane(lds_addr(bbuf));
   const uint4* transit = reinterpret_cast<const uint4*>(smem + S::bbuf_bytes) + wave * (RG * 128);
   const unsigned transit_addr = __builtin_amdgcn_readfirstlane(lds_addr(transit));
+  const uint4* zero = g_zero_line;
 
   // neighbour index of this lane's gather row through a tap, per row group (-1: none)
   auto load_idx = [&](int tap, int (&idx)[RG]) {
@@ -183,28 +184,17 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     for (int rg = 0; rg < RG; ++rg)
       idx[rg] = ((mg[rg] >> tap) & 1u) ? base_cur[rg] + __popc(mg[rg] & below) : -1;
   };
-  // A row without a neighbour through the tap is not requested: its gather lanes write zeros into their own transit
-  // slots instead -- once, the slots stay zero until a DMA lands in them again (bit rg of `live`: this lane's slots of
-  // row group rg hold data).  profiles/r04_dma_knockouts.txt: the gathers are 23-30 % of these layers and 18-44 % of
-  // them were zero-line reads.
-  unsigned live = (1u << RG) - 1u;        // unknown contents count as data
-  uint4* transit_w = const_cast<uint4*>(transit);
   auto issue_A = [&](int tap, int ch, const int (&idx)[RG]) {
     if constexpr ((ISF_DMA_KNOCKOUT & 1) != 0) return;
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
       if ((rgm[rg] >> tap) & 1u) {                                  // wave-uniform
-        if (idx[rg] >= 0) {
-          const uint4* src = F16IO ? xs + (size_t)idx[rg] * CH8 + ch * 4 + gpiece
-                                   : xs + ((size_t)idx[rg] * CH8 + ch * 4) * 2 + gpiece;
-          glds16(src, transit_addr + (unsigned)(rg * 2) * 1024u);
-          if (!HALF) glds16(src + 4, transit_addr + (unsigned)(rg * 2 + 1) * 1024u);
-          live |= 1u << rg;
-        } else if ((live >> rg) & 1u) {
-          transit_w[(rg * 2) * 64 + lane] = make_uint4(0, 0, 0, 0);
-          if (!HALF) transit_w[(rg * 2 + 1) * 64 + lane] = make_uint4(0, 0, 0, 0);
-          live &= ~(1u << rg);
-        }
+        const uint4* src = zero + gpiece;
+        if (idx[rg] >= 0)
+          src = F16IO ? xs + (size_t)idx[rg] * CH8 + ch * 4 + gpiece
+                      : xs + ((size_t)idx[rg] * CH8 + ch * 4) * 2 + gpiece;
+        glds16(src, transit_addr + (unsigned)(rg * 2) * 1024u);
+        if (!HALF) glds16(src + 4, transit_addr + (unsigned)(rg * 2 + 1) * 1024u);   // zero line: 8 pieces long
       }
     }
   };
