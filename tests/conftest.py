@@ -11,8 +11,17 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--isf-lib", default="", help="run the tests against this build of libisf_hip.so instead of the "
+                     "in-tree one (probe builds: tools/probes/build_side_lib.sh)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    lib = config.getoption("--isf-lib")
+    if lib:
+        from isfusion_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(lib)
 
 
 @pytest.fixture(scope="session")
