@@ -266,6 +266,19 @@ int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, cons
                           const float* shift, const void* residual_split, int relu, void* out_split,
                           const int32_t* order, long long* trace, int trace_capacity_blocks, int* grid_blocks,
                           isf_stream_t stream);
+/* DIAGNOSTIC: isf_sparse_conv_trace plus per-WAVE phase stamps of every step of the multiply loop (shader clock,
+ * s_memtime: 1 tick = 1 shader cycle): top of the step / after its s_waitcnt vmcnt(0) / after the barrier / after issuing
+ * the next step's loads; the multiply section is what is left until the next top.  This image's rocprofv3 has no
+ * thread-trace decoder (--att: "rocprof-trace-decoder library path not found"), so this is the instruction-level account of
+ * the dominant kernel.  trace: [*grid_blocks][8] int64 as isf_sparse_conv_trace, then per wave (*waves_per_block per
+ * workgroup) *dwords_per_wave uint32: {clock at loop entry lo, hi, HW_ID, steps, tap mask of row group 0, of row group 1,
+ * tap mask of the workgroup, clock at loop exit lo} + 4 per step; trace_bytes is checked against the launch (zero the
+ * buffer first).  tools/conv_phase_trace.py -> profiles/r05_att_256.txt. */
+int isf_sparse_conv_phase_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                                int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                                const float* shift, const void* residual_split, int relu, void* out_split,
+                                const int32_t* order, long long* trace, size_t trace_bytes, int* grid_blocks,
+                                int* waves_per_block, int* dwords_per_wave, isf_stream_t stream);
 /* The same convolution for the NARROW layers (c_in, c_out in {32, 64}) with the gathered rows brought in by LDS-DMA
  * (isf_spconv_dma.hip; mode 0 | 1 | 257, +32; order: NULL or isf_sparse_conv_tile_order's table).  A gather instruction of
  * isf_sparse_conv_forward_f16x3 loads straight into the MFMA operand layout -- four different rows = four cache lines per

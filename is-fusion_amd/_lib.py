@@ -153,6 +153,9 @@ SIGNATURES = {
     "isf_sparse_conv_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                       ctypes.POINTER(c_int), c_void_p]),
+    "isf_sparse_conv_phase_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                            ctypes.c_size_t, c_int_p, c_int_p, c_int_p, c_void_p]),
     "isf_rulebook_to_lines": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isf_lines_to_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_sparse_conv_forward_dma_lines": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

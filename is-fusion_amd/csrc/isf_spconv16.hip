@@ -31,6 +31,15 @@
 namespace isf {
 
 
+// phase trace (MODE bit 2048): dwords per wave record = kPhaseHdr + 4 * kPhaseMaxSteps
+constexpr int kPhaseHdr = 8, kPhaseMaxSteps = kMaxTaps * 8;
+
+__device__ __forceinline__ unsigned long long shader_clock64() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+
 template <int NT, int RG, int KCH, int NW>
 struct Conv16Smem {
   static constexpr int TM = 16 * RG * NW;                                // rows per workgroup
@@ -65,6 +74,14 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // MODE bit 512: per-workgroup trace (isf_sparse_conv_trace): 8 x int64 per workgroup -- constant-clock time stamps at
   // entry / after the prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half << 32
   constexpr bool TRACE = (MODE & 512) != 0;
+  // MODE bit 2048 (with 512): PHASE TRACE (isf_sparse_conv_phase_trace; the image has no thread-trace decoder, so this is
+  // the kernel's own instruction-level account): every wave stamps the shader clock (s_memtime, 1 tick = 1 shader cycle)
+  // at the top of each step / after its s_waitcnt vmcnt(0) / after the barrier / after issuing the next step's loads;
+  // the multiply section is what is left until the next top.  Per wave, behind the per-workgroup records:
+  // kPhaseHdr dwords {clock at loop entry lo, hi, HW_ID, steps, rgm[0], rgm[1], wg_mask, clock at loop exit lo} +
+  // 4 dwords per step.  The stamps cost ~4 scalar-memory round trips per step (measured against the untraced launch
+  // by tools/conv_phase_trace.py).
+  constexpr bool PHASE = (MODE & 2048) != 0;
   long long t_entry = 0, t_pro = 0, t_loop = 0;
   if (TRACE) t_entry = wall_clock64();
   constexpr bool HALF = (MODE & 1) != 0, NOGATHER = (MODE & 2) != 0, NODMA = (MODE & 4) != 0, NOLOOP = (MODE & 8) != 0;
@@ -254,6 +271,20 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     load_A(cur.tap, cur.ch, -1);
     stage_B(cur.tap, cur.ch, 0);
   }
+  unsigned* ph = nullptr;          // this wave's phase record
+  unsigned ph_top = 0, ph_wait = 0, ph_bar = 0, ph_issue = 0;
+  if (PHASE) {
+    ph = reinterpret_cast<unsigned*>(trace + (size_t)gridDim.x * 8) +
+         ((size_t)blockIdx.x * NW + wave) * (kPhaseHdr + 4 * kPhaseMaxSteps);
+    const unsigned long long t = shader_clock64();
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    if (lane == 0) {
+      ph[0] = (unsigned)t; ph[1] = (unsigned)(t >> 32); ph[2] = hw_id; ph[3] = (unsigned)nsteps;
+      ph[4] = rgm[0]; ph[5] = RG > 1 ? rgm[RG > 1 ? 1 : 0] : 0u; ph[6] = wg_mask;
+    }
+    ph_top = (unsigned)t;
+  }
   for (int s = 0; s < nsteps; ++s) {
     const int tap = cur.tap, ch = cur.ch;
 #pragma unroll
@@ -264,12 +295,15 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     // (the builtin, not inline asm, so that hipcc's own scoreboard knows every tracked load has landed too and
     //  does not re-wait for the A(s) registers in the middle of the next prefetch; simm16 0x0F70 = vmcnt(0))
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (PHASE) ph_wait = (unsigned)shader_clock64();
     __syncthreads();  // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
+    if (PHASE) ph_bar = (unsigned)shader_clock64();
     if (s + 1 < nsteps) {
       advance(cur);
       load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);   // a_cur = (tap, ch), landed (vmcnt(0) above)
       stage_B(cur.tap, cur.ch, (s + 1) & 1);
     }
+    if (PHASE) ph_issue = (unsigned)shader_clock64();
     if ((wmask >> tap) & 1u) {
       const uint4* b = bbuf + (s & 1) * (KCH * NT * 128) + lane;
       bool need[RG];
@@ -301,7 +335,14 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
         }
       }
     }
+    if (PHASE) {
+      const unsigned t_end = (unsigned)shader_clock64();
+      if (lane == 0 && s < kPhaseMaxSteps)
+        *reinterpret_cast<uint4*>(ph + kPhaseHdr + 4 * s) = make_uint4(ph_top, ph_wait, ph_bar, ph_issue);
+      ph_top = t_end;
+    }
   }
+  if (PHASE && lane == 0) ph[7] = ph_top;
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
   if (TRACE) t_loop = wall_clock64();
@@ -452,6 +493,22 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
                          const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
                          Conv16LaunchInfo* query) {
 #define ISF_ARGS16 (mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
+  // mode bits 4096 / 8192 (round 5 experiment, valid results, bit-identical): the 256-COLUMN layers as ONE column block
+  // -- a workgroup owns all 256 output columns of its rows, so a row is gathered ONCE per tap and chunk instead of once per
+  // column block.  The phase trace (profiles/r05_att_256.txt) shows the step bound by the vector-memory issue path (a
+  // gather in the MFMA operand layout costs 64 address cycles, 12 resident waves x (3 gathers + 4 weight DMA pieces) =
+  // the step time): per MFMA this halves the gather instructions.  4096: 4 waves x 32 rows (two workgroups per CU:
+  // 64 KiB weight stage); 8192: 8 waves x 16 rows.  Tile-order tables belong to the two-block launch plan: ignored.
+  if constexpr (NT == 8 && CIN >= 128) {
+    if ((mode & (4096 | 8192)) && cout == 256 && (mode & ~(32 | 1024 | 4096 | 8192)) == 0) {
+      if (mode & 8192)
+        return launch16<CIN, 16, 1, 8>(false, false, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual,
+                                       relu, ys, st, nullptr, query);
+      return launch16<CIN, 16, 2, 4>((mode & 32) == 0, false, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift,
+                                     residual, relu, ys, st, nullptr, query);
+    }
+  }
+  mode &= ~(4096 | 8192);
   switch (mode & ~(32 | 1024)) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
     case 0: break;
     case 1: return launch16<CIN, NT, 2, 4, 1>(ISF_ARGS16);
@@ -522,7 +579,8 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
 int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
                            int nbr_stride, int n_out, const float* scale, const float* shift, const void* residual,
                            int relu, void* ys, const int32_t* order, long long* trace, int trace_capacity_blocks,
-                           int* grid_blocks, hipStream_t st) {
+                           int* grid_blocks, hipStream_t st, bool phase = false, size_t phase_capacity_bytes = 0,
+                           int* waves_per_block = nullptr) {
   ISF_REQUIRE((c_in == 256 && c_out == 256) || (c_in == 128 && c_out == 128), ISF_ERR_UNSUPPORTED,
               "sparse_conv_trace: built for 128 -> 128 and 256 -> 256, got %d -> %d", c_in, c_out);
   ISF_REQUIRE(K >= 1 && K <= kMaxTaps && n_out > 0 && nbr_stride % 128 == 0 && nbr_stride >= n_out, ISF_ERR_ARG,
@@ -541,7 +599,16 @@ int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K
                   "sparse_conv_trace: the launch has %d workgroups, the trace buffer holds %d", 8 * (info.full + info.half),
                   trace_capacity_blocks);
     int rc;
-    if (c_in == 256) rc = launch16<256, 8, 2, 4, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    if (phase) {   // the per-wave phase records sit behind the per-workgroup records: [grid][8] int64, then dwords
+      const int nw = (c_in == 256 || !wide) ? 4 : 8;
+      if (waves_per_block) *waves_per_block = nw;
+      if (pass == 1)
+        ISF_REQUIRE((size_t)8 * (info.full + info.half) * (64 + (size_t)nw * (kPhaseHdr + 4 * kPhaseMaxSteps) * 4) <=
+                        phase_capacity_bytes, ISF_ERR_ARG, "sparse_conv_phase_trace: trace buffer too small");
+      if (c_in == 256) rc = launch16<256, 8, 2, 4, 512 | 2048>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+      else if (wide) rc = launch16<128, 8, 2, 8, 512 | 2048>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+      else rc = launch16<128, 8, 2, 4, 512 | 2048>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
+    } else if (c_in == 256) rc = launch16<256, 8, 2, 4, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
     else if (wide) rc = launch16<128, 8, 2, 8, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
     else rc = launch16<128, 8, 2, 4, 512>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
     ISF_TRY(rc);
@@ -795,7 +862,8 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  const int m = mode & ~32;   // bit 32 = uniform tiles (no full / half mix), combinable
+  const int m = mode & ~(32 | 4096 | 8192);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
+                                               // column block for the 256-column layers (4 x 32-row / 8 x 16-row waves)
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "
               "8 / 16, +32)", mode);
@@ -905,6 +973,24 @@ int isf_sparse_conv_trace(const void* features_split, int num_in, int c_in, cons
   return isf::sparse_conv_trace_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
                                      shift, residual_split, relu, out_split, order, trace, trace_capacity_blocks,
                                      grid_blocks, isf::as_stream(stream));
+}
+
+/* DIAGNOSTIC: isf_sparse_conv_trace plus per-WAVE phase stamps (shader clock, s_memtime) of every step of the multiply
+ * loop -- top of the step / after s_waitcnt vmcnt(0) / after the barrier / after issuing the next step's loads.  The
+ * image ships rocprofv3 without the thread-trace decoder library (rocprofv3 --att: "rocprof-trace-decoder library path
+ * not found"), so this is the instruction-level account of the dominant kernel: tools/conv_phase_trace.py. */
+int isf_sparse_conv_phase_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                                int c_out, const int32_t* nbr, int nbr_stride, int num_out, const float* scale,
+                                const float* shift, const void* residual_split, int relu, void* out_split,
+                                const int32_t* order, long long* trace, size_t trace_bytes, int* grid_blocks,
+                                int* waves_per_block, int* dwords_per_wave, isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && features_split && packed16 && nbr && out_split && trace && grid_blocks && waves_per_block &&
+                  dwords_per_wave && ((scale == nullptr) == (shift == nullptr)), ISF_ERR_ARG,
+              "sparse_conv_phase_trace: bad arguments");
+  *dwords_per_wave = isf::kPhaseHdr + 4 * isf::kPhaseMaxSteps;
+  return isf::sparse_conv_trace_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
+                                     shift, residual_split, relu, out_split, order, trace, 1 << 30, grid_blocks,
+                                     isf::as_stream(stream), true, trace_bytes, waves_per_block);
 }
 
 }  // extern "C"

@@ -409,6 +409,28 @@ def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, 
     return ys, trace[:n.value * 8].view(n.value, 8)
 
 
+def sparse_conv_phase_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,
+                            order=None):
+    """DIAGNOSTIC (isf_sparse_conv_phase_trace): sparse_conv_trace plus, per wave, shader-clock stamps of every step of
+    the multiply loop -> (out_split, wg int64 [workgroups, 8], waves uint32 [workgroups, waves, 8 + 4 * 216]): header
+    {clock lo, hi at loop entry, HW_ID, steps, tap masks of the wave's two row groups, of the workgroup, clock at loop
+    exit} then (top, after vmcnt(0), after barrier, after load issue) per step.  tools/conv_phase_trace.py."""
+    _lib.require_cuda(xs)
+    lib = _lib.load()
+    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
+    nbytes = 8 * 255 * (64 + 8 * (8 + 4 * 216) * 4)
+    trace = torch.zeros((nbytes // 8,), dtype=torch.int64, device=xs.device)
+    n, nw, dpw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.isf_sparse_conv_phase_trace(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+        _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual_split), int(bool(relu)), _lib.ptr(ys), _lib.ptr(order),
+        _lib.ptr(trace), nbytes, ctypes.byref(n), ctypes.byref(nw), ctypes.byref(dpw), _lib.stream()),
+        "isf_sparse_conv_phase_trace")
+    wg = trace[:n.value * 8].view(n.value, 8)
+    waves = trace[n.value * 8:].view(torch.int32)[:n.value * nw.value * dpw.value].view(n.value, nw.value, dpw.value)
+    return ys, wg, waves
+
+
 def stage_tables(rb):
     """(slots uint16 [K, stride], ulist int32 [stride / 64, cap], ucount int32 [stride / 64]) of a Rulebook
     (isf_rulebook_stage_tables), cached on it: the distinct input rows of every 64-row unit and where each table entry

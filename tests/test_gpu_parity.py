@@ -495,6 +495,22 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
 
 
+def test_conv_one_column_block_variants_reproduce_the_two_block_bits(dev):
+    """round 5: the 256-column layers with ONE column block per workgroup (conv mode 4096: 4 waves x 32 rows, 8192: 8 waves
+    x 16 rows; encoder diagnostic 262144 / 524288) gather a row once per tap and chunk instead of once per column block;
+    every accumulator sees the same products in the same order, so the outputs equal the production launch bit for bit."""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(900 + i, n), dev) for i in range(frames)]
+        want = lb(pl)
+        assert torch.isfinite(want).all() and want.abs().max().item() > 0.1
+        assert torch.equal(lb(pl, conv_diag=262144), want), n
+        assert torch.equal(lb(pl, conv_diag=524288), want), n
+        assert torch.equal(lb(pl, conv_diag=262144 + 32), want), n
+
+
 def test_conv_tile_order_is_a_per_part_permutation_and_keeps_the_bits(dev):
     """isf_sparse_conv_tile_order hands the tiles of a one-round launch to the workgroup slots longest first / least
     loaded CU first: per XCD part a permutation of the tiles, the first 32 slots (one per CU) holding the 32 heaviest
