@@ -196,30 +196,68 @@ def main_rehearsal(args):
         if world > 1:
             dist.barrier()
 
-    x = torch.ones(64, 64)
+    real = bool(getattr(args, "real_step", False))
+    checksum = None
+    if real:
+        # --real-step: every rank runs the REAL LidarBranch forward of its own frames on cuda:0 (a 1-GPU box: the ranks
+        # share the device; gloo carries only the barrier and the clock reduction).  What it proves before the first
+        # 8-GPU run: two processes of libisf_hip.so coexist (arena, count mailbox, pinned rings), the self-launch /
+        # rendezvous / one-line path works with the actual step inside it, and the line carries n_gpus = world.
+        assert torch.cuda.is_available(), "--real-step needs a GPU"
+        import isfusion_amd as m
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+        pts = [torch.from_numpy(p).to(dev) for p in make_frames(rank, world, args.batch, args.points)]
+
+        def step():
+            return lb(pts)
+    else:
+        x = torch.ones(64, 64)
+
+        def step():
+            nonlocal x
+            x = (x @ x) / 64.0       # the stub step
+            return x
     for _ in range(args.warmup):
-        x = (x @ x) / 64.0
+        step()
+    if real:
+        torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x = (x @ x) / 64.0       # the stub step
+        out = step()
+    if real:
+        torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    pids, frames = [os.getpid()], [mine]
+    if real:
+        checksum = [float(out.double().abs().sum().item()), bool(torch.isfinite(out).all().item())]
+    pids, frames, sums = [os.getpid()], [mine], [checksum]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        pids, frames = [None] * world, [None] * world
+        pids, frames, sums = [None] * world, [None] * world, [None] * world
         dist.all_gather_object(pids, os.getpid())
         dist.all_gather_object(frames, mine)
+        dist.all_gather_object(sums, checksum)
     if rank == 0:
-        print(json.dumps({"metric": "REHEARSAL (gloo, stub step): launch / clock / line plumbing only", "value": 0.0,
-                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "rehearsal",
-                          "config": {"workload": "stub", "parallelism": f"dp{world}", "backend": "gloo",
-                                     "rank_pids": pids, "rank_frames": frames}}))
+        line = {"metric": "REHEARSAL (gloo, stub step): launch / clock / line plumbing only", "value": 0.0,
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "rehearsal",
+                "config": {"workload": "stub", "parallelism": f"dp{world}", "backend": "gloo",
+                           "rank_pids": pids, "rank_frames": frames,
+                           "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}
+        if real:
+            line["metric"] = ("REHEARSAL (gloo clock, REAL LidarBranch step, all ranks share cuda:0): coexistence of the "
+                              "ranks' library state + the launch / clock / line path; not a scaling measurement")
+            line["value"] = round(args.batch * world * args.steps / dt, 2)
+            line["dtype"], line["data"] = "f32 (f16x3 split-precision MFMA, fp32 accumulate)", "synthetic"
+            line["config"].update(workload=f"LidarBranch forward, {args.points}-pt sweeps, batch={args.batch} per rank",
+                                  rank_checksums=sums)
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 
@@ -612,6 +650,9 @@ def main():
                     help="DIAGNOSTIC ONLY: f16 storage + single-pass f16 conv kernels (isf_encoder_options.precision 2: the "
                          "reference's indice_conv_half data types, BASELINE configs[4] dtype); reduced precision, never "
                          "the headline line")
+    ap.add_argument("--real-step", action="store_true",
+                    help="with --backend gloo: the REAL LidarBranch forward per rank, all ranks on cuda:0 (1-GPU rehearsal "
+                         "of the multi-rank run; -m gpu test)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (the measurement); gloo = CPU REHEARSAL of the multi-rank launch / clock / JSON "
                          "line with a stub step (tests/test_host.py), never a measurement")

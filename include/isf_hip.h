@@ -610,6 +610,30 @@ int isf_sparse_conv_backward_input(const float* grad_out, int num_out, int c_out
 int isf_sparse_conv_backward_filter(const float* features, int num_in, int c_in, const float* grad_out, int num_out,
                                     int c_out, const int32_t* nbr, int nbr_stride, int num_taps,
                                     float* grad_filters, isf_stream_t stream);
+/* Round 5: the FILTER gradient on the f16 matrix cores (isf_spconv_wgrad16.hip), the half instantiation of the reference's
+ * indice_conv_backward (spconv_ops.h:363-456 with T = half, all.cc:35-51) carried at fp32 accuracy by the f16x3 split.
+ * isf_rulebook_pair_lists: the neighbour table -> the spconv-1 interchange format the reference's backward walks,
+ *   indice_pairs [K, 2, capacity] (input rows, output rows of a tap's pairs, ordered by output row, -1 padded for at
+ *   least 32 entries past the count) + indice_num [K]; capacity = isf_pair_list_capacity(num_in, num_out) (a multiple of
+ *   32).  Same content as isf_rulebook_to_indice_pairs (whose second dimension is num_in), built by a two-pass ordered
+ *   compaction over 2048-row blocks instead of one workgroup per tap.  Once per rulebook.
+ * isf_grad_to_split: grad [n] fp32 -> split rows of grad * s, s = the power of two that brings max|grad| into
+ *   [2^9, 2^10) (non-finite entries do not set it); scale_out (device float[2]) = {s, 1 / s}.  Gradients of 1e-6 .. 1e-9
+ *   would otherwise lie in f16's subnormal range.  No host sync.
+ * isf_split_to_f32_scaled: split rows -> fp32 * *mul (device scalar, NULL = 1): the way back for dX.
+ * isf_sparse_conv_backward_filter_f16x3: grad_filters [K, Cin, Cout] = (*grad_inv_scale) * sum over the pairs of tap k of
+ *   x[in]^T dY[out], x and dY in the split format (x: what the forward pass stored; dY: isf_grad_to_split), products as
+ *   x_lo*g_hi + x_hi*g_lo + x_hi*g_hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation; Cin, Cout in {32, 64, 128, 256};
+ *   pair chunks -> partial blocks -> ordered second pass: deterministic.  All asynchronous. */
+int isf_pair_list_capacity(int num_in, int num_out);
+int isf_rulebook_pair_lists(const int32_t* nbr, int nbr_stride, int num_out, int num_taps, int capacity,
+                            int32_t* indice_pairs, int32_t* indice_num, isf_stream_t stream);
+int isf_grad_to_split(const float* grad, size_t num_elems, void* grad_split, float* scale_out, isf_stream_t stream);
+int isf_split_to_f32_scaled(const void* xs, size_t num_elems, const float* mul, float* x, isf_stream_t stream);
+int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in, int c_in, const void* grad_out_split,
+                                          int num_out, int c_out, const int32_t* indice_pairs, const int32_t* indice_num,
+                                          int capacity, int num_taps, const float* grad_inv_scale, float* grad_filters,
+                                          isf_stream_t stream);
 
 /* 8f #3  input pre-pass: multi-sweep assembly + augmentation + range filter ---------------------------------
  * replaces, per batch, the dataloader-side numpy / torch code of LoadPointsFromMultiSweeps.__call__

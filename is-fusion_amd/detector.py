@@ -177,7 +177,7 @@ class ISFusionPtsPath(nn.Module):
             cam = ops.h2d_async(ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
                                                       kwargs["lidar_aug_matrix"]), dev)
         main = torch.cuda.current_stream()
-        if self.__dict__.get("_graph_pillar_side", True):
+        if self.__dict__.get("_graph_pillar_side", False):
             # as in extract_pts_feat: the pillar voxelization's per-sample host round trips wait for the pillar kernels
             # only, on a side stream, while the LiDAR branch keeps the GPU busy on the launch stream
             side = self.__dict__.setdefault("_side_streams", {}).setdefault(dev, None)
@@ -212,7 +212,7 @@ class ISFusionPtsPath(nn.Module):
         return self.pts_neck(feats), ins_heatmap
 
     # ------------------------------------------------------------------------------------------- HIP graph
-    def enable_graph(self, flag=True, pillar_side_stream=True, on_null_stream=False):
+    def enable_graph(self, flag=True, pillar_side_stream=False, on_null_stream=False):
         """Inference deployment: `forward_pts` replays everything behind Point-to-Grid -- conv_fusion, Grid-to-Region,
         instance fusion, SECONDV2 stages, neck, head: ~330 launches whose shapes depend on the batch size only -- as ONE
         HIP graph per batch size (captured on the first call), so the host no longer paces those launches (the GPU was
@@ -221,8 +221,11 @@ class ISFusionPtsPath(nn.Module):
         (freeze()); freeze() / a load_state_dict below this module / train() drop the captured graphs together with the
         packed-weight caches their kernels point into (fusion_ops.drop_caches)."""
         self.__dict__["_graph_on"] = bool(flag)
-        # diagnostics of tools/graph_fault.py (DESIGN.md section 7): pillar_side_stream=False keeps the pillar voxelization
-        # on the launch stream; on_null_stream=True lets the forward run on the legacy NULL stream (the faulting set-up)
+        # pillar_side_stream: the pillar voxelization beside the LiDAR branch on a side stream.  OFF by default in graph
+        # mode since round 5 (ADVICE r4): the round-3 / round-4 memory fault needed exactly that hand-over (side-stream
+        # tensors read by the launch that precedes hipGraphLaunch) and its cause is narrowed (legacy NULL stream), not
+        # proven; the eager path keeps the side stream (never faulted, tests/test_gpu_e2e.py soak).  on_null_stream=True
+        # lets the forward run on the legacy NULL stream (the faulting set-up; tools/graph_fault.py, DESIGN.md section 7)
         self.__dict__["_graph_pillar_side"] = bool(pillar_side_stream)
         self.__dict__["_graph_on_null_stream"] = bool(on_null_stream)
         self.__dict__["_graphs"] = {}

@@ -477,6 +477,76 @@ def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=
     return out
 
 
+def sparse_conv_split(xs, packed16, K, c_in, c_out, rb):
+    """the f16x3 convolution on SPLIT rows in and out (no epilogue, no format passes): the kernel choice of
+    sparse_conv_forward_best -- LDS-DMA gathers for the narrow shapes, tile-order table for one-round launches."""
+    lib = _lib.load()
+    ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
+    args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+            None, None, None, 0, _lib.ptr(ys), 0)
+    if c_in <= 64 and c_out <= 64:
+        _lib.check(lib.isf_sparse_conv_forward_dma(*args, _lib.ptr(tile_order(rb, c_in, c_out, 0, dma=True)),
+                                                   _lib.stream()), "isf_sparse_conv_forward_dma")
+    else:
+        order = tile_order(rb, c_in, c_out, 0)
+        if order is None:
+            _lib.check(lib.isf_sparse_conv_forward_f16x3(*args, _lib.stream()), "isf_sparse_conv_forward_f16x3")
+        else:
+            _lib.check(lib.isf_sparse_conv_forward_f16x3_ordered(*args, _lib.ptr(order), _lib.stream()),
+                       "isf_sparse_conv_forward_f16x3_ordered")
+    return ys
+
+
+def pair_lists(rb):
+    """(indice_pairs int32 [K, 2, cap], indice_num int32 [K], cap) of a Rulebook (isf_rulebook_pair_lists): the spconv-1
+    interchange format the reference's backward walks, cached on the rulebook (every layer of a level shares it)."""
+    if getattr(rb, "_pairs", None) is None:
+        lib = _lib.load()
+        K = rb.nbr.numel() // rb.stride
+        cap = lib.isf_pair_list_capacity(rb.num_in, rb.num_out)
+        pairs = torch.empty((K, 2, cap), dtype=torch.int32, device=rb.nbr.device)
+        num = torch.empty((K,), dtype=torch.int32, device=rb.nbr.device)
+        _lib.check(lib.isf_rulebook_pair_lists(_lib.ptr(rb.nbr), rb.stride, rb.num_out, K, cap, _lib.ptr(pairs),
+                                               _lib.ptr(num), _lib.stream()), "isf_rulebook_pair_lists")
+        rb._pairs = (pairs, num, cap)
+    return rb._pairs
+
+
+def grad_to_split(g):
+    """fp32 gradient rows -> (split rows of g * s, scale float32 [2] = {s, 1 / s}): s the power of two that brings
+    max|g| into [2^9, 2^10) (isf_grad_to_split; device-side, no host sync)."""
+    g = g.contiguous().float()
+    gs = torch.empty(g.numel() * 4, dtype=torch.uint8, device=g.device)
+    sc = torch.empty(2, dtype=torch.float32, device=g.device)
+    _lib.check(_lib.load().isf_grad_to_split(_lib.ptr(g), g.numel(), _lib.ptr(gs), _lib.ptr(sc), _lib.stream()),
+               "isf_grad_to_split")
+    return gs, sc
+
+
+def from_split_scaled(xs, shape, mul):
+    """split rows -> fp32 * mul[0] (mul: device float tensor)"""
+    out = torch.empty(shape, dtype=torch.float32, device=xs.device)
+    _lib.check(_lib.load().isf_split_to_f32_scaled(_lib.ptr(xs), out.numel(), _lib.ptr(mul), _lib.ptr(out),
+                                                   _lib.stream()), "isf_split_to_f32_scaled")
+    return out
+
+
+def sparse_conv_backward_filter_f16x3(xs, c_in, gs, c_out, rb, inv_scale, wshape):
+    """dW [*wshape] on the f16 matrix cores (isf_sparse_conv_backward_filter_f16x3): xs / gs split rows of the layer's
+    input / of its scaled output gradient, inv_scale a device float (1 / the gradient's scale)."""
+    pairs, num, cap = pair_lists(rb)
+    K = pairs.shape[0]
+    grad_w = torch.empty(wshape, dtype=torch.float32, device=xs.device)
+    _lib.check(_lib.load().isf_sparse_conv_backward_filter_f16x3(
+        _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(gs), rb.num_out, c_out, _lib.ptr(pairs), _lib.ptr(num), cap, K,
+        _lib.ptr(inv_scale), _lib.ptr(grad_w), _lib.stream()), "isf_sparse_conv_backward_filter_f16x3")
+    return grad_w
+
+
+# round 5: dW on the f16 matrix cores + the gradient split once per layer (False: the round-2 path -- fp32-MFMA dW,
+# torch-op gradient scaling -- kept as the cross-check the tests compare against)
+WGRAD_F16X3 = True
+
 # Backward kernels (isf_spconv_bwd.hip): validated on an MI355X in round 2 (tests/test_gpu_widened.py: dX / dW against the
 # C restatement of indice_conv_backward on the golden geometries, every channel shape, a two-layer training step against
 # dense torch autograd) and on by default since.  False restores the loud NotImplementedError for autograd calls.
@@ -520,14 +590,20 @@ class SparseConvFunction(torch.autograd.Function):
         c_in, c_out = weight.shape[-2], weight.shape[-1]
         w = weight.detach().float().contiguous()
         features = features.detach().float().contiguous()
-        if _f16x3_shape(c_in, c_out):      # the inference kernel (f16x3 split MFMA): 3-4x the fp32-MFMA kernel's rate
+        xs = None
+        if _f16x3_shape(c_in, c_out) and WGRAD_F16X3 and rb.num_out > 0 and rb.num_in > 0:
+            # split rows once: the conv reads them, and so will dW in the backward pass (saved INSTEAD of the fp32 rows)
+            xs = to_split(features)
+            out = from_split(sparse_conv_split(xs, pack_filters_f16x3(w), K, c_in, c_out, rb), (rb.num_out, c_out))
+        elif _f16x3_shape(c_in, c_out):    # the inference kernel (f16x3 split MFMA): 3-4x the fp32-MFMA kernel's rate
             out = sparse_conv_forward_best(features, pack_filters_f16x3(w), K, c_in, c_out, rb)
         else:
             out = torch.empty((rb.num_out, c_out), dtype=torch.float32, device=features.device)
             _lib.check(_lib.load().isf_sparse_conv_forward(
                 _lib.ptr(features), rb.num_in, c_in, _lib.ptr(w), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
                 None, None, None, 0, _lib.ptr(out), _lib.stream()), "isf_sparse_conv_forward")
-        ctx.save_for_backward(features, w)
+        ctx.split_saved = xs is not None
+        ctx.save_for_backward(xs if xs is not None else features, w)
         ctx.rb, ctx.wshape = rb, tuple(weight.shape)
         return out
 
@@ -540,6 +616,21 @@ class SparseConvFunction(torch.autograd.Function):
         g = grad_out.contiguous().float()
         lib = _lib.load()
         grad_in = grad_w = None
+        if ctx.split_saved:
+            # one scaled split of the gradient serves dX (the forward kernel over the transposed rulebook with the
+            # transposed filters) and dW (isf_spconv_wgrad16.hip); the scale is a device scalar, undone in the last pass
+            gs, sc = grad_to_split(g)
+            if ctx.needs_input_grad[0]:
+                nbr_t, st = transposed_nbr(rb)
+                wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*ctx.wshape[:-2], c_out, c_in)
+                rbt = rb.__dict__.get("_rbt")
+                if rbt is None:      # cached: its tile-order tables are built once per rulebook, not once per layer
+                    rbt = rb._rbt = _TransposedRulebook(nbr_t, st, rb.num_out, rb.num_in)
+                grad_in = from_split_scaled(sparse_conv_split(gs, pack_filters_f16x3(wt), K, c_out, c_in, rbt),
+                                            (rb.num_in, c_in), sc[1:])
+            if ctx.needs_input_grad[1]:
+                grad_w = sparse_conv_backward_filter_f16x3(features, c_in, gs, c_out, rb, sc[1:], ctx.wshape)
+            return grad_in, grad_w, None
         if ctx.needs_input_grad[0]:
             nbr_t, st = transposed_nbr(rb)
             if _f16x3_shape(c_out, c_in):

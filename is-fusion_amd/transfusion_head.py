@@ -4,8 +4,9 @@ kernel as the encoder's instance mining) -> one transformer decoder layer (200-q
 cross-attention over the BEV map with learned position embeddings, FFN) -> per-proposal regression / class heads.
 
 Parameter / sub-module names equal the reference's (96 state-dict keys; checked with ``load_state_dict(strict=True)``
-into the reference class in tests/golden/make_golden_head.py).  Inference forward only: losses, target assignment and box
-decoding (``loss``, ``get_targets``, ``get_bboxes``) are control plane around this path and are not built.
+into the reference class in tests/golden/make_golden_head.py).  Inference: ``forward`` / ``forward_split`` and the box
+decoding ``get_bboxes`` (isf_decode_boxes, below) are built and pinned by reference goldens; losses and target assignment
+(``loss``, ``get_targets``) are training control plane around this path and are not.
 
 HIP path: the two 3x3 convs on the f16x3 sparse-conv kernel over the dense grid, top-k through ``isf_instance_topk``,
 all Linear layers through ``isf_linear_forward`` (the key / value projection of the 32400 x B BEV tokens folds the

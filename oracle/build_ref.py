@@ -10,7 +10,7 @@ entry points are compiled out (voxelization.h:21).  No stand-in headers are writ
 The vendored spconv-1.x tree (mmdet3d/ops/bevfusion-ops/spconv) is NOT built: it includes
 <cuda_runtime_api.h> and <ATen/cuda/CUDAContext.h>, which this ROCm image lacks, and providing
 stand-ins for them is not allowed -> "unbuildable here"; the sparse-conv oracle is pinned by the
-dense-conv3d identity instead (tests/test_oracle_spconv.py).
+dense-conv3d identity instead (tests/test_oracle.py: the oracle against tests/golden/spconv_dense_ref.npz).
 
 Usage:  python oracle/build_ref.py        (about 1 min; only works where /root/reference exists)
 """

@@ -313,6 +313,109 @@ def test_sparse_conv_backward_channel_shapes(dev, oracle_mod, cin, cout, gscale)
     assert torch.equal(x.grad, x2.grad) and torch.equal(wt.grad, w2.grad)
 
 
+def test_pair_lists_equal_the_interchange_format_and_its_counts(dev):
+    """isf_rulebook_pair_lists (two-pass ordered compaction, round 5) == isf_rulebook_to_indice_pairs (one workgroup per
+    tap): same pairs in the same order, same counts, -1 padding behind them; SubM and strided rulebooks, a level larger
+    than one 2048-row block and an empty one"""
+    from isfusion_amd import _lib, spconv
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    B, shape = 2, [12, 40, 40]
+    for n, subm in ((9000, True), (9000, False), (700, True), (0, True)):
+        cells = np.sort(rng.choice(B * int(np.prod(shape)), n, replace=False))
+        idx = np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32).reshape(-1, 4)
+        if n == 0:
+            continue   # build_rulebook of an empty tensor is covered elsewhere; the C entry's num_out == 0 path below
+        rb = spconv.build_rulebook(_T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1] if subm else [2, 2, 2], [1, 1, 1], subm)
+        K = rb.nbr.numel() // rb.stride
+        pairs, num, cap = spconv.pair_lists(rb)
+        ref_pairs = torch.full((K, 2, max(rb.num_in, 1)), -7, dtype=torch.int32, device=dev)
+        ref_num = torch.zeros(K, dtype=torch.int32, device=dev)
+        _lib.check(lib.isf_rulebook_to_indice_pairs(_lib.ptr(rb.nbr), rb.stride, rb.num_out, K, rb.num_in, _lib.ptr(ref_pairs),
+                                                    _lib.ptr(ref_num), _lib.stream()))
+        assert torch.equal(num, ref_num)
+        assert cap % 32 == 0 and cap >= int(num.max()) + 32
+        for k in range(K):
+            c = int(num[k])
+            assert torch.equal(pairs[k, :, :c], ref_pairs[k, :, :c]), (n, subm, k)
+            assert (pairs[k, :, c:c + 32] == -1).all()
+    num = torch.full((27,), 5, dtype=torch.int32, device=dev)
+    pairs = torch.zeros((27, 2, 32), dtype=torch.int32, device=dev)
+    nbr = torch.zeros((27 * 128,), dtype=torch.int32, device=dev)
+    _lib.check(lib.isf_rulebook_pair_lists(_lib.ptr(nbr), 128, 0, 27, 32, _lib.ptr(pairs), _lib.ptr(num), _lib.stream()))
+    assert int(num.abs().sum()) == 0 and (pairs == -1).all()
+
+
+@pytest.mark.parametrize("cin,cout,n,subm", [(32, 32, 30000, True), (64, 32, 12000, True), (32, 64, 12000, False),
+                                            (64, 64, 30000, True), (128, 128, 9000, True), (128, 256, 9000, False),
+                                            (256, 256, 6000, True), (256, 128, 777, True)])
+def test_wgrad_f16x3_matches_fp64_and_the_fp32_mfma_kernel(dev, cin, cout, n, subm):
+    """isf_sparse_conv_backward_filter_f16x3 (round 5: dW on v_mfma_f32_16x16x32_f16 in the f16x3 split, pair lists,
+    LDS-transposed staging) against a float64 sum over the pairs and against the fp32-MFMA kernel it replaces: every
+    block shape, several pair chunks per tap, taps with zero / ragged pair counts, strided rulebooks (num_in != num_out),
+    gradients of the size a real backward carries; deterministic"""
+    from isfusion_amd import _lib, spconv
+    lib = _lib.load()
+    rng = np.random.default_rng(cin + 7 * cout + n)
+    B, shape = 2, [10, 48, 48]
+    cells = np.sort(rng.choice(B * int(np.prod(shape)), n, replace=False))
+    idx = np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32)
+    rb = spconv.build_rulebook(_T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1] if subm else [2, 2, 2], [1, 1, 1], subm)
+    K = 27
+    x = torch.randn(rb.num_in, cin, device=dev) * 0.7
+    g = torch.randn(rb.num_out, cout, device=dev) * 3e-7
+    g[::17] *= 40.0                                     # a few large rows set the scale
+    xs = spconv.to_split(x)
+    gs, sc = spconv.grad_to_split(g)
+    s = float(sc[0])
+    assert s == 2.0 ** round(np.log2(s)) and 2 ** 9 <= float(g.abs().max()) * s < 2 ** 10
+    assert abs(float(sc[1]) * s - 1.0) < 1e-6
+    got = spconv.sparse_conv_backward_filter_f16x3(xs, cin, gs, cout, rb, sc[1:], (3, 3, 3, cin, cout)).view(K, cin, cout)
+    again = spconv.sparse_conv_backward_filter_f16x3(xs, cin, gs, cout, rb, sc[1:], (3, 3, 3, cin, cout)).view(K, cin, cout)
+    assert torch.equal(got, again)
+    old = torch.empty(K, cin, cout, device=dev)
+    _lib.check(lib.isf_sparse_conv_backward_filter(_lib.ptr(x), rb.num_in, cin, _lib.ptr(g), rb.num_out, cout,
+                                                   _lib.ptr(rb.nbr), rb.stride, K, _lib.ptr(old), _lib.stream()))
+    nbr = rb.nbr.view(K, rb.stride)[:, :rb.num_out]
+    x64, g64 = x.double(), g.double()
+    want = torch.zeros(K, cin, cout, dtype=torch.float64, device=dev)
+    for k in range(K):
+        o = torch.nonzero(nbr[k] >= 0).flatten()
+        if o.numel():
+            want[k] = x64[nbr[k][o].long()].T @ g64[o]
+    scale = float(want.abs().max())
+    assert scale > 0
+    assert float((got.double() - want).abs().max()) < 2e-5 * scale, float((got.double() - want).abs().max()) / scale
+    assert float((old.double() - want).abs().max()) < 2e-5 * scale
+
+
+def test_training_path_without_the_f16_wgrad_still_works(dev):
+    """spconv.WGRAD_F16X3 = False restores the round-2 backward (fp32-MFMA dW, torch-op gradient scaling); both paths
+    agree to fp32 rounding"""
+    from isfusion_amd import spconv
+    rng = np.random.default_rng(3)
+    B, shape, n, cin, cout = 2, [9, 24, 24], 1500, 64, 128
+    cells = np.sort(rng.choice(B * int(np.prod(shape)), n, replace=False))
+    idx = np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32)
+    rb = spconv.build_rulebook(_T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    feats = torch.randn(n, cin, device=dev)
+    w = torch.randn(3, 3, 3, cin, cout, device=dev) / np.sqrt(27 * cin)
+    gout = torch.randn(n, cout, device=dev) * 1e-6
+    res = []
+    try:
+        for flag in (True, False):
+            spconv.WGRAD_F16X3 = flag
+            x, wt = feats.clone().requires_grad_(), w.clone().requires_grad_()
+            out = spconv.SparseConvFunction.apply(x, wt, rb)
+            out.backward(gout)
+            res.append((out.detach(), x.grad, wt.grad))
+    finally:
+        spconv.WGRAD_F16X3 = True
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert float((a - b).abs().max()) < 1e-4 * float(b.abs().max())
+
+
 def test_sparse_encoder_training_step_matches_torch_dense_autograd(dev):
     """SparseEncoder in train() mode (module-by-module: HIP conv Function + stock BatchNorm1d / ReLU, as the reference
     composes them) -- loss.backward() vs the same network written with dense torch conv3d on the zero-filled grid

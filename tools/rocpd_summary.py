@@ -11,6 +11,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "anon::")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "").replace("isf::", "")
     return name[:96]

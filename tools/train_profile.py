@@ -20,7 +20,7 @@ def main():
     print(f"# per training step (difference of the two traces / {n} steps): {sum(r[0] for r in rows) / 1e3:.2f} ms of kernels, "
           f"{sum(r[1] for r in rows):.0f} launches")
     print(f"{'us/step':>10s} {'calls':>7s}  kernel")
-    for us, c, k in rows[:45]:
+    for us, c, k in rows[:70]:
         print(f"{us:10.1f} {c:7.1f}  {k}")
 
 

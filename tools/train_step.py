@@ -37,19 +37,25 @@ def main():
     ap.add_argument("--autocast", action="store_true",
                     help="run forward + loss under torch.autocast(bfloat16): stock convs / linears in bf16, the HIP "
                          "autograd Functions cast their inputs to fp32")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo with --shared-device = a 1-GPU REHEARSAL of the "
+                         "multi-rank step (DDP's bucketed all-reduce and the sync-BN exchange go through gloo)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="every rank uses cuda:0 (1-GPU box): proves that several processes of libisf_hip.so train side "
+                         "by side; with --backend gloo")
     a = ap.parse_args()
     from isfusion_amd import launch, synthetic
     if a.gpus > 0:
-        launch.self_launch(a.gpus, "nccl")
+        launch.self_launch(a.gpus, a.backend)
     from isfusion_amd.detector import ISFusionPtsPath
     from isfusion_amd.fusion_modules import seeded_state_dict
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.shared_device else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29540")
-    dist.init_process_group("nccl", rank=rank, world_size=world)     # RCCL on ROCm
+    dist.init_process_group(a.backend, rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
     net = ISFusionPtsPath().train()
     net._lidar.randomize_weights_(0).randomize_bn_(1)
     for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250)):
@@ -91,7 +97,7 @@ def main():
     dist.barrier()
     dt = (time.perf_counter() - t0) / max(a.steps, 1)
     if rank == 0:
-        print(json.dumps({"world_size": world, "n_gpus": world, "parallelism": f"dp{world}", "rccl": launch.rccl_version(), "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16, "autocast_bf16": a.autocast,
+        print(json.dumps({"world_size": world, "n_gpus": world, "parallelism": f"dp{world}", "rccl": launch.rccl_version(), "backend": a.backend, "shared_device": a.shared_device, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16, "autocast_bf16": a.autocast,
                           "ms_per_train_step": round(dt * 1e3, 2), "losses": [round(v, 5) for v in losses]}))
     dist.destroy_process_group()
 

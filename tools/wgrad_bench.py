@@ -2,7 +2,9 @@
 
     python tools/wgrad_bench.py [--rows 40000] [--cin 256] [--cout 256]
 
-Prints ms per call and the fp32-MFMA fraction (2 * pairs * Cin * Cout flops against 157.3 TFLOP/s)."""
+Prints ms per call and the fp32-MFMA fraction (2 * pairs * Cin * Cout flops against 157.3 TFLOP/s); with --f16x3 the
+round-5 kernel (isf_sparse_conv_backward_filter_f16x3: f16x3 split on v_mfma_f32_16x16x32_f16, pair lists) and its
+fraction of the f16x3 roofline (2500 / 3 TFLOP/s), the gradient split and the pair-list build timed beside it."""
 import argparse
 import ctypes
 import os
@@ -20,6 +22,7 @@ def main():
     ap.add_argument("--cin", type=int, default=256)
     ap.add_argument("--cout", type=int, default=256)
     ap.add_argument("--lib", default="", help="A/B: load this build of libisf_hip.so instead of the in-tree one")
+    ap.add_argument("--f16x3", action="store_true", help="the f16 matrix-core dW (round 5) instead of the fp32-MFMA kernel")
     a = ap.parse_args()
     from isfusion_amd import _lib, spconv as sp
     if a.lib:
@@ -27,6 +30,8 @@ def main():
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
     B, shape = 2, [12, 96, 96]
+    while a.rows > 0.4 * B * shape[0] * shape[1] * shape[2]:
+        shape = [shape[0], shape[1] * 2, shape[2] * 2]
     cells = B * int(np.prod(shape))
     lin = np.sort(rng.choice(cells, a.rows, replace=False))
     D, H, W = shape
@@ -42,6 +47,45 @@ def main():
         _lib.check(lib.isf_sparse_conv_backward_filter(_lib.ptr(x), rb.num_in, a.cin, _lib.ptr(g), rb.num_out, a.cout,
                                                        _lib.ptr(rb.nbr), rb.stride, 27, _lib.ptr(dw), _lib.stream()),
                    "isf_sparse_conv_backward_filter")
+    if a.f16x3:
+        xs = sp.to_split(x)
+        g.mul_(1e-6)                       # the size a real backward carries: exercises the power-of-two scale
+
+        def timed(fn, n=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(n):
+                fn()
+            t1.record()
+            torch.cuda.synchronize()
+            return t0.elapsed_time(t1) / n
+
+        def build_pairs():
+            rb._pairs = None
+            sp.pair_lists(rb)
+        ms_pairs = timed(build_pairs)
+        ms_split = timed(lambda: sp.grad_to_split(g))
+        gs, sc = sp.grad_to_split(g)
+        out = {}
+
+        def call():
+            out["dw"] = sp.sparse_conv_backward_filter_f16x3(xs, a.cin, gs, a.cout, rb, sc[1:], (27, a.cin, a.cout))
+        ms = timed(call)
+        dw = out["dw"]
+        fl = 2.0 * pairs * a.cin * a.cout
+        nb = rb.nbr.view(27, rb.stride)[:, :rb.num_out]
+        err = 0.0
+        for k in (0, 13, 26):
+            m = nb[k] >= 0
+            ref = x[nb[k][m].long()].double().T.mm(g[m].double())
+            err = max(err, float((dw[k].double() - ref).abs().max() / ref.abs().max()))
+        print(f"rows {a.rows} {a.cin}->{a.cout}: {pairs} pairs, f16x3 dW {ms:.3f} ms = {fl / ms / 1e9:.1f} TFLOP/s = "
+              f"{fl / ms / 1e9 / 833.3:.3f} of the f16x3 roofline (+ once per layer: gradient split {ms_split:.3f} ms; once "
+              f"per rulebook: pair lists {ms_pairs:.3f} ms); rel err vs float64 {err:.1e}")
+        return
     for _ in range(3):
         call()
     torch.cuda.synchronize()
