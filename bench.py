@@ -283,6 +283,90 @@ def main_fusion(args):
         dist.destroy_process_group()
 
 
+def attention_rooflines(net, dev, B, timed, p2g_ms=None, pillars=None):
+    """north_star: "MFMA utilisation (attention)" -- the three attention kernels of the full path timed on their cfg-3
+    shapes (own weights of the built network, random activations; HIP events around 10 launches each), algorithmic flops
+    per DESIGN.md section 4 against the matrix peak of the arithmetic each computes in.  + Point-to-Grid in GB/s."""
+    import torch
+    from isfusion_amd import fusion_ops as ops
+    enc = net.fusion_encoder
+    out = {}
+    with torch.no_grad():
+        # fused window block (d = 128, 180 x 180 grid, 6 x 6 windows, 8 heads): per token 2*d*3d (qkv) + 2*2*36*d (scores,
+        # PV) + 2*d*d (out projection) flop
+        sst = enc.grid2region_att[0]
+        win = enc.get_regions[0].window_shape[0]
+        layer = sst.block_list[0].encoder_list[0]
+        d = layer.win_attn.self_attn.out_proj.in_features
+        S = enc.bev_size
+        pc = ops._encoder_layer_cache(layer, S, win, 0, float(enc.get_regions[0].pos_temperature), dev, B)
+        if pc.get("block") is not None:
+            x = torch.randn(B * S * S, d, device=dev)
+            ms, _ = timed(lambda: ops.window_block(x, pc["block"], pc["in_bias"], pc["table"], pc["out_bias"], layer.norm1, B,
+                                                   S, d, layer.win_attn.nhead, win, 0))
+            fl = B * S * S * (2.0 * d * 3 * d + 4.0 * win * win * d + 2.0 * d * d)
+            out["window_block_kernel<128,16>"] = dict(
+                ms=round(ms, 4), gflop=round(fl / 1e9, 2), tflops=round(fl / ms / 1e9, 1), peak=round(MFMA_F16_PEAK_TFLOPS / 3, 1),
+                frac=round(3 * fl / ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), bound="mfma (f16x3)",
+                shape=f"{B * S * S} tokens, d {d}, {win}x{win} windows: qkv + attention + out projection + LN in one launch")
+        # instance-to-scene cross attention: 32400 scene queries x 200 instance keys, 8 heads of 16 (flash style, MFMA)
+        E, Q, nh = 128, 200, 8
+        q = torch.randn(B * S * S, E, device=dev)
+        kv = torch.randn(B * Q, 2 * E, device=dev)
+        ms, _ = timed(lambda: ops.attention(q, kv, kv[:, E:], B, S * S, Q, E, nh, ldkv=2 * E))
+        fl = 4.0 * B * S * S * Q * E
+        out["attention_mfma16_kernel (32400 x 200)"] = dict(
+            ms=round(ms, 4), gflop=round(fl / 1e9, 2), tflops=round(fl / ms / 1e9, 1), peak=round(MFMA_F16_PEAK_TFLOPS / 3, 1),
+            frac=round(3 * fl / ms / 1e9 / MFMA_F16_PEAK_TFLOPS, 4), bound="mfma (f16x3)",
+            shape=f"B {B}: {S * S} queries x {Q} keys, {nh} heads of {E // nh}")
+        # per-channel 180 x 180 map attention (fp32 MFMA): 4 R^3 flop per map, B * C maps
+        C = 128
+        a, b = torch.randn(B, C, S, S, device=dev), torch.randn(B, C, S, S, device=dev)
+        ms, _ = timed(lambda: ops.channel_attention(a, b))
+        fl = 4.0 * S ** 3 * B * C
+        out["channel_attention_mfma_kernel"] = dict(
+            ms=round(ms, 4), gflop=round(fl / 1e9, 2), tflops=round(fl / ms / 1e9, 1), peak=MFMA_F32_PEAK_TFLOPS,
+            frac=round(fl / ms / 1e9 / MFMA_F32_PEAK_TFLOPS, 4), bound="mfma (fp32)", shape=f"{B * C} maps of {S} x {S}")
+    if p2g_ms and pillars is not None:
+        M, T = int(pillars.shape[0]), int(pillars.shape[1])
+        by = M * T * 12.0 + B * 6 * 24 * 66 * 256 * 4.0 + B * 256 * S * S * 4.0   # pillar points + NHWC camera map + canvas
+        out["p2g_kernel"] = dict(ms=round(p2g_ms, 4), algorithmic_gbs=round(by / p2g_ms / 1e6, 1), peak=HBM_PEAK_GBS,
+                                 frac=round(by / p2g_ms / 1e6 / HBM_PEAK_GBS, 4), bound="hbm / L2 latency",
+                                 shape=f"{M} pillars x {T} points, 6 cameras, canvas [{B}, 256, {S}, {S}]")
+    return out
+
+
+def voxel_scatter_roofline(lb, frames, n=10):
+    """north_star: "HBM GB/s (voxel scatter)" -- dynamic voxelization + DynamicVFE (hash-free rank index, counting sort
+    of the points by voxel, two fused VFE layers with segmented max) timed standalone on the step's frames (HIP events
+    around `n` calls of the two C entries; inside the engine the same kernels run fused with the frame marking), against
+    the algorithmic bytes of DESIGN.md section 4: voxelize P * (20 + 16), VFE 3 passes over 32-byte point records +
+    3 x N x 64 floats of voxel rows."""
+    import torch
+    from isfusion_amd.voxelize import dynamic_voxelize_batched
+    vfe = lb.pts_voxel_encoder
+
+    def run():
+        pts, coors = dynamic_voxelize_batched(frames, lb.voxel_size, lb.point_cloud_range)
+        return pts, vfe(pts.float(), coors)
+    with torch.no_grad():
+        pts, (vf, vc) = run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    P, N = int(pts.shape[0]), int(vf.shape[0])
+    by = P * (20.0 + 16.0) + 3.0 * P * 32.0 + 3.0 * N * 64 * 4.0
+    return dict(ms=round(ms, 4), points=P, voxels=N, algorithmic_gbs=round(by / ms / 1e6, 1), peak=HBM_PEAK_GBS,
+                frac=round(by / ms / 1e6 / HBM_PEAK_GBS, 4), bound="hbm + latency",
+                kernels="dynamic_voxelize + vfe_prep / count / scan / order / mean / layer1 / layer2 (isf_voxelize.hip, "
+                        "isf_vfe.hip), two host read-backs included")
+
+
 def fusion_leg(args, rank, world, dev, B, steps, warmup, with_cpu_baseline):
     """BASELINE configs[2]: full IS-Fusion HSF + IGF forward -- LiDAR branch, pillar voxelization, ISFusionEncoder
     (Point-to-Grid, conv_fusion, Grid-to-Region x2, instance mining / context / instance-to-scene), SECONDV2 stages,
@@ -404,6 +488,10 @@ def fusion_leg(args, rank, world, dev, B, steps, warmup, with_cpu_baseline):
                                            note="SECONDV2 stage 1 + 2: twelve 3x3 convs on the sparse-conv kernel over "
                                                 "the dense-grid rulebook (includes their layout conversions)"),
                     stages_ms=stages, stages_sum_ms=round(sum(stages.values()), 3))
+        try:
+            roof["attention_kernels"] = attention_rooflines(net, dev, B, timed, stages.get("p2g"), pil)
+        except Exception as e:                              # the line stands without the extra entries
+            roof["attention_kernels"] = {"error": str(e)[:200]}
         line = {
             "metric": "nuScenes frames/sec forward (0.075 voxel), full HSF+IGF point-cloud path incl. neck + head forward",
             "value": round(B * world * steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
@@ -531,13 +619,14 @@ def f16_stress_leg(args, rank, world, dev, steps=16, warmup=4, B=4, points=50000
             "voxels_level0": int(st.num_in[0]), "per_kernel": per}
 
 
-def train_leg(args, rank, world, dev, steps=3, B=2, points=60000):
+def train_leg(args, rank, world, dev, steps=10, B=2, points=300000):
     """BASELINE configs[3] on one GPU, attached as "cfg4_train": the full point-cloud path's training step (forward with
     gradients through LiDAR branch, fusion encoder, SECONDV2 stages and neck + stand-in loss + backward + SGD step) under
     torch.autocast(bfloat16), B frames per GPU.  ms per step from the wall clock around `steps` synchronised steps;
     launches and the device-time share from one further step under torch.profiler (None when the profiler is not
     usable on the box).  The 8-GPU leg wraps the same module in DDP (tools/train_step.py --gpus 8: RCCL all-reduce of the
-    gradients only)."""
+    gradients only).  Round 5: the leg runs at the headline's sweep size (2 x 300 000 points, the config's
+    batch of 2 per GPU) for 10 timed steps after 2 warm-ups; rounds 2-4 reported 60 000-point sweeps x 3 steps."""
     import torch
     from isfusion_amd import synthetic
     from isfusion_amd.detector import ISFusionPtsPath
@@ -797,6 +886,10 @@ def main():
                                         if v["ms"] > 0 else 0, gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
                                         if v["ms"] > 0 else 0, launches=v["launches"]) for k, v in groups.items()},
                     voxels_per_level=[int(samples[-1][1][0])] + [int(samples[-1][2][i]) for i, t in enumerate(tab) if t[0] == "spconv"])
+        try:
+            roof["voxel_scatter"] = voxel_scatter_roofline(lb, frame_sets[0])
+        except Exception as e:                              # the line stands without the extra entry
+            roof["voxel_scatter"] = {"error": str(e)[:200]}
         frames_total = args.batch * world * args.steps
         line = {
             "metric": "nuScenes frames/sec forward (0.075 voxel), LiDAR branch voxelize+spconv->BEV",

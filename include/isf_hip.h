@@ -245,12 +245,14 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
  * tiles carry 3x different matrix work (scene density), so the launch ends with its densest CU.  isf_sparse_conv_tile_table
  * deals the 16-row groups of every XCD's row range to that XCD's compute units as contiguous runs of about EQUAL WORK
  * (taps with a neighbour per group) and cuts a CU's run into full tiles plus one remainder tile, slot = where the
- * dispatcher places it: table [parts][workgroups per CU * CUs per XCD][2] = (first group, groups); scratch holds
- * 2 * ceil(num_out / 16) ints; *num_ints = ints written (0: the launch is not one round -- use the plain entry).
+ * dispatcher places it: table [parts][workgroups per CU * CUs per XCD][2] = (first group, groups), a buffer of 3072 ints
+ * (8 parts x 2 x 192 slots per XCD; a launch that would need more is refused with ISF_ERR_UNSUPPORTED, never written past the
+ * buffer); scratch holds 2 * ceil(num_out / 16) ints; *num_ints = ints written (0: the launch is not one round -- use the
+ * plain entry).
  * isf_sparse_conv_forward_f16x3_tiled runs the convolution over it: BIT-IDENTICAL results (a row's products and their
  * order do not depend on the tile it falls into); the table belongs to one (c_in, c_out, mode): the workgroup shape depends
  * on all three.  MEASURED SLOWER than uniform tiles + isf_sparse_conv_tile_order on the MI355X (256 -> 256: 1.32 vs 1.265 ms
- * per step; profiles/r04_tile_tables.txt, DESIGN.md section 5.4: a tile's time follows its STEP count, not its matrix
+ * per step; profiles/r04_tile_tables.txt, profiles/EXPERIMENTS.md section 5.4: a tile's time follows its STEP count, not its matrix
  * work), so it is an OPT-IN: isf_sparse_encoder_forward builds the tables with diagnostic +32768.
  * isf_sparse_conv_tile_table_host: the same arithmetic on the host (tests). */
 int isf_sparse_conv_tile_table(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int c_in, int c_out,
@@ -320,11 +322,13 @@ int isf_sparse_conv_forward_dma_lines(const void* features_split, int num_in, in
  * its own weight stage.  isf_sparse_conv_cu_plan cuts the rows of a rulebook into units of whole 16-row groups with EQUAL
  * matrix work (taps with a neighbour per group; <= 256 rows; cus * r units) -- plan_buf holds
  * isf_sparse_conv_cu_plan_ints(num_out) int32, the plan struct points into it, no host sync (the grid is sized by
- * max_units) -- once per rulebook; isf_sparse_conv_forward_cu runs one 8-wave workgroup per unit over ALL 256 output columns:
- * wave w owns columns [32 w, 32 w + 32), its weight fragments go global -> VGPR (no LDS, one stream per CU instead of one
- * per tile), the gathered rows come in by LDS-DMA once per CU through a three-stage ring (two steps ahead).  Results are
+ * max_units) -- once per rulebook; isf_sparse_conv_forward_cu runs one workgroup per unit over ALL 256 output columns; the
+ * production variant (variant 0 = kCuWavesProd) is FOUR waves, wave w owns columns [64 w, 64 w + 64) (256 accumulator
+ * registers = the AGPR half of the file; variants 6 / 7 are the 8-wave x 32-column shape), its weight fragments go
+ * global -> VGPR (no LDS, one stream per CU instead of one per tile), the gathered rows come in by LDS-DMA once per CU
+ * through a ring of prefetch depth + 1 stages.  Results are
  * BIT-IDENTICAL to isf_sparse_conv_forward_f16x3 (mode 0).  MEASURED SLOWER than the tile kernel on the MI355X (256 -> 256:
- * 1.39 .. 1.50 ms per step against 1.26; profiles/r04_cu_kernel_ab.txt), so it is an OPT-IN:
+ * 1.39 .. 1.50 ms per step against 1.26; profiles/r04_cu_kernel_ab.txt, profiles/EXPERIMENTS.md section 5.2), so it is an OPT-IN:
  * isf_sparse_encoder_forward / isf_lidar_branch_forward run their 256-column layers on it with diagnostic +512.  isf_sparse_conv_cu_plan_host / _max_units: the plan
  * arithmetic on the host (tests, tools; no device work): work [num_groups] -> units [max_units][2] = (first group, groups).
  * Replaces the reference's per-tap gather -> GEMM -> scatter-add (spconv_ops.h:260-361) for those layers. */
@@ -620,6 +624,8 @@ int isf_sparse_conv_backward_filter(const float* features, int num_in, int c_in,
  * isf_grad_to_split: grad [n] fp32 -> split rows of grad * s, s = the power of two that brings max|grad| into
  *   [2^9, 2^10) (non-finite entries do not set it); scale_out (device float[2]) = {s, 1 / s}.  Gradients of 1e-6 .. 1e-9
  *   would otherwise lie in f16's subnormal range.  No host sync.
+ * isf_grad_rescale: the same scale with fp32 rows out (out = grad * s; the fused linear's dX GEMM splits its input itself):
+ *   two launches instead of the nine torch ops of the round-2 form (_lib.pow2_rescale), ~50 calls per training step.
  * isf_split_to_f32_scaled: split rows -> fp32 * *mul (device scalar, NULL = 1): the way back for dX.
  * isf_sparse_conv_backward_filter_f16x3: grad_filters [K, Cin, Cout] = (*grad_inv_scale) * sum over the pairs of tap k of
  *   x[in]^T dY[out], x and dY in the split format (x: what the forward pass stored; dY: isf_grad_to_split), products as
@@ -629,11 +635,34 @@ int isf_pair_list_capacity(int num_in, int num_out);
 int isf_rulebook_pair_lists(const int32_t* nbr, int nbr_stride, int num_out, int num_taps, int capacity,
                             int32_t* indice_pairs, int32_t* indice_num, isf_stream_t stream);
 int isf_grad_to_split(const float* grad, size_t num_elems, void* grad_split, float* scale_out, isf_stream_t stream);
+int isf_grad_rescale(const float* grad, size_t num_elems, float* out, float* scale_out, isf_stream_t stream);
 int isf_split_to_f32_scaled(const void* xs, size_t num_elems, const float* mul, float* x, isf_stream_t stream);
 int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in, int c_in, const void* grad_out_split,
                                           int num_out, int c_out, const int32_t* indice_pairs, const int32_t* indice_num,
                                           int capacity, int num_taps, const float* grad_inv_scale, float* grad_filters,
                                           isf_stream_t stream);
+
+/* Round 5: BatchNorm1d with BATCH statistics (+ residual, + ReLU) on [N, C] fp32 rows, forward and backward
+ * (isf_bn_train.hip) -- the norm / activation of the reference's sparse blocks and DynamicVFE layers in TRAINING mode:
+ * nn.BatchNorm1d / naiveSyncBN1d.forward (ops/norm.py:136-211) + ReLU (+ the identity add of SparseBasicBlock,
+ * ops/sparse_block.py:117-134), and what autograd derives for them.  channels = 4 * a divisor of 256.
+ *   isf_bn1d_stats: stats [2C] = (sum x, sum x^2) per channel (partial sums per block -> ordered second level:
+ *     deterministic).  The caller all-reduces stats (and the row count) across ranks for sync-BN.
+ *   isf_bn1d_apply: y = relu?(x * gamma * invstd + beta - mean * gamma * invstd + residual?), mean / var from stats /
+ *     count; running_mean / running_var (may be NULL) += momentum * (batch - running), the variance unbiased (nn.BatchNorm1d)
+ *     or biased (naiveSyncBN1d) by unbiased_running_var; mean_invstd [2C] saved for the backward pass.
+ *   isf_bn1d_backward_sums: sums [2C] = (sum g, sum g * xhat), g = grad_y masked by y_relu > 0 (y_relu NULL: no ReLU).
+ *   isf_bn1d_backward_apply: grad_x = gamma * invstd * (g - sum_g / count - xhat * sum_gx / count); grad_residual (may be
+ *     NULL) = g; grad_gamma = sum_gx, grad_beta = sum_g (may be NULL).  All asynchronous. */
+int isf_bn1d_stats(const float* x, int num_rows, int channels, float* stats, isf_stream_t stream);
+int isf_bn1d_apply(const float* x, int num_rows, int channels, const float* stats, float count, const float* gamma,
+                   const float* beta, float eps, float momentum, int unbiased_running_var, float* running_mean,
+                   float* running_var, const float* residual, int relu, float* y, float* mean_invstd, isf_stream_t stream);
+int isf_bn1d_backward_sums(const float* grad_y, const float* x, const float* y_relu, int num_rows, int channels,
+                           const float* mean_invstd, float* sums, isf_stream_t stream);
+int isf_bn1d_backward_apply(const float* grad_y, const float* x, const float* y_relu, int num_rows, int channels,
+                            const float* mean_invstd, const float* gamma, const float* sums, float count, float* grad_x,
+                            float* grad_residual, float* grad_gamma, float* grad_beta, isf_stream_t stream);
 
 /* 8f #3  input pre-pass: multi-sweep assembly + augmentation + range filter ---------------------------------
  * replaces, per batch, the dataloader-side numpy / torch code of LoadPointsFromMultiSweeps.__call__

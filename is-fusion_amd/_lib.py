@@ -221,9 +221,16 @@ SIGNATURES = {
                                                c_void_p, c_void_p]),
     "isf_sparse_conv_backward_filter": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                                 c_int, c_void_p, c_void_p]),
+    "isf_bn1d_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "isf_bn1d_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_void_p, c_void_p, ctypes.c_float,
+                               ctypes.c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "isf_bn1d_backward_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "isf_bn1d_backward_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isf_pair_list_capacity": (c_int, [c_int, c_int]),
     "isf_rulebook_pair_lists": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "isf_grad_to_split": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p]),
+    "isf_grad_rescale": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p]),
     "isf_split_to_f32_scaled": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p]),
     "isf_sparse_conv_backward_filter_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                                       c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -297,6 +304,17 @@ def f6(v):
 
 def i3(v):
     return _I3(*[int(x) for x in v])
+
+
+def grad_rescale(g):
+    """(g * s, scale float32 [2] = {s, 1 / s}) through isf_grad_rescale: the power-of-two scale of pow2_rescale (largest
+    finite |g| into [2^9, 2^10)) in two launches, no host sync"""
+    import torch
+    g = g.contiguous().float()
+    out = torch.empty_like(g)
+    sc = torch.empty(2, dtype=torch.float32, device=g.device)
+    check(load().isf_grad_rescale(ptr(g), g.numel(), ptr(out), ptr(sc), stream()), "isf_grad_rescale")
+    return out, sc
 
 
 def pow2_rescale(g):

@@ -1,4 +1,7 @@
 // isf_runtime.hip -- error state, per-device workspace arena, occupancy-index (rank bitmap) kernels.
+#include <atomic>
+#include <thread>
+
 #include "isf_common.h"
 
 #include <map>
@@ -161,7 +164,9 @@ __global__ void publish_int_kernel(const int* __restrict__ src, volatile int* bo
 int post_int(Arena& a, const int* dev, hipStream_t st, unsigned* ticket) {
   if (!a.mailbox_host) {
     void* h = nullptr;
-    ISF_HIP_TRY(hipHostMalloc(&h, kMailboxSlots * 2 * sizeof(int), hipHostMallocMapped));
+    // coherent (fine-grained) explicitly: the host polls this memory while the kernel that writes it may still be
+    // running; the default follows HIP_HOST_COHERENT
+    ISF_HIP_TRY(hipHostMalloc(&h, kMailboxSlots * 2 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     memset(h, 0, kMailboxSlots * 2 * sizeof(int));
     void* d = nullptr;
     ISF_HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
@@ -200,7 +205,9 @@ int wait_int(Arena& a, unsigned ticket, hipStream_t st, int* value) {
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
+    if (spins > (1u << 22)) std::this_thread::yield();   // a count that takes this long: stop burning the core
   }
+  std::atomic_thread_fence(std::memory_order_acquire);   // the value was written before the ticket (device-side fence)
   *value = box[0];
   return ISF_OK;
 }

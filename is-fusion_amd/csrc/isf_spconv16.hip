@@ -924,6 +924,10 @@ int isf_sparse_conv_tile_table(const int32_t* nbr, int nbr_stride, int num_taps,
   ISF_TRY(isf::sparse_conv_forward_f16x3_impl(nullptr, c_in, nullptr, num_taps, c_out, nbr, nbr_stride, num_out, nullptr,
                                               nullptr, nullptr, 0, nullptr, mode, isf::as_stream(stream), nullptr, &info));
   if (!isf::conv16_table_applies(info)) return ISF_OK;
+  // `table` holds 3072 ints (include/isf_hip.h): 8 parts x 2 x (workgroups per CU x CUs per XCD <= 192); a device with
+  // more slots per XCD is refused instead of written past the buffer
+  ISF_REQUIRE(isf::conv16_table_ints(info) <= 3072, ISF_ERR_UNSUPPORTED,
+              "sparse_conv_tile_table: the launch needs %d table ints, the interface holds 3072", isf::conv16_table_ints(info));
   const int ng = isf::ceil_div(num_out, 16);
   ISF_TRY(isf::conv_group_masks_impl(nbr, nbr_stride, num_taps, num_out, scratch, scratch + ng, isf::as_stream(stream)));
   ISF_TRY(isf::conv16_tile_table_impl(scratch + ng, num_out, info, table, isf::as_stream(stream)));

@@ -128,6 +128,24 @@ __global__ __launch_bounds__(256) void grad_split_kernel(const float* __restrict
   gs[o + 4] = lo;
 }
 
+// out = g * s (fp32 rows, not split): the fused linear's dX GEMM takes fp32 rows and splits them itself
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ g, size_t n, const float* __restrict__ bmax,
+                                                         int nb, float* __restrict__ out, float* __restrict__ scale_out) {
+  __shared__ float w[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) m = fmaxf(m, bmax[i]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+  int e = 0;
+  if (m > 0.f) (void)frexpf(m, &e);
+  const float s = m > 0.f ? ldexpf(1.f, 10 - e) : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = s; scale_out[1] = 1.f / s; }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = g[i] * s;
+}
+
 __global__ void split_to_f32_scaled_kernel(const uint4* __restrict__ xs, size_t n8, const float* __restrict__ mul,
                                            float* __restrict__ x) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,65 +166,107 @@ __host__ __device__ __forceinline__ int wg16_addr(int c, int kg) {   // byte off
   return ((c ^ ((c >> 3) & 1)) << 6) + (((kg ^ wg16_g((c >> 2) & 3) ^ wg16_h((c >> 4) & 3)) & 3) << 4);
 }
 
-template <int BC>   // stage one operand tile: 32 pairs x BC channels (hi and lo) of the rows idx[0..3] (this lane's quad)
-__device__ __forceinline__ void wg16_load(const uint4* __restrict__ src, int row_u4 /* uint4 per row */, int chunk0,
-                                          const int (&idx)[4], int lane, uint4 (&r)[BC / 32][4]) {
+// Staging of one operand tile (32 pairs x BC channels, hi and lo halves) by one wave.  Everything lane-dependent that does
+// not change from step to step is computed ONCE (Wg16Lane): the byte offset of the lane's 16-byte pieces inside a row and
+// the two LDS base addresses its eight ds_write_b64 per item go to (immediate offsets from there).  The loads of a step
+// are UNCONDITIONAL 32-bit-offset loads (an `if (row >= 0) load` form compiled to a branch and an s_waitcnt vmcnt(0) per
+// load -- sixteen serialised memory round trips per step: 0.09 of the roofline, profiles/r05_wgrad16.txt); positions past
+// the wave's pair range load a valid row (index clamped to 0 / the next wave's pairs) and are zeroed on the x side in the
+// one step that can contain them.
+template <int BC>
+struct Wg16Lane {
+  unsigned piece_off[BC / 32];   // byte offset of this lane's piece inside a row, per item (hi / lo)
+  unsigned lds0[BC / 32];        // LDS byte offset (within the operand image) of records 0..3 / 4..7 of the lane's channel
+  unsigned lds1[BC / 32];        // octet, per item
+  bool swap;                     // odd channel octet: records 2d / 2d + 1 hold channels 2d + 1 / 2d (wg16_addr's record XOR)
+};
+
+template <int BC>
+__device__ __forceinline__ Wg16Lane<BC> wg16_lane(int lane, int chunk0) {
+  Wg16Lane<BC> L;
   const int cg = BC == 64 ? (lane & 7) : (lane & 3);
+  const int q = BC == 64 ? ((lane >> 3) & 7) : ((lane >> 2) & 7);
+  L.swap = (cg & 1) != 0;
 #pragma unroll
   for (int it = 0; it < BC / 32; ++it) {
     const int hl = BC == 64 ? it : (lane >> 5);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      r[it][j] = make_uint4(0, 0, 0, 0);
-      if (idx[j] >= 0) r[it][j] = src[(size_t)idx[j] * row_u4 + (chunk0 + (cg >> 2)) * 8 + hl * 4 + (cg & 3)];
-    }
+    L.piece_off[it] = (unsigned)(((chunk0 + (cg >> 2)) * 8 + hl * 4 + (cg & 3)) * 16);
+    const int base = hl * (BC * 64) + (q & 1) * 8;
+    // channel 8 cg + e sits in record 8 cg + (e ^ swap); its slot depends on e >> 2 only: wg16_addr(8 cg + e, q >> 1) =
+    // wg16_addr(8 cg + (e & 4), q >> 1) + 64 * ((e ^ swap) & 3)   (checked against wg16_addr in the host test)
+    L.lds0[it] = (unsigned)(base + (wg16_addr(8 * cg, q >> 1) & ~0x1c0) + 0);
+    L.lds1[it] = (unsigned)(base + (wg16_addr(8 * cg + 4, q >> 1) & ~0x1c0) + 256);
   }
+  return L;
 }
 
 template <int BC>
-__device__ __forceinline__ void wg16_store(char* region /* this operand's LDS image */, int lane,
+__device__ __forceinline__ void wg16_load(const char* __restrict__ src, unsigned row_bytes, const Wg16Lane<BC>& L,
+                                          const int (&idx)[4], uint4 (&r)[BC / 32][4]) {
+#pragma unroll
+  for (int it = 0; it < BC / 32; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      r[it][j] = *reinterpret_cast<const uint4*>(src + (__umul24((unsigned)idx[j], row_bytes) + L.piece_off[it]));
+}
+
+template <int BC>
+__device__ __forceinline__ void wg16_store(char* img /* this operand's LDS image */, const Wg16Lane<BC>& L,
                                            const uint4 (&r)[BC / 32][4]) {
-  const int cg = BC == 64 ? (lane & 7) : (lane & 3);
-  const int q = BC == 64 ? ((lane >> 3) & 7) : ((lane >> 2) & 7);
 #pragma unroll
   for (int it = 0; it < BC / 32; ++it) {
-    const int hl = BC == 64 ? it : (lane >> 5);
-    char* base = region + hl * (BC * 64) + (q & 1) * 8;
+    char* a0 = reinterpret_cast<char*>(__builtin_assume_aligned(img + L.lds0[it], 8));
+    char* a1 = reinterpret_cast<char*>(__builtin_assume_aligned(img + L.lds1[it], 8));
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const unsigned r0 = d == 0 ? r[it][0].x : d == 1 ? r[it][0].y : d == 2 ? r[it][0].z : r[it][0].w;
       const unsigned r1 = d == 0 ? r[it][1].x : d == 1 ? r[it][1].y : d == 2 ? r[it][1].z : r[it][1].w;
       const unsigned r2 = d == 0 ? r[it][2].x : d == 1 ? r[it][2].y : d == 2 ? r[it][2].z : r[it][2].w;
       const unsigned r3 = d == 0 ? r[it][3].x : d == 1 ? r[it][3].y : d == 2 ? r[it][3].z : r[it][3].w;
-      // channel 8 cg + 2 d: the low halves of the four rows; 8 cg + 2 d + 1: the high halves
-      const uint2 ev = make_uint2((r0 & 0xffffu) | (r1 << 16), (r2 & 0xffffu) | (r3 << 16));
-      const uint2 od = make_uint2((r0 >> 16) | (r1 & 0xffff0000u), (r2 >> 16) | (r3 & 0xffff0000u));
-      const int c = 8 * cg + 2 * d;
-      *reinterpret_cast<uint2*>(__builtin_assume_aligned(base + wg16_addr(c, q >> 1), 8)) = ev;        // ds_write_b64
-      *reinterpret_cast<uint2*>(__builtin_assume_aligned(base + wg16_addr(c + 1, q >> 1), 8)) = od;
+      // channel 2 d of the lane's octet: the low halves of the four rows; 2 d + 1: the high halves
+      // (v_perm_b32: selector bytes 0-3 pick from the second operand, 4-7 from the first)
+      const uint2 ev = make_uint2(__builtin_amdgcn_perm(r1, r0, 0x05040100u), __builtin_amdgcn_perm(r3, r2, 0x05040100u));
+      const uint2 od = make_uint2(__builtin_amdgcn_perm(r1, r0, 0x07060302u), __builtin_amdgcn_perm(r3, r2, 0x07060302u));
+      const uint2 lo = L.swap ? od : ev, hi = L.swap ? ev : od;
+      char* a = d < 2 ? a0 : a1;
+      *reinterpret_cast<uint2*>(a + 64 * ((2 * d) & 3)) = lo;          // ds_write_b64, immediate offsets
+      *reinterpret_cast<uint2*>(a + 64 * ((2 * d + 1) & 3)) = hi;
     }
   }
 }
 
-template <int BM, int BN>
+// WM x WN waves of a workgroup own WM x WN adjacent BM x BN blocks of dW[k] and walk the SAME pairs (the x slice of a
+// block row is fetched by WN waves, the dY slice of a block column by WM: the second fetch hits the CU's L1), the
+// remaining factor WK = 4 / (WM * WN) splits the workgroup's pair range; waves with the same block are added through LDS.
+// Workgroup ids are dealt to the 8 XCDs round-robin by the dispatcher: id -> (XCD, slot), and the (tap, pair chunk) GROUP of
+// a workgroup is chosen so that all blocks of a group run on ONE XCD, back to back -- the group's x / dY rows are read
+// from HBM once and then served by that XCD's L2 (launch order put 2 of a group's 16 blocks on each XCD: every XCD
+// streamed every row).
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict__ xs, int cin,
                                                          const uint4* __restrict__ gs, int cout,
                                                          const int32_t* __restrict__ pairs,
                                                          const int32_t* __restrict__ counts, int cap, int chunk_pairs,
-                                                         int K, float* __restrict__ partial) {
-  constexpr int MT = BM / 16, NTL = BN / 16;
+                                                         int chunks, int K, float* __restrict__ partial) {
+  constexpr int MT = BM / 16, NTL = BN / 16, WK = 4 / (WM * WN);
   constexpr int REGION = (BM + BN) * 128;               // bytes per wave: x image (hi, lo) then dY image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int k = blockIdx.y;
+  const int blocks = (cin / (BM * WM)) * (cout / (BN * WN));
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int group = (slot / blocks) * 8 + xcd;           // (tap, chunk) group: taps outer, chunks inner
+  const int blk = slot % blocks;
+  if (group >= K * chunks) return;
+  const int k = group / chunks, chunk = group % chunks;
   const int cnt = counts[k];
-  const int p_begin = blockIdx.z * chunk_pairs;
+  const int p_begin = chunk * chunk_pairs;
   if (p_begin >= cnt) return;                            // whole workgroup: nothing of this tap in this chunk
-  const int co_blocks = cout / BN;
-  const int ci_base = (blockIdx.x / co_blocks) * BM, co_base = (blockIdx.x % co_blocks) * BN;
-  const int wp = chunk_pairs >> 2;                       // pairs per wave (a multiple of 32)
-  const int my_begin = p_begin + wave * wp;
+  const int co_blocks = cout / (BN * WN);
+  const int wk = wave / (WM * WN), wm = (wave % (WM * WN)) / WN, wn = wave % WN;
+  const int ci_base = ((blk / co_blocks) * WM + wm) * BM, co_base = ((blk % co_blocks) * WN + wn) * BN;
+  const int wp = chunk_pairs / WK;                       // pairs per wave (a multiple of 32)
+  const int my_begin = p_begin + wk * wp;
   const int my_end = min(min(my_begin + wp, p_begin + chunk_pairs), cnt);
   const int32_t* pin = pairs + ((size_t)k * 2 + 0) * cap;
   const int32_t* pout = pairs + ((size_t)k * 2 + 1) * cap;
@@ -222,17 +282,19 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict
 
   const int qx = BM == 64 ? ((lane >> 3) & 7) : ((lane >> 2) & 7);   // this lane's row quad in the x tile / the dY tile
   const int qg = BN == 64 ? ((lane >> 3) & 7) : ((lane >> 2) & 7);
+  const Wg16Lane<BM> LX = wg16_lane<BM>(lane, ci_base >> 5);
+  const Wg16Lane<BN> LG = wg16_lane<BN>(lane, co_base >> 5);
+  const char* xb = reinterpret_cast<const char*>(xs);
+  const char* gb = reinterpret_cast<const char*>(gs);
+  const unsigned x_row = (unsigned)cin * 4u, g_row = (unsigned)cout * 4u;   // bytes per split row
+  // the four pair entries of this lane's row quad at step position p0: unconditional load from a clamped position (the
+  // lists are readable up to cap), entries clamped to row 0 where the list holds its -1 padding
   auto fetch_idx = [&](const int32_t* list, int p0, int q, int (&idx)[4]) {
-    const int p = p0 + 4 * q;                            // p0 is a multiple of 32, cap of 32: 16-byte aligned, in bounds
-    int4 v = make_int4(-1, -1, -1, -1);
-    if (p < my_end) v = *reinterpret_cast<const int4*>(list + p);
-    idx[0] = v.x;
-    idx[1] = p + 1 < my_end ? v.y : -1;
-    idx[2] = p + 2 < my_end ? v.z : -1;
-    idx[3] = p + 3 < my_end ? v.w : -1;
+    const int p = min(p0 + 4 * q, cap - 4);              // p0 multiple of 32, cap of 32: 16-byte aligned, in bounds
+    const int4 v = *reinterpret_cast<const int4*>(list + p);
+    idx[0] = max(v.x, 0); idx[1] = max(v.y, 0); idx[2] = max(v.z, 0); idx[3] = max(v.w, 0);
   };
-  // fragment read offsets: lane (m = lane & 15, kg = lane >> 4) -> channel m of a 16-channel tile, row octet kg
-  const int m16 = lane & 15, kg = lane >> 4;
+  const int m16 = lane & 15, kg = lane >> 4;             // fragment lane: channel m16 of a 16-channel tile, row octet kg
 
   if (my_begin < my_end) {
     int ix[4], ig[4], ix_n[4], ig_n[4];
@@ -241,17 +303,26 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict
     fetch_idx(pout, my_begin, qg, ig);
     fetch_idx(pin, my_begin + 32, qx, ix_n);
     fetch_idx(pout, my_begin + 32, qg, ig_n);
-    wg16_load<BM>(xs, cin >> 2, ci_base >> 5, ix, lane, rx);
-    wg16_load<BN>(gs, cout >> 2, co_base >> 5, ig, lane, rg);
+    wg16_load<BM>(xb, x_row, LX, ix, rx);
+    wg16_load<BN>(gb, g_row, LG, ig, rg);
     for (int p0 = my_begin; p0 < my_end; p0 += 32) {
-      wg16_store<BM>(xr, lane, rx);                      // waits for this step's rows
-      wg16_store<BN>(gr, lane, rg);
+      if (p0 + 32 > my_end) {                            // the one step with positions past the range: zero their x rows
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (p0 + 4 * qx + j >= my_end) {
+#pragma unroll
+            for (int it = 0; it < BM / 32; ++it) rx[it][j] = make_uint4(0, 0, 0, 0);
+          }
+        }
+      }
+      wg16_store<BM>(xr, LX, rx);                        // waits for this step's rows
+      wg16_store<BN>(gr, LG, rg);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ix[j] = ix_n[j]; ig[j] = ig_n[j]; }
       fetch_idx(pin, p0 + 64, qx, ix_n);                 // indices two steps ahead, rows one step ahead
       fetch_idx(pout, p0 + 64, qg, ig_n);
-      wg16_load<BM>(xs, cin >> 2, ci_base >> 5, ix, lane, rx);
-      wg16_load<BN>(gs, cout >> 2, co_base >> 5, ig, lane, rg);
+      wg16_load<BM>(xb, x_row, LX, ix, rx);
+      wg16_load<BN>(gb, g_row, LG, ig, rg);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private images: LDS ops of a wave complete in order
       uint4 ah[MT], al[MT];
 #pragma unroll
@@ -278,23 +349,24 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict
     }
   }
   // accumulators -> this wave's region as a [BM][BN] fp32 block (C layout: row 4 * (lane >> 4) + r, column lane & 15),
-  // then the four waves' blocks are added in wave order and written as this chunk's partial
-  float* blk = reinterpret_cast<float*>(region);
+  // then the WK waves of a block are added in wave order and written as this chunk's partial
+  float* blkp = reinterpret_cast<float*>(region);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) blk[(mt * 16 + 4 * kg + r) * BN + nt * 16 + m16] = acc[mt][nt][r];
+      for (int r = 0; r < 4; ++r) blkp[(mt * 16 + 4 * kg + r) * BN + nt * 16 + m16] = acc[mt][nt][r];
   __syncthreads();
-  float* out = partial + ((size_t)blockIdx.z * K + k) * cin * cout;
-  for (int e = threadIdx.x; e < BM * BN / 4; e += 256) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(smem + 0 * REGION + e * 16);
-    s += *reinterpret_cast<const f32x4*>(smem + 1 * REGION + e * 16);
-    s += *reinterpret_cast<const f32x4*>(smem + 2 * REGION + e * 16);
-    s += *reinterpret_cast<const f32x4*>(smem + 3 * REGION + e * 16);
-    const int ci = (e * 4) / BN, co = (e * 4) % BN;
-    *reinterpret_cast<f32x4*>(out + (size_t)(ci_base + ci) * cout + co_base + co) = s;
+  float* out = partial + ((size_t)chunk * K + k) * cin * cout;
+  const int cb0 = (blk / co_blocks) * WM * BM, cn0 = (blk % co_blocks) * WN * BN;   // the workgroup's first channels
+  for (int e = threadIdx.x; e < WM * WN * BM * BN / 4; e += 256) {
+    const int b = e / (BM * BN / 4), o = e % (BM * BN / 4);   // block (wm, wn) = b, float4 o of it
+    f32x4 sum = *reinterpret_cast<const f32x4*>(smem + b * REGION + o * 16);
+#pragma unroll
+    for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4*>(smem + (w * WM * WN + b) * REGION + o * 16);
+    const int ci = cb0 + (b / WN) * BM + (o * 4) / BN, co = cn0 + (b % WN) * BN + (o * 4) % BN;
+    *reinterpret_cast<f32x4*>(out + (size_t)ci * cout + co) = sum;
   }
 }
 
@@ -311,11 +383,11 @@ __global__ void wgrad16_reduce_kernel(const float* __restrict__ partial, const i
   dw[e] = acc * (inv_scale ? *inv_scale : 1.f);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN>
 static int launch_wgrad16(const uint4* xs, int cin, const uint4* gs, int cout, const int32_t* pairs, const int32_t* counts,
                           int cap, int chunk_pairs, int chunks, int K, float* partial, hipStream_t st) {
   constexpr int bytes = 4 * (BM + BN) * 128;
-  auto kern = wgrad16_kernel<BM, BN>;
+  auto kern = wgrad16_kernel<BM, BN, WM, WN>;
   if (bytes > 48 * 1024) {
     static bool once = false;
     if (!once) {
@@ -323,10 +395,20 @@ static int launch_wgrad16(const uint4* xs, int cin, const uint4* gs, int cout, c
       once = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((cin / BM) * (cout / BN), K, chunks), dim3(256), bytes, st, xs, cin, gs, cout, pairs, counts,
-                     cap, chunk_pairs, K, partial);
+  const int blocks = (cin / (BM * WM)) * (cout / (BN * WN));
+  const int slots = ceil_div(K * chunks, 8) * blocks;    // per XCD: its groups, all blocks of a group back to back
+  hipLaunchKernelGGL(kern, dim3(8 * slots), dim3(256), bytes, st, xs, cin, gs, cout, pairs, counts, cap, chunk_pairs, chunks,
+                     K, partial);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
+}
+
+// workgroup shape per channel shape: blocks of 64 (32 for 32-channel sides), up to 2 x 2 blocks per workgroup
+static inline void wgrad16_shape(int c_in, int c_out, int& BM, int& BN, int& WM, int& WN) {
+  BM = c_in >= 64 ? 64 : 32;
+  BN = c_out >= 64 ? 64 : 32;
+  WM = c_in / BM >= 2 ? 2 : 1;
+  WN = c_out / BN >= 2 ? 2 : 1;
 }
 
 }  // namespace isf
@@ -379,6 +461,22 @@ int isf_grad_to_split(const float* grad, size_t num_elems, void* grad_split, flo
   return ISF_OK;
 }
 
+int isf_grad_rescale(const float* grad, size_t num_elems, float* out, float* scale_out, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(scale_out && (num_elems == 0 || (grad && out)), ISF_ERR_ARG, "grad_rescale: null pointer");
+  hipStream_t st = as_stream(stream);
+  Arena& a = arena_for_stream(st);
+  ISF_TRY(a.reset());
+  const int nb = (int)std::min<size_t>(1024, std::max<size_t>(1, (num_elems + 4095) / 4096));
+  float* bmax = nullptr;
+  ISF_TRY(a.alloc_n(&bmax, 1024));
+  hipLaunchKernelGGL(grad_absmax_kernel, dim3(nb), dim3(256), 0, st, grad, num_elems, bmax);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)std::min<size_t>(4096, std::max<size_t>(1, (num_elems + 1023) / 1024))),
+                     dim3(256), 0, st, grad, num_elems, bmax, nb, out, scale_out);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 int isf_split_to_f32_scaled(const void* xs, size_t num_elems, const float* mul, float* x, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(num_elems == 0 || (x && xs), ISF_ERR_ARG, "split_to_f32_scaled: null pointer");
@@ -407,10 +505,15 @@ int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in
   }
   ISF_REQUIRE(features_split && grad_out_split && indice_pairs && indice_num && capacity >= 32 && capacity % 32 == 0,
               ISF_ERR_ARG, "sparse_conv_backward_filter_f16x3: null pointer / capacity (isf_pair_list_capacity)");
-  const int BM = c_in >= 64 ? 64 : 32, BN = c_out >= 64 ? 64 : 32;
-  const int blocks = (c_in / BM) * (c_out / BN);
+  ISF_REQUIRE((unsigned long long)num_in * c_in * 4 < (1ull << 32) && (unsigned long long)num_out * c_out * 4 < (1ull << 32) &&
+                  num_in < (1 << 24) && num_out < (1 << 24), ISF_ERR_UNSUPPORTED,
+              "sparse_conv_backward_filter_f16x3: feature buffers of 4 GiB / 16 M rows and more are not addressed (32-bit "
+              "row offsets)");
+  int BM, BN, WM, WN;
+  wgrad16_shape(c_in, c_out, BM, BN, WM, WN);
+  const int blocks = (c_in / (BM * WM)) * (c_out / (BN * WN));
   // pairs per workgroup: ~3000 workgroups if every tap were full (the centre tap of a SubM layer is, the others hold
-  // 0.2-0.6 of it), at least 256 pairs (64 per wave), at most what keeps the partial blocks under 256 MiB
+  // 0.2-0.6 of it), at least 256 pairs, at most what keeps the partial blocks under 256 MiB
   long long chunk = ((long long)num_taps * capacity * blocks / 3000 + 127) / 128 * 128;
   chunk = std::max<long long>(256, std::min<long long>(chunk, 16384));
   while (((long long)capacity + chunk - 1) / chunk * (long long)elems * 4 > (256ll << 20) && chunk < (1 << 24)) chunk *= 2;
@@ -421,11 +524,14 @@ int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in
   ISF_TRY(a.alloc_n(&partial, elems * (size_t)chunks));
   const uint4* x = reinterpret_cast<const uint4*>(features_split);
   const uint4* g = reinterpret_cast<const uint4*>(grad_out_split);
-  int rc;
-  if (BM == 64 && BN == 64) rc = launch_wgrad16<64, 64>(x, c_in, g, c_out, indice_pairs, indice_num, capacity, chunk_pairs, chunks, num_taps, partial, st);
-  else if (BM == 64) rc = launch_wgrad16<64, 32>(x, c_in, g, c_out, indice_pairs, indice_num, capacity, chunk_pairs, chunks, num_taps, partial, st);
-  else if (BN == 64) rc = launch_wgrad16<32, 64>(x, c_in, g, c_out, indice_pairs, indice_num, capacity, chunk_pairs, chunks, num_taps, partial, st);
-  else rc = launch_wgrad16<32, 32>(x, c_in, g, c_out, indice_pairs, indice_num, capacity, chunk_pairs, chunks, num_taps, partial, st);
+  int rc = ISF_ERR_UNSUPPORTED;
+#define ISF_WG16(bm, bn, wm, wn)                                                                                       \
+  if (BM == bm && BN == bn && WM == wm && WN == wn)                                                                    \
+    rc = launch_wgrad16<bm, bn, wm, wn>(x, c_in, g, c_out, indice_pairs, indice_num, capacity, chunk_pairs, chunks,    \
+                                        num_taps, partial, st)
+  ISF_WG16(64, 64, 2, 2); ISF_WG16(64, 64, 2, 1); ISF_WG16(64, 64, 1, 2); ISF_WG16(64, 64, 1, 1);
+  ISF_WG16(64, 32, 2, 1); ISF_WG16(64, 32, 1, 1); ISF_WG16(32, 64, 1, 2); ISF_WG16(32, 64, 1, 1); ISF_WG16(32, 32, 1, 1);
+#undef ISF_WG16
   ISF_TRY(rc);
   const size_t tap4 = (size_t)c_in * c_out / 4;
   hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3(ceil_div((long long)(tap4 * num_taps), 256)), dim3(256), 0, st, partial,

@@ -123,8 +123,8 @@ class LinearFunction(torch.autograd.Function):
         g = gy.contiguous().float()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gs, s = _lib.pow2_rescale(g)            # gradients are tiny: keep the GEMM's f16 halves in range (exact)
-            gx = (ops.linear(gs, ops.PackedLinear(wd.t().contiguous())) / s).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
+            gs, sc = _lib.grad_rescale(g)           # gradients are tiny: keep the GEMM's f16 halves in range (exact)
+            gx = (ops.linear(gs, ops.PackedLinear(wd.t().contiguous())) * sc[1]).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(g, xd)                                                      # dW = dY^T X (library GEMM)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -210,6 +210,29 @@ def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, i
 
 
 # ------------------------------------------------------------------------------------------------ A10 / A11
+class _WindowTableAdd(torch.autograd.Function):
+    """qkv + tab[slot(token)] for the dense grid's window-position table ([win * win, 3d], slot(y, x) =
+    ((y + off) % win) * win + (x + off) % win).  autograd's own backward of `tab[index]` is a sort-based
+    indexing_backward_kernel over all B * S * S tokens (1 ms per layer at S = 180: four of them were the second largest
+    kernel of a training step, profiles/r05_train_step_mid.txt); the slots are a regular pattern, so the table gradient
+    is a strided sum of the token gradient: fold [B, S, S, C] over (B, S / win, S / win) and roll by the window offset."""
+
+    @staticmethod
+    def forward(ctx, qkv, tab, index, B, S, win, off):
+        ctx.geom = (B, S, win, off)
+        return qkv + tab[index.long().repeat(B)]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, S, win, off = ctx.geom
+        C = g.size(1)
+        gt = None
+        if ctx.needs_input_grad[1]:
+            t = g.view(B, S // win, win, S // win, win, C).sum(dim=(0, 1, 3))        # [y % win, x % win, C]
+            gt = torch.roll(t, shifts=(off % win, off % win), dims=(0, 1)).reshape(win * win, C)
+        return g, gt, None, None, None, None, None
+
+
 def sstv2_forward(sst, bev, win, temperature=1000.0):
     """get_regions[i] + grid2region_att[i] (sst_v2.py:65-133, sst_basic_block_v2.py:77-126) on the dense grid with
     gradients: [B, C, S, S] -> [B, d, S, S]."""
@@ -228,7 +251,10 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
             tab = torch.cat([pos @ w[:2 * d].t(), pos.new_zeros((pos.size(0), d))], 1)
             # three d-column GEMMs (the dX GEMM contracts over the output columns: at most 256 per call)
             qkv = torch.cat([linear_w(x, w[i * d:(i + 1) * d], b[i * d:(i + 1) * d]) for i in range(3)], 1)
-            qkv = qkv + tab[index.long().repeat(B)]
+            if S % win == 0:   # the config's grids (180, 90 with 6 x 6 windows): structured table gradient
+                qkv = _WindowTableAdd.apply(qkv, tab, index, B, S, win, win // 2 if shift else win)
+            else:
+                qkv = qkv + tab[index.long().repeat(B)]
             att = ops.WindowAttentionFunction.apply(qkv, B, S, d, layer.win_attn.nhead, win, shift)
             y = F.layer_norm(x + linear(att, attn.out_proj), (d,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
             h = F.gelu(linear(y, layer.linear1))

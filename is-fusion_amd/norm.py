@@ -43,6 +43,93 @@ def _sync_bn(mod, x, reduce_dims):
     return x * scale.reshape(shape) + shift.reshape(shape)
 
 
+# ---------------------------------------------------------------------------------------------- fused training BN
+FUSED_BN_TRAIN = True   # False: the stock composition (nn.BatchNorm1d -> ReLU -> add) everywhere
+
+
+class _BN1dReLUFunction(Function):
+    """relu?(BatchNorm1d_train(x) + residual?) on [N, C] fp32 rows through isf_bn1d_* (isf_bn_train.hip): two launches +
+    an ordered second-level sum per direction instead of ~10; the statistics (and the backward sums) are all-reduced
+    across ranks when the module is a naiveSyncBN in a multi-rank job -- one all_reduce of [2C] per direction, what the
+    reference's naiveSyncBN1d does (ops/norm.py:186-190; equal weight per rank, biased running variance)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, mod, relu, sync):
+        from . import _lib
+        lib = _lib.load()
+        n, c = x.shape
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        _lib.check(lib.isf_bn1d_stats(_lib.ptr(x), n, c, _lib.ptr(stats), _lib.stream()), "isf_bn1d_stats")
+        count, bwd_count = float(n), float(n)
+        if sync:
+            # the reference averages the per-rank mean / mean-of-squares with EQUAL weights (ops/norm.py:186-190), whatever
+            # the ranks' row counts: (sum / n_r) summed over ranks with count = world size is exactly that
+            world = dist.get_world_size()
+            stats.mul_(1.0 / n)
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            count, bwd_count = float(world), float(world) * n
+        y = torch.empty_like(x)
+        saved = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        rm, rv = (mod.running_mean, mod.running_var) if mod.track_running_stats else (None, None)
+        mom = mod.momentum if mod.momentum is not None else 0.1
+        _lib.check(lib.isf_bn1d_apply(_lib.ptr(x), n, c, _lib.ptr(stats), count, _lib.ptr(gamma), _lib.ptr(beta),
+                                      float(mod.eps), float(mom), 0 if sync else 1, _lib.ptr(rm), _lib.ptr(rv),
+                                      _lib.ptr(res), int(bool(relu)), _lib.ptr(y), _lib.ptr(saved), _lib.stream()),
+                   "isf_bn1d_apply")
+        if mod.track_running_stats and mod.num_batches_tracked is not None:
+            mod.num_batches_tracked.add_(1)
+        ctx.save_for_backward(x, y if relu else None, gamma, saved)
+        ctx.geom = (n, c, bwd_count, bool(relu), residual is not None, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        lib = _lib.load()
+        x, y, gamma, saved = ctx.saved_tensors
+        n, c, count, relu, has_res, sync = ctx.geom
+        dy = dy.contiguous().float()
+        sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+        _lib.check(lib.isf_bn1d_backward_sums(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), n, c, _lib.ptr(saved),
+                                              _lib.ptr(sums), _lib.stream()), "isf_bn1d_backward_sums")
+        local = sums
+        if sync:                      # dgamma / dbeta stay the LOCAL sums (DDP averages parameter gradients itself);
+            local = sums.clone()      # dx needs the global ones
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device) if gamma is not None else None
+        _lib.check(lib.isf_bn1d_backward_apply(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), n, c, _lib.ptr(saved),
+                                               _lib.ptr(gamma), _lib.ptr(sums), count, _lib.ptr(dx), _lib.ptr(dres),
+                                               _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.stream()),
+                   "isf_bn1d_backward_apply")
+        if sync and gamma is not None:
+            dbeta, dgamma = local[:c].contiguous(), local[c:].contiguous()
+        return dx, dgamma, dbeta, dres, None, None, None
+
+
+def bn1d_relu(mod, x, residual=None, relu=True):
+    """relu?(mod(x) + residual?) for a BatchNorm1d-like module on [N, C] rows.  Training mode on CUDA fp32 rows with a
+    channel count the kernels tile: the fused HIP path above; anything else (eval mode, odd channel counts, CPU tensors,
+    FUSED_BN_TRAIN = False): the stock composition, op for op what the reference runs."""
+    c = x.shape[1] if x.dim() == 2 else 0
+    ok = (FUSED_BN_TRAIN and mod.training and isinstance(mod, nn.BatchNorm1d) and x.dim() == 2 and x.is_cuda and
+          x.dtype == torch.float32 and x.shape[0] > 1 and c % 4 == 0 and 4 <= c <= 1024 and 256 % (c // 4) == 0 and
+          torch.is_grad_enabled())
+    if not ok:
+        out = mod(x)
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
+    sync = isinstance(mod, NaiveSyncBatchNorm1d) and _needs_sync(mod)
+    with torch.autocast("cuda", enabled=False):
+        return _BN1dReLUFunction.apply(x, mod.weight, mod.bias, residual.float() if residual is not None else None,
+                                       mod, relu, sync)
+
+
 def _needs_sync(mod):
     return mod.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 

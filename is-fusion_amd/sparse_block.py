@@ -6,7 +6,7 @@ types the IS-Fusion config uses.
 """
 from torch import nn
 
-from .norm import build_norm_layer
+from .norm import bn1d_relu, build_norm_layer
 from .spconv import SparseConv3d, SparseModule, SparseSequential, SubMConv3d
 
 CONV_TYPES = {"SubMConv3d": SubMConv3d, "SparseConv3d": SparseConv3d}
@@ -50,9 +50,11 @@ class SparseBasicBlock(SparseModule):
         identity = x.features
         assert x.features.dim() == 2, f"x.features.dim()={x.features.dim()}"
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        # bn1d_relu: relu(bn(x) + identity) -- one fused HIP pass per direction in training mode (norm.py), the stock
+        # modules otherwise
+        out = out.replace_feature(bn1d_relu(self.bn1, out.features))
         out = self.conv2(out)
-        out = out.replace_feature(self.relu(self.bn2(out.features) + identity))
+        out = out.replace_feature(bn1d_relu(self.bn2, out.features, residual=identity))
         return out
 
 

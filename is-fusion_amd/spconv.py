@@ -14,6 +14,8 @@ Differences that matter to a maintainer:
 import ctypes
 import math
 
+import weakref
+
 import numpy as np
 import torch
 from torch import nn
@@ -477,10 +479,21 @@ def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=
     return out
 
 
-def sparse_conv_split(xs, packed16, K, c_in, c_out, rb):
+def sparse_conv_split(xs, packed16, K, c_in, c_out, rb, ordered=True):
     """the f16x3 convolution on SPLIT rows in and out (no epilogue, no format passes): the kernel choice of
-    sparse_conv_forward_best -- LDS-DMA gathers for the narrow shapes, tile-order table for one-round launches."""
+    sparse_conv_forward_best -- LDS-DMA gathers for the narrow shapes, tile-order table for one-round launches
+    (ordered=False: tiles in launch order; the training path rebuilds its rulebooks every step and the three kernels that
+    build a table -- 0.6 ms per step over the encoder -- cost more than the 2 % an ordered launch gains)."""
     lib = _lib.load()
+    if not ordered:
+        ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
+        args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
+                None, None, None, 0, _lib.ptr(ys), 0)
+        if c_in <= 64 and c_out <= 64:
+            _lib.check(lib.isf_sparse_conv_forward_dma(*args, None, _lib.stream()), "isf_sparse_conv_forward_dma")
+        else:
+            _lib.check(lib.isf_sparse_conv_forward_f16x3(*args, _lib.stream()), "isf_sparse_conv_forward_f16x3")
+        return ys
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
     args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
             None, None, None, 0, _lib.ptr(ys), 0)
@@ -577,6 +590,26 @@ class _TransposedRulebook:
         self.nbr, self.stride, self.num_in, self.num_out = nbr_t, stride_t, num_out, num_in
 
 
+_PACKED_PAIRS = {}   # id(weight parameter) -> (version, data_ptr, packed forward filters, packed transposed filters, weakref)
+
+
+def _packed_pair(weight, w, K, c_in, c_out):
+    """(packed filters of the forward conv, packed per-tap TRANSPOSED filters of the dX conv) of a weight parameter,
+    packed once per parameter version: the forward pass packs both, the backward pass finds its half here instead of
+    transposing + packing again (5 launches per layer and step)."""
+    key = id(weight)
+    hit = _PACKED_PAIRS.get(key)
+    # the weak reference tells a live parameter from a new tensor that reuses a dead one's id / address / version 0
+    if hit is not None and hit[4]() is weight and hit[0] == weight._version and hit[1] == weight.data_ptr():
+        return hit[2], hit[3]
+    wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*weight.shape[:-2], c_out, c_in)
+    pair = (pack_filters_f16x3(w), pack_filters_f16x3(wt))
+    if len(_PACKED_PAIRS) > 256:
+        _PACKED_PAIRS.clear()
+    _PACKED_PAIRS[key] = (weight._version, weight.data_ptr(), pair[0], pair[1], weakref.ref(weight))
+    return pair
+
+
 class SparseConvFunction(torch.autograd.Function):
     """SparseConvFunction / SubMConvFunction of the reference (ops/spconv/functional.py:22-97): forward =
     indice_conv, backward = indice_conv_backward -> (input_bp, filters_bp), on the HIP kernels.  `weight` is the
@@ -594,7 +627,8 @@ class SparseConvFunction(torch.autograd.Function):
         if _f16x3_shape(c_in, c_out) and WGRAD_F16X3 and rb.num_out > 0 and rb.num_in > 0:
             # split rows once: the conv reads them, and so will dW in the backward pass (saved INSTEAD of the fp32 rows)
             xs = to_split(features)
-            out = from_split(sparse_conv_split(xs, pack_filters_f16x3(w), K, c_in, c_out, rb), (rb.num_out, c_out))
+            out = from_split(sparse_conv_split(xs, _packed_pair(weight, w, K, c_in, c_out)[0], K, c_in, c_out, rb, ordered=False),
+                             (rb.num_out, c_out))
         elif _f16x3_shape(c_in, c_out):    # the inference kernel (f16x3 split MFMA): 3-4x the fp32-MFMA kernel's rate
             out = sparse_conv_forward_best(features, pack_filters_f16x3(w), K, c_in, c_out, rb)
         else:
@@ -603,6 +637,7 @@ class SparseConvFunction(torch.autograd.Function):
                 _lib.ptr(features), rb.num_in, c_in, _lib.ptr(w), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
                 None, None, None, 0, _lib.ptr(out), _lib.stream()), "isf_sparse_conv_forward")
         ctx.split_saved = xs is not None
+        ctx.packed_t = _packed_pair(weight, w, K, c_in, c_out)[1] if xs is not None else None   # dX's filters
         ctx.save_for_backward(xs if xs is not None else features, w)
         ctx.rb, ctx.wshape = rb, tuple(weight.shape)
         return out
@@ -622,11 +657,10 @@ class SparseConvFunction(torch.autograd.Function):
             gs, sc = grad_to_split(g)
             if ctx.needs_input_grad[0]:
                 nbr_t, st = transposed_nbr(rb)
-                wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*ctx.wshape[:-2], c_out, c_in)
                 rbt = rb.__dict__.get("_rbt")
                 if rbt is None:      # cached: its tile-order tables are built once per rulebook, not once per layer
                     rbt = rb._rbt = _TransposedRulebook(nbr_t, st, rb.num_out, rb.num_in)
-                grad_in = from_split_scaled(sparse_conv_split(gs, pack_filters_f16x3(wt), K, c_out, c_in, rbt),
+                grad_in = from_split_scaled(sparse_conv_split(gs, ctx.packed_t, K, c_out, c_in, rbt, ordered=False),
                                             (rb.num_in, c_in), sc[1:])
             if ctx.needs_input_grad[1]:
                 grad_w = sparse_conv_backward_filter_f16x3(features, c_in, gs, c_out, rb, sc[1:], ctx.wshape)
@@ -827,13 +861,24 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        from .norm import bn1d_relu
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
+                    if (isinstance(module, nn.BatchNorm1d) and module.training and i + 1 < len(mods) and
+                            isinstance(mods[i + 1], nn.ReLU)):
+                        # norm -> act of a make_sparse_convmodule block in training mode: one fused pass (norm.bn1d_relu)
+                        input = input.replace_feature(bn1d_relu(module, input.features))
+                        i += 1
+                    else:
+                        input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
+            i += 1
         return input

@@ -12,7 +12,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import _lib
-from .norm import build_norm_layer, fold_bn
+from .norm import bn1d_relu, build_norm_layer, fold_bn
 from .scatter_points import dynamic_point_to_voxel_forward, dynamic_scatter
 
 
@@ -47,7 +47,7 @@ class DynamicVFELayer(nn.Module):
         self.linear = nn.Linear(in_channels, out_channels, bias=False)
 
     def forward(self, inputs):
-        return F.relu(self.norm(self.linear(inputs)))
+        return bn1d_relu(self.norm, self.linear(inputs))   # fused BN + ReLU pass in training mode (norm.py)
 
 
 class DynamicVFE(nn.Module):

@@ -321,3 +321,53 @@ def test_two_ranks_train_side_by_side_with_ddp_over_gloo(dev):
                       "--steps", "2", "--points", "6000", "--batch", "1"], 1200)
     assert line["n_gpus"] == 2 and line["backend"] == "gloo" and line["shared_device"]
     assert len(line["losses"]) == 3 and all(np.isfinite(v) for v in line["losses"])
+
+
+@pytest.mark.parametrize("c,n,relu,with_res", [(16, 50000, True, False), (32, 120000, True, True), (64, 300000, True, False),
+                                               (128, 7001, False, True), (256, 3, True, True), (64, 2, True, False)])
+def test_fused_bn1d_relu_matches_the_stock_modules(dev, c, n, relu, with_res):
+    """norm.bn1d_relu in training mode (isf_bn1d_stats / _apply / _backward_sums / _backward_apply: BatchNorm1d with batch
+    statistics + residual + ReLU in two launches per direction) against nn.BatchNorm1d -> add -> relu: outputs, input /
+    residual / affine gradients, running statistics (unbiased variance, momentum), num_batches_tracked; deterministic"""
+    from isfusion_amd import norm
+    torch.manual_seed(c + n)
+    x0 = torch.randn(n, c, device=dev) * 1.7 + 0.3
+    r0 = torch.randn(n, c, device=dev) if with_res else None
+    g = torch.randn(n, c, device=dev)
+    outs = []
+    for fused in (True, False, True):
+        bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.2, 0.2, c))
+        x = x0.clone().requires_grad_()
+        r = r0.clone().requires_grad_() if with_res else None
+        norm.FUSED_BN_TRAIN = fused
+        try:
+            y = norm.bn1d_relu(bn, x, residual=r, relu=relu)
+            y.backward(g)
+        finally:
+            norm.FUSED_BN_TRAIN = True
+        outs.append([y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()] +
+                    ([r.grad] if with_res else []))
+        assert int(bn.num_batches_tracked) == 1
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6, (float((a - b).abs().max()), float(b.abs().max()))
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)                       # ordered two-level sums: the same bits on a second run
+
+
+def test_fused_sync_bn_on_two_ranks_matches_the_reference_composition(dev):
+    """the fused BatchNorm in SYNC mode (naiveSyncBN1d in a 2-rank job; ranks with different row counts) against the
+    restatement of the reference's all-gather formulation -- tests/sync_bn_check.py under torch.distributed.run"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    from isfusion_amd import launch
+    cmd = launch.launch_command(os.path.join(root, "tests", "sync_bn_check.py"), [], 2, launch.free_port())
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("SYNC_BN_MAX_REL_ERR")]
+    assert len(lines) == 1 and float(lines[0].split()[1]) < 5e-4, lines

@@ -378,6 +378,17 @@ def test_wgrad16_lds_image_is_a_bijection_and_conflict_free():
                         assert a + 2 * j not in mem
                         mem[a + 2 * j] = (4 * q + j, c, hl)
         assert len(mem) == BC * 64
+        # the kernel's store path (Wg16Lane): two base addresses per item + immediate record offsets + an even / odd
+        # data swap for odd channel octets must hit exactly wg16_addr's bytes
+        for lane in range(64):
+            cg, q = lane_of(lane)
+            swap = cg & 1
+            lds0 = (addr(8 * cg, q >> 1) & ~0x1c0)
+            lds1 = (addr(8 * cg + 4, q >> 1) & ~0x1c0) + 256
+            for d in range(4):
+                a = lds0 if d < 2 else lds1
+                for rec, ch in (((2 * d) & 3, 2 * d + (1 if swap else 0)), ((2 * d + 1) & 3, 2 * d + (0 if swap else 1))):
+                    assert a + 64 * rec == addr(8 * cg + ch, q >> 1), (BC, lane, d)
         for hl in range(2):
             for mt in range(BC // 16):
                 for lane in range(64):
@@ -395,3 +406,25 @@ def test_wgrad16_lds_image_is_a_bijection_and_conflict_free():
                         hl = it if BC == 64 else lane >> 5
                         slots.add(((hl * BC * 64 + addr(8 * cg + e, q >> 1) + (q & 1) * 8) // 8) % 16)
                     assert len(slots) == 16
+
+
+def test_window_table_gradient_fold_equals_autograd():
+    """fusion_train._WindowTableAdd: the gradient of the 36-row window-position table as a strided fold of the token
+    gradient (instead of autograd's sort-based index backward over all tokens) -- both shifts, several grid sizes"""
+    from isfusion_amd import fusion_ops as ops
+    from isfusion_amd import fusion_train as ft
+    torch.manual_seed(0)
+    for S, win, shift in ((12, 6, 0), (12, 6, 1), (18, 6, 1), (30, 6, 0)):
+        B, d = 2, 8
+        index, _ = ops._window_tables(S, win, shift, d, 1000.0, "cpu")
+        off = win // 2 if shift else win
+        tab = torch.randn(win * win, 3 * d, dtype=torch.float64, requires_grad=True)
+        qkv = torch.randn(B * S * S, 3 * d, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(B * S * S, 3 * d, dtype=torch.float64)
+        a = qkv + tab[index.long().repeat(B)]
+        (a * w).sum().backward()
+        g1, q1 = tab.grad.clone(), qkv.grad.clone()
+        tab.grad = qkv.grad = None
+        b = ft._WindowTableAdd.apply(qkv, tab, index, B, S, win, off)
+        (b * w).sum().backward()
+        assert torch.allclose(a, b) and torch.allclose(tab.grad, g1) and torch.allclose(qkv.grad, q1), (S, win, shift)

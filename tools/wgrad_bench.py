@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--cin", type=int, default=256)
     ap.add_argument("--cout", type=int, default=256)
     ap.add_argument("--lib", default="", help="A/B: load this build of libisf_hip.so instead of the in-tree one")
+    ap.add_argument("--level", type=int, default=0, choices=[0, 2, 3],
+                    help="2 / 3: the benchmark geometry's level-2 / level-3 SubM rulebook (B = 4 x 300 k-point synthetic "
+                         "sweeps: 119 k / 40.7 k rows, 16 / 15.4 pairs per row) instead of the random-sparse grid")
     ap.add_argument("--f16x3", action="store_true", help="the f16 matrix-core dW (round 5) instead of the fp32-MFMA kernel")
     a = ap.parse_args()
     from isfusion_amd import _lib, spconv as sp
@@ -37,6 +40,12 @@ def main():
     D, H, W = shape
     idx = np.stack([lin // (D * H * W), (lin // (H * W)) % D, (lin // W) % H, lin % W], 1).astype(np.int32)
     rb = sp.build_rulebook(torch.from_numpy(idx).to(dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    if a.level:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import bench
+        from conv_trace import level_rulebooks
+        rb = level_rulebooks([torch.from_numpy(p).to(dev) for p in bench.make_frames(0, 1, 4, 300000, 0)], 4, a.level)
+        a.rows = rb.num_in
     pairs = int((rb.nbr.view(27, rb.stride)[:, :rb.num_out] >= 0).sum().item())
     x = torch.randn(a.rows, a.cin, device=dev)
     g = torch.randn(rb.num_out, a.cout, device=dev)
