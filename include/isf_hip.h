@@ -630,7 +630,11 @@ int isf_sparse_conv_backward_filter(const float* features, int num_in, int c_in,
  * isf_sparse_conv_backward_filter_f16x3: grad_filters [K, Cin, Cout] = (*grad_inv_scale) * sum over the pairs of tap k of
  *   x[in]^T dY[out], x and dY in the split format (x: what the forward pass stored; dY: isf_grad_to_split), products as
  *   x_lo*g_hi + x_hi*g_lo + x_hi*g_hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation; Cin, Cout in {32, 64, 128, 256};
- *   pair chunks -> partial blocks -> ordered second pass: deterministic.  All asynchronous. */
+ *   pair chunks -> partial blocks -> ordered second pass: deterministic.  mode 0 = that (fp32-class); mode 1 = SINGLE-PASS
+ *   f16: only the hi halves are read and multiplied -- fp16 operands, fp32 accumulation: the arithmetic of the reference's
+ *   indice_conv_backward<at::Half>, which is what its sparse convolutions run under autocast (functional.py:24
+ *   custom_fwd(cast_inputs=torch.half)); the forward / dX counterpart is mode 1 of isf_sparse_conv_forward_f16x3 / _dma.
+ *   All asynchronous. */
 int isf_pair_list_capacity(int num_in, int num_out);
 int isf_rulebook_pair_lists(const int32_t* nbr, int nbr_stride, int num_out, int num_taps, int capacity,
                             int32_t* indice_pairs, int32_t* indice_num, isf_stream_t stream);
@@ -640,7 +644,7 @@ int isf_split_to_f32_scaled(const void* xs, size_t num_elems, const float* mul, 
 int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in, int c_in, const void* grad_out_split,
                                           int num_out, int c_out, const int32_t* indice_pairs, const int32_t* indice_num,
                                           int capacity, int num_taps, const float* grad_inv_scale, float* grad_filters,
-                                          isf_stream_t stream);
+                                          int mode, isf_stream_t stream);
 
 /* Round 5: BatchNorm1d with BATCH statistics (+ residual, + ReLU) on [N, C] fp32 rows, forward and backward
  * (isf_bn_train.hip) -- the norm / activation of the reference's sparse blocks and DynamicVFE layers in TRAINING mode:

@@ -233,7 +233,7 @@ SIGNATURES = {
     "isf_grad_rescale": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p]),
     "isf_split_to_f32_scaled": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p, c_void_p]),
     "isf_sparse_conv_backward_filter_f16x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                                                      c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                                      c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "isf_msda_backward": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p] * 4),
     "isf_attention_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                        c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,

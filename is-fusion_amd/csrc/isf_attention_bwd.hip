@@ -12,6 +12,8 @@
 //                                                            dK_j = scale * sum_i p_ij (dO_i.v_j - D_i) q_i
 //   window  the 36-token windows of the dense grid: one wave per (window, head) does both roles out of LDS.
 // fp32 VALU like the forward cores (head dim 16: these are dot products of 16 floats).
+#include <algorithm>
+
 #include "isf_common.h"
 
 namespace isf {
@@ -101,15 +103,25 @@ __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------- cols
+// Round 5: the query range is cut into `chunks` pieces (grid.x = key blocks x chunks): with one wave per (key, head,
+// sample) walking ALL queries, the 32400 x 200 instance-to-scene attention had 3 200 waves of 506 iterations each -- a
+// dozen waves per CU -- and took 0.72 ms per call (profiles/r05_train_step_after.txt).  chunks > 1: gk / gv are the
+// partial buffers [chunks][B * Lk][ldgkv], added in chunk order by attention_bwd_cols_reduce_kernel (deterministic).
 template <int HD>
 __global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
     const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale, const float* __restrict__ stat,
-    float* __restrict__ gk, float* __restrict__ gv, int ldgkv) {
+    float* __restrict__ gk, float* __restrict__ gv, int ldgkv, int chunks, int batch) {
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int kblocks = (Lk + 3) / 4;
+  const int chunk = blockIdx.x / kblocks;
+  const int j = (blockIdx.x % kblocks) * 4 + (threadIdx.x >> 6);
   const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
   if (j >= Lk) return;                                     // wave-uniform
+  const int qc = (Lq + chunks - 1) / chunks;
+  const int i_begin = chunk * qc, i_end = min(Lq, i_begin + qc);
+  gk += (size_t)chunk * batch * Lk * ldgkv;
+  gv += (size_t)chunk * batch * Lk * ldgkv;
   float kj[HD], vj[HD], dk[HD], dv[HD];
   load_row<HD>(k + ((size_t)b * Lk + j) * ldkv + head * HD, kj);
   load_row<HD>(v + ((size_t)b * Lk + j) * ldkv + head * HD, vj);
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
   const float* qb = q + (size_t)b * Lq * ldq + head * HD;
   const float* gb = gout + (size_t)b * Lq * ldo + head * HD;
   const float* st = stat + ((size_t)b * heads + head) * Lq * 2;
-  for (int i = lane; i < Lq; i += 64) {
+  for (int i = i_begin + lane; i < i_end; i += 64) {
     float qi[HD], go[HD];
     load_row<HD>(qb + (size_t)i * ldq, qi);
     load_row<HD>(gb + (size_t)i * ldo, go);
@@ -145,6 +157,22 @@ __global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
       *reinterpret_cast<float4*>(g2 + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
     }
   }
+}
+
+// gk / gv [rows][ld] (first `cols` columns) = sum over chunks, in order, of the partial buffers
+__global__ void attention_bwd_cols_reduce_kernel(const float* __restrict__ pk, const float* __restrict__ pv, int chunks,
+                                                 size_t rows, int cols, int ld, float* __restrict__ gk,
+                                                 float* __restrict__ gv) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * (size_t)cols) return;
+  const size_t r = e / cols, o = r * ld + e % cols;
+  float a = 0.f, b = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    a += pk[(size_t)c * rows * ld + o];
+    b += pv[(size_t)c * rows * ld + o];
+  }
+  gk[o] = a;
+  gv[o] = b;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- window
@@ -296,8 +324,22 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
   hipLaunchKernelGGL((attention_bwd_rows_kernel<16>), dim3(ceil_div(num_queries, 4), num_heads, batch_size), dim3(256),
                      0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
   ISF_LAUNCH_CHECK();
-  hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4), num_heads, batch_size), dim3(256), 0,
-                     st, q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, grad_k, grad_v, ldgkv);
+  const int chunks = std::max(1, std::min(64, num_queries / 1024));
+  if (chunks == 1) {
+    hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4), num_heads, batch_size), dim3(256), 0,
+                       st, q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, grad_k, grad_v, ldgkv, 1,
+                       batch_size);
+  } else {
+    const size_t rows = (size_t)batch_size * num_keys;
+    float *pk = nullptr, *pv = nullptr;
+    ISF_TRY(a.alloc_n(&pk, (size_t)chunks * rows * ldgkv));
+    ISF_TRY(a.alloc_n(&pv, (size_t)chunks * rows * ldgkv));
+    hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4) * chunks, num_heads, batch_size),
+                       dim3(256), 0, st, q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, pk, pv,
+                       ldgkv, chunks, batch_size);
+    hipLaunchKernelGGL(attention_bwd_cols_reduce_kernel, dim3(ceil_div((long long)rows * embed_dims, 256)), dim3(256), 0, st,
+                       pk, pv, chunks, rows, embed_dims, ldgkv, grad_k, grad_v);
+  }
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

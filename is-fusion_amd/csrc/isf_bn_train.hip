@@ -69,12 +69,17 @@ __global__ __launch_bounds__(kBnThreads) void bn_partial_kernel(const float* __r
   }
 }
 
-__global__ void bn_final_sum_kernel(const float* __restrict__ partial, int blocks, int c2, float* __restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= c2) return;
+// second level: one wave per output value, lane l adds partials l, l + 64, ... and the wave folds its 64 sums in a fixed
+// butterfly -- ordered (deterministic) and 64-way parallel (one thread walking 512 partials serially took 100 us per call:
+// 4.8 ms of a training step, profiles/r05_train_step_after.txt)
+__global__ __launch_bounds__(64) void bn_final_sum_kernel(const float* __restrict__ partial, int blocks, int c2,
+                                                          float* __restrict__ out) {
+  const int e = blockIdx.x;
   float t = 0.f;
-  for (int b = 0; b < blocks; ++b) t += partial[(size_t)b * c2 + e];
-  out[e] = t;
+  for (int b = threadIdx.x; b < blocks; b += 64) t += partial[(size_t)b * c2 + e];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+  if (threadIdx.x == 0) out[e] = t;
 }
 
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __restrict__ x, long long n4 /* n * c / 4 */, int c,
@@ -168,7 +173,7 @@ static int bn_reduce(const float* a, const float* x, const float* y, const float
   const int stripes = kBnThreads / (c >> 2);
   hipLaunchKernelGGL(bn_partial_kernel<MODE>, dim3(blocks), dim3(kBnThreads), (size_t)stripes * 2 * c * sizeof(float), st, a,
                      x, y, mean_invstd, n, c, partial);
-  hipLaunchKernelGGL(bn_final_sum_kernel, dim3(ceil_div(2 * c, 256)), dim3(256), 0, st, partial, blocks, 2 * c, out);
+  hipLaunchKernelGGL(bn_final_sum_kernel, dim3(2 * c), dim3(64), 0, st, partial, blocks, 2 * c, out);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // reference's indice_conv_half data type end to end: src/all.cc:35-37) instead of 4-byte split rows; half the
   // activation bytes of every layer (BASELINE configs[4], the HBM-bound run).  isf_encoder_options.precision = 2.
   constexpr bool F16IO = (MODE & 256) != 0;
+  constexpr bool STAG = (MODE & 65536) != 0;   // staggered issue phases, see the main loop
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   // neighbour sharing of the gathers (load_A below) where it was measured to pay -- the layers whose gathers saturate
   // the vector-memory path: 64 -> 64 0.91 -> 0.76 ms, 64 -> 32 0.138 -> 0.128, 32 -> 32 0.312 -> 0.301 per step; the
@@ -298,24 +299,20 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     if (PHASE) ph_wait = (unsigned)shader_clock64();
     __syncthreads();  // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
     if (PHASE) ph_bar = (unsigned)shader_clock64();
-    if (s + 1 < nsteps) {
-      advance(cur);
-      load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);   // a_cur = (tap, ch), landed (vmcnt(0) above)
-      stage_B(cur.tap, cur.ch, (s + 1) & 1);
-    }
-    if (PHASE) ph_issue = (unsigned)shader_clock64();
-    if ((wmask >> tap) & 1u) {
+    // column tiles [i0, i1) of this step's products (i = kc * NT + nt); B fragments one tile ahead
+    auto multiply = [&](int i0, int i1) {
+      if (!((wmask >> tap) & 1u)) return;
       const uint4* b = bbuf + (s & 1) * (KCH * NT * 128) + lane;
       bool need[RG];
 #pragma unroll
       for (int rg = 0; rg < RG; ++rg) need[rg] = (rgm[rg] >> tap) & 1u;   // scalar (wave-uniform)
-      uint4 bhu_n = b[0], blu_n = make_uint4(0, 0, 0, 0);   // the next B fragments are read from LDS while these multiply
-      if (!HALF) blu_n = b[64];
+      uint4 bhu_n = b[(i0 * 2 + 0) * 64], blu_n = make_uint4(0, 0, 0, 0);   // the next B fragments are read from LDS while these multiply
+      if (!HALF) blu_n = b[(i0 * 2 + 1) * 64];
 #pragma unroll
-      for (int i = 0; i < KCH * NT; ++i) {   // i = kc * NT + nt
+      for (int i = i0; i < i1; ++i) {
         const int kc = i / NT, nt = i % NT;
         const uint4 bhu = bhu_n, blu = blu_n;
-        if (i + 1 < KCH * NT) {
+        if (i + 1 < i1) {
           bhu_n = b[((i + 1) * 2 + 0) * 64];
           if (!HALF) blu_n = b[((i + 1) * 2 + 1) * 64];
         }
@@ -334,6 +331,33 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
           }
         }
       }
+    };
+    if (STAG) {
+      // STAGGERED issue phases (MODE bit 65536, round 5): the barrier releases all waves into their issue phase at once
+      // and a gather costs the CU's address path 64 cycles -- the burst, not the average load, is what a wave waits out
+      // (profiles/r05_att_256.txt: 31 % of the loop).  Every wave queues its weight pieces first (the others need them
+      // at the next barrier); the first half of the workgroup's waves then gathers and multiplies as before, the second
+      // half multiplies the first half of the column tiles while the others own the address path, gathers, multiplies
+      // the rest.  Same products in the same order per accumulator: bit-identical.
+      const bool late = (wave & (NW / 2)) != 0;          // wave-uniform
+      const bool more = s + 1 < nsteps;
+      if (more) {
+        advance(cur);
+        stage_B(cur.tap, cur.ch, (s + 1) & 1);
+        if (!late) load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);
+      }
+      multiply(0, KCH * NT / 2);
+      if (more && late) load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);
+      if (PHASE) ph_issue = (unsigned)shader_clock64();
+      multiply(KCH * NT / 2, KCH * NT);
+    } else {
+      if (s + 1 < nsteps) {
+        advance(cur);
+        load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);   // a_cur = (tap, ch), landed (vmcnt(0) above)
+        stage_B(cur.tap, cur.ch, (s + 1) & 1);
+      }
+      if (PHASE) ph_issue = (unsigned)shader_clock64();
+      multiply(0, KCH * NT);
     }
     if (PHASE) {
       const unsigned t_end = (unsigned)shader_clock64();
@@ -509,6 +533,13 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
     }
   }
   mode &= ~(4096 | 8192);
+  if constexpr (NT == 8) {   // mode bit 65536: staggered issue phases (deep layers; valid results, bit-identical)
+    if ((mode & ~(32 | 1024)) == 65536) {
+      if (cout == 128 && n_out >= 8 * 256) return launch16<CIN, NT, 2, 8, 65536>(ISF_ARGS16);
+      return launch16<CIN, NT, 2, 4, 65536>(ISF_ARGS16);
+    }
+  }
+  mode &= ~65536;
   switch (mode & ~(32 | 1024)) {   // single-pass f16 (opt-in) and the timing diagnostics run on the 4-wave shape
     case 0: break;
     case 1: return launch16<CIN, NT, 2, 4, 1>(ISF_ARGS16);
@@ -862,7 +893,7 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  const int m = mode & ~(32 | 4096 | 8192);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
+  const int m = mode & ~(32 | 4096 | 8192 | 65536);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
                                                // column block for the 256-column layers (4 x 32-row / 8 x 16-row waves)
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "
@@ -904,9 +935,9 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3_ordered: null pointer");
-  const int m = mode & ~32;
+  const int m = mode & ~(32 | 65536);
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 16 || m == 257), ISF_ERR_ARG,
-              "sparse_conv_forward_f16x3_ordered: mode %d (0, 1, 16, 257, +32)", mode);
+              "sparse_conv_forward_f16x3_ordered: mode %d (0, 1, 16, 257, +32, +65536)", mode);
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
                                              num_out, scale, shift, residual_split, relu, out_split, mode,
                                              isf::as_stream(stream), order);

@@ -200,21 +200,21 @@ __device__ __forceinline__ Wg16Lane<BC> wg16_lane(int lane, int chunk0) {
   return L;
 }
 
-template <int BC>
+template <int BC, bool HALF = false>   // HALF: the hi halves only (BC = 64: item 0; BC = 32 keeps both half-waves busy)
 __device__ __forceinline__ void wg16_load(const char* __restrict__ src, unsigned row_bytes, const Wg16Lane<BC>& L,
                                           const int (&idx)[4], uint4 (&r)[BC / 32][4]) {
 #pragma unroll
-  for (int it = 0; it < BC / 32; ++it)
+  for (int it = 0; it < ((HALF && BC == 64) ? 1 : BC / 32); ++it)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       r[it][j] = *reinterpret_cast<const uint4*>(src + (__umul24((unsigned)idx[j], row_bytes) + L.piece_off[it]));
 }
 
-template <int BC>
+template <int BC, bool HALF = false>
 __device__ __forceinline__ void wg16_store(char* img /* this operand's LDS image */, const Wg16Lane<BC>& L,
                                            const uint4 (&r)[BC / 32][4]) {
 #pragma unroll
-  for (int it = 0; it < BC / 32; ++it) {
+  for (int it = 0; it < ((HALF && BC == 64) ? 1 : BC / 32); ++it) {
     char* a0 = reinterpret_cast<char*>(__builtin_assume_aligned(img + L.lds0[it], 8));
     char* a1 = reinterpret_cast<char*>(__builtin_assume_aligned(img + L.lds1[it], 8));
 #pragma unroll
@@ -242,7 +242,10 @@ __device__ __forceinline__ void wg16_store(char* img /* this operand's LDS image
 // a workgroup is chosen so that all blocks of a group run on ONE XCD, back to back -- the group's x / dY rows are read
 // from HBM once and then served by that XCD's L2 (launch order put 2 of a group's 16 blocks on each XCD: every XCD
 // streamed every row).
-template <int BM, int BN, int WM, int WN>
+// HALF: single-pass f16 -- only the hi halves of x and dY are fetched, staged and multiplied (one MFMA per product): the
+// arithmetic of the reference's indice_conv_backward<at::Half> (fp16 operands, fp32 accumulation), what its sparse convs
+// run under autocast (functional.py:24,46 custom_fwd(cast_inputs=torch.half)).
+template <int BM, int BN, int WM, int WN, bool HALF>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict__ xs, int cin,
                                                          const uint4* __restrict__ gs, int cout,
                                                          const int32_t* __restrict__ pairs,
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict
     fetch_idx(pout, my_begin, qg, ig);
     fetch_idx(pin, my_begin + 32, qx, ix_n);
     fetch_idx(pout, my_begin + 32, qg, ig_n);
-    wg16_load<BM>(xb, x_row, LX, ix, rx);
-    wg16_load<BN>(gb, g_row, LG, ig, rg);
+    wg16_load<BM, HALF>(xb, x_row, LX, ix, rx);
+    wg16_load<BN, HALF>(gb, g_row, LG, ig, rg);
     for (int p0 = my_begin; p0 < my_end; p0 += 32) {
       if (p0 + 32 > my_end) {                            // the one step with positions past the range: zero their x rows
 #pragma unroll
@@ -315,33 +318,37 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(const uint4* __restrict
           }
         }
       }
-      wg16_store<BM>(xr, LX, rx);                        // waits for this step's rows
-      wg16_store<BN>(gr, LG, rg);
+      wg16_store<BM, HALF>(xr, LX, rx);                  // waits for this step's rows
+      wg16_store<BN, HALF>(gr, LG, rg);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ix[j] = ix_n[j]; ig[j] = ig_n[j]; }
       fetch_idx(pin, p0 + 64, qx, ix_n);                 // indices two steps ahead, rows one step ahead
       fetch_idx(pout, p0 + 64, qg, ig_n);
-      wg16_load<BM>(xb, x_row, LX, ix, rx);
-      wg16_load<BN>(gb, g_row, LG, ig, rg);
+      wg16_load<BM, HALF>(xb, x_row, LX, ix, rx);
+      wg16_load<BN, HALF>(gb, g_row, LG, ig, rg);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private images: LDS ops of a wave complete in order
       uint4 ah[MT], al[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         ah[mt] = *reinterpret_cast<const uint4*>(xr + wg16_addr(mt * 16 + m16, kg));
-        al[mt] = *reinterpret_cast<const uint4*>(xr + BM * 64 + wg16_addr(mt * 16 + m16, kg));
+        al[mt] = make_uint4(0, 0, 0, 0);
+        if (!HALF) al[mt] = *reinterpret_cast<const uint4*>(xr + BM * 64 + wg16_addr(mt * 16 + m16, kg));
       }
 #pragma unroll
       for (int nt = 0; nt < NTL; ++nt) {
         const uint4 bhu = *reinterpret_cast<const uint4*>(gr + wg16_addr(nt * 16 + m16, kg));
-        const uint4 blu = *reinterpret_cast<const uint4*>(gr + BN * 64 + wg16_addr(nt * 16 + m16, kg));
+        uint4 blu = make_uint4(0, 0, 0, 0);
+        if (!HALF) blu = *reinterpret_cast<const uint4*>(gr + BN * 64 + wg16_addr(nt * 16 + m16, kg));
         const h8 bh = *reinterpret_cast<const h8*>(&bhu);
         const h8 bl = *reinterpret_cast<const h8*>(&blu);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const h8 xh = *reinterpret_cast<const h8*>(&ah[mt]);
           const h8 xl = *reinterpret_cast<const h8*>(&al[mt]);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl, acc[mt][nt], 0, 0, 0);
+          if (!HALF) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl, acc[mt][nt], 0, 0, 0);
+          }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh, acc[mt][nt], 0, 0, 0);
         }
       }
@@ -383,11 +390,11 @@ __global__ void wgrad16_reduce_kernel(const float* __restrict__ partial, const i
   dw[e] = acc * (inv_scale ? *inv_scale : 1.f);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool HALF>
 static int launch_wgrad16(const uint4* xs, int cin, const uint4* gs, int cout, const int32_t* pairs, const int32_t* counts,
                           int cap, int chunk_pairs, int chunks, int K, float* partial, hipStream_t st) {
   constexpr int bytes = 4 * (BM + BN) * 128;
-  auto kern = wgrad16_kernel<BM, BN, WM, WN>;
+  auto kern = wgrad16_kernel<BM, BN, WM, WN, HALF>;
   if (bytes > 48 * 1024) {
     static bool once = false;
     if (!once) {
@@ -491,10 +498,10 @@ int isf_split_to_f32_scaled(const void* xs, size_t num_elems, const float* mul, 
 int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in, int c_in, const void* grad_out_split,
                                           int num_out, int c_out, const int32_t* indice_pairs, const int32_t* indice_num,
                                           int capacity, int num_taps, const float* grad_inv_scale, float* grad_filters,
-                                          isf_stream_t stream) {
+                                          int mode, isf_stream_t stream) {
   using namespace isf;
-  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && num_taps > 0 && grad_filters, ISF_ERR_ARG,
-              "sparse_conv_backward_filter_f16x3: bad arguments");
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && num_taps > 0 && grad_filters && (mode == 0 || mode == 1), ISF_ERR_ARG,
+              "sparse_conv_backward_filter_f16x3: bad arguments (mode 0 = f16x3 split, 1 = single-pass f16)");
   ISF_REQUIRE(sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "sparse_conv_backward_filter_f16x3: (Cin,Cout)=(%d,%d) not built (32 / 64 / 128 / 256)", c_in, c_out);
   hipStream_t st = as_stream(stream);
@@ -527,8 +534,10 @@ int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in
   int rc = ISF_ERR_UNSUPPORTED;
 #define ISF_WG16(bm, bn, wm, wn)                                                                                       \
   if (BM == bm && BN == bn && WM == wm && WN == wn)                                                                    \
-    rc = launch_wgrad16<bm, bn, wm, wn>(x, c_in, g, c_out, indice_pairs, indice_num, capacity, chunk_pairs, chunks,    \
-                                        num_taps, partial, st)
+    rc = mode == 1 ? launch_wgrad16<bm, bn, wm, wn, true>(x, c_in, g, c_out, indice_pairs, indice_num, capacity,       \
+                                                          chunk_pairs, chunks, num_taps, partial, st)                  \
+                   : launch_wgrad16<bm, bn, wm, wn, false>(x, c_in, g, c_out, indice_pairs, indice_num, capacity,      \
+                                                           chunk_pairs, chunks, num_taps, partial, st)
   ISF_WG16(64, 64, 2, 2); ISF_WG16(64, 64, 2, 1); ISF_WG16(64, 64, 1, 2); ISF_WG16(64, 64, 1, 1);
   ISF_WG16(64, 32, 2, 1); ISF_WG16(64, 32, 1, 1); ISF_WG16(32, 64, 1, 2); ISF_WG16(32, 64, 1, 1); ISF_WG16(32, 32, 1, 1);
 #undef ISF_WG16

@@ -479,7 +479,7 @@ def sparse_conv_forward(features, packed, K, c_in, c_out, rb, scale=None, shift=
     return out
 
 
-def sparse_conv_split(xs, packed16, K, c_in, c_out, rb, ordered=True):
+def sparse_conv_split(xs, packed16, K, c_in, c_out, rb, ordered=True, mode=0):
     """the f16x3 convolution on SPLIT rows in and out (no epilogue, no format passes): the kernel choice of
     sparse_conv_forward_best -- LDS-DMA gathers for the narrow shapes, tile-order table for one-round launches
     (ordered=False: tiles in launch order; the training path rebuilds its rulebooks every step and the three kernels that
@@ -488,12 +488,13 @@ def sparse_conv_split(xs, packed16, K, c_in, c_out, rb, ordered=True):
     if not ordered:
         ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
         args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
-                None, None, None, 0, _lib.ptr(ys), 0)
+                None, None, None, 0, _lib.ptr(ys), int(mode))   # mode 1: single-pass f16 (hi halves only)
         if c_in <= 64 and c_out <= 64:
             _lib.check(lib.isf_sparse_conv_forward_dma(*args, None, _lib.stream()), "isf_sparse_conv_forward_dma")
         else:
             _lib.check(lib.isf_sparse_conv_forward_f16x3(*args, _lib.stream()), "isf_sparse_conv_forward_f16x3")
         return ys
+    assert mode == 0, "ordered launches: fp32-class mode only (the training path passes ordered=False)"
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
     args = (_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
             None, None, None, 0, _lib.ptr(ys), 0)
@@ -544,17 +545,22 @@ def from_split_scaled(xs, shape, mul):
     return out
 
 
-def sparse_conv_backward_filter_f16x3(xs, c_in, gs, c_out, rb, inv_scale, wshape):
+def sparse_conv_backward_filter_f16x3(xs, c_in, gs, c_out, rb, inv_scale, wshape, mode=0):
     """dW [*wshape] on the f16 matrix cores (isf_sparse_conv_backward_filter_f16x3): xs / gs split rows of the layer's
-    input / of its scaled output gradient, inv_scale a device float (1 / the gradient's scale)."""
+    input / of its scaled output gradient, inv_scale a device float (1 / the gradient's scale); mode 1: single-pass f16."""
     pairs, num, cap = pair_lists(rb)
     K = pairs.shape[0]
     grad_w = torch.empty(wshape, dtype=torch.float32, device=xs.device)
     _lib.check(_lib.load().isf_sparse_conv_backward_filter_f16x3(
         _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(gs), rb.num_out, c_out, _lib.ptr(pairs), _lib.ptr(num), cap, K,
-        _lib.ptr(inv_scale), _lib.ptr(grad_w), _lib.stream()), "isf_sparse_conv_backward_filter_f16x3")
+        _lib.ptr(inv_scale), _lib.ptr(grad_w), int(mode), _lib.stream()), "isf_sparse_conv_backward_filter_f16x3")
     return grad_w
 
+
+# under torch.autocast the reference's sparse convolutions compute in half (functional.py:24 custom_fwd(cast_inputs=torch.half)
+# -> indice_conv_half / indice_conv_backward_half); True: ours run the single-pass f16 kernels there (fp16 operands, fp32
+# accumulation, fp32 rows in and out), False: fp32-class f16x3 arithmetic under autocast too
+AUTOCAST_HALF = True
 
 # round 5: dW on the f16 matrix cores + the gradient split once per layer (False: the round-2 path -- fp32-MFMA dW,
 # torch-op gradient scaling -- kept as the cross-check the tests compare against)
@@ -617,7 +623,11 @@ class SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, features, weight, rb):
+    def forward(ctx, features, weight, rb, half=False):
+        """half: single-pass f16 arithmetic (fp16 operands, fp32 accumulation) in forward, dX and dW -- the reference's
+        SparseConvFunction is decorated custom_fwd(cast_inputs=torch.half) (bevfusion-ops/spconv/functional.py:24,46): under
+        autocast its sparse convolutions run indice_conv_half / indice_conv_backward_half.  SparseConvolution.forward sets
+        it from torch.is_autocast_enabled() when AUTOCAST_HALF is on; inputs and outputs stay fp32 rows either way."""
         _lib.require_cuda(features, weight)
         K = int(np.prod(weight.shape[:-2]))
         c_in, c_out = weight.shape[-2], weight.shape[-1]
@@ -627,8 +637,8 @@ class SparseConvFunction(torch.autograd.Function):
         if _f16x3_shape(c_in, c_out) and WGRAD_F16X3 and rb.num_out > 0 and rb.num_in > 0:
             # split rows once: the conv reads them, and so will dW in the backward pass (saved INSTEAD of the fp32 rows)
             xs = to_split(features)
-            out = from_split(sparse_conv_split(xs, _packed_pair(weight, w, K, c_in, c_out)[0], K, c_in, c_out, rb, ordered=False),
-                             (rb.num_out, c_out))
+            out = from_split(sparse_conv_split(xs, _packed_pair(weight, w, K, c_in, c_out)[0], K, c_in, c_out, rb, ordered=False,
+                                               mode=1 if half else 0), (rb.num_out, c_out))
         elif _f16x3_shape(c_in, c_out):    # the inference kernel (f16x3 split MFMA): 3-4x the fp32-MFMA kernel's rate
             out = sparse_conv_forward_best(features, pack_filters_f16x3(w), K, c_in, c_out, rb)
         else:
@@ -637,6 +647,7 @@ class SparseConvFunction(torch.autograd.Function):
                 _lib.ptr(features), rb.num_in, c_in, _lib.ptr(w), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
                 None, None, None, 0, _lib.ptr(out), _lib.stream()), "isf_sparse_conv_forward")
         ctx.split_saved = xs is not None
+        ctx.half = bool(half) and xs is not None
         ctx.packed_t = _packed_pair(weight, w, K, c_in, c_out)[1] if xs is not None else None   # dX's filters
         ctx.save_for_backward(xs if xs is not None else features, w)
         ctx.rb, ctx.wshape = rb, tuple(weight.shape)
@@ -660,11 +671,13 @@ class SparseConvFunction(torch.autograd.Function):
                 rbt = rb.__dict__.get("_rbt")
                 if rbt is None:      # cached: its tile-order tables are built once per rulebook, not once per layer
                     rbt = rb._rbt = _TransposedRulebook(nbr_t, st, rb.num_out, rb.num_in)
-                grad_in = from_split_scaled(sparse_conv_split(gs, ctx.packed_t, K, c_out, c_in, rbt, ordered=False),
+                grad_in = from_split_scaled(sparse_conv_split(gs, ctx.packed_t, K, c_out, c_in, rbt, ordered=False,
+                                                              mode=1 if ctx.half else 0),
                                             (rb.num_in, c_in), sc[1:])
             if ctx.needs_input_grad[1]:
-                grad_w = sparse_conv_backward_filter_f16x3(features, c_in, gs, c_out, rb, sc[1:], ctx.wshape)
-            return grad_in, grad_w, None
+                grad_w = sparse_conv_backward_filter_f16x3(features, c_in, gs, c_out, rb, sc[1:], ctx.wshape,
+                                                           mode=1 if ctx.half else 0)
+            return grad_in, grad_w, None, None
         if ctx.needs_input_grad[0]:
             nbr_t, st = transposed_nbr(rb)
             if _f16x3_shape(c_out, c_in):
@@ -686,7 +699,7 @@ class SparseConvFunction(torch.autograd.Function):
                                                            rb.num_out, c_out, _lib.ptr(rb.nbr), rb.stride, K,
                                                            _lib.ptr(grad_w), _lib.stream()),
                        "isf_sparse_conv_backward_filter")
-        return grad_in, grad_w, None
+        return grad_in, grad_w, None, None
 
 
 class SparseModule(nn.Module):
@@ -790,7 +803,8 @@ class SparseConvolution(SparseModule):
         if training:
             # training: the reference's SparseConvFunction / SubMConvFunction (functional.py:22-97) -- conv without
             # epilogue through autograd, the bias added by a stock broadcast (conv.py:209-210)
-            out_f = SparseConvFunction.apply(feats.contiguous().float(), self.weight, rb)
+            half = AUTOCAST_HALF and torch.is_autocast_enabled()
+            out_f = SparseConvFunction.apply(feats.contiguous().float(), self.weight, rb, half)
             if self.bias is not None:
                 out_f = out_f + self.bias
             return self._wrap(input, out_f, rb)

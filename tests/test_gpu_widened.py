@@ -389,6 +389,81 @@ def test_wgrad_f16x3_matches_fp64_and_the_fp32_mfma_kernel(dev, cin, cout, n, su
     assert float((old.double() - want).abs().max()) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("cin,cout,subm", [(32, 32, True), (64, 128, False), (128, 128, True), (256, 256, True)])
+def test_sparse_conv_half_mode_is_the_references_autocast_arithmetic(dev, cin, cout, subm):
+    """SparseConvFunction(half=True) -- what SparseConvolution.forward selects under torch.autocast, as the reference's
+    custom_fwd(cast_inputs=torch.half) does: fp16 operands (the hi halves only), fp32 accumulation, in forward, dX and dW.
+    Against float64 on f16-ROUNDED operands the three results are fp32-accurate (the rounding of the operands is the whole
+    difference to the fp32-class mode); against the unrounded float64 result they sit within fp16's 2^-11 operand error."""
+    from isfusion_amd import spconv
+    rng = np.random.default_rng(cin + cout)
+    B, shape, n = 2, [10, 40, 40], 6000
+    cells = np.sort(rng.choice(B * int(np.prod(shape)), n, replace=False))
+    idx = np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32)
+    rb = spconv.build_rulebook(_T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1] if subm else [2, 2, 2], [1, 1, 1], subm)
+    K = 27
+    x = torch.randn(rb.num_in, cin, device=dev)
+    w = torch.randn(3, 3, 3, cin, cout, device=dev) / np.sqrt(9 * cin)
+    g = torch.randn(rb.num_out, cout, device=dev) * 1e-6
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    out = spconv.SparseConvFunction.apply(xr, wr, rb, True)
+    out.backward(g)
+    nbr = rb.nbr.view(K, rb.stride)[:, :rb.num_out].long()
+
+    def ref(xq, wq, gq):
+        y = torch.zeros(rb.num_out, cout, dtype=torch.float64, device=dev)
+        dx = torch.zeros(rb.num_in, cin, dtype=torch.float64, device=dev)
+        dw = torch.zeros(K, cin, cout, dtype=torch.float64, device=dev)
+        wk = wq.view(K, cin, cout)
+        for k in range(K):
+            o = torch.nonzero(nbr[k] >= 0).flatten()
+            if o.numel():
+                i = nbr[k][o]
+                y[o] += xq[i] @ wk[k]
+                dx.index_add_(0, i, gq[o] @ wk[k].T)
+                dw[k] = xq[i].T @ gq[o]
+        return y, dx, dw
+    # the kernels scale weights / gradients by a power of two before rounding to f16: rounding commutes with it
+    sw = 2.0 ** (12 - np.ceil(np.log2(float(w.abs().max()))))
+    sg = float(spconv.grad_to_split(g)[1][0])
+    h = lambda t, s=1.0: ((t * s).half().double() / s)
+    ya, dxa, dwa = ref(h(x), h(w, sw), h(g, sg))
+    for got, want in ((out, ya), (xr.grad, dxa), (wr.grad.view(K, cin, cout), dwa)):
+        assert float((got.double() - want).abs().max()) < 3e-5 * float(want.abs().max())
+    yb, dxb, dwb = ref(x.double(), w.double(), g.double())
+    for got, want in ((out, yb), (xr.grad, dxb), (wr.grad.view(K, cin, cout), dwb)):
+        e = float((got.double() - want).abs().max()) / float(want.abs().max())
+        assert 1e-7 < e < 5e-3, e            # NOT the fp32-class path: fp16 operand rounding is visible, and bounded
+
+
+def test_sparse_conv_modules_use_the_half_kernels_under_autocast_only(dev):
+    """SubMConv3d.forward in training mode: fp32-class arithmetic by default, the half kernels under torch.autocast (the
+    reference's custom_fwd(cast_inputs=torch.half)), and fp32-class again with spconv.AUTOCAST_HALF = False"""
+    import isfusion_amd as m
+    from isfusion_amd import spconv
+    rng = np.random.default_rng(5)
+    B, shape, n, c = 2, [9, 24, 24], 2500, 64
+    cells = np.sort(rng.choice(B * int(np.prod(shape)), n, replace=False))
+    idx = _T(np.stack(np.unravel_index(cells, (B, *shape)), 1).astype(np.int32), dev)
+    conv = m.SubMConv3d(c, c, 3, padding=1, bias=False).to(dev).train()
+    x = torch.randn(n, c, device=dev)
+
+    def run():
+        return conv(m.SparseConvTensor(x, idx, shape, B)).features.detach()
+    full = run()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        half = run()
+        assert half.dtype == torch.float32
+        spconv.AUTOCAST_HALF = False
+        try:
+            full2 = run()
+        finally:
+            spconv.AUTOCAST_HALF = True
+    assert torch.equal(full, full2)
+    e = float((half - full).abs().max()) / float(full.abs().max())
+    assert 1e-6 < e < 5e-3, e
+
+
 def test_training_path_without_the_f16_wgrad_still_works(dev):
     """spconv.WGRAD_F16X3 = False restores the round-2 backward (fp32-MFMA dW, torch-op gradient scaling); both paths
     agree to fp32 rounding"""
@@ -501,10 +576,11 @@ def _torch_mha_core(q, k, v, B, Lq, Lk, heads):
     return (p @ vh).transpose(1, 2).reshape(B * Lq, E)
 
 
-@pytest.mark.parametrize("B,Lq,Lk", [(2, 50, 37), (1, 300, 200), (1, 70, 1500)])
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 50, 37), (1, 300, 200), (1, 70, 1500), (2, 5000, 200), (1, 32400, 200)])
 def test_attention_backward_matches_torch_autograd(dev, B, Lq, Lk):
     """isf_attention_backward (rows + cols kernels) vs torch autograd of the same formula in float64: few keys, the
-    32400 x 200-shaped case (more queries than keys) and the many-keys (split-key forward) case"""
+    32400 x 200-shaped case (more queries than keys), the many-keys (split-key forward) case, and -- round 5 -- query counts
+    large enough for the chunked key-gradient pass (partial buffers + ordered reduce), up to the real 32400 x 200"""
     from isfusion_amd import fusion_ops as ops
     g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
     q, k, v = [torch.randn((B * n, 128), generator=g) for n in (Lq, Lk, Lk)]
