@@ -159,6 +159,168 @@ __global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------- many queries (round 5)
+// The two kernels above put a WAVE on a row (or column) and spread the other index over its lanes: every lane fetches its
+// own 64-byte key / query row from L1 for a handful of FMAs, and every result ends in a 64-lane reduction -- 20 GB of L1
+// traffic and 2.6 + 2.2 ms per training step on the 32400 x 200 instance-to-scene attention
+// (profiles/r05_train_step_after.txt).  With thousands of queries the natural owner of a row is a LANE:
+//   rows_lanes   lane = query i (q_i, dO_i, O_i in registers), the (b, head)'s keys and values staged in LDS tile by tile
+//                and read as BROADCASTS (all lanes the same address: conflict-free, no per-lane loads); two passes over
+//                the keys (L_i, then dQ_i); no cross-lane reduction at all.
+//   cols_lanes   lane = key j (k_j, v_j, dK_j, dV_j in registers), a tile of queries (q_i, dO_i, L_i, D_i) staged in LDS and
+//                broadcast; query chunks -> partial buffers -> the ordered reduce above.
+// Same sums as the wave kernels in a different (fixed) order: deterministic, equal to fp32 rounding.
+constexpr int kAttTile = 128;   // keys (rows_lanes) / queries (cols_lanes) per LDS tile
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_rows_lanes_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
+    const float* __restrict__ out, const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale,
+    float* __restrict__ gq, int ldgq, float* __restrict__ stat) {
+  __shared__ __attribute__((aligned(16))) float ks[kAttTile][HD];
+  __shared__ __attribute__((aligned(16))) float vs[kAttTile][HD];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+  const bool live = i < Lq;
+  const int ic = live ? i : Lq - 1;
+  float qi[HD], go[HD], oi[HD];
+  load_row<HD>(q + ((size_t)b * Lq + ic) * ldq + head * HD, qi);
+  load_row<HD>(gout + ((size_t)b * Lq + ic) * ldo + head * HD, go);
+  load_row<HD>(out + ((size_t)b * Lq + ic) * ldo + head * HD, oi);
+#pragma unroll
+  for (int c = 0; c < HD; ++c) qi[c] *= scale;                 // s_ij = (scale q_i) . k_j
+  const float D = dot_row<HD>(go, oi);
+  const float* kb = k + (size_t)b * Lk * ldkv + head * HD;
+  const float* vb = v + (size_t)b * Lk * ldkv + head * HD;
+  auto stage = [&](int j0, bool with_v) {                      // rows j0 .. j0 + kAttTile of K (and V) -> LDS
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAttTile * (HD / 4); e += 256) {
+      const int r = e / (HD / 4), c4 = (e % (HD / 4)) * 4;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
+      if (j0 + r < Lk) {
+        a = *reinterpret_cast<const float4*>(kb + (size_t)(j0 + r) * ldkv + c4);
+        if (with_v) bb = *reinterpret_cast<const float4*>(vb + (size_t)(j0 + r) * ldkv + c4);
+      }
+      *reinterpret_cast<float4*>(&ks[r][c4]) = a;
+      if (with_v) *reinterpret_cast<float4*>(&vs[r][c4]) = bb;
+    }
+    __syncthreads();
+  };
+  // pass 1: L_i = logsumexp_j s_ij (running maximum per lane)
+  float m = -INFINITY, sum = 0.f;
+  for (int j0 = 0; j0 < Lk; j0 += kAttTile) {
+    stage(j0, false);
+    const int nj = min(kAttTile, Lk - j0);
+    for (int j = 0; j < nj; ++j) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) sdot = fmaf(qi[c], ks[j][c], sdot);
+      const float nm = fmaxf(m, sdot);
+      sum = sum * __expf(m - nm) + __expf(sdot - nm);
+      m = nm;
+    }
+  }
+  const float L = m + __logf(sum);
+  // pass 2: dQ_i = scale * sum_j p_ij (dO_i . v_j - D_i) k_j
+  float acc[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+  for (int j0 = 0; j0 < Lk; j0 += kAttTile) {
+    stage(j0, true);
+    const int nj = min(kAttTile, Lk - j0);
+    for (int j = 0; j < nj; ++j) {
+      float sdot = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        sdot = fmaf(qi[c], ks[j][c], sdot);
+        dp = fmaf(go[c], vs[j][c], dp);
+      }
+      const float ds = __expf(sdot - L) * (dp - D);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, ks[j][c], acc[c]);
+    }
+  }
+  if (live) {
+    float* g = gq + ((size_t)b * Lq + i) * ldgq + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4)
+      *reinterpret_cast<float4*>(g + c) = make_float4(acc[c] * scale, acc[c + 1] * scale, acc[c + 2] * scale, acc[c + 3] * scale);
+    float* st = stat + (((size_t)b * heads + head) * Lq + i) * 2;
+    st[0] = L;
+    st[1] = D;
+  }
+}
+
+// grid.x = key blocks (256 keys each) x chunks of the query range; writes the chunk's partial dK / dV rows
+template <int HD>
+__global__ __launch_bounds__(256) void attention_bwd_cols_lanes_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
+    const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale, const float* __restrict__ stat,
+    float* __restrict__ gk, float* __restrict__ gv, int ldgkv, int chunks, int batch) {
+  __shared__ __attribute__((aligned(16))) float qs[kAttTile][HD];
+  __shared__ __attribute__((aligned(16))) float gs[kAttTile][HD];
+  __shared__ float2 ld_s[kAttTile];
+  const int kblocks = (Lk + 255) / 256;
+  const int chunk = blockIdx.x / kblocks;
+  const int j = (blockIdx.x % kblocks) * 256 + threadIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+  const bool live = j < Lk;
+  const int jc = live ? j : Lk - 1;
+  float kj[HD], vj[HD], dk[HD], dv[HD];
+  load_row<HD>(k + ((size_t)b * Lk + jc) * ldkv + head * HD, kj);
+  load_row<HD>(v + ((size_t)b * Lk + jc) * ldkv + head * HD, vj);
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { kj[c] *= scale; dk[c] = dv[c] = 0.f; }   // s_ij = q_i . (scale k_j)
+  const int qc = (Lq + chunks - 1) / chunks;
+  const int i_begin = chunk * qc, i_end = min(Lq, i_begin + qc);
+  const float* qb = q + (size_t)b * Lq * ldq + head * HD;
+  const float* gb = gout + (size_t)b * Lq * ldo + head * HD;
+  const float* st = stat + ((size_t)b * heads + head) * Lq * 2;
+  for (int i0 = i_begin; i0 < i_end; i0 += kAttTile) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < kAttTile * (HD / 4); e += 256) {
+      const int r = e / (HD / 4), c4 = (e % (HD / 4)) * 4;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
+      if (i0 + r < i_end) {
+        a = *reinterpret_cast<const float4*>(qb + (size_t)(i0 + r) * ldq + c4);
+        bb = *reinterpret_cast<const float4*>(gb + (size_t)(i0 + r) * ldo + c4);
+      }
+      *reinterpret_cast<float4*>(&qs[r][c4]) = a;
+      *reinterpret_cast<float4*>(&gs[r][c4]) = bb;
+    }
+    if (threadIdx.x < kAttTile)
+      ld_s[threadIdx.x] = i0 + (int)threadIdx.x < i_end ? *reinterpret_cast<const float2*>(st + (size_t)(i0 + threadIdx.x) * 2)
+                                                        : make_float2(INFINITY, 0.f);   // p = exp(s - inf) = 0
+    __syncthreads();
+    const int ni = min(kAttTile, i_end - i0);
+    for (int i = 0; i < ni; ++i) {
+      float sdot = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        sdot = fmaf(qs[i][c], kj[c], sdot);
+        dp = fmaf(gs[i][c], vj[c], dp);
+      }
+      const float2 ld = ld_s[i];
+      const float p = __expf(sdot - ld.x);
+      const float ds = p * (dp - ld.y);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        dv[c] = fmaf(p, gs[i][c], dv[c]);
+        dk[c] = fmaf(ds, qs[i][c], dk[c]);
+      }
+    }
+  }
+  if (live) {
+    float* g1 = gk + ((size_t)chunk * batch * Lk + (size_t)b * Lk + j) * ldgkv + head * HD;
+    float* g2 = gv + ((size_t)chunk * batch * Lk + (size_t)b * Lk + j) * ldgkv + head * HD;
+#pragma unroll
+    for (int c = 0; c < HD; c += 4) {
+      *reinterpret_cast<float4*>(g1 + c) = make_float4(dk[c] * scale, dk[c + 1] * scale, dk[c + 2] * scale, dk[c + 3] * scale);
+      *reinterpret_cast<float4*>(g2 + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+    }
+  }
+}
+
 // gk / gv [rows][ld] (first `cols` columns) = sum over chunks, in order, of the partial buffers
 __global__ void attention_bwd_cols_reduce_kernel(const float* __restrict__ pk, const float* __restrict__ pv, int chunks,
                                                  size_t rows, int cols, int ld, float* __restrict__ gk,
@@ -321,9 +483,30 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
   float* stat = nullptr;
   ISF_TRY(a.alloc_n(&stat, (size_t)batch_size * num_heads * num_queries * 2));
   const float scale = 1.f / sqrtf(16.f);
-  hipLaunchKernelGGL((attention_bwd_rows_kernel<16>), dim3(ceil_div(num_queries, 4), num_heads, batch_size), dim3(256),
-                     0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
+  const bool many = num_queries >= 2048;   // lanes own queries / keys (see attention_bwd_rows_lanes_kernel)
+  if (many)
+    hipLaunchKernelGGL((attention_bwd_rows_lanes_kernel<16>), dim3(ceil_div(num_queries, 256), num_heads, batch_size), dim3(256),
+                       0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
+  else
+    hipLaunchKernelGGL((attention_bwd_rows_kernel<16>), dim3(ceil_div(num_queries, 4), num_heads, batch_size), dim3(256),
+                       0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
   ISF_LAUNCH_CHECK();
+  if (many) {
+    // enough (key block, chunk, head, sample) workgroups to fill the chip: ~2000 of them, at least 2 query tiles each
+    const int kblocks = ceil_div(num_keys, 256);
+    int chunks = std::max(1, 2048 / std::max(1, kblocks * num_heads * batch_size));
+    chunks = std::max(1, std::min(chunks, num_queries / (2 * kAttTile)));
+    const size_t rows = (size_t)batch_size * num_keys;
+    float *pk = nullptr, *pv = nullptr;
+    ISF_TRY(a.alloc_n(&pk, (size_t)chunks * rows * ldgkv));
+    ISF_TRY(a.alloc_n(&pv, (size_t)chunks * rows * ldgkv));
+    hipLaunchKernelGGL((attention_bwd_cols_lanes_kernel<16>), dim3(kblocks * chunks, num_heads, batch_size), dim3(256), 0, st,
+                       q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, pk, pv, ldgkv, chunks, batch_size);
+    hipLaunchKernelGGL(attention_bwd_cols_reduce_kernel, dim3(ceil_div((long long)rows * embed_dims, 256)), dim3(256), 0, st,
+                       pk, pv, chunks, rows, embed_dims, ldgkv, grad_k, grad_v);
+    ISF_LAUNCH_CHECK();
+    return ISF_OK;
+  }
   const int chunks = std::max(1, std::min(64, num_queries / 1024));
   if (chunks == 1) {
     hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4), num_heads, batch_size), dim3(256), 0,

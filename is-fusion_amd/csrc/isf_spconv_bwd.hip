@@ -42,110 +42,9 @@ __global__ void transpose_filters_kernel(const float* __restrict__ w, int K, int
   wt[idx] = w[((size_t)k * cin + ci) * cout + co];   // wt [K][cout][cin]
 }
 
-// Probe builds only (tools/probes/build_side_lib.sh isf_spconv_bwd.hip ISF_WGRAD_COMPACT=1; the shipped library is built
-// with 0): the same wave-per-block kernel over COMPACTED rows.  The kernel below multiplies 4 consecutive output rows per
-// MFMA group and skips a group only if none of the four has a neighbour through the tap -- at 6-15 pairs per row of 27
-// taps most groups carry one or two live rows.  Here a wave scans 256 rows at a time (coalesced index loads, ballot +
-// mbcnt ranks), writes the live (input row, output row) pairs to a list in LDS and feeds the MFMAs four LIVE rows at a
-// time, a remainder of < 4 pairs carried into the next batch.  Rows are visited in the same order, only the rows that
-// contribute nothing are gone; the k-slot a row lands in changes, so sums agree to fp32 rounding, not bit for bit.
-// NOT YET RUN ON HARDWARE (written after round 4's GPU budget was spent): tools/wgrad_bench.py --lib and the backward
-// tests with the side library are the first thing to do with it.
-#ifndef ISF_WGRAD_COMPACT
-#define ISF_WGRAD_COMPACT 0
-#endif
-#if ISF_WGRAD_COMPACT
-__global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict__ x, int cin,
-                                                        const float* __restrict__ dy, int cout,
-                                                        const int32_t* __restrict__ nbr, int nbr_stride, int n_out,
-                                                        int rows_per_chunk, int K, float* __restrict__ partial) {
-  constexpr int kBatch = 256;                   // rows scanned per batch (4 coalesced index loads per lane)
-  __shared__ int2 list[kBatch + 4];             // (input row, output row) of the live rows + < 4 carried over
-  const int lane = threadIdx.x, sub = lane & 15, kslot = lane >> 4;
-  const int co_blocks = (cout + 63) >> 6;
-  const int ci_base = (blockIdx.x / co_blocks) * 64, co_base = (blockIdx.x % co_blocks) * 64;
-  const int k = blockIdx.y, chunk = blockIdx.z;
-  const bool a_ok = ci_base + 4 * sub < cin, b_ok = co_base + 4 * sub < cout;
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int r_begin = chunk * rows_per_chunk, r_end = min(n_out, r_begin + rows_per_chunk);
-  const int32_t* nk = nbr + (size_t)k * nbr_stride;
-  auto fetch_batch = [&](int r0, int (&v)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = r0 + q * 64 + lane;
-      v[q] = row < r_end ? nk[row] : -1;
-    }
-  };
-  auto load_rows = [&](const int2 e, f32x4& a, f32x4& b) {   // e = (input row or -1, output row)
-    a = f32x4{0.f, 0.f, 0.f, 0.f};
-    b = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (e.x >= 0) {
-      if (a_ok) a = *reinterpret_cast<const f32x4*>(x + (size_t)e.x * cin + ci_base + 4 * sub);
-      if (b_ok) b = *reinterpret_cast<const f32x4*>(dy + (size_t)e.y * cout + co_base + 4 * sub);
-    }
-  };
-  int ahead[4];
-  fetch_batch(r_begin, ahead);
-  int carried = 0;                              // wave-uniform: pairs already at list[0 .. carried)
-  for (int r0 = r_begin; r0 < r_end; r0 += kBatch) {
-    int cur[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = ahead[q];
-    fetch_batch(r0 + kBatch, ahead);            // the next batch's indices fly during this batch's MFMAs
-    int n = carried;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool live = cur[q] >= 0;
-      const unsigned long long m = __ballot(live);
-      const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      if (live) list[n + rank] = make_int2(cur[q], r0 + q * 64 + lane);
-      n += __popcll(m);
-    }
-    const bool last = r0 + kBatch >= r_end;
-    const int groups = last ? (n + 3) >> 2 : n >> 2;
-    if (last && lane < 4 * groups - n) list[n + lane] = make_int2(-1, 0);   // pad the final group
-    __syncthreads();                            // one wave: orders the list writes before the reads below
-    if (groups > 0) {
-      f32x4 a_cur, b_cur, a_nxt, b_nxt;
-      load_rows(list[kslot], a_cur, b_cur);
-      for (int g = 0; g < groups; ++g) {
-        int2 e = make_int2(-1, 0);
-        if (g + 1 < groups) e = list[4 * (g + 1) + kslot];
-        load_rows(e, a_nxt, b_nxt);             // the next four live rows, one group ahead
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[t], acc[s][t], 0, 0, 0);
-        a_cur = a_nxt;
-        b_cur = b_nxt;
-      }
-    }
-    carried = n - 4 * groups;                   // 0 on the last batch
-    int2 keep = make_int2(-1, 0);
-    if (!last && lane < carried) keep = list[4 * groups + lane];
-    __syncthreads();
-    if (!last && lane < carried) list[lane] = keep;
-    __syncthreads();
-  }
-  float* out = partial + ((size_t)chunk * K + k) * cin * cout;
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ci = ci_base + 4 * (4 * kslot + r) + s;
-      if (ci >= cin) continue;
-      const int co = co_base + 4 * sub;
-      if (co >= cout) continue;
-      *reinterpret_cast<f32x4*>(out + (size_t)ci * cout + co) =
-          f32x4{acc[s][0][r], acc[s][1][r], acc[s][2][r], acc[s][3][r]};
-    }
-}
-#else
+// (Round 4's compacted-rows probe of this kernel ran in round 5: 2.1x, 34 TFLOP/s -- profiles/r05_wgrad_compact_probe.txt --
+// and was superseded by the f16 matrix-core kernel of isf_spconv_wgrad16.hip: 189 TFLOP/s.  This fp32-MFMA kernel stays as
+// the fp32 reference entry the new one is tested against.)
 // one wave per (64 x 64 block of dW[k], tap, row chunk)
 __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict__ x, int cin,
                                                         const float* __restrict__ dy, int cout,
@@ -214,7 +113,6 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const float* __restrict_
     }
 }
 
-#endif  // ISF_WGRAD_COMPACT
 
 // any channel count (not a multiple of 4): one thread per dW element, rows in order
 __global__ void wgrad_generic_kernel(const float* __restrict__ x, int cin, const float* __restrict__ dy, int cout,

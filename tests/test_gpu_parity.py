@@ -498,7 +498,8 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
 def test_conv_one_column_block_variants_reproduce_the_two_block_bits(dev):
     """round 5: the 256-column layers with ONE column block per workgroup (conv mode 4096: 4 waves x 32 rows, 8192: 8 waves
     x 16 rows; encoder diagnostic 262144 / 524288) gather a row once per tap and chunk instead of once per column block;
-    every accumulator sees the same products in the same order, so the outputs equal the production launch bit for bit."""
+    every accumulator sees the same products in the same order, so the outputs equal the production launch bit for bit.
+    So does the staggered-issue variant (encoder diagnostic 1048576).  All three measured SLOWER."""
     import isfusion_amd as m
     from isfusion_amd import synthetic
     lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
@@ -509,6 +510,8 @@ def test_conv_one_column_block_variants_reproduce_the_two_block_bits(dev):
         assert torch.equal(lb(pl, conv_diag=262144), want), n
         assert torch.equal(lb(pl, conv_diag=524288), want), n
         assert torch.equal(lb(pl, conv_diag=262144 + 32), want), n
+        # staggered issue phases inside the deep layers' workgroups (conv mode 65536): the same products in the same order
+        assert torch.equal(lb(pl, conv_diag=1048576), want), n
 
 
 def test_conv_tile_order_is_a_per_part_permutation_and_keeps_the_bits(dev):

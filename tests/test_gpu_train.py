@@ -97,7 +97,11 @@ def test_training_mode_applies_the_reference_dropouts_and_p2g_noise(dev):
     """ISFusionEncoder.forward_train: DeformableTransformerDecoderLayer.dropout1..4 and Instane2SceneAtt.dropout
     (fusion_encoder.py:604-668, :478-492; p = 0.1) and the random_noise jitter of the camera-frame points (:992-995)
     are live in training mode: two calls differ, a re-seeded call repeats, and with both switched off the training
-    forward equals itself call after call"""
+    forward equals itself call after call
+    NOT applied (stated here as the review asked): the dropout on the attention PROBABILITIES inside the two
+    nn.MultiheadAttention modules of the IGF (fusion_encoder.py:476, :614 -> :458) -- the flash-style HIP attention core
+    never materialises the probabilities, so in train mode that one stochastic op of the reference is absent (DESIGN.md
+    section 9)."""
     import random
     cfg = CONFIGS["small"]
     enc, bb = build_modules(cfg, dev)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A side build of libisf_hip.so with ONE source file compiled under a probe macro; the other objects are the in-tree
 # build's (make -C is-fusion_amd/csrc first).  The shipped library is never touched.
-#   bash tools/probes/build_side_lib.sh isf_spconv_bwd.hip ISF_WGRAD_COMPACT=1 [name]
+#   bash tools/probes/build_side_lib.sh isf_spconv_dma.hip ISF_DMA_KNOCKOUT=1 [name]
 #   -> tools/probes/_build/libisf_hip_<name>.so   (load with bench.py --lib / tools/wgrad_bench.py --lib, or
 #      isfusion_amd._lib.LIB_PATH = ... before the first call)
 set -eu

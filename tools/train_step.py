@@ -84,7 +84,9 @@ def main():
               lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
     metas = [dict(input_shape=inp["input_shape"]) for _ in range(a.batch)]
     losses, t0 = [], None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 2)]   # per-step GPU time stamps (no extra sync)
     for step in range(a.steps + 1):
+        marks[step].record()
         if step == 1:
             torch.cuda.synchronize()
             dist.barrier()
@@ -96,12 +98,14 @@ def main():
         loss.backward()                                              # bucketed RCCL all-reduce inside
         opt.step()
         losses.append(float(loss))
+    marks[a.steps + 1].record()
     torch.cuda.synchronize()
     dist.barrier()
     dt = (time.perf_counter() - t0) / max(a.steps, 1)
+    per_step = [round(marks[i].elapsed_time(marks[i + 1]), 1) for i in range(a.steps + 1)]   # [0] = the warm-up step
     if rank == 0:
         print(json.dumps({"world_size": world, "n_gpus": world, "parallelism": f"dp{world}", "rccl": launch.rccl_version(), "backend": a.backend, "shared_device": a.shared_device, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "batch_per_gpu": a.batch, "points": a.points, "bf16_camera_features": a.bf16, "autocast_bf16": a.autocast,
-                          "ms_per_train_step": round(dt * 1e3, 2), "losses": [round(v, 5) for v in losses]}))
+                          "ms_per_train_step": round(dt * 1e3, 2), "ms_each_step_gpu_clock": per_step, "losses": [round(v, 5) for v in losses]}))
     dist.destroy_process_group()
 
 
