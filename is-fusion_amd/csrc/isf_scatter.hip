@@ -3,28 +3,33 @@
 // The reference sorts the coordinate rows (at::unique_dim) to number the voxels; here the voxel number
 // of a coordinate is its rank in an occupancy bitmap spanning the coordinate extents, which yields the
 // same lexicographically sorted numbering with one streaming scan instead of a radix sort.
+#include <algorithm>
+
 #include "isf_common.h"
 
 namespace isf {
 
-__global__ void sc_extent_kernel(const int32_t* __restrict__ coors, int P, int* __restrict__ ext) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// grid-stride over the rows, one atomic triple per WORKGROUP of a bounded grid: three hot words take ~88 memory-side
+// updates per microsecond, and one triple per wave of a P / 256-block launch was 28 k updates = 320 us per call at
+// 600 k points (six calls per training step: profiles/r05_train_step_300k.txt)
+__global__ __launch_bounds__(256) void sc_extent_kernel(const int32_t* __restrict__ coors, int P, int* __restrict__ ext) {
   int m0 = -1, m1 = -1, m2 = -1;
-  if (i < P) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
     const int a = coors[(size_t)i * 3], b = coors[(size_t)i * 3 + 1], c = coors[(size_t)i * 3 + 2];
-    if (a >= 0 && b >= 0 && c >= 0) { m0 = a; m1 = b; m2 = c; }
+    if (a >= 0 && b >= 0 && c >= 0) { m0 = max(m0, a); m1 = max(m1, b); m2 = max(m2, c); }
   }
-  // wave-level max, one atomic per wave
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     m0 = max(m0, __shfl_xor(m0, d, 64));
     m1 = max(m1, __shfl_xor(m1, d, 64));
     m2 = max(m2, __shfl_xor(m2, d, 64));
   }
-  if ((threadIdx.x & 63) == 0 && m0 >= 0) {
-    atomicMax(&ext[0], m0);
-    atomicMax(&ext[1], m1);
-    atomicMax(&ext[2], m2);
+  __shared__ int w[4][3];
+  if ((threadIdx.x & 63) == 0) { w[threadIdx.x >> 6][0] = m0; w[threadIdx.x >> 6][1] = m1; w[threadIdx.x >> 6][2] = m2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int m = max(max(w[0][threadIdx.x], w[1][threadIdx.x]), max(w[2][threadIdx.x], w[3][threadIdx.x]));
+    if (m >= 0) atomicMax(&ext[threadIdx.x], m);
   }
 }
 
@@ -105,7 +110,7 @@ int dynamic_scatter_forward_impl(Arena& a, const float* feats, const int32_t* co
   int* ext = nullptr;
   ISF_TRY(a.alloc_n(&ext, 64));
   ISF_HIP_TRY(hipMemsetAsync(ext, 0xff, 3 * sizeof(int), st));  // -1
-  hipLaunchKernelGGL(sc_extent_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, coors, P, ext);
+  hipLaunchKernelGGL(sc_extent_kernel, dim3(std::min(512, ceil_div(P, 256))), dim3(256), 0, st, coors, P, ext);
   ISF_LAUNCH_CHECK();
   int h_ext[3];
   ISF_HIP_TRY(hipMemcpyAsync(h_ext, ext, sizeof(h_ext), hipMemcpyDeviceToHost, st));

@@ -37,6 +37,27 @@ class HardSimpleVFE(nn.Module):
         return out.contiguous()
 
 
+class _RowsLinear(torch.autograd.Function):
+    """y = x W^T on [P, K] point rows (P in the hundreds of thousands, K, N <= 128).  autograd's weight gradient of a stock
+    F.linear is ONE library GEMM whose reduction runs over all P rows inside a couple of macro tiles (8.4 ms per training step
+    at 2 x 300 k points, profiles/r05_train_step_300k.txt); here it is the chunked batched form the fused linears use
+    (fusion_train._weight_grad: row chunks reduced side by side, then summed)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return x.matmul(weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        from .fusion_train import _weight_grad
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g.matmul(weight) if ctx.needs_input_grad[0] else None
+        gw = _weight_grad(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
 class DynamicVFELayer(nn.Module):
     """Linear(no bias) + norm + ReLU (voxel_encoders/utils.py:116-144); parameter holder + torch forward."""
 
@@ -47,7 +68,11 @@ class DynamicVFELayer(nn.Module):
         self.linear = nn.Linear(in_channels, out_channels, bias=False)
 
     def forward(self, inputs):
-        return bn1d_relu(self.norm, self.linear(inputs))   # fused BN + ReLU pass in training mode (norm.py)
+        if self.training and inputs.is_cuda and torch.is_grad_enabled() and inputs.dtype == torch.float32:
+            y = _RowsLinear.apply(inputs.contiguous(), self.linear.weight)
+        else:
+            y = self.linear(inputs)
+        return bn1d_relu(self.norm, y)   # fused BN + ReLU pass in training mode (norm.py)
 
 
 class DynamicVFE(nn.Module):
