@@ -800,7 +800,9 @@ int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void
   ISF_TRY(a.alloc_n(&amax, 64));
   ISF_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
   const size_t n = (size_t)K * cin * cout;
-  hipLaunchKernelGGL(absmax_kernel, dim3(ceil_div((long long)n, 1024) < 1024 ? ceil_div((long long)n, 1024) : 1024),
+  // at most 64 workgroups: every wave ends in an atomicMax on ONE word (~88 memory-side updates per microsecond), and
+  // 1024 workgroups x 4 waves made this 19 us per call -- 42 calls per training step (profiles/r05_train_step_after.txt)
+  hipLaunchKernelGGL(absmax_kernel, dim3(ceil_div((long long)n, 4096) < 64 ? ceil_div((long long)n, 4096) : 64),
                      dim3(256), 0, st, w, n, amax);
   const long long total = (long long)K * (cin >> 5) * (cout >> 4) * 64;
   hipLaunchKernelGGL(pack_filters16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, w, K, cin, cout, amax,

@@ -231,6 +231,58 @@ def test_back_to_back_forwards_without_host_sync(dev):
                 assert torch.equal(g[k], want[i % 2][k]), (graph, stream is not None, i, k)
 
 
+def test_soak_unsynchronised_forwards_on_several_non_null_streams(dev):
+    """the graph-mode fault was narrowed to the legacy NULL stream, not root-caused; before trusting the
+    stream hop, soak it.  450 full-path forwards (B = 2 x 60 k points, two alternating frame sets) queued WITHOUT any host
+    synchronisation on three streams of torch's pool in turn -- 150 eager, 150 as HIP-graph replays with the pillar
+    voxelization on the launch stream (the round-5 default), 150 as replays with it on the side stream (the set-up that
+    faulted on the NULL stream) -- every one of them bit-identical to the synchronised reference."""
+    from isfusion_amd import synthetic
+    from isfusion_amd.detector import ISFusionPtsPath
+    from isfusion_amd.fusion_modules import seeded_state_dict
+    B = 2
+    net = ISFusionPtsPath().eval()
+    net._lidar.randomize_weights_(0).randomize_bn_(1)
+    for mod, seed in ((net.fusion_encoder, 100), (net.pts_backbone, 200), (net.pts_neck, 250), (net.pts_bbox_head, 300)):
+        mod.load_state_dict(seeded_state_dict(mod, seed))
+    net = net.to(dev).freeze()
+    sets = []
+    for fs in range(2):
+        pts = [torch.from_numpy(synthetic.lidar_sweeps(8100 + 10 * fs + i, 60000)).to(dev) for i in range(B)]
+        inp = synthetic.fusion_inputs(190 + fs, B)
+        img_feats = tuple(torch.from_numpy(a).to(dev) for a in inp["img_feats"])
+        kw = dict(lidar2img=torch.from_numpy(inp["lidar2img"]), img_aug_matrix=torch.from_numpy(inp["img_aug_matrix"]),
+                  lidar_aug_matrix=torch.from_numpy(inp["lidar_aug_matrix"]))
+        sets.append((pts, img_feats, [dict(input_shape=inp["input_shape"]) for _ in range(B)], kw))
+    keys = ("center", "heatmap", "dense_heatmap")
+
+    def run(i):
+        pts, img_feats, metas, kw = sets[i % 2]
+        out = net.forward_pts(pts, img_feats, metas, **kw)[0][0]
+        return torch.stack([out[k].double().abs().sum() for k in keys])      # a checksum per forward (device side)
+
+    want = []
+    for i in range(2):
+        want.append(run(i).clone())
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for graph, side in ((False, False), (True, False), (True, True)):
+        net.enable_graph(graph, pillar_side_stream=side)
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        sums = []
+        for k in range(150):
+            st = streams[(k // 5) % 3]                      # five in a row per stream, then the next stream
+            with torch.cuda.stream(st):
+                sums.append(run(k))
+            if k % 5 == 4:                                  # order the streams behind each other, on the device only
+                streams[((k // 5) + 1) % 3].wait_stream(st)
+        torch.cuda.synchronize()
+        for k, c in enumerate(sums):
+            assert torch.equal(c, want[k % 2]), (graph, side, k)
+    net.enable_graph(False)
+
+
 def test_lidar_branch_batches_in_flight_on_two_streams_reproduce_serial_bits(dev):
     """bench.py's "pipelined" leg: consecutive LiDAR-branch calls alternate between two HIP streams (workspaces, count
     mailboxes and geometry side streams are per (device, stream)), so that one batch's voxelization / VFE / geometry runs
