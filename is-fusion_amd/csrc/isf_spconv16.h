@@ -36,6 +36,32 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base_bytes
       : "memory");
 }
 
+// N consecutive KiB in one go: LDS[lds_base + i * 1024 + lane * 16] = gsrc[i * 64] for i < N -- ONE M0 set-up and N loads with
+// immediate offsets (the offset field moves the global AND the LDS address).  The phase trace put the four separate
+// glds16 of a wave's weight share at 410 cycles per step, 12 % of it (profiles/r05_att_256_v2.txt): each carried its own
+// m0 save / set / nop / restore and address arithmetic.
+template <int N>
+__device__ __forceinline__ void glds16_run(const void* gsrc, unsigned lds_base_bytes /* wave-uniform */) {
+  static_assert(N == 1 || N == 2 || N == 4, "1, 2 or 4 KiB");
+  unsigned keep;
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base_bytes) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base_bytes) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base_bytes) : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }

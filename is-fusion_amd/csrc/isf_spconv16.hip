@@ -31,14 +31,16 @@
 namespace isf {
 
 
-// phase trace (MODE bit 2048): dwords per wave record = kPhaseHdr + 4 * kPhaseMaxSteps
-constexpr int kPhaseHdr = 8, kPhaseMaxSteps = kMaxTaps * 8;
+// phase trace (MODE bit 2048): dwords per wave record = kPhaseHdr + kPhaseStep * kPhaseMaxSteps
+constexpr int kPhaseHdr = 8, kPhaseMaxSteps = kMaxTaps * 8, kPhaseStep = 8;
 
 __device__ __forceinline__ unsigned long long shader_clock64() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
   return t;
 }
+
+__device__ uint4 g_zero_line16[8];   // 128 zero bytes: what a lane without a neighbour gathers in the A2 loop
 
 template <int NT, int RG, int KCH, int NW>
 struct Conv16Smem {
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // at the top of each step / after its s_waitcnt vmcnt(0) / after the barrier / after issuing the next step's loads;
   // the multiply section is what is left until the next top.  Per wave, behind the per-workgroup records:
   // kPhaseHdr dwords {clock at loop entry lo, hi, HW_ID, steps, rgm[0], rgm[1], wg_mask, clock at loop exit lo} +
-  // 4 dwords per step.  The stamps cost ~4 scalar-memory round trips per step (measured against the untraced launch
-  // by tools/conv_phase_trace.py).
+  // 8 dwords per step {top, after wait, after barrier, after issue, after the index reads, after the gathers, 0, 0}.  The
+  // stamps cost ~6 scalar-memory round trips per step (measured against the untraced launch by tools/conv_phase_trace.py).
   constexpr bool PHASE = (MODE & 2048) != 0;
   long long t_entry = 0, t_pro = 0, t_loop = 0;
   if (TRACE) t_entry = wall_clock64();
@@ -90,6 +92,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // activation bytes of every layer (BASELINE configs[4], the HBM-bound run).  isf_encoder_options.precision = 2.
   constexpr bool F16IO = (MODE & 256) != 0;
   constexpr bool STAG = (MODE & 65536) != 0;   // staggered issue phases, see the main loop
+  // MODE bit 262144: the gathered rows TWO steps ahead (three register sets in rotation, loop unrolled by three, counted
+  // vmcnt waits) -- the A2 loop below; 4-wave deep shapes only
+  constexpr bool A2 = (MODE & 262144) != 0;
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   // neighbour sharing of the gathers (load_A below) where it was measured to pay -- the layers whose gathers saturate
   // the vector-memory path: 64 -> 64 0.91 -> 0.76 ms, 64 -> 32 0.138 -> 0.128, 32 -> 32 0.312 -> 0.301 per step; the
@@ -252,7 +257,14 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     }
   };
   const unsigned bbuf_addr = __builtin_amdgcn_readfirstlane(lds_addr(bbuf));
+  constexpr int PW = NT * 128 / NW;                       // 16-byte weight pieces per wave and step (KCH = 1)
+  constexpr bool RUNS = (MODE & 131072) == 0 && KCH == 1 && !HALF && !NODMA && (PW == 64 || PW == 128 || PW == 256);
   auto stage_B = [&](int tap, int cg, int buf) {
+    if constexpr (RUNS) {   // this wave's share as ONE contiguous run: one M0 set-up, PW / 64 loads (glds16_run)
+      const uint4* src = wpk + (((size_t)tap * NCH + cg) * ntiles_total + cb * NT) * 128 + wave * PW + lane;
+      glds16_run<PW / 64>(src, bbuf_addr + (unsigned)(buf * (NT * 128) + wave * PW) * 16u);
+      return;
+    }
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc) {
       const uint4* src = wpk + (((size_t)tap * NCH + cg * KCH + kc) * ntiles_total + cb * NT) * 128;
@@ -266,17 +278,129 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     }
   };
 
+  if constexpr (A2) {
+    static_assert(KCH == 1 && NW == 4 && !SHARE && !HALF, "the A2 loop is built for the 4-wave deep shapes");
+    uint4 A0[RG][2], A1[RG][2], A2s[RG][2];
+    auto read_idx = [&](int tap_, int (&idx)[RG]) {
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+        idx[rg] = ((rgm[rg] >> tap_) & 1u) ? nbr_l[tap_ * TM + wave * WR + rg * 16 + col] : -1;
+    };
+    // The gathers are inline asm: hipcc's scoreboard must NOT know them, or it drains vmcnt(0) in front of the first MFMA
+    // that reads a set -- i.e. waits for the rows of the step after next as well (seen in the ISA of the first version).
+    // No exec-masked loads either (a lane without a neighbour reads a zero line): a merge of "loaded" and "not loaded"
+    // lanes is where the compiler would touch the registers before our counted wait.  The sets are only read by the
+    // MFMAs of their own step, behind that wait.
+    auto gather = [&](uint4 (&S)[RG][2], int tap_, int ch_, const int (&idx)[RG]) -> int {
+      int n = 0;
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) {
+        if ((rgm[rg] >> tap_) & 1u) {                      // wave-uniform
+          const uint4* p = idx[rg] >= 0 ? xs + ((size_t)idx[rg] * CH8 + ch_ * 4) * 2 + kg : g_zero_line16 + kg;
+          asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+                       : "=&v"(S[rg][0]), "=&v"(S[rg][1]) : "v"(p) : "memory");
+          n += 2;
+        }
+      }
+      return n;
+    };
+    auto mult = [&](const uint4 (&S)[RG][2], int tap_, int buf) {
+      if (!((wmask >> tap_) & 1u)) return;
+      const uint4* b = bbuf + buf * (NT * 128) + lane;
+      uint4 bhu_n = b[0], blu_n = b[64];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint4 bhu = bhu_n, blu = blu_n;
+        if (nt + 1 < NT) {
+          bhu_n = b[((nt + 1) * 2 + 0) * 64];
+          blu_n = b[((nt + 1) * 2 + 1) * 64];
+        }
+        const h8 bh = *reinterpret_cast<const h8*>(&bhu);
+        const h8 bl = *reinterpret_cast<const h8*>(&blu);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          if ((rgm[rg] >> tap_) & 1u) {
+            const h8 ah = *reinterpret_cast<const h8*>(&S[rg][0]);
+            const h8 al = *reinterpret_cast<const h8*>(&S[rg][1]);
+            acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[rg][nt], 0, 0, 0);
+            acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[rg][nt], 0, 0, 0);
+            acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[rg][nt], 0, 0, 0);
+          }
+        }
+      }
+    };
+    // cursors of steps s (multiply), s + 1 (weights), s + 2 (gathers), s + 3 (index reads)
+    Cursor cs{0u, -1, -1}, cb, cg, ci;
+    int idx_pre[RG];
+    int pend = 0;              // gather instructions issued AFTER the newest weight run: what may stay in flight at the wait
+    if (nsteps > 0) {
+      advance(cs);
+      cb = cs; cg = cs; ci = cs;
+      int i0[RG];
+      read_idx(cs.tap, i0);
+      (void)gather(A0, cs.tap, cs.ch, i0);
+      stage_B(cs.tap, cs.ch, 0);
+      if (nsteps > 1) {
+        advance(cb);
+        cg = cb; ci = cb;
+        int i1[RG];
+        read_idx(cb.tap, i1);
+        pend = gather(A1, cb.tap, cb.ch, i1);
+        if (nsteps > 2) {
+          advance(cg);
+          ci = cg;
+          read_idx(cg.tap, idx_pre);
+        }
+      }
+    }
+    auto body = [&](int s, const uint4 (&Su)[RG][2], uint4 (&Sl)[RG][2]) {
+      // A(s) and this wave's share of B(s) have landed once at most `pend` (the gathers of A(s + 1)) are still in flight
+      if (pend >= 4) __builtin_amdgcn_s_waitcnt(0x0F74);        // vmcnt(4)
+      else if (pend >= 2) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2)
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+      __syncthreads();
+      const int tap_s = cs.tap;
+      pend = 0;
+      if (s + 1 < nsteps) stage_B(cb.tap, cb.ch, (s + 1) & 1);  // weights FIRST: the counted wait above relies on the order
+      if (s + 2 < nsteps) {
+        pend = gather(Sl, cg.tap, cg.ch, idx_pre);
+        if (s + 3 < nsteps) {
+          advance(ci);
+          read_idx(ci.tap, idx_pre);
+        }
+        advance(cg);
+      }
+      if (s + 1 < nsteps) advance(cb);
+      mult(Su, tap_s, s & 1);
+      advance(cs);
+    };
+    for (int s = 0; s < nsteps; s += 3) {
+      body(s, A0, A2s);
+      if (s + 1 < nsteps) body(s + 1, A1, A0);
+      if (s + 2 < nsteps) body(s + 2, A2s, A1);
+    }
+  }
   Cursor cur{0u, -1, -1};
-  if (nsteps > 0) {
+  int idx_pre[RG];   // deep layers: row indices of the step after the current one (see the main loop)
+#pragma unroll
+  for (int rg = 0; rg < RG; ++rg) idx_pre[rg] = -1;
+  if (!A2 && nsteps > 0) {
     advance(cur);
     load_A(cur.tap, cur.ch, -1);
     stage_B(cur.tap, cur.ch, 0);
+    if (nsteps > 1) {
+      Cursor la = cur;
+      advance(la);
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg)
+        idx_pre[rg] = ((rgm[rg] >> la.tap) & 1u) ? nbr_l[la.tap * TM + wave * WR + rg * 16 + col] : -1;
+    }
   }
   unsigned* ph = nullptr;          // this wave's phase record
-  unsigned ph_top = 0, ph_wait = 0, ph_bar = 0, ph_issue = 0;
+  unsigned ph_top = 0, ph_wait = 0, ph_bar = 0, ph_issue = 0, ph_idx = 0, ph_gath = 0;
   if (PHASE) {
     ph = reinterpret_cast<unsigned*>(trace + (size_t)gridDim.x * 8) +
-         ((size_t)blockIdx.x * NW + wave) * (kPhaseHdr + 4 * kPhaseMaxSteps);
+         ((size_t)blockIdx.x * NW + wave) * (kPhaseHdr + kPhaseStep * kPhaseMaxSteps);
     const unsigned long long t = shader_clock64();
     unsigned hw_id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
@@ -286,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     }
     ph_top = (unsigned)t;
   }
-  for (int s = 0; s < nsteps; ++s) {
+  for (int s = 0; s < (A2 ? 0 : nsteps); ++s) {
     const int tap = cur.tap, ch = cur.ch;
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg)
@@ -350,6 +474,73 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
       if (more && late) load_A(cur.tap, cur.ch, cur.ch == ch ? tap : -1);
       if (PHASE) ph_issue = (unsigned)shader_clock64();
       multiply(KCH * NT / 2, KCH * NT);
+    } else if (PHASE && !SHARE && (NW != 4 || (MODE & 131072) != 0)) {
+      // the same issue phase in three stamped pieces: index reads from LDS (+ their wait) | the gathers | the weight DMA
+      if (s + 1 < nsteps) {
+        advance(cur);
+        int idxs[RG];
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg)
+          idxs[rg] = ((rgm[rg] >> cur.tap) & 1u) ? nbr_l[cur.tap * TM + wave * WR + rg * 16 + col] : -1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ph_idx = (unsigned)shader_clock64();
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          if ((rgm[rg] >> cur.tap) & 1u) {
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+              a_nxt[rg][kc][0] = make_uint4(0, 0, 0, 0);
+              a_nxt[rg][kc][1] = make_uint4(0, 0, 0, 0);
+              if (idxs[rg] >= 0) {
+                const uint4* p = xs + ((size_t)idxs[rg] * CH8 + (cur.ch * KCH + kc) * 4) * 2 + kg;
+                a_nxt[rg][kc][0] = p[0];
+                a_nxt[rg][kc][1] = p[4];
+              }
+            }
+          }
+        }
+        ph_gath = (unsigned)shader_clock64();
+        stage_B(cur.tap, cur.ch, (s + 1) & 1);
+      } else {
+        ph_idx = ph_gath = (unsigned)shader_clock64();
+      }
+      ph_issue = (unsigned)shader_clock64();
+      multiply(0, KCH * NT);
+    } else if (!SHARE && (MODE & 131072) == 0 && NW == 4) {   // (8-wave workgroups: the two extra registers cost a wave)
+      // deep layers (no neighbour sharing): the row indices of the NEXT step's gathers were read from the LDS table one
+      // step ago (idx_pre) -- the phase trace put the index ds_reads + their wait at 230 exposed cycles per step
+      // (profiles/r05_att_256_v2.txt) -- and this step ends by reading the ones of the step after next
+      if (s + 1 < nsteps) {
+        advance(cur);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) {
+          if ((rgm[rg] >> cur.tap) & 1u) {
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+              a_nxt[rg][kc][0] = make_uint4(0, 0, 0, 0);
+              a_nxt[rg][kc][1] = make_uint4(0, 0, 0, 0);
+              if (idx_pre[rg] >= 0 && !NOGATHER) {
+                const uint4* p = F16IO ? xs + (size_t)idx_pre[rg] * CH8 + (cur.ch * KCH + kc) * 4 + kg
+                                       : xs + ((size_t)idx_pre[rg] * CH8 + (cur.ch * KCH + kc) * 4) * 2 + kg;
+                a_nxt[rg][kc][0] = p[0];
+                if (!HALF) a_nxt[rg][kc][1] = p[4];
+              }
+            }
+          }
+        }
+        if (PHASE) ph_idx = ph_bar, ph_gath = (unsigned)shader_clock64();   // no index wait any more: idx piece = 0
+        stage_B(cur.tap, cur.ch, (s + 1) & 1);   // (weights BEFORE the gathers measured 0.8 % slower: profiles/r05_issue_phase_ab.txt)
+        if (s + 2 < nsteps) {
+          Cursor la = cur;
+          advance(la);
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg)
+            idx_pre[rg] = ((rgm[rg] >> la.tap) & 1u) ? nbr_l[la.tap * TM + wave * WR + rg * 16 + col] : -1;
+        }
+      }
+      else if (PHASE) ph_idx = ph_gath = ph_bar;
+      if (PHASE) ph_issue = (unsigned)shader_clock64();
+      multiply(0, KCH * NT);
     } else {
       if (s + 1 < nsteps) {
         advance(cur);
@@ -361,8 +552,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     }
     if (PHASE) {
       const unsigned t_end = (unsigned)shader_clock64();
-      if (lane == 0 && s < kPhaseMaxSteps)
-        *reinterpret_cast<uint4*>(ph + kPhaseHdr + 4 * s) = make_uint4(ph_top, ph_wait, ph_bar, ph_issue);
+      if (lane == 0 && s < kPhaseMaxSteps) {
+        *reinterpret_cast<uint4*>(ph + kPhaseHdr + kPhaseStep * s) = make_uint4(ph_top, ph_wait, ph_bar, ph_issue);
+        *reinterpret_cast<uint4*>(ph + kPhaseHdr + kPhaseStep * s + 4) = make_uint4(ph_idx, ph_gath, 0u, 0u);
+      }
       ph_top = t_end;
     }
   }
@@ -533,6 +726,17 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
     }
   }
   mode &= ~(4096 | 8192);
+  if constexpr (NT == 8 && CIN >= 128) {   // mode bit 262144: gathered rows two steps ahead (A2 loop; 4-wave shapes)
+    if ((mode & ~(32 | 1024)) == 262144 && !(cout == 128 && n_out >= 8 * 256)) return launch16<CIN, NT, 2, 4, 262144>(ISF_ARGS16);
+  }
+  mode &= ~262144;
+  if constexpr (NT == 8) {   // mode bit 131072: round 4's issue phase (index reads in the step, four separate DMA pieces): A/B
+    if ((mode & ~(32 | 1024)) == 131072) {
+      if (cout == 128 && n_out >= 8 * 256) return launch16<CIN, NT, 2, 8, 131072>(ISF_ARGS16);
+      return launch16<CIN, NT, 2, 4, 131072>(ISF_ARGS16);
+    }
+  }
+  mode &= ~131072;
   if constexpr (NT == 8) {   // mode bit 65536: staggered issue phases (deep layers; valid results, bit-identical)
     if ((mode & ~(32 | 1024)) == 65536) {
       if (cout == 128 && n_out >= 8 * 256) return launch16<CIN, NT, 2, 8, 65536>(ISF_ARGS16);
@@ -634,7 +838,7 @@ int sparse_conv_trace_impl(const void* xs, int c_in, const void* packed16, int K
       const int nw = (c_in == 256 || !wide) ? 4 : 8;
       if (waves_per_block) *waves_per_block = nw;
       if (pass == 1)
-        ISF_REQUIRE((size_t)8 * (info.full + info.half) * (64 + (size_t)nw * (kPhaseHdr + 4 * kPhaseMaxSteps) * 4) <=
+        ISF_REQUIRE((size_t)8 * (info.full + info.half) * (64 + (size_t)nw * (kPhaseHdr + kPhaseStep * kPhaseMaxSteps) * 4) <=
                         phase_capacity_bytes, ISF_ERR_ARG, "sparse_conv_phase_trace: trace buffer too small");
       if (c_in == 256) rc = launch16<256, 8, 2, 4, 512 | 2048>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
       else if (wide) rc = launch16<128, 8, 2, 8, 512 | 2048>(true, false, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, q, trace);
@@ -895,7 +1099,7 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  const int m = mode & ~(32 | 4096 | 8192 | 65536);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
+  const int m = mode & ~(32 | 4096 | 8192 | 65536 | 131072 | 262144);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
                                                // column block for the 256-column layers (4 x 32-row / 8 x 16-row waves)
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "
@@ -937,9 +1141,9 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3_ordered: null pointer");
-  const int m = mode & ~(32 | 65536);
+  const int m = mode & ~(32 | 65536 | 131072 | 262144);
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 16 || m == 257), ISF_ERR_ARG,
-              "sparse_conv_forward_f16x3_ordered: mode %d (0, 1, 16, 257, +32, +65536)", mode);
+              "sparse_conv_forward_f16x3_ordered: mode %d (0, 1, 16, 257, +32, +65536, +131072)", mode);
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,
                                              num_out, scale, shift, residual_split, relu, out_split, mode,
                                              isf::as_stream(stream), order);
@@ -1024,7 +1228,7 @@ int isf_sparse_conv_phase_trace(const void* features_split, int num_in, int c_in
   ISF_REQUIRE(num_in >= 0 && features_split && packed16 && nbr && out_split && trace && grid_blocks && waves_per_block &&
                   dwords_per_wave && ((scale == nullptr) == (shift == nullptr)), ISF_ERR_ARG,
               "sparse_conv_phase_trace: bad arguments");
-  *dwords_per_wave = isf::kPhaseHdr + 4 * isf::kPhaseMaxSteps;
+  *dwords_per_wave = isf::kPhaseHdr + isf::kPhaseStep * isf::kPhaseMaxSteps;
   return isf::sparse_conv_trace_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
                                      shift, residual_split, relu, out_split, order, trace, 1 << 30, grid_blocks,
                                      isf::as_stream(stream), true, trace_bytes, waves_per_block);

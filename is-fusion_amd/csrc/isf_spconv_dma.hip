@@ -40,6 +40,9 @@ namespace isf {
 #ifndef ISF_DMA_KNOCKOUT
 #define ISF_DMA_KNOCKOUT 0
 #endif
+#ifndef ISF_DMA_EARLY_B
+#define ISF_DMA_EARLY_B 1
+#endif
 __device__ uint4 g_zero_line[8];   // 128 zero bytes: what a row without a neighbour reads
 
 template <int NT, int NW, int RG = 2>
@@ -198,8 +201,14 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       }
     }
   };
+  constexpr int PW = NT * 128 / NW;     // 16-byte weight pieces per wave and step
   auto stage_B = [&](int tap, int ch, int buf) {
     if constexpr ((ISF_DMA_KNOCKOUT & 2) != 0) return;
+    if constexpr (!HALF && (PW == 64 || PW == 128 || PW == 256)) {   // one contiguous run per wave: one M0 set-up (glds16_run)
+      const uint4* srun = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128 + wave * PW + lane;
+      glds16_run<PW / 64>(srun, bbuf_addr + (unsigned)(buf * (NT * 128) + wave * PW) * 16u);
+      return;
+    }
     const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
     const unsigned dst = bbuf_addr + (unsigned)(buf * (NT * 128)) * 16u;
 #pragma unroll
@@ -262,12 +271,24 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     const uint4* b = bbuf + (s & 1) * (NT * 128) + lane;
     uint4 bhu_n = b[0], blu_n = make_uint4(0, 0, 0, 0);
     if (!HALF) blu_n = b[64];
+    // the next step's weight run goes out while the transit reads are still in flight (it lands in the other weight
+    // buffer); the rows follow once the transit has been read
+    const bool more = s + 1 < nsteps;
+#if ISF_DMA_EARLY_B
+    if (more) {
+      advance();
+      stage_B(tap, ch, (s + 1) & 1);
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transit has been read, the next rows may overwrite it
-    if (s + 1 < nsteps) {
+    if (more) issue_A(tap, ch, idx_cur);
+#else   // probe builds (tools/probes/build_side_lib.sh isf_spconv_dma.hip ISF_DMA_EARLY_B=0): round 4's order, for A/B
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (more) {
       advance();
       issue_A(tap, ch, idx_cur);
       stage_B(tap, ch, (s + 1) & 1);
     }
+#endif
     if (((wmask >> tap_s) & 1u) && (ISF_DMA_KNOCKOUT & 4) == 0) {
       bool need[RG];
 #pragma unroll

@@ -414,13 +414,13 @@ def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, 
 def sparse_conv_phase_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,
                             order=None):
     """DIAGNOSTIC (isf_sparse_conv_phase_trace): sparse_conv_trace plus, per wave, shader-clock stamps of every step of
-    the multiply loop -> (out_split, wg int64 [workgroups, 8], waves uint32 [workgroups, waves, 8 + 4 * 216]): header
+    the multiply loop -> (out_split, wg int64 [workgroups, 8], waves uint32 [workgroups, waves, 8 + 8 * 216]): header
     {clock lo, hi at loop entry, HW_ID, steps, tap masks of the wave's two row groups, of the workgroup, clock at loop
-    exit} then (top, after vmcnt(0), after barrier, after load issue) per step.  tools/conv_phase_trace.py."""
+    exit} then (top, after vmcnt(0), after barrier, after load issue, after the index reads, after the gathers, 0, 0) per step.  tools/conv_phase_trace.py."""
     _lib.require_cuda(xs)
     lib = _lib.load()
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
-    nbytes = 8 * 255 * (64 + 8 * (8 + 4 * 216) * 4)
+    nbytes = 8 * 255 * (64 + 8 * (8 + 8 * 216) * 4)
     trace = torch.zeros((nbytes // 8,), dtype=torch.int64, device=xs.device)
     n, nw, dpw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(lib.isf_sparse_conv_phase_trace(

@@ -512,6 +512,11 @@ def test_conv_one_column_block_variants_reproduce_the_two_block_bits(dev):
         assert torch.equal(lb(pl, conv_diag=262144 + 32), want), n
         # staggered issue phases inside the deep layers' workgroups (conv mode 65536): the same products in the same order
         assert torch.equal(lb(pl, conv_diag=1048576), want), n
+        # round 4's issue phase (index reads inside the step, four separate weight-DMA pieces; conv mode 131072) against
+        # the production one (indices a step ahead, one M0 set-up per weight run)
+        assert torch.equal(lb(pl, conv_diag=2097152), want), n
+        # the gathered rows two steps ahead (three register sets, counted waits; conv mode 262144), 4-wave deep shapes
+        assert torch.equal(lb(pl, conv_diag=4194304), want), n
 
 
 def test_conv_tile_order_is_a_per_part_permutation_and_keeps_the_bits(dev):

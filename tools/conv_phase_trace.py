@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HDR = 8
+STEP = 8              # dwords per step record: top, after wait, after barrier, after issue, after index reads, after gathers
 MFMA_CYC = 16            # v_mfma_f32_16x16x32_f16: 4 passes x 4 cycles
 
 
@@ -44,6 +45,7 @@ def analyse(wg, waves, C, nt_cols, untraced_us, plain_span_us):
           f"{100 * (span_us / plain_span_us - 1):.0f} % on top of the plain trace")
     tot = dict(wait=0.0, bar=0.0, issue=0.0, mul=0.0)
     rows = []          # per (wave, step): wait, bar, issue, mul, mfmas
+    sub = []           # per (wave, step): the issue phase's index reads | gathers | weight DMA
     clk = []
     simd_iv = {}       # (xcc, se, cu, simd) -> list of (start, end, mfmas) in absolute cycles
     for b in range(nwg):
@@ -55,7 +57,7 @@ def analyse(wg, waves, C, nt_cols, untraced_us, plain_span_us):
             if steps == 0:
                 continue
             base = (int(h[1]) << 32) | int(h[0])
-            st = h[HDR:HDR + 4 * steps].reshape(steps, 4)
+            st = h[HDR:HDR + STEP * steps].reshape(steps, STEP)
             rel = (st - (base & 0xffffffff)) & 0xffffffff                      # cycles since loop entry
             end = (int(h[7]) - (base & 0xffffffff)) & 0xffffffff
             top, twait, tbar, tiss = rel[:, 0], rel[:, 1], rel[:, 2], rel[:, 3]
@@ -66,6 +68,8 @@ def analyse(wg, waves, C, nt_cols, untraced_us, plain_span_us):
             groups = ((g0 >> tap_of) & 1) + ((g1 >> tap_of) & 1)
             mf = groups * (nt_cols * 3)
             wait, bar, iss, mul = twait - top, tbar - twait, tiss - tbar, nxt - tiss
+            tidx, tgath = rel[:, 4], rel[:, 5]
+            sub.append(np.stack([(tidx - tbar) & 0xffffffff, (tgath - tidx) & 0xffffffff, (tiss - tgath) & 0xffffffff], 1))
             rows.append(np.stack([wait, bar, iss, mul, mf], 1))
             for k, v in zip(("wait", "bar", "issue", "mul"), (wait, bar, iss, mul)):
                 tot[k] += float(v.sum())
@@ -86,6 +90,13 @@ def analyse(wg, waves, C, nt_cols, untraced_us, plain_span_us):
                     ("issue", "issue of the next step's loads (index reads, 4 gathers, 4 DMA pieces)"),
                     ("mul", "multiply section (16 ds_read_b128 + 24 MFMAs per active row group)")):
         print(f"   {100 * tot[k] / allc:5.1f} %  {name}")
+    SB = np.concatenate(sub).astype(np.float64)
+    SB = SB[(SB < 1e6).all(1)]
+    if SB.size and SB.sum() > 0:
+        tot_iss = SB.sum()
+        print(f"   the issue phase in three pieces: index ds_reads + their wait {100 * SB[:, 0].sum() / tot_iss:.0f} % ({pct(SB[:, 0])}), "
+              f"the <= 4 gathers {100 * SB[:, 1].sum() / tot_iss:.0f} % ({pct(SB[:, 1])}), the 4 weight-DMA pieces "
+              f"{100 * SB[:, 2].sum() / tot_iss:.0f} % ({pct(SB[:, 2])}) -- each piece ends in a ~70-cycle stamp")
     ideal = R[:, 4].sum() * MFMA_CYC
     print(f"   MFMA issue cycles the waves own: {100 * ideal / allc:.1f} % of their loop cycles "
           f"({R[:, 4].sum() / len(rows):.0f} MFMAs per wave; a wave alone on a SIMD would need {100 * ideal / tot['mul']:.0f} % "
