@@ -202,7 +202,11 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * times are meaningful; 16 = gather every row (no neighbour sharing): results valid and
  * bit-identical to mode 0, the reference the sharing is tested against; +32 (combinable) = uniform row tiles instead
  * of the full / half-tile mix that evens out the row groups per SIMD on launches of a single round of workgroups
- * (results bit-identical: a row's products and their order do not depend on the tile it falls into). */
+ * (results bit-identical: a row's products and their order do not depend on the tile it falls into).
+ * Round 5, mode 0 only, results valid and bit-identical, deep (128 / 256-column) shapes: +4096 / +8192 = one column block
+ * for the 256-column layers (4 x 32-row / 8 x 16-row waves), +65536 = staggered issue phases, +131072 = round 4's issue
+ * phase (index reads inside the step, separate weight-DMA pieces), +262144 = gathered rows two steps ahead -- experiments
+ * measured slower than the default, kept as tested opt-ins. */
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
 int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
                            isf_stream_t stream);
@@ -418,7 +422,13 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            instead of the fused voxelize + mark launch -- bit-identical;
  *            +32768 = equal-work tile tables for the deep levels instead of uniform tiles + tile order (opt-in:
  *            measured slower) -- bit-identical;
- *            layers run on the gather kernel whenever a diagnostic other than 32 is set. */
+ *            layers run on the gather kernel whenever a diagnostic other than 32 is set.
+ *            Round 5 (all bit-identical to the default, all measured SLOWER, kept as tested opt-ins):
+ *            +262144 / +524288 = the 256-column layers as ONE column block, 4 x 32-row / 8 x 16-row waves (conv mode 4096 /
+ *            8192); +1048576 = staggered issue phases inside the deep layers' workgroups (conv mode 65536); +4194304 = the
+ *            gathered rows two steps ahead (conv mode 262144); +2097152 = round 4's issue phase (row-index reads inside the
+ *            step, four separate weight-DMA pieces; conv mode 131072) -- the A/B partner of the default, which reads the
+ *            indices one step ahead and stages a wave's weight share as one run. */
 typedef struct isf_encoder_options {
   int precision;
   int diagnostic;
