@@ -62,6 +62,22 @@ __device__ __forceinline__ void glds16_run(const void* gsrc, unsigned lds_base_b
                  "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base_bytes) : "memory");
 }
 
+// the hi halves only (single-pass f16 modes): of the N KiB of a run, the even ones -- N / 2 loads at offsets 0, 2048
+template <int N>
+__device__ __forceinline__ void glds16_run_hi(const void* gsrc, unsigned lds_base_bytes /* wave-uniform */) {
+  static_assert(N == 2 || N == 4, "2 or 4 KiB");
+  unsigned keep;
+  if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base_bytes) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base_bytes) : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }

@@ -258,11 +258,14 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   };
   const unsigned bbuf_addr = __builtin_amdgcn_readfirstlane(lds_addr(bbuf));
   constexpr int PW = NT * 128 / NW;                       // 16-byte weight pieces per wave and step (KCH = 1)
-  constexpr bool RUNS = (MODE & 131072) == 0 && KCH == 1 && !HALF && !NODMA && (PW == 64 || PW == 128 || PW == 256);
+  constexpr bool RUNS = (MODE & 131072) == 0 && KCH == 1 && !NODMA && (HALF ? (PW == 128 || PW == 256)
+                                                                                 : (PW == 64 || PW == 128 || PW == 256));
   auto stage_B = [&](int tap, int cg, int buf) {
     if constexpr (RUNS) {   // this wave's share as ONE contiguous run: one M0 set-up, PW / 64 loads (glds16_run)
       const uint4* src = wpk + (((size_t)tap * NCH + cg) * ntiles_total + cb * NT) * 128 + wave * PW + lane;
-      glds16_run<PW / 64>(src, bbuf_addr + (unsigned)(buf * (NT * 128) + wave * PW) * 16u);
+      const unsigned dst = bbuf_addr + (unsigned)(buf * (NT * 128) + wave * PW) * 16u;
+      if constexpr (HALF) glds16_run_hi<PW / 64>(src, dst);   // single-pass f16: the hi KiB of each column tile only
+      else glds16_run<PW / 64>(src, dst);
       return;
     }
 #pragma unroll

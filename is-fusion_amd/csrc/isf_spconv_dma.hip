@@ -204,9 +204,11 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   constexpr int PW = NT * 128 / NW;     // 16-byte weight pieces per wave and step
   auto stage_B = [&](int tap, int ch, int buf) {
     if constexpr ((ISF_DMA_KNOCKOUT & 2) != 0) return;
-    if constexpr (!HALF && (PW == 64 || PW == 128 || PW == 256)) {   // one contiguous run per wave: one M0 set-up (glds16_run)
+    if constexpr (HALF ? (PW == 128 || PW == 256) : (PW == 64 || PW == 128 || PW == 256)) {   // one run per wave (glds16_run)
       const uint4* srun = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128 + wave * PW + lane;
-      glds16_run<PW / 64>(srun, bbuf_addr + (unsigned)(buf * (NT * 128) + wave * PW) * 16u);
+      const unsigned drun = bbuf_addr + (unsigned)(buf * (NT * 128) + wave * PW) * 16u;
+      if constexpr (HALF) glds16_run_hi<PW / 64>(srun, drun);   // single-pass f16: the hi KiB of each column tile only
+      else glds16_run<PW / 64>(srun, drun);
       return;
     }
     const uint4* src = wpk + (((size_t)tap * NCH + ch) * ntiles_total + cb * NT) * 128;
