@@ -428,3 +428,36 @@ def test_window_table_gradient_fold_equals_autograd():
         b = ft._WindowTableAdd.apply(qkv, tab, index, B, S, win, off)
         (b * w).sum().backward()
         assert torch.allclose(a, b) and torch.allclose(tab.grad, g1) and torch.allclose(qkv.grad, q1), (S, win, shift)
+
+
+def test_rows_linear_and_bn_fallback_gradients_on_the_cpu():
+    """voxel_encoder._RowsLinear (chunked weight gradient of the DynamicVFE linears) against F.linear's autograd, and
+    norm.bn1d_relu's stock fallback (CPU tensors / eval mode: nn.BatchNorm1d -> add -> relu, op for op the reference's
+    composition) against the same composition written out"""
+    from isfusion_amd import norm
+    from isfusion_amd.voxel_encoder import _RowsLinear
+    torch.manual_seed(0)
+    x = torch.randn(20000, 11, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(64, 11, dtype=torch.float64, requires_grad=True)
+    g = torch.randn(20000, 64, dtype=torch.float64)
+    y = _RowsLinear.apply(x, w)
+    y.backward(g)
+    got = (y.detach(), x.grad.clone(), w.grad.clone())
+    x.grad = w.grad = None
+    y2 = torch.nn.functional.linear(x, w)
+    y2.backward(g)
+    for a, b in zip(got, (y2.detach(), x.grad, w.grad)):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-12)
+    for train in (True, False):
+        bn = torch.nn.BatchNorm1d(8).train(train)
+        bn2 = torch.nn.BatchNorm1d(8).train(train)
+        bn2.load_state_dict(bn.state_dict())
+        xa = torch.randn(50, 8, requires_grad=True)
+        xb = xa.detach().clone().requires_grad_()
+        res = torch.randn(50, 8)
+        out = norm.bn1d_relu(bn, xa, residual=res, relu=True)          # CPU tensors: the stock composition
+        ref = torch.relu(bn2(xb) + res)
+        out.sum().backward()
+        ref.sum().backward()
+        assert torch.allclose(out, ref) and torch.allclose(xa.grad, xb.grad)
+        assert torch.allclose(bn.running_mean, bn2.running_mean) and torch.allclose(bn.running_var, bn2.running_var)
