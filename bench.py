@@ -266,6 +266,9 @@ def main_fusion(args):
     """--config 3: BASELINE configs[2] as the line of its own (same JSON contract as the headline)."""
     import torch
     import torch.distributed as dist
+    if args.lib:   # a side build of the library (tools/probes/build_side_lib.sh)
+        from isfusion_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   int cb, row0, row_end;
   bool half_tile;   // every wave owns one 16-row group (rows row0 + 16 * wave ..) instead of RG
   if (!conv16_tile_of_block(ncb, plan, TM, n_out, cb, row0, row_end, half_tile, order)) return;
+  if constexpr (RG == 1) half_tile = false;   // one 16-row group per wave already: a short tile is a full tile with fewer rows
   const int ntiles_total = cout >> 4;
 
   // ---- prologue: neighbour tile -> LDS, per-wave tap mask
@@ -687,7 +688,7 @@ static int launch16(bool balance, bool table /* `order` is a tile table (conv16_
   const int ncb = cout / (16 * NT);
   ISF_REQUIRE(ncb == 1 || ncb == 2, ISF_ERR_UNSUPPORTED, "sparse_conv16: %d column blocks", ncb);
   Conv16Plan plan = conv16_plan(n_out, S::TM, ncb, wgs_per_cu.load(std::memory_order_relaxed),
-                                cus_per_xcd.load(std::memory_order_relaxed), balance);
+                                cus_per_xcd.load(std::memory_order_relaxed), balance && RG > 1);
   if (table && !query) plan = Conv16Plan{wgs_per_cu.load(std::memory_order_relaxed) * cus_per_xcd.load(std::memory_order_relaxed),
                                          -1, plan.part_rows};
   if (query) {   // what this launch would look like (conv16_tile_order_impl works on exactly these tiles)
@@ -707,6 +708,27 @@ static int launch16(bool balance, bool table /* `order` is a tile table (conv16_
 // else on 4 waves x 32 rows: the narrow layers lose with wider workgroups (fewer independent workgroups to hide the
 // gather latency) and the 256-column layers of the small deep levels do not have enough tiles (8 waves: 1.41 -> 1.67 ms;
 // 12 waves = one 384-row workgroup per CU: 1.42 -> 1.55 ms, profiles/r02_call3_sharing.txt).
+// SMALL LAUNCHES (round 5, profiles/r05_small_launch_ab.txt).  Below these row counts conv16_plan cuts a launch into HALF
+// tiles only (every compute unit still gets a workgroup): on the two-group kernel a half tile leaves half of each wave's
+// accumulators and of its prefetch registers idle.  The one-group instantiation (RG = 1: the same 16 rows per wave, the
+// same tiles, the same order of operations per output element -- bit-identical) runs them 16-19 % faster: 256 -> 256 at
+// 20 k rows 0.908 -> 0.764 ms per five launches, 128 -> 256 0.106 -> 0.088, 128 -> 128 at 30 k rows 0.434 -> 0.382 ms per four;
+// single-sweep line 454 -> 507 frames/s, two sweeps 706 -> 765.  Above the bound full tiles win by as much (40 k rows:
+// 1.22 -> 1.48 ms; 128 -> 128 at 119 k rows 0.835 -> 0.98 ms), so the bound is exactly where the plan stops being all-half:
+// rows <= 3 workgroups x 4 groups x 16 rows x CUs / 2 column blocks (24 576 on 256 CUs) for the 256-column layers,
+// rows <= 2 x 8 x 16 x CUs (65 536) for the 8-wave 128-column shape.
+static int conv16_device_cus() {
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_acquire);
+  if (c == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)
+      c = 256;
+    cus.store(c, std::memory_order_release);
+  }
+  return c;
+}
+
 template <int CIN, int NT>
 static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
@@ -764,8 +786,14 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
       ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv16: mode %d (single-pass precision and the diagnostics {2,4,6,8} "
                   "are not combinable)", mode);
   }
+  if constexpr (NT == 8) {   // small launches: one 16-row group per wave (see conv16_device_cus above)
+    if (cout == 128 && n_out >= 8 * 256 && n_out <= 256 * conv16_device_cus()) return launch16<CIN, NT, 1, 8>(ISF_ARGS16);
+  }
   if (NT == 8 && cout == 128 && n_out >= 8 * 256)
     return launch16<CIN, (NT == 8 ? NT : 2), 2, 8>(ISF_ARGS16);
+  if constexpr (NT == 8 && CIN >= 128) {
+    if (cout == 256 && n_out <= 96 * conv16_device_cus()) return launch16<CIN, NT, 1, 4>(ISF_ARGS16);
+  }
   return launch16<CIN, NT, 2, 4>(ISF_ARGS16);
 #undef ISF_ARGS16
 }

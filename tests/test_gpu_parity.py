@@ -519,6 +519,36 @@ def test_conv_one_column_block_variants_reproduce_the_two_block_bits(dev):
         assert torch.equal(lb(pl, conv_diag=4194304), want), n
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 128), (256, 128), (128, 256), (256, 256)])
+def test_small_launch_shapes_reproduce_the_two_group_bits_and_the_oracle(dev, oracle_mod, cin, cout):
+    """round 5: a launch small enough that conv16_plan would cut it into half tiles only (<= 96 x CUs rows for the
+    256-column layers, 2048 .. 256 x CUs rows for the 8-wave 128-column shape) runs on the ONE-GROUP instantiation (16 rows
+    per wave).  Same rows per wave, same order of operations per output element as the two-group kernel, which mode 16
+    (no neighbour sharing: a no-op for these shapes) still launches: bit-identical.  And against the oracle."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(1000 + cin + cout)
+    B, shape = 2, [9, 40, 36]
+    for n in (2500, 9000):   # 2500 rows: 40 tiles of 64 rows; 9000: a ragged last tile in every part
+        idx = _random_geometry(rng, B, shape, n)
+        feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
+        w = rng.normal(0, (1.0 / (6 * cin)) ** 0.5, (3, 3, 3, cin, cout)).astype(np.float32)
+        scale = (rng.random(cout, dtype=np.float32) + 0.5)
+        shift = rng.normal(0, 0.2, cout).astype(np.float32)
+        res = rng.normal(0, 1, (n, cout)).astype(np.float32)
+        rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+        p16 = sp.pack_filters_f16x3(T(w, dev))
+        a = (T(feats, dev), p16, 27, cin, cout, rb, T(scale, dev), T(shift, dev), T(res, dev))
+        got = sp.sparse_conv_forward_f16x3(*a, relu=True)
+        assert torch.equal(got, sp.sparse_conv_forward_f16x3(*a, relu=True, mode=16)), ("bits vs two-group", cin, cout, n)
+        assert torch.equal(got, sp.sparse_conv_forward_f16x3(*a, relu=True, mode=32)), ("bits vs launch order", cin, cout, n)
+        oidx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], subm=True)
+        o1, o2 = lexsort4(rb.out_indices.cpu().numpy()), lexsort4(oidx)
+        raw = oracle_mod.indice_conv(feats, w, pairs, num, len(oidx))[o2]
+        want = oracle_mod.bn_act(raw, scale, shift, res[o1], relu=True)
+        err = np.abs(got.cpu().numpy()[o1] - want).max()   # 2e-4 on O(1) outputs: the bound of the oracle test above
+        assert err < 2e-4, ("oracle", cin, cout, n, err, np.abs(raw).max())
+
+
 def test_conv_tile_order_is_a_per_part_permutation_and_keeps_the_bits(dev):
     """isf_sparse_conv_tile_order hands the tiles of a one-round launch to the workgroup slots longest first / least
     loaded CU first: per XCD part a permutation of the tiles, the first 32 slots (one per CU) holding the 32 heaviest
