@@ -206,7 +206,11 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * Round 5, mode 0 only, results valid and bit-identical, deep (128 / 256-column) shapes: +4096 / +8192 = one column block
  * for the 256-column layers (4 x 32-row / 8 x 16-row waves), +65536 = staggered issue phases, +131072 = round 4's issue
  * phase (index reads inside the step, separate weight-DMA pieces), +262144 = gathered rows two steps ahead -- experiments
- * measured slower than the default, kept as tested opt-ins. */
+ * measured slower than the default, kept as tested opt-ins.
+ * Workgroup shape (mode 0 / +32; chosen per launch from c_out and num_out, never changes a result): 4 waves x 32 rows and two
+ * 128-column blocks for c_out = 256, 8 waves x 32 rows for c_out = 128 from 2048 rows up; launches the tile plan would cut
+ * into half tiles only (c_out = 256: num_out <= 96 x CUs; c_out = 128: 2048 <= num_out <= 256 x CUs) run with 16 rows per
+ * wave instead.  Mode 16 keeps the 32-row shapes: the bit-equality reference of that rule too. */
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
 int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
                            isf_stream_t stream);
