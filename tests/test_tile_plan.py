@@ -87,6 +87,27 @@ def test_one_round_launches_are_dealt_evenly(plan_exe):
     assert plan6[1] == 0
 
 
+@pytest.mark.parametrize("TM,ncb,k,bound", [(128, 2, 3, 96 * 256), (256, 1, 2, 256 * 256)])
+def test_small_launch_bounds_are_where_the_plan_stops_being_all_half(plan_exe, TM, ncb, k, bound):
+    """round 5 (isf_spconv16.hip: launch16_rows / conv16_device_cus): a launch of at most
+    96 x CUs rows (256-column layers: 128-row tiles, two column blocks, 3 workgroups per CU) or 256 x CUs rows (the 8-wave
+    128-column shape: 256-row tiles, 2 per CU) is cut into HALF tiles only -- the launches the one-group instantiation
+    takes over -- and the first row past the bound brings full tiles in.  The one-group launch itself (tiles of TM / 2 rows,
+    uniform: half tiles make no sense with one 16-row group per wave) covers every row exactly once."""
+    for n_out in (2048, bound // 3, bound - 17, bound):
+        plan, _ = tiles_of(plan_exe, n_out, TM, ncb, k)
+        assert plan[0] == 0 and plan[1] > 0, (n_out, plan)
+    for n_out in (bound + 1, bound + 5000):
+        plan, _ = tiles_of(plan_exe, n_out, TM, ncb, k)
+        assert plan[0] > 0, (n_out, plan)
+    for n_out in (2048, 9000, bound - 17, bound):
+        plan, tiles = tiles_of(plan_exe, n_out, TM // 2, ncb, k + 1, balance=0)
+        assert plan[1] == 0
+        covered = sorted((r0, r1) for _, _, r0, r1, _ in tiles if r1 > r0)
+        assert covered[0][0] == 0 and covered[-1][1] == n_out
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Unit plan of the one-workgroup-per-CU kernel (csrc/isf_spconv16.h: conv_cu_cut / conv_cu_piece, walked on the host by
 # isf_sparse_conv_cu_plan_host -- the same functions the device planner calls; no GPU work).
