@@ -22,6 +22,7 @@
 // are BIT-IDENTICAL to it.  Replaces, like it, the reference's gather -> GEMM -> scatter-add loop of
 // bevfusion-ops/spconv/include/spconv/spconv_ops.h:260-361.
 #include "isf_spconv16.h"
+#include "isf_spconv_cu_mult.h"
 
 #include <atomic>
 
@@ -30,6 +31,7 @@ namespace isf {
 __device__ uint4 g_zero_line_cu[8];   // 128 zero bytes: what a row without a neighbour reads (one per translation unit: no RDC)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int kCuRows = 16 * kCuCapGroups;       // 256
 static constexpr int kCuCout = 256;
@@ -88,7 +90,9 @@ struct CuCursor {
 // fragment is read from LDS by 4 waves instead of 8 and a row-group block is 12 MFMAs instead of 6 per fragment read).
 // D: prefetch depth in steps (weights: D + 1 register sets, gathered rows: D + 1 LDS stages).  KNOCK: TIMING DIAGNOSTICS
 // (results garbage): bit 1 = no gathers, bit 2 = no weight loads.
-template <int CIN, int NW, int D, int KNOCK>
+// PIPE (round 6): the multiply phase as a LOOP over the step's active row groups with the A fragments in two register sets
+// used alternately (the loop is unrolled by two) and the accumulators picked by a switch -- see the multiply section.
+template <int CIN, int NW, int D, int KNOCK, bool PIPE = false>
 __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -162,6 +166,13 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
   for (int j = 0; j < kCuCapGroups; ++j)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // PIPE: the same accumulators as eight 16-register tuples pinned to v[128:255] (group j, tile nt = accT[j / 2], elements
+  // 8 (j & 1) + 4 nt ..): what the assembly multiply phase works on; copied into acc[][] for the epilogue
+  f32x16 accT[PIPE ? 8 : 1];
+#pragma unroll
+  for (int i = 0; i < (PIPE ? 8 : 1); ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accT[i][e] = 0.f;
 
   auto advance = [&](CuCursor& c) {     // chunk outer, taps (set bits of unit_mask, increasing) inner
     if (c.rem == 0) {
@@ -296,6 +307,33 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
         bh[nt] = *reinterpret_cast<const h8*>(&bn[2 * nt]);
         bl[nt] = *reinterpret_cast<const h8*>(&bn[2 * nt + 1]);
       }
+      // per accumulator: a_lo b_hi -> a_hi b_lo -> a_hi b_hi (the order of spconv_f16x3_kernel), the column tiles
+      // interleaved so that consecutive MFMAs are independent
+      auto mm = [&](f32x4 (&c)[NTW], const uint4 ahu, const uint4 alu) {
+        const h8 ah = *reinterpret_cast<const h8*>(&ahu);
+        const h8 al = *reinterpret_cast<const h8*>(&alu);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], c[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], c[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], c[nt], 0, 0, 0);
+      };
+      if constexpr (PIPE) {
+        // the hand-scheduled multiply phase (isf_spconv_cu_mult.h): accumulators pinned to v[128:255]
+        static_assert(!PIPE || (NW == 8 && NTW == 2), "the assembly multiply phase is written for 8 waves x 32 columns");
+        const unsigned vb = lds_addr(sa);            // this lane's fragment position in group 0 of the stage
+        i32x4 xh, xl, yh, yl;
+        unsigned va;
+        int t, t2;
+        asm volatile(ISF_CUM_TEXT
+                     : "+{v[128:143]}"(accT[0]), "+{v[144:159]}"(accT[1]), "+{v[160:175]}"(accT[2]),
+                       "+{v[176:191]}"(accT[3]), "+{v[192:207]}"(accT[4]), "+{v[208:223]}"(accT[5]),
+                       "+{v[224:239]}"(accT[6]), "+{v[240:255]}"(accT[7]), [xh] "=&v"(xh), [xl] "=&v"(xl),
+                       [yh] "=&v"(yh), [yl] "=&v"(yl), [va] "=&v"(va), [t] "=&s"(t), [t2] "=&s"(t2)
+                     : [b0h] "v"(bn[0]), [b0l] "v"(bn[1]), [b1h] "v"(bn[2]), [b1l] "v"(bn[3]), [vb] "v"(vb), [m] "s"(m)
+                     : "scc", "memory");
+      } else {
       const int jf = __ffs(m) - 1;
       uint4 ah_n = sa[jf * 128], al_n = sa[jf * 128 + 64];
 #pragma unroll
@@ -308,17 +346,9 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
             ah_n = sa[jn * 128];
             al_n = sa[jn * 128 + 64];
           }
-          const h8 ah = *reinterpret_cast<const h8*>(&ahu);
-          const h8 al = *reinterpret_cast<const h8*>(&alu);
-          // per accumulator: a_lo b_hi -> a_hi b_lo -> a_hi b_hi (the order of spconv_f16x3_kernel), the column tiles
-          // interleaved so that consecutive MFMAs are independent
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[j][nt], 0, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[j][nt], 0, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[j][nt], 0, 0, 0);
+          mm(acc[j], ahu, alu);
         }
+      }
       }
     }
     if (++stage == NS) stage = 0;
@@ -333,6 +363,18 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
     else ISF_CU_WAIT8_ALL(bs[0]);
   }
   __syncthreads();   // every wave is done with the ring -> reuse as the epilogue transpose tiles
+  if constexpr (PIPE) {
+    // the last MFMAs were issued from assembly: hipcc's hazard recogniser has not seen them (XDL write -> VALU / LDS read)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (NTW == 2) {
+#pragma unroll
+      for (int j = 0; j < kCuCapGroups; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[j][nt][e] = accT[j >> 1][8 * (j & 1) + 4 * nt + e];
+    }
+  }
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NTW, kCuCapGroups>::wave_bytes / 4);
   conv16_epilogue<NTW, kCuCapGroups, false>(acc, tile_l, lane, row0, 16 * NTW * wave, kCuCout, *w_inv_scale, scale, shift,
@@ -500,10 +542,10 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
   const dim3 grid(8 * ceil_div(plan.max_units, 8));
   // variant (DIAGNOSTIC; 0 = production): 1 / 2 / 3 = no gathers / no weight loads / neither (results garbage, timing
   // only); 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2 (results valid)
-#define ISF_CU_LAUNCH(CI, WW, DD, KK)                                                                                   \
+#define ISF_CU_LAUNCH(CI, WW, DD, KK, PP)                                                                                 \
   do {                                                                                                                  \
     constexpr int smem_bytes = ConvCuSmem<DD, WW>::bytes;                                                               \
-    auto kern = spconv_cu_kernel<CI, WW, DD, KK>;                                                                         \
+    auto kern = spconv_cu_kernel<CI, WW, DD, KK, PP>;                                                                       \
     static std::atomic<int> attr_set{0};                                                                                \
     if (attr_set.load(std::memory_order_acquire) == 0) {                                                                \
       ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
@@ -516,14 +558,21 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
   } while (0)
 #define ISF_CU_VARIANTS(CI)                                                                                             \
   switch (plan.variant) {                                                                                               \
-    case 0: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 0); break;                                                        \
-    case 1: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 1); break;                                                        \
-    case 2: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 2); break;                                                        \
-    case 3: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 3); break;                                                        \
-    case 4: ISF_CU_LAUNCH(CI, 4, 1, 0); break;                                                                          \
-    case 5: ISF_CU_LAUNCH(CI, 4, 2, 0); break;                                                                          \
-    case 6: ISF_CU_LAUNCH(CI, 8, 1, 0); break;                                                                          \
-    case 7: ISF_CU_LAUNCH(CI, 8, 2, 0); break;                                                                          \
+    case 0: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 0, false); break;                                                        \
+    case 1: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 1, false); break;                                                        \
+    case 2: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 2, false); break;                                                        \
+    case 3: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 3, false); break;                                                        \
+    case 4: ISF_CU_LAUNCH(CI, 4, 1, 0, false); break;                                                                          \
+    case 5: ISF_CU_LAUNCH(CI, 4, 2, 0, false); break;                                                                          \
+    case 6: ISF_CU_LAUNCH(CI, 8, 1, 0, false); break;                                                                          \
+    case 7: ISF_CU_LAUNCH(CI, 8, 2, 0, false); break;                                                              \
+    case 8: ISF_CU_LAUNCH(CI, 8, 1, 0, true); break;                                                               \
+    case 9: ISF_CU_LAUNCH(CI, 8, 2, 0, true); break;                                                               \
+    case 11: ISF_CU_LAUNCH(CI, 8, 1, 3, true); break;                                                                          \
+    case 12: ISF_CU_LAUNCH(CI, 8, 1, 1, true); break;                                                              \
+    case 13: ISF_CU_LAUNCH(CI, 8, 1, 2, true); break;                                                              \
+    case 14: ISF_CU_LAUNCH(CI, 8, 2, 1, true); break;                                                              \
+    case 15: ISF_CU_LAUNCH(CI, 8, 2, 2, true); break;                                                                          \
     default: ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_cu: variant %d", plan.variant);                               \
   }
   if (c_in == 128) { ISF_CU_VARIANTS(128) } else { ISF_CU_VARIANTS(256) }

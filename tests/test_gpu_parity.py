@@ -684,7 +684,7 @@ def test_cu_unit_kernel_bit_identical_to_tile_kernel(dev, cin):
             assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks)
             got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb)          # no epilogue terms
             assert torch.equal(got, sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb)), (n, subm, ks)
-            for variant in (4, 5, 6, 7):                                      # 4 / 8 waves x prefetch depth 1 / 2
+            for variant in (4, 5, 6, 7, 8, 9):          # 4 / 8 waves x prefetch depth 1 / 2; 8 / 9 = assembly multiply phase
                 got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, variant=variant)
                 assert torch.equal(got, ref), (n, subm, ks, variant)
             # the plan: device == host walk; groups covered once; masks = taps with a neighbour per 16-row group

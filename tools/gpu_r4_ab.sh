@@ -15,15 +15,6 @@ REPS=${4:-"1 2 3"}
 for rep in $REPS; do
   for v in $VARIANTS; do
     timeout 300 python bench.py --steps 40 --warmup 8 --no-cfg3 --no-cfg4 --no-cfg5 --no-pipelined --no-cpu-baseline --conv-diag $v > $OUT/bench_diag${v}_$rep.json 2> $OUT/bench_diag${v}_$rep.err
-    python - <<PY
-import json
-try:
-    l = json.loads(open("$OUT/bench_diag${v}_$rep.json").read().strip().splitlines()[-1])
-    pk = l["roofline"]["per_kernel"]
-    print("diag", $v, "rep", $rep, l["value"], "frames/s", l["ms_per_step"], "ms; conv", l["roofline"]["conv_ms_per_step"],
-          {k.replace("spconv_mfma", ""): v["ms"] for k, v in pk.items() })
-except Exception as e:
-    print("diag", $v, "rep", $rep, "FAILED", e)
-PY
+    python tools/ab_summary.py $OUT/bench_diag${v}_$rep.json
   done
 done 2>&1 | tee $OUT/ab_summary.txt
