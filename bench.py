@@ -828,7 +828,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a launcher (torch.distributed.run exports MASTER_PORT) the collective path runs even with ONE rank: RCCL
+    # init, the barriers around the timed region, the max-reduce of the clock -- so that the only thing a multi-GPU run
+    # adds to a tested path is N (tests/test_gpu_train.py)
+    use_dist = world > 1 or ("MASTER_PORT" in os.environ and "WORLD_SIZE" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
 
@@ -848,7 +852,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -878,7 +882,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -966,7 +970,7 @@ def main():
                                     + ("f16 storage" if args.f16 else "fp32-class")),
                        "points_per_frame": args.points, "batch_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "collectives": f"RCCL {launch.rccl_version()} over xGMI (barrier + clock reduction only: the "
-                                      f"forward has no data-path collective)" if world > 1 else "none (1 rank)",
+                                      f"forward has no data-path collective)" if use_dist else "none (1 rank)",
                        "frame_sets_rotated": len(frame_sets),
                        "frozen_caches": "lb.freeze(): inference deployment, the packed-weight caches skip their per-call "
                                         "parameter-change scan"},
@@ -1017,7 +1021,7 @@ def main():
             print(json.dumps(dict({"leg": name}, **leg)))
         sys.stdout.flush()
         print(json.dumps(final))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

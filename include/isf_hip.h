@@ -348,7 +348,11 @@ typedef struct isf_conv_cu_plan {
   int num_out;                  /* rows the plan was built for */
   int variant;                  /* 0 = production.  DIAGNOSTICS: 1 / 2 / 3 = no gathers / no weight loads / neither (TIMING
                                    ONLY, results garbage); 4 / 5 = 4-wave workgroups at prefetch depth 1 / 2 steps, 6 / 7 =
-                                   8-wave workgroups at depth 1 / 2 (results valid) */
+                                   8-wave workgroups at depth 1 / 2 (results valid); round 6, hand-scheduled assembly
+                                   multiply phase: 8 = 8 waves, one workgroup per CU; 9 / 10 = two 4-wave workgroups per
+                                   CU over units of <= 8 groups at depth 1 / 2 (valid); 11-15 their knock-outs (timing
+                                   only).  isf_sparse_conv_cu_plan READS this field: the variant decides the unit shape */
+  int cap;                      /* groups per unit the plan was cut for (16 or 8); set by isf_sparse_conv_cu_plan */
 } isf_conv_cu_plan;
 int isf_sparse_conv_cu_plan_ints(int num_out, size_t* num_ints);
 int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, int num_out, int32_t* plan_buf,
@@ -676,6 +680,16 @@ int isf_bn1d_stats(const float* x, int num_rows, int channels, float* stats, isf
 int isf_bn1d_apply(const float* x, int num_rows, int channels, const float* stats, float count, const float* gamma,
                    const float* beta, float eps, float momentum, int unbiased_running_var, float* running_mean,
                    float* running_var, const float* residual, int relu, float* y, float* mean_invstd, isf_stream_t stream);
+/* The same two with the sums taken ABOUT A PIVOT ROW (pivot [C], device; NULL = 0): stats = (sum (x - p), sum (x - p)^2),
+ * mean = p + sum / count, var = sumsq / count - (sum / count)^2 -- any pivot gives the same statistics in exact arithmetic,
+ * a pivot near the mean (the host mirror passes the batch's first row) keeps fp32 from cancelling when |mean| >> std, as
+ * torch's native batch_norm does with its two-pass variance (the single-process nn.BatchNorm1d case; the multi-rank
+ * naiveSyncBN keeps pivot NULL = the reference's E[x^2] - E[x]^2 of ops/norm.py:186-190). */
+int isf_bn1d_stats_pivot(const float* x, int num_rows, int channels, const float* pivot, float* stats, isf_stream_t stream);
+int isf_bn1d_apply_pivot(const float* x, int num_rows, int channels, const float* stats, const float* pivot, float count,
+                         const float* gamma, const float* beta, float eps, float momentum, int unbiased_running_var,
+                         float* running_mean, float* running_var, const float* residual, int relu, float* y,
+                         float* mean_invstd, isf_stream_t stream);
 int isf_bn1d_backward_sums(const float* grad_y, const float* x, const float* y_relu, int num_rows, int channels,
                            const float* mean_invstd, float* sums, isf_stream_t stream);
 int isf_bn1d_backward_apply(const float* grad_y, const float* x, const float* y_relu, int num_rows, int channels,

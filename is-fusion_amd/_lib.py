@@ -58,7 +58,7 @@ def encoder_options(precision=0, diagnostic=0, stage_rows=0, stage_mask=0):
 class ConvCuPlan(ctypes.Structure):
     """struct isf_conv_cu_plan: unit plan of the one-workgroup-per-CU sparse-conv kernel (pointers into plan_buf)."""
     _fields_ = [("group_masks", c_void_p), ("units", c_void_p), ("num_units", c_void_p), ("max_units", c_int),
-                ("num_out", c_int), ("variant", c_int)]
+                ("num_out", c_int), ("variant", c_int), ("cap", c_int)]
 
 
 class VfeParams(ctypes.Structure):
@@ -224,6 +224,10 @@ SIGNATURES = {
     "isf_bn1d_stats": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "isf_bn1d_apply": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_float, c_void_p, c_void_p, ctypes.c_float,
                                ctypes.c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "isf_bn1d_stats_pivot": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "isf_bn1d_apply_pivot": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p,
+                                     ctypes.c_float, ctypes.c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_void_p]),
     "isf_bn1d_backward_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "isf_bn1d_backward_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

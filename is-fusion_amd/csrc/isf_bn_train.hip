@@ -36,16 +36,20 @@ __global__ __launch_bounds__(kBnThreads) void bn_partial_kernel(const float* __r
   const int q = threadIdx.x % cq, stripe = threadIdx.x / cq;
   f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, is = f32x4{1.f, 1.f, 1.f, 1.f};
+  f32x4 pv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (MODE == 1) {
     mu = *reinterpret_cast<const f32x4*>(mean_invstd + 4 * q);
     is = *reinterpret_cast<const f32x4*>(mean_invstd + c + 4 * q);
+  } else if (x) {                                        // MODE 0: `x` carries the pivot row [c] (or nullptr)
+    pv = *reinterpret_cast<const f32x4*>(x + 4 * q);
   }
   if (stripe < stripes) {
     for (long long r = (long long)blockIdx.x * stripes + stripe; r < n; r += (long long)gridDim.x * stripes) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(a + r * c + 4 * q);
       if (MODE == 0) {
-        s0 += v;
-        s1 += v * v;
+        const f32x4 d = v - pv;           // sums about the pivot row (zero when none): see isf_bn1d_stats_pivot
+        s0 += d;
+        s1 += d * d;
       } else {
         f32x4 g = v;
         if (y) {
@@ -88,13 +92,15 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
                                                               float eps, float momentum, int unbiased,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               const float* __restrict__ residual, int relu,
-                                                              float* __restrict__ y, float* __restrict__ mean_invstd) {
+                                                              float* __restrict__ y, float* __restrict__ mean_invstd,
+                                                              const float* __restrict__ pivot /* [c] or nullptr */) {
   const int cq = c >> 2;
   const float inv_n = 1.f / count;
   if (blockIdx.x == 0) {                                 // the layer's buffers: running statistics, saved mean / invstd
     for (int ch = threadIdx.x; ch < c; ch += kBnThreads) {
-      const float m = stats[ch] * inv_n;
-      const float var = fmaxf(stats[c + ch] * inv_n - m * m, 0.f);
+      const float d = stats[ch] * inv_n;                 // mean about the pivot
+      const float var = fmaxf(stats[c + ch] * inv_n - d * d, 0.f);
+      const float m = d + (pivot ? pivot[ch] : 0.f);
       mean_invstd[ch] = m;
       mean_invstd[c + ch] = rsqrtf(var + eps);
       if (running_mean) {
@@ -110,12 +116,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
     const f32x4 sq = *reinterpret_cast<const f32x4*>(stats + c + 4 * q) * inv_n;
     const f32x4 ga = gamma ? *reinterpret_cast<const f32x4*>(gamma + 4 * q) : f32x4{1.f, 1.f, 1.f, 1.f};
     const f32x4 be = beta ? *reinterpret_cast<const f32x4*>(beta + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 pv = pivot ? *reinterpret_cast<const f32x4*>(pivot + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float var = fmaxf(sq[j] - su[j] * su[j], 0.f);
       const float sc = ga[j] * rsqrtf(var + eps);
-      v[j] = fmaf(v[j], sc, be[j] - su[j] * sc);
+      v[j] = fmaf(v[j], sc, be[j] - (su[j] + pv[j]) * sc);
     }
     if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
     if (relu) {
@@ -191,9 +198,24 @@ int isf_bn1d_stats(const float* x, int num_rows, int channels, float* stats, isf
   return bn_reduce<0>(x, nullptr, nullptr, nullptr, num_rows, channels, stats, as_stream(stream));
 }
 
+int isf_bn1d_stats_pivot(const float* x, int num_rows, int channels, const float* pivot, float* stats, isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(x && stats && num_rows > 0, ISF_ERR_ARG, "bn1d_stats_pivot: bad arguments");
+  ISF_REQUIRE(bn_channels_ok(channels), ISF_ERR_UNSUPPORTED, "bn1d_stats_pivot: %d channels (4 * a divisor of 256)", channels);
+  return bn_reduce<0>(x, pivot, nullptr, nullptr, num_rows, channels, stats, as_stream(stream));
+}
+
 int isf_bn1d_apply(const float* x, int num_rows, int channels, const float* stats, float count, const float* gamma,
                    const float* beta, float eps, float momentum, int unbiased_running_var, float* running_mean,
                    float* running_var, const float* residual, int relu, float* y, float* mean_invstd, isf_stream_t stream) {
+  return isf_bn1d_apply_pivot(x, num_rows, channels, stats, nullptr, count, gamma, beta, eps, momentum, unbiased_running_var,
+                              running_mean, running_var, residual, relu, y, mean_invstd, stream);
+}
+
+int isf_bn1d_apply_pivot(const float* x, int num_rows, int channels, const float* stats, const float* pivot, float count,
+                         const float* gamma, const float* beta, float eps, float momentum, int unbiased_running_var,
+                         float* running_mean, float* running_var, const float* residual, int relu, float* y,
+                         float* mean_invstd, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(x && stats && y && mean_invstd && num_rows > 0 && count >= 1.f && (running_mean == nullptr) == (running_var == nullptr),
               ISF_ERR_ARG, "bn1d_apply: bad arguments");
@@ -202,7 +224,7 @@ int isf_bn1d_apply(const float* x, int num_rows, int channels, const float* stat
   const int blocks = (int)std::min<long long>(4096, (n4 + kBnThreads * 4 - 1) / (kBnThreads * 4));
   hipLaunchKernelGGL(bn_apply_kernel, dim3(std::max(1, blocks)), dim3(kBnThreads), 0, as_stream(stream), x, n4, channels, stats,
                      count, gamma, beta, eps, momentum, unbiased_running_var, running_mean, running_var, residual, relu, y,
-                     mean_invstd);
+                     mean_invstd, pivot);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

@@ -270,11 +270,13 @@ struct ConvCuPlan {
   int max_units = 0;                      // host-side bound of *num_units (sizes the grid: no host sync)
   int n_out = 0;
   int variant = 0;                        // 0 = production; timing diagnostics / pipeline depths: isf_spconv_cu.hip
+  int cap = 16;                           // groups per unit the plan was cut for (16: one workgroup per CU; 8: two)
 };
+int conv_cu_variant_cap(int variant);     // the unit shape a kernel variant works on
 bool sparse_conv_cu_supported(int c_in, int c_out);
-size_t conv_cu_plan_ints(int n_out);
+size_t conv_cu_plan_ints(int n_out);      // enough for either shape
 int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int32_t* buf /* conv_cu_plan_ints(n_out) */,
-                      ConvCuPlan* plan, hipStream_t st);
+                      ConvCuPlan* plan, hipStream_t st, int cap = 16);
 int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
                                 int nbr_stride, int n_out, const float* scale, const float* shift, const void* residual,
                                 int relu, void* ys, const ConvCuPlan& plan, hipStream_t st);

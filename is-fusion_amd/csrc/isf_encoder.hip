@@ -162,10 +162,11 @@ struct LevelState {
 };
 
 // unit plan of one neighbour table (isf_spconv_cu.hip), built behind it on the geometry stream
-static int build_cu_plan(Arena& a, const int32_t* nbr, int stride, int K, int n_out, ConvCuPlan* plan, hipStream_t sg) {
+static int build_cu_plan(Arena& a, const int32_t* nbr, int stride, int K, int n_out, ConvCuPlan* plan, hipStream_t sg,
+                         int cap = 16) {
   int32_t* buf = nullptr;
   ISF_TRY(a.alloc_n(&buf, conv_cu_plan_ints(n_out)));
-  return conv_cu_plan_impl(nbr, stride, K, n_out, buf, plan, sg);
+  return conv_cu_plan_impl(nbr, stride, K, n_out, buf, plan, sg, cap);
 }
 
 // tile order / tile table of one conv launch over a neighbour table, built behind the table on the geometry stream.  A
@@ -247,6 +248,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   const bool mailbox = (diagnostic & 131072) == 0;         // bit 131072: data-dependent counts through hipMemcpyAsync + sync
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
+  const int cu_cap = conv_cu_variant_cap((diagnostic >> 10) & 15);   // unit shape of the requested kernel variant
   ISF_REQUIRE(precision >= 0 && precision <= 2 && diagnostic >= 0 &&
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
@@ -385,7 +387,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
         }
-        if (cu) ISF_TRY(build_cu_plan(a, nbr, stride, K, n_out, &L.cache_cu, sg));
+        if (cu) ISF_TRY(build_cu_plan(a, nbr, stride, K, n_out, &L.cache_cu, sg, cu_cap));
         ISF_TRY(stream_wait_stream(a, st, sg));   // this level's convolutions wait for its table
       } else {
         nbr = L.cache_nbr;
@@ -402,7 +404,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
         if (cu && L.cache_cu.n_out == 0) {   // an earlier layer of the level did not need the unit plan
-          ISF_TRY(build_cu_plan(a, nbr, stride, K, n_out, &L.cache_cu, sg));
+          ISF_TRY(build_cu_plan(a, nbr, stride, K, n_out, &L.cache_cu, sg, cu_cap));
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
       }
@@ -452,7 +454,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
       if (want_order)
         ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask, &order_is_table, tile_tables));
-      if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg));
+      if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg, cu_cap));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_cu = ConvCuPlan();
       Nx.cache_lmask = nullptr;

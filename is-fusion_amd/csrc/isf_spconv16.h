@@ -223,14 +223,21 @@ static inline Conv16Plan conv16_plan(int n_out, int TM, int ncb, int wgs_per_cu,
 static constexpr int kCuCapGroups = 16;       // 256 rows x 256 columns of fp32 accumulators in 8 waves x 128 registers
 static constexpr int kCuAvgGroups = 12;       // a launch gets cus * r balanced units with n_groups / (cus * r) <= this
 
-__host__ __device__ inline int conv_cu_balanced_units(int n_groups, int cus) {
-  const int per = cus * kCuAvgGroups;
+// Two shapes (round 6): cap 16 = one 8-wave workgroup per compute unit (the unit's 256 x 256 accumulator tile is the CU's
+// register file); cap 8 = two 4-wave workgroups per compute unit, each over a unit of <= 8 groups (128 rows x 256 columns,
+// a wave = 8 groups x 64 columns): the two workgroups of a CU run unsynchronised, one's load-issue phase under the other's
+// multiply phase.  `slots` = compute units x workgroups per compute unit.
+static constexpr int kCuCapGroups8 = 8;
+static constexpr int kCuAvgGroups8 = 6;
+__host__ __device__ inline int conv_cu_avg_of_cap(int cap) { return cap == kCuCapGroups8 ? kCuAvgGroups8 : kCuAvgGroups; }
+__host__ __device__ inline int conv_cu_balanced_units(int n_groups, int slots, int cap = kCuCapGroups) {
+  const int per = slots * conv_cu_avg_of_cap(cap);
   const int r = n_groups > per ? (n_groups + per - 1) / per : 1;
-  return cus * r;
+  return slots * r;
 }
-// upper bound of the final unit count (splitting adds at most one unit per kCuCapGroups groups)
-__host__ __device__ inline int conv_cu_max_units(int n_groups, int cus) {
-  return conv_cu_balanced_units(n_groups, cus) + (n_groups + kCuCapGroups - 1) / kCuCapGroups;
+// upper bound of the final unit count (splitting adds at most one unit per `cap` groups)
+__host__ __device__ inline int conv_cu_max_units(int n_groups, int slots, int cap = kCuCapGroups) {
+  return conv_cu_balanced_units(n_groups, slots, cap) + (n_groups + cap - 1) / cap;
 }
 // first group of balanced unit u (0 <= u <= U0): W = inclusive prefix of the per-group work
 __host__ __device__ inline int conv_cu_cut(const int32_t* W, int n_groups, int U0, int u) {
@@ -244,10 +251,10 @@ __host__ __device__ inline int conv_cu_cut(const int32_t* W, int n_groups, int U
   }
   return lo;
 }
-__host__ __device__ inline int conv_cu_pieces(int len) { return len <= 0 ? 0 : (len + kCuCapGroups - 1) / kCuCapGroups; }
+__host__ __device__ inline int conv_cu_pieces(int len, int cap = kCuCapGroups) { return len <= 0 ? 0 : (len + cap - 1) / cap; }
 // piece p of a balanced unit of `len` groups starting at group c -> (first group, groups)
-__host__ __device__ inline void conv_cu_piece(int c, int len, int p, int& g0, int& ng) {
-  const int P = conv_cu_pieces(len);
+__host__ __device__ inline void conv_cu_piece(int c, int len, int p, int& g0, int& ng, int cap = kCuCapGroups) {
+  const int P = conv_cu_pieces(len, cap);
   const int a = (int)((long long)p * len / P), b = (int)((long long)(p + 1) * len / P);
   g0 = c + a;
   ng = b - a;

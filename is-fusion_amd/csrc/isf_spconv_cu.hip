@@ -38,13 +38,13 @@ static constexpr int kCuCout = 256;
 static constexpr int kCuDepth = 1;                      // production prefetch depth (steps)
 static constexpr int kCuWavesProd = 4;                  // production workgroup: 4 waves x 64 columns
 
-template <int D, int NW>   // D = prefetch depth in steps; D + 1 stages of gathered rows
+template <int D, int NW, int CAP = kCuCapGroups>   // D = prefetch depth in steps; D + 1 stages of gathered rows; CAP groups per unit
 struct ConvCuSmem {
-  static constexpr int nbr_bytes = kMaxTaps * kCuRows * 4;            // [27][256] int32
-  static constexpr int stage_bytes = kCuCapGroups * 2048;             // [16 groups][hi, lo][64 x 16 B]
+  static constexpr int nbr_bytes = kMaxTaps * 16 * CAP * 4;           // [27][16 CAP] int32
+  static constexpr int stage_bytes = CAP * 2048;                      // [CAP groups][hi, lo][64 x 16 B]
   static constexpr int ring_bytes = (D + 1) * stage_bytes;
   static constexpr int tapm_bytes = 32 * 4;                           // per tap: bit j = group j multiplies through it
-  static constexpr int epi_bytes = NW * Conv16Epi<16 / NW, kCuCapGroups>::wave_bytes;   // overlays the ring
+  static constexpr int epi_bytes = NW * Conv16Epi<16 / NW, CAP>::wave_bytes;   // overlays the ring
   static_assert(epi_bytes <= ring_bytes, "epilogue tile must fit the ring");
   static constexpr int bytes = ring_bytes + nbr_bytes + tapm_bytes;
   static_assert(bytes <= 160 * 1024, "LDS of one compute unit");
@@ -62,8 +62,11 @@ __device__ __forceinline__ void gload16(i32x4& dst, const void* src) {
 // results in front of which hipcc would copy registers whose data has not landed (separate statements under an
 // if / else did exactly that).
 #define ISF_CU_W1(N) "s_cmp_ge_u32 %[al], " #N "\n\ts_cbranch_scc0 " #N "0f\n\ts_waitcnt vmcnt(" #N ")\n\ts_branch 99f\n" #N "0:\n\t"
+// (counts below 10 -- every count of the 8-wave shapes -- skip the upper half of the chain: each miss is a taken branch,
+//  and six of them per step were 0.1 ms of the five 256 -> 256 launches at depth 2, profiles/r06_cu_asm.txt)
 #define ISF_CU_WCHAIN                                                                                                 \
-  ISF_CU_W1(24) ISF_CU_W1(20) ISF_CU_W1(16) ISF_CU_W1(14) ISF_CU_W1(12) ISF_CU_W1(10) ISF_CU_W1(8) ISF_CU_W1(6)       \
+  "s_cmp_lt_u32 %[al], 10\n\ts_cbranch_scc1 98f\n\t"                                                                  \
+  ISF_CU_W1(24) ISF_CU_W1(20) ISF_CU_W1(16) ISF_CU_W1(14) ISF_CU_W1(12) ISF_CU_W1(10) "98:\n\t" ISF_CU_W1(8) ISF_CU_W1(6)       \
       ISF_CU_W1(4) ISF_CU_W1(2) "s_waitcnt vmcnt(0)\n"                                                                \
                                 "99:"
 #define ISF_CU_WAIT4_ALL(bn) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])::"memory")
@@ -92,18 +95,23 @@ struct CuCursor {
 // (results garbage): bit 1 = no gathers, bit 2 = no weight loads.
 // PIPE (round 6): the multiply phase as a LOOP over the step's active row groups with the A fragments in two register sets
 // used alternately (the loop is unrolled by two) and the accumulators picked by a switch -- see the multiply section.
-template <int CIN, int NW, int D, int KNOCK, bool PIPE = false>
-__global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
+// CAP (round 6): groups per unit.  16 = one workgroup per compute unit; 8 (with NW = 4: a wave = 8 groups x 64 columns, 128
+// accumulator registers) = TWO workgroups per compute unit, each with its own barrier: they drift apart, and the load-issue
+// phase of one (index reads, address selects, M0 set-ups, 8 weight loads -- in-order in front of its multiply phase, worth
+// 0.3 of the 1.2 ms of the five 256 -> 256 launches by the knock-outs of profiles/r06_cu_asm.txt) runs under the other's MFMAs.
+template <int CIN, int NW, int D, int KNOCK, bool PIPE = false, int CAP = kCuCapGroups, bool STAG = false>
+__global__ __launch_bounds__(64 * NW, CAP == 8 ? 2 : 1) void spconv_cu_kernel(
     const uint4* __restrict__ xs, const int32_t* __restrict__ nbr, int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, const float* __restrict__ scale, const float* __restrict__ shift,
     const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     const int32_t* __restrict__ group_masks, const int2* __restrict__ units, const int32_t* __restrict__ num_units) {
-  using S = ConvCuSmem<D, NW>;
+  using S = ConvCuSmem<D, NW, CAP>;
+  constexpr int kRows = 16 * CAP;
   constexpr int NCH = CIN / 32, CH8 = CIN / 8, NS = D + 1;
   constexpr int NTW = 16 / NW;          // 16-column tiles per wave
   constexpr int NF = 2 * NTW;           // weight fragments per wave and step: [column tile][hi, lo]
-  constexpr int GQ = kCuCapGroups / NW; // row groups whose rows a wave gathers: wave + NW q
-  constexpr bool NOGATHER = (KNOCK & 1) != 0, NOWEIGHT = (KNOCK & 2) != 0;
+  constexpr int GQ = CAP / NW;          // row groups whose rows a wave gathers: wave + NW q
+  constexpr bool NOGATHER = (KNOCK & 1) != 0, NOWEIGHT = (KNOCK & 2) != 0;   // KNOCK & 4: no wait for the loads (step())
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* ring = reinterpret_cast<uint4*>(smem);
   int* nbr_l = reinterpret_cast<int*>(smem + S::ring_bytes);                       // [27][256]
@@ -115,6 +123,7 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
 
   // workgroup -> unit: XCD x (workgroups are dealt round-robin to the 8 XCDs) takes one contiguous range of units =
   // of rows, so its L2 holds the sliding window of y / z neighbour rows
+  static_assert(CAP == 16 || (CAP == 8 && NW == 4 && PIPE), "shapes: 16 groups per unit, or 8 with 4 waves and the assembly multiply");
   const int U = *num_units;
   const int per_xcd = (U + 7) >> 3;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -128,19 +137,19 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
   // ---- prologue: neighbour table of the unit -> LDS; per-tap group masks
   {
     constexpr int NTHR = 64 * NW;
-    constexpr int NB_IT = (kMaxTaps * kCuRows + NTHR - 1) / NTHR;
+    constexpr int NB_IT = (kMaxTaps * kRows + NTHR - 1) / NTHR;
     int tmp[NB_IT];
 #pragma unroll
     for (int it = 0; it < NB_IT; ++it) {
       const int i = tid + it * NTHR;
-      const int k = i >> 8, r = i & 255;
+      const int k = i / kRows, r = i % kRows;
       tmp[it] = -1;
       if (k < K && row0 + r < row_end) tmp[it] = nbr[(size_t)k * nbr_stride + row0 + r];
     }
 #pragma unroll
     for (int it = 0; it < NB_IT; ++it) {
       const int i = tid + it * NTHR;
-      if (i < kMaxTaps * kCuRows) nbr_l[i] = tmp[it];
+      if (i < kMaxTaps * kRows) nbr_l[i] = tmp[it];
     }
   }
   unsigned unit_mask = 0;     // taps any group of the unit multiplies through
@@ -161,9 +170,9 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
   const int ntaps = __popc(unit_mask);
   const int nsteps = ntaps * NCH;
 
-  f32x4 acc[kCuCapGroups][NTW];
+  f32x4 acc[CAP][NTW];
 #pragma unroll
-  for (int j = 0; j < kCuCapGroups; ++j)
+  for (int j = 0; j < CAP; ++j)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // PIPE: the same accumulators as eight 16-register tuples pinned to v[128:255] (group j, tile nt = accT[j / 2], elements
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
 
   auto read_idx = [&](int tap, int (&ix)[GQ]) {     // this lane's gather rows through `tap` (groups wave + NW q)
 #pragma unroll
-    for (int q = 0; q < GQ; ++q) ix[q] = nbr_l[tap * kCuRows + (wave + NW * q) * 16 + grow_l];
+    for (int q = 0; q < GQ; ++q) ix[q] = nbr_l[tap * kRows + (wave + NW * q) * 16 + grow_l];
   };
   auto dma_count = [&](int tap) -> int {
     int n = 0;
@@ -209,7 +218,8 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
 #pragma unroll
     for (int q = 0; q < GQ; ++q) {
       if ((dm[q] >> tap) & 1u) {
-        const uint4* src = ix[q] >= 0 ? xs + ((size_t)ix[q] * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
+        // KNOCK & 16 (timing only): every gather reads row 0 -- the same instructions, always cache hits
+        const uint4* src = ix[q] >= 0 ? xs + ((size_t)((KNOCK & 16) ? 0 : ix[q]) * CH8 + ch * 4) * 2 + gpiece : zero + gpiece;
         glds16(src, base + (unsigned)(wave + NW * q) * 2048u);
         glds16(src + 4, base + (unsigned)(wave + NW * q) * 2048u + 1024u);
       }
@@ -226,7 +236,8 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
     for (int f = 0; f < NF; ++f) bs[k][f] = i32x4{0, 0, 0, 0};
   auto load_B = [&](int tap, int ch, i32x4 (&bn)[NF]) -> int {
     if (NOWEIGHT) return 0;
-    const uint4* src = wpk + (((size_t)tap * NCH + ch) * (kCuCout / 16) + NTW * wave) * 128 + lane;
+    // KNOCK & 8 (timing only): every step reads the weights of (tap 0, chunk 0) -- the same bytes, always cache hits
+    const uint4* src = wpk + ((KNOCK & 8) ? (size_t)0 : ((size_t)tap * NCH + ch) * (kCuCout / 16) + NTW * wave) * 128 + lane;
 #pragma unroll
     for (int f = 0; f < NF; ++f) gload16(bn[f], src + 64 * f);
     return NF;
@@ -276,7 +287,9 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
     int allowed = 0;
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) allowed += inq[i];
-    if constexpr (D == 1) {                 // nothing younger than G(t - 1) exists: drain
+    if constexpr ((KNOCK & 4) != 0) {       // TIMING DIAGNOSTIC: no wait for the loads at all (results garbage): what is
+                                            // left of the memory cost is issue + contention, not exposed latency
+    } else if constexpr (D == 1) {          // nothing younger than G(t - 1) exists: drain
       if constexpr (NF == 4) ISF_CU_WAIT4_ALL(bn);
       else ISF_CU_WAIT8_ALL(bn);
     } else {
@@ -290,15 +303,28 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
       advance(cm);
       m_cur = (unsigned)tapm_l[cm.tap];
     }
-    int n = 0;
-    if (issued_steps < nsteps) {
-      int s_new = stage + D;
-      if (s_new >= NS) s_new -= NS;
-      n = issue_group(bo, s_new);
-    }
+    auto issue_next = [&]() {
+      int n = 0;
+      if (issued_steps < nsteps) {
+        int s_new = stage + D;
+        if (s_new >= NS) s_new -= NS;
+        n = issue_group(bo, s_new);
+      }
 #pragma unroll
-    for (int i = 0; i + 1 < D - 1; ++i) inq[i] = inq[i + 1];
-    if (D > 1) inq[D > 1 ? D - 2 : 0] = n;
+      for (int i = 0; i + 1 < D - 1; ++i) inq[i] = inq[i + 1];
+      if (D > 1) inq[D > 1 ? D - 2 : 0] = n;
+    };
+    // STAG (round 6): the two waves of a SIMD (wave w and w + NW / 2 land on the same SIMD) run the two halves of a step in
+    // OPPOSITE order -- the first half of the workgroup issues the loads of step t + D and then multiplies, the second half
+    // multiplies first -- so that between two barriers a SIMD's matrix pipe always has one wave in its multiply phase
+    // while the other is in its issue phase (index reads, address selects, M0 set-ups, weight loads: in-order in front
+    // of the MFMAs otherwise, and both waves of a SIMD at the same time because the barrier aligns them).  Needs D >= 2:
+    // the late half's loads are issued only half a step before the next barrier.
+    static_assert(!STAG || D >= 2, "staggered halves need a prefetch depth of two steps");
+    // (two workgroups per CU, CAP = 8: a workgroup has one wave per SIMD, its SIMD partner is the wave of the CU's OTHER
+    //  workgroup -- slots j and j + 32 of an XCD share a compute unit -- so the whole second-round workgroup runs late)
+    const bool late = STAG && (CAP == 8 ? ((slot >> 5) & 1) != 0 : wave >= NW / 2);     // wave-uniform
+    if (!late) issue_next();
     if (m) {
       const uint4* sa = ring + stage * (S::stage_bytes / 16) + rpos;
       h8 bh[NTW], bl[NTW];
@@ -321,26 +347,38 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
       };
       if constexpr (PIPE) {
         // the hand-scheduled multiply phase (isf_spconv_cu_mult.h): accumulators pinned to v[128:255]
-        static_assert(!PIPE || (NW == 8 && NTW == 2), "the assembly multiply phase is written for 8 waves x 32 columns");
+        static_assert(!PIPE || (NW == 8 && NTW == 2 && CAP == 16) || (NW == 4 && NTW == 4 && CAP == 8),
+                      "the assembly multiply phase is written for 8 waves x 32 columns x 16 groups and 4 waves x 64 columns x 8 groups");
         const unsigned vb = lds_addr(sa);            // this lane's fragment position in group 0 of the stage
         i32x4 xh, xl, yh, yl;
         unsigned va;
         int t, t2;
-        asm volatile(ISF_CUM_TEXT
-                     : "+{v[128:143]}"(accT[0]), "+{v[144:159]}"(accT[1]), "+{v[160:175]}"(accT[2]),
-                       "+{v[176:191]}"(accT[3]), "+{v[192:207]}"(accT[4]), "+{v[208:223]}"(accT[5]),
-                       "+{v[224:239]}"(accT[6]), "+{v[240:255]}"(accT[7]), [xh] "=&v"(xh), [xl] "=&v"(xl),
-                       [yh] "=&v"(yh), [yl] "=&v"(yl), [va] "=&v"(va), [t] "=&s"(t), [t2] "=&s"(t2)
-                     : [b0h] "v"(bn[0]), [b0l] "v"(bn[1]), [b1h] "v"(bn[2]), [b1l] "v"(bn[3]), [vb] "v"(vb), [m] "s"(m)
-                     : "scc", "memory");
+        if constexpr (NTW == 2) {
+          asm volatile(ISF_CUM_TEXT
+                       : "+{v[128:143]}"(accT[0]), "+{v[144:159]}"(accT[1]), "+{v[160:175]}"(accT[2]),
+                         "+{v[176:191]}"(accT[3]), "+{v[192:207]}"(accT[4]), "+{v[208:223]}"(accT[5]),
+                         "+{v[224:239]}"(accT[6]), "+{v[240:255]}"(accT[7]), [xh] "=&v"(xh), [xl] "=&v"(xl),
+                         [yh] "=&v"(yh), [yl] "=&v"(yl), [va] "=&v"(va), [t] "=&s"(t), [t2] "=&s"(t2)
+                       : [b0h] "v"(bn[0]), [b0l] "v"(bn[1]), [b1h] "v"(bn[2]), [b1l] "v"(bn[3]), [vb] "v"(vb), [m] "s"(m)
+                       : "scc", "memory");
+        } else {
+          asm volatile(ISF_CUM4_TEXT
+                       : "+{v[128:143]}"(accT[0]), "+{v[144:159]}"(accT[1]), "+{v[160:175]}"(accT[2]),
+                         "+{v[176:191]}"(accT[3]), "+{v[192:207]}"(accT[4]), "+{v[208:223]}"(accT[5]),
+                         "+{v[224:239]}"(accT[6]), "+{v[240:255]}"(accT[7]), [xh] "=&v"(xh), [xl] "=&v"(xl),
+                         [yh] "=&v"(yh), [yl] "=&v"(yl), [va] "=&v"(va), [t] "=&s"(t), [t2] "=&s"(t2)
+                       : [b0h] "v"(bn[0]), [b0l] "v"(bn[1]), [b1h] "v"(bn[2]), [b1l] "v"(bn[3]), [b2h] "v"(bn[4]),
+                         [b2l] "v"(bn[5]), [b3h] "v"(bn[6]), [b3l] "v"(bn[7]), [vb] "v"(vb), [m] "s"(m)
+                       : "scc", "memory");
+        }
       } else {
       const int jf = __ffs(m) - 1;
       uint4 ah_n = sa[jf * 128], al_n = sa[jf * 128 + 64];
 #pragma unroll
-      for (int j = 0; j < kCuCapGroups; ++j) {
+      for (int j = 0; j < CAP; ++j) {
         if ((m >> j) & 1u) {
           const uint4 ahu = ah_n, alu = al_n;
-          const unsigned rest = j < 15 ? m >> (j + 1) : 0u;
+          const unsigned rest = j < CAP - 1 ? m >> (j + 1) : 0u;
           if (rest) {                            // the next group's fragments are read while this one multiplies
             const int jn = j + __ffs(rest);
             ah_n = sa[jn * 128];
@@ -351,6 +389,7 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
       }
       }
     }
+    if (late) issue_next();
     if (++stage == NS) stage = 0;
   };
   for (int t = 0; t < nsteps; t += NS) {
@@ -366,18 +405,19 @@ __global__ __launch_bounds__(64 * NW, 1) void spconv_cu_kernel(
   if constexpr (PIPE) {
     // the last MFMAs were issued from assembly: hipcc's hazard recogniser has not seen them (XDL write -> VALU / LDS read)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    if constexpr (NTW == 2) {
 #pragma unroll
-      for (int j = 0; j < kCuCapGroups; ++j)
+    for (int j = 0; j < CAP; ++j)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[j][nt][e] = accT[j >> 1][8 * (j & 1) + 4 * nt + e];
-    }
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (NTW == 2) acc[j][nt][e] = accT[j >> 1][8 * (j & 1) + 4 * nt + e];
+          else acc[j][nt][e] = accT[j][4 * nt + e];
+        }
   }
 
-  float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NTW, kCuCapGroups>::wave_bytes / 4);
-  conv16_epilogue<NTW, kCuCapGroups, false>(acc, tile_l, lane, row0, 16 * NTW * wave, kCuCout, *w_inv_scale, scale, shift,
+  float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NTW, CAP>::wave_bytes / 4);
+  conv16_epilogue<NTW, CAP, false>(acc, tile_l, lane, row0, 16 * NTW * wave, kCuCout, *w_inv_scale, scale, shift,
                                             residual, ys, row_end, relu, n_rg);
 }
 
@@ -406,7 +446,7 @@ __global__ __launch_bounds__(256) void cu_group_mask_kernel(const int32_t* __res
 
 // One workgroup: inclusive prefix of the work, the balanced cuts, the split of over-long units, the unit table.
 // scratch: W [n_groups] | cuts [U0 + 1] | offs [U0 + 1]
-__global__ __launch_bounds__(1024) void cu_plan_kernel(const int32_t* __restrict__ work, int n_groups, int U0,
+__global__ __launch_bounds__(1024) void cu_plan_kernel(const int32_t* __restrict__ work, int n_groups, int U0, int cap,
                                                        int32_t* W, int32_t* cuts, int32_t* offs,
                                                        int2* __restrict__ units,
                                                        int32_t* __restrict__ num_units) {
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(1024) void cu_plan_kernel(const int32_t* __restrict
   for (int base = 0; base < U0; base += 1024) {
     const int uu = base + tid;
     int tot;
-    const int p = uu < U0 ? conv_cu_pieces(cuts[uu + 1] - cuts[uu]) : 0;
+    const int p = uu < U0 ? conv_cu_pieces(cuts[uu + 1] - cuts[uu], cap) : 0;
     const int inc = block_scan(p, tot);
     const int carry = carry_s;
     if (uu < U0) offs[uu] = inc - p + carry;
@@ -464,10 +504,10 @@ __global__ __launch_bounds__(1024) void cu_plan_kernel(const int32_t* __restrict
   }
   if (tid == 0) *num_units = carry_s;
   for (int uu = tid; uu < U0; uu += 1024) {
-    const int c = cuts[uu], len = cuts[uu + 1] - c, P = conv_cu_pieces(len), o = offs[uu];
+    const int c = cuts[uu], len = cuts[uu + 1] - c, P = conv_cu_pieces(len, cap), o = offs[uu];
     for (int p = 0; p < P; ++p) {
       int g0, ng;
-      conv_cu_piece(c, len, p, g0, ng);
+      conv_cu_piece(c, len, p, g0, ng, cap);
       units[o + p] = make_int2(g0, ng);
     }
   }
@@ -496,18 +536,28 @@ static int cu_count() {
 
 bool sparse_conv_cu_supported(int c_in, int c_out) { return c_out == kCuCout && (c_in == 128 || c_in == 256); }
 
-size_t conv_cu_plan_ints(int n_out) {   // int32 entries a plan of n_out rows needs (masks, work, W, cuts, offs, units, count)
-  const int ng = ceil_div(n_out > 0 ? n_out : 1, 16), cus = cu_count();
-  const int U0 = conv_cu_balanced_units(ng, cus), UM = conv_cu_max_units(ng, cus);
-  return (size_t)ng * 3 + 2 * (size_t)(U0 + 1) + 2 * (size_t)UM + 64;
+// the unit shape of a kernel variant: 9, 10, 14, 15 = two 4-wave workgroups per compute unit over units of <= 8 groups
+int conv_cu_variant_cap(int variant) { return (variant == 9 || variant == 15) ? kCuCapGroups8 : kCuCapGroups; }
+static int cu_slots(int cap) { return cap == kCuCapGroups8 ? 2 * cu_count() : cu_count(); }
+
+size_t conv_cu_plan_ints(int n_out) {   // int32 entries a plan of n_out rows needs (masks, work, W, cuts, offs, units, count); either shape
+  const int ng = ceil_div(n_out > 0 ? n_out : 1, 16);
+  size_t most = 0;
+  for (int cap : {kCuCapGroups, kCuCapGroups8}) {
+    const int U0 = conv_cu_balanced_units(ng, cu_slots(cap), cap), UM = conv_cu_max_units(ng, cu_slots(cap), cap);
+    const size_t n = (size_t)ng * 3 + 2 * (size_t)(U0 + 1) + 2 * (size_t)UM + 64;
+    most = n > most ? n : most;
+  }
+  return most;
 }
 
 int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int32_t* buf, ConvCuPlan* plan,
-                      hipStream_t st) {
+                      hipStream_t st, int cap) {
   ISF_REQUIRE(nbr && buf && plan && n_out > 0 && K >= 1 && K <= kMaxTaps && nbr_stride >= n_out, ISF_ERR_ARG,
               "sparse_conv_cu_plan: bad arguments");
-  const int ng = ceil_div(n_out, 16), cus = cu_count();
-  const int U0 = conv_cu_balanced_units(ng, cus), UM = conv_cu_max_units(ng, cus);
+  ISF_REQUIRE(cap == kCuCapGroups || cap == kCuCapGroups8, ISF_ERR_ARG, "sparse_conv_cu_plan: cap %d", cap);
+  const int ng = ceil_div(n_out, 16), slots = cu_slots(cap);
+  const int U0 = conv_cu_balanced_units(ng, slots, cap), UM = conv_cu_max_units(ng, slots, cap);
   int32_t* masks = buf;
   int32_t* work = masks + ng;
   int32_t* W = work + ng;
@@ -517,7 +567,7 @@ int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int3
   int2* units = reinterpret_cast<int2*>(cnt + 2 + ((cnt + 2 - buf) & 1));   // 8-byte aligned behind the count
   hipLaunchKernelGGL(cu_group_mask_kernel, dim3(ceil_div(ng, 16)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, ng, masks,
                      work);
-  hipLaunchKernelGGL(cu_plan_kernel, dim3(1), dim3(1024), 0, st, work, ng, U0, W, cuts, offs, units, cnt);
+  hipLaunchKernelGGL(cu_plan_kernel, dim3(1), dim3(1024), 0, st, work, ng, U0, cap, W, cuts, offs, units, cnt);
   ISF_LAUNCH_CHECK();
   plan->group_masks = masks;
   plan->units = units;
@@ -525,6 +575,7 @@ int conv_cu_plan_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, int3
   plan->max_units = UM;
   plan->n_out = n_out;
   plan->variant = 0;
+  plan->cap = cap;
   return ISF_OK;
 }
 
@@ -537,15 +588,21 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
   ISF_REQUIRE(K >= 1 && K <= kMaxTaps && nbr_stride >= n_out, ISF_ERR_ARG, "sparse_conv_cu: bad rulebook");
   ISF_REQUIRE(plan.group_masks && plan.units && plan.num_units && plan.n_out == n_out && plan.max_units > 0, ISF_ERR_ARG,
               "sparse_conv_cu: the unit plan was built for %d rows, the launch has %d", plan.n_out, n_out);
+  ISF_REQUIRE(plan.cap == conv_cu_variant_cap(plan.variant), ISF_ERR_ARG,
+              "sparse_conv_cu: variant %d works on units of <= %d groups, the plan was cut for %d", plan.variant,
+              conv_cu_variant_cap(plan.variant), plan.cap);
   const uint4* w = reinterpret_cast<const uint4*>(packed16);
   const float* winv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(packed16) + (size_t)K * c_in * c_out * 4);
   const dim3 grid(8 * ceil_div(plan.max_units, 8));
-  // variant (DIAGNOSTIC; 0 = production): 1 / 2 / 3 = no gathers / no weight loads / neither (results garbage, timing
-  // only); 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2 (results valid)
-#define ISF_CU_LAUNCH(CI, WW, DD, KK, PP)                                                                                 \
+  // variant (0 = round 4's production shape): 1 / 2 / 3 = no gathers / no weight loads / neither (results garbage, timing
+  // only); 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2 (results valid); round 6, assembly
+  // multiply phase: 8 = 8 waves, one workgroup per CU; 9 / 10 = 4 waves x 64 columns, units of <= 8 groups, TWO workgroups
+  // per CU, depth 1 / 2 (valid); 11 / 12 / 13 = variant 8 without both / gathers / weights, 14 / 15 = variant 9 without
+  // both / gathers (timing only)
+#define ISF_CU_LAUNCH(CI, WW, DD, KK, PP, CC, SS)                                                                                 \
   do {                                                                                                                  \
-    constexpr int smem_bytes = ConvCuSmem<DD, WW>::bytes;                                                               \
-    auto kern = spconv_cu_kernel<CI, WW, DD, KK, PP>;                                                                       \
+    constexpr int smem_bytes = ConvCuSmem<DD, WW, CC>::bytes;                                                               \
+    auto kern = spconv_cu_kernel<CI, WW, DD, KK, PP, CC, SS>;                                                                       \
     static std::atomic<int> attr_set{0};                                                                                \
     if (attr_set.load(std::memory_order_acquire) == 0) {                                                                \
       ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
@@ -558,21 +615,22 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
   } while (0)
 #define ISF_CU_VARIANTS(CI)                                                                                             \
   switch (plan.variant) {                                                                                               \
-    case 0: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 0, false); break;                                                        \
-    case 1: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 1, false); break;                                                        \
-    case 2: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 2, false); break;                                                        \
-    case 3: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 3, false); break;                                                        \
-    case 4: ISF_CU_LAUNCH(CI, 4, 1, 0, false); break;                                                                          \
-    case 5: ISF_CU_LAUNCH(CI, 4, 2, 0, false); break;                                                                          \
-    case 6: ISF_CU_LAUNCH(CI, 8, 1, 0, false); break;                                                                          \
-    case 7: ISF_CU_LAUNCH(CI, 8, 2, 0, false); break;                                                              \
-    case 8: ISF_CU_LAUNCH(CI, 8, 1, 0, true); break;                                                               \
-    case 9: ISF_CU_LAUNCH(CI, 8, 2, 0, true); break;                                                               \
-    case 11: ISF_CU_LAUNCH(CI, 8, 1, 3, true); break;                                                                          \
-    case 12: ISF_CU_LAUNCH(CI, 8, 1, 1, true); break;                                                              \
-    case 13: ISF_CU_LAUNCH(CI, 8, 1, 2, true); break;                                                              \
-    case 14: ISF_CU_LAUNCH(CI, 8, 2, 1, true); break;                                                              \
-    case 15: ISF_CU_LAUNCH(CI, 8, 2, 2, true); break;                                                                          \
+    case 0: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 0, false, 16, false); break;                                             \
+    case 1: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 1, false, 16, false); break;                                             \
+    case 2: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 2, false, 16, false); break;                                             \
+    case 3: ISF_CU_LAUNCH(CI, kCuWavesProd, kCuDepth, 3, false, 16, false); break;                                             \
+    case 4: ISF_CU_LAUNCH(CI, 4, 1, 0, false, 16, false); break;                                                               \
+    case 5: ISF_CU_LAUNCH(CI, 4, 2, 0, false, 16, false); break;                                                               \
+    case 6: ISF_CU_LAUNCH(CI, 8, 1, 0, false, 16, false); break;                                                               \
+    case 7: ISF_CU_LAUNCH(CI, 8, 2, 0, false, 16, false); break;                                                               \
+    case 8: ISF_CU_LAUNCH(CI, 8, 1, 0, true, 16, false); break;                                                                \
+    case 9: ISF_CU_LAUNCH(CI, 4, 1, 0, true, 8, false); break;                                                                 \
+    case 10: ISF_CU_LAUNCH(CI, 8, 2, 0, true, 16, true); break;                                                                \
+    case 11: ISF_CU_LAUNCH(CI, 8, 1, 24, true, 16, false); break;                                                               \
+    case 12: ISF_CU_LAUNCH(CI, 8, 1, 8, true, 16, false); break;                                                               \
+    case 13: ISF_CU_LAUNCH(CI, 8, 1, 16, true, 16, false); break;                                                               \
+    case 14: ISF_CU_LAUNCH(CI, 8, 2, 0, true, 16, false); break;                                                                \
+    case 15: ISF_CU_LAUNCH(CI, 4, 2, 0, true, 8, true); break;                                                                \
     default: ISF_REQUIRE(false, ISF_ERR_ARG, "sparse_conv_cu: variant %d", plan.variant);                               \
   }
   if (c_in == 128) { ISF_CU_VARIANTS(128) } else { ISF_CU_VARIANTS(256) }
@@ -596,13 +654,16 @@ int isf_sparse_conv_cu_plan(const int32_t* nbr, int nbr_stride, int num_taps, in
                             isf_conv_cu_plan* plan, isf_stream_t stream) {
   ISF_REQUIRE(plan, ISF_ERR_ARG, "sparse_conv_cu_plan: null plan");
   isf::ConvCuPlan p;
-  ISF_TRY(isf::conv_cu_plan_impl(nbr, nbr_stride, num_taps, num_out, plan_buf, &p, isf::as_stream(stream)));
+  const int variant = plan->variant;    // INPUT: the kernel variant the plan is for decides the unit shape (0: 16 groups)
+  ISF_TRY(isf::conv_cu_plan_impl(nbr, nbr_stride, num_taps, num_out, plan_buf, &p, isf::as_stream(stream),
+                                 isf::conv_cu_variant_cap(variant >= 0 && variant < 16 ? variant : 0)));
   plan->group_masks = p.group_masks;
   plan->units = reinterpret_cast<const int32_t*>(p.units);
   plan->num_units = p.num_units;
   plan->max_units = p.max_units;
   plan->num_out = p.n_out;
-  plan->variant = 0;
+  plan->variant = variant >= 0 && variant < 16 ? variant : 0;
+  plan->cap = p.cap;
   return ISF_OK;
 }
 
@@ -622,6 +683,7 @@ int isf_sparse_conv_forward_cu(const void* features_split, int num_in, int c_in,
   p.max_units = plan->max_units;
   p.n_out = plan->num_out;
   p.variant = plan->variant;
+  p.cap = plan->cap;
   return isf::sparse_conv_forward_cu_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride, num_out, scale,
                                           shift, residual_split, relu, out_split, p, isf::as_stream(stream));
 }

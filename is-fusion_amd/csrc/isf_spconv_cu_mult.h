@@ -93,3 +93,74 @@
   ISF_CUM_SET("X", "Y", "%[xh]", "%[xl]", "%[yh]", "%[yl]")                                                             \
   ISF_CUM_SET("Y", "X", "%[yh]", "%[yl]", "%[xh]", "%[xl]")                                                             \
   "LEND_%=:\n\t"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same phase for the TWO-WORKGROUPS-PER-CU shape: a unit has <= 8 groups, a wave owns 4 column tiles (64 columns) of
+// every group: accumulators of (group j, tile nt) = v[128 + 16 j + 4 nt .. + 3], 12 MFMAs per block (per accumulator still
+// a_lo b_hi -> a_hi b_lo -> a_hi b_hi; consecutive MFMAs on one accumulator are four instructions apart).
+#define ISF_CUM4_ACC(J, NT) "v[128+16*" #J "+4*" #NT ":131+16*" #J "+4*" #NT "]"
+#define ISF_CUM4_MFMA(J, NT, A, B) "v_mfma_f32_16x16x32_f16 " ISF_CUM4_ACC(J, NT) ", " A ", " B ", " ISF_CUM4_ACC(J, NT) "\n\t"
+
+#define ISF_CUM4_BLK(J, J1, J2, ME, OT, MH, ML, OH, OL)                                                                 \
+  "LB" ME #J "_%=:\n\t"                                                                                                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                            \
+  "ds_read_b128 " OH ", %[va]\n\t"                                                                                      \
+  "ds_read_b128 " OL ", %[va] offset:1024\n\t"                                                                          \
+  ISF_CUM4_MFMA(J, 0, ML, "%[b0h]")                                                                                     \
+  "s_lshr_b32 %[t], %[m], " #J1 "\n\t"                                                                                  \
+  ISF_CUM4_MFMA(J, 1, ML, "%[b1h]")                                                                                     \
+  "s_add_i32 %[t2], %[t], -1\n\t"                                                                                       \
+  ISF_CUM4_MFMA(J, 2, ML, "%[b2h]")                                                                                     \
+  "s_and_b32 %[t], %[t], %[t2]\n\t"                                                                                     \
+  ISF_CUM4_MFMA(J, 3, ML, "%[b3h]")                                                                                     \
+  "s_ff1_i32_b32 %[t2], %[t]\n\t"                                                                                       \
+  ISF_CUM4_MFMA(J, 0, MH, "%[b0l]")                                                                                     \
+  "s_max_i32 %[t2], %[t2], 0\n\t"                                                                                       \
+  ISF_CUM4_MFMA(J, 1, MH, "%[b1l]")                                                                                     \
+  "s_lshl_b32 %[t2], %[t2], 11\n\t"                                                                                     \
+  ISF_CUM4_MFMA(J, 2, MH, "%[b2l]")                                                                                     \
+  "s_add_i32 %[t2], %[t2], 2048*" #J1 "\n\t"                                                                            \
+  ISF_CUM4_MFMA(J, 3, MH, "%[b3l]")                                                                                     \
+  "v_add_u32 %[va], %[t2], %[vb]\n\t"                                                                                   \
+  ISF_CUM4_MFMA(J, 0, MH, "%[b0h]")                                                                                     \
+  ISF_CUM4_MFMA(J, 1, MH, "%[b1h]")                                                                                     \
+  ISF_CUM4_MFMA(J, 2, MH, "%[b2h]")                                                                                     \
+  "s_bitcmp1_b32 %[m], " #J1 "\n\t"                                                                                     \
+  ISF_CUM4_MFMA(J, 3, MH, "%[b3h]")                                                                                     \
+  "s_cbranch_scc1 LB" OT #J1 "_%=\n\t"                                                                                  \
+  "s_branch LT" OT #J2 "_%=\n\t"
+
+#define ISF_CUM4_BLK_LAST(ME, MH, ML)                                                                                   \
+  "LB" ME "7_%=:\n\t"                                                                                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                            \
+  ISF_CUM4_MFMA(7, 0, ML, "%[b0h]") ISF_CUM4_MFMA(7, 1, ML, "%[b1h]") ISF_CUM4_MFMA(7, 2, ML, "%[b2h]")                 \
+  ISF_CUM4_MFMA(7, 3, ML, "%[b3h]") ISF_CUM4_MFMA(7, 0, MH, "%[b0l]") ISF_CUM4_MFMA(7, 1, MH, "%[b1l]")                 \
+  ISF_CUM4_MFMA(7, 2, MH, "%[b2l]") ISF_CUM4_MFMA(7, 3, MH, "%[b3l]") ISF_CUM4_MFMA(7, 0, MH, "%[b0h]")                 \
+  ISF_CUM4_MFMA(7, 1, MH, "%[b1h]") ISF_CUM4_MFMA(7, 2, MH, "%[b2h]") ISF_CUM4_MFMA(7, 3, MH, "%[b3h]")                 \
+  "s_branch LEND_%=\n\t"
+
+#define ISF_CUM4_SET(ME, OT, MH, ML, OH, OL)                                                                            \
+  ISF_CUM_TEST(0, ME) ISF_CUM_TEST(1, ME) ISF_CUM_TEST(2, ME) ISF_CUM_TEST(3, ME) ISF_CUM_TEST(4, ME)                   \
+  ISF_CUM_TEST(5, ME) ISF_CUM_TEST(6, ME) ISF_CUM_TEST(7, ME)                                                           \
+  "LT" ME "8_%=:\n\t"                                                                                                   \
+  "s_branch LEND_%=\n\t"                                                                                                \
+  ISF_CUM4_BLK(0, 1, 2, ME, OT, MH, ML, OH, OL) ISF_CUM4_BLK(1, 2, 3, ME, OT, MH, ML, OH, OL)                           \
+  ISF_CUM4_BLK(2, 3, 4, ME, OT, MH, ML, OH, OL) ISF_CUM4_BLK(3, 4, 5, ME, OT, MH, ML, OH, OL)                           \
+  ISF_CUM4_BLK(4, 5, 6, ME, OT, MH, ML, OH, OL) ISF_CUM4_BLK(5, 6, 7, ME, OT, MH, ML, OH, OL)                           \
+  ISF_CUM4_BLK(6, 7, 8, ME, OT, MH, ML, OH, OL) ISF_CUM4_BLK_LAST(ME, MH, ML)
+
+#define ISF_CUM4_TEXT                                                                                                   \
+  "s_ff1_i32_b32 %[t2], %[m]\n\t"                                                                                       \
+  "s_lshl_b32 %[t2], %[t2], 11\n\t"                                                                                     \
+  "v_add_u32 %[va], %[t2], %[vb]\n\t"                                                                                   \
+  "s_add_i32 %[t], %[m], -1\n\t"                                                                                        \
+  "ds_read_b128 %[xh], %[va]\n\t"                                                                                       \
+  "ds_read_b128 %[xl], %[va] offset:1024\n\t"                                                                           \
+  "s_and_b32 %[t], %[t], %[m]\n\t"                                                                                      \
+  "s_ff1_i32_b32 %[t2], %[t]\n\t"                                                                                       \
+  "s_max_i32 %[t2], %[t2], 0\n\t"                                                                                       \
+  "s_lshl_b32 %[t2], %[t2], 11\n\t"                                                                                     \
+  "v_add_u32 %[va], %[t2], %[vb]\n\t"                                                                                   \
+  ISF_CUM4_SET("X", "Y", "%[xh]", "%[xl]", "%[yh]", "%[yl]")                                                            \
+  ISF_CUM4_SET("Y", "X", "%[yh]", "%[yl]", "%[xh]", "%[xl]")                                                            \
+  "LEND_%=:\n\t"

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void grad_split_kernel(const float* __restrict
   m = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
   int e = 0;
   if (m > 0.f) (void)frexpf(m, &e);
-  const float s = m > 0.f ? ldexpf(1.f, 10 - e) : 1.f;
+  const float s = m > 0.f ? ldexpf(1.f, min(10 - e, 126)) : 1.f;   // clamped: a denormal max |g| must not give s = inf (0 * inf = NaN)
   if (blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = s; scale_out[1] = 1.f / s; }
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict
   m = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
   int e = 0;
   if (m > 0.f) (void)frexpf(m, &e);
-  const float s = m > 0.f ? ldexpf(1.f, 10 - e) : 1.f;
+  const float s = m > 0.f ? ldexpf(1.f, min(10 - e, 126)) : 1.f;   // clamped: a denormal max |g| must not give s = inf (0 * inf = NaN)
   if (blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = s; scale_out[1] = 1.f / s; }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = g[i] * s;
 }

@@ -228,9 +228,9 @@ class _WindowTableAdd(torch.autograd.Function):
         C = g.size(1)
         gt = None
         if ctx.needs_input_grad[1]:
-            t = g.view(B, S // win, win, S // win, win, C).sum(dim=(0, 1, 3))        # [y % win, x % win, C]
-            gt = torch.roll(t, shifts=(off % win, off % win), dims=(0, 1)).reshape(win * win, C)
-        return g, gt, None, None, None, None, None
+            t = g.reshape(B, S // win, win, S // win, win, C).sum(dim=(0, 1, 3))     # [y % win, x % win, C]; reshape: autograd
+            gt = torch.roll(t, shifts=(off % win, off % win), dims=(0, 1)).reshape(win * win, C)   # may hand over a strided g
+        return (g if ctx.needs_input_grad[0] else None), gt, None, None, None, None, None
 
 
 def sstv2_forward(sst, bev, win, temperature=1000.0):

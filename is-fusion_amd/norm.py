@@ -61,7 +61,11 @@ class _BN1dReLUFunction(Function):
         x = x.contiguous()
         res = residual.contiguous() if residual is not None else None
         stats = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-        _lib.check(lib.isf_bn1d_stats(_lib.ptr(x), n, c, _lib.ptr(stats), _lib.stream()), "isf_bn1d_stats")
+        # single process: sums about the batch's first row (no cancellation when |mean| >> std; torch's native batch_norm is
+        # two-pass).  Multi-rank naiveSyncBN: plain (sum x, sum x^2) -- the reference's own formulation (ops/norm.py:186-190)
+        pivot = None if sync else x[0]
+        _lib.check(lib.isf_bn1d_stats_pivot(_lib.ptr(x), n, c, _lib.ptr(pivot), _lib.ptr(stats), _lib.stream()),
+                   "isf_bn1d_stats_pivot")
         count, bwd_count = float(n), float(n)
         if sync:
             # the reference averages the per-rank mean / mean-of-squares with EQUAL weights (ops/norm.py:186-190), whatever
@@ -74,10 +78,10 @@ class _BN1dReLUFunction(Function):
         saved = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         rm, rv = (mod.running_mean, mod.running_var) if mod.track_running_stats else (None, None)
         mom = mod.momentum if mod.momentum is not None else 0.1
-        _lib.check(lib.isf_bn1d_apply(_lib.ptr(x), n, c, _lib.ptr(stats), count, _lib.ptr(gamma), _lib.ptr(beta),
-                                      float(mod.eps), float(mom), 0 if sync else 1, _lib.ptr(rm), _lib.ptr(rv),
-                                      _lib.ptr(res), int(bool(relu)), _lib.ptr(y), _lib.ptr(saved), _lib.stream()),
-                   "isf_bn1d_apply")
+        _lib.check(lib.isf_bn1d_apply_pivot(_lib.ptr(x), n, c, _lib.ptr(stats), _lib.ptr(pivot), count, _lib.ptr(gamma),
+                                            _lib.ptr(beta), float(mod.eps), float(mom), 0 if sync else 1, _lib.ptr(rm),
+                                            _lib.ptr(rv), _lib.ptr(res), int(bool(relu)), _lib.ptr(y), _lib.ptr(saved),
+                                            _lib.stream()), "isf_bn1d_apply_pivot")
         if mod.track_running_stats and mod.num_batches_tracked is not None:
             mod.num_batches_tracked.add_(1)
         ctx.save_for_backward(x, y if relu else None, gamma, saved)
@@ -116,9 +120,14 @@ def bn1d_relu(mod, x, residual=None, relu=True):
     channel count the kernels tile: the fused HIP path above; anything else (eval mode, odd channel counts, CPU tensors,
     FUSED_BN_TRAIN = False): the stock composition, op for op what the reference runs."""
     c = x.shape[1] if x.dim() == 2 else 0
+    # the choice must be the same on every rank of a synchronised module: the fused and the stock path all-reduce different
+    # quantities in backward ((sum g, sum g xhat) vs d / d(mean, meansqr)), both [2C], so a rank-local row count would
+    # pair them up silently.  Synchronised: any row count >= 1 takes the fused kernels (count = all ranks' rows);
+    # single-process BatchNorm1d keeps torch's n > 1 requirement
+    synced = isinstance(mod, NaiveSyncBatchNorm1d) and _needs_sync(mod)
     ok = (FUSED_BN_TRAIN and mod.training and isinstance(mod, nn.BatchNorm1d) and x.dim() == 2 and x.is_cuda and
-          x.dtype == torch.float32 and x.shape[0] > 1 and c % 4 == 0 and 4 <= c <= 1024 and 256 % (c // 4) == 0 and
-          torch.is_grad_enabled())
+          x.dtype == torch.float32 and (x.shape[0] > 1 or (synced and x.shape[0] == 1)) and c % 4 == 0 and
+          4 <= c <= 1024 and 256 % (c // 4) == 0 and torch.is_grad_enabled() and mod.momentum is not None)
     if not ok:
         out = mod(x)
         if residual is not None:

@@ -6,7 +6,8 @@ Same constructor kwargs, same sub-module names (``conv_input``, ``encoder_layers
 Eval / no-grad forward is ONE C call (``isf_sparse_encoder_forward``): the module tree is flattened once
 into a plan of conv layers with folded BatchNorm, ReLU and residual sources; the library builds one
 rulebook per resolution, runs 21 fused conv kernels and writes the dense BEV tensor.  In that mode
-``encode_features`` (unused by ISFusionDetector, isfusion.py:111) is returned empty.
+``encode_features`` (unused by ISFusionDetector, isfusion.py:111) is a lazy list: the per-stage tensors are computed by
+the module path the first time somebody reads it (the fused engine does not keep them).
 """
 import ctypes
 
@@ -18,6 +19,38 @@ from . import _lib
 from .norm import fold_bn
 from .sparse_block import SparseBasicBlock, make_sparse_convmodule
 from .spconv import SparseConvolution, SparseConvTensor, SparseSequential
+
+
+class _LazyEncodeFeatures(list):
+    """The `encode_features` entry of SparseEncoder.forward's 3-tuple on the fused path: a list whose content (the output
+    SparseConvTensor of every encoder stage, mmdet3d/models/middle_encoders/sparse_encoder.py:131-138) is produced by
+    `make()` -- the module-by-module forward -- on the first read.  ISFusionDetector.extract_pts_feat never reads it
+    (isfusion.py:111), so the hot path pays nothing; a caller that does gets the reference's list."""
+
+    def __init__(self, make):
+        super().__init__()
+        self._make = make
+
+    def _fill(self):
+        if self._make is not None:
+            make, self._make = self._make, None
+            with torch.no_grad():
+                super().extend(make())
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __getitem__(self, i):
+        self._fill()
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __repr__(self):
+        return "<encode_features: not computed>" if self._make is not None else super().__repr__()
 
 
 class SparseEncoder(nn.Module):
@@ -237,6 +270,9 @@ class SparseEncoder(nn.Module):
             and self.order[0] == "conv"
         if fused_ok:
             with torch.no_grad():
-                return self.forward_fused(voxel_features, coors, batch_size), [], kwargs
+                # encode_features (the reference's per-stage SparseConvTensor list, sparse_encoder.py:131-138; unused by
+                # isfusion.py:111): materialised by the module path on first access, never on the hot path
+                lazy = _LazyEncodeFeatures(lambda: self.forward_modules(voxel_features, coors, batch_size)[1])
+                return self.forward_fused(voxel_features, coors, batch_size), lazy, kwargs
         spatial, enc = self.forward_modules(voxel_features, coors, batch_size)
         return spatial, enc, kwargs

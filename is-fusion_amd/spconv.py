@@ -319,25 +319,32 @@ def sparse_conv_forward_dma_lines(features, packed16, K, c_in, c_out, rb, scale=
     return from_half(ys, (rb.num_out, c_out)) if f16io else from_split(ys, (rb.num_out, c_out))
 
 
-def cu_plan(rb):
-    """Unit plan of the one-workgroup-per-CU kernel for a Rulebook (isf_sparse_conv_cu_plan), cached on it:
-    (isf_conv_cu_plan struct, the int32 buffer it points into).  One plan serves every 256-column layer on the rulebook."""
-    if getattr(rb, "_cu_plan", None) is None:
+CU_CAP8_VARIANTS = (9, 15)      # isf_conv_cu_plan.variant values that work on units of <= 8 groups
+
+
+def cu_plan(rb, variant=0):
+    """Unit plan of the one-workgroup-per-CU kernel for a Rulebook (isf_sparse_conv_cu_plan), cached on it per unit shape
+    (16 groups per unit; 8 for the two-workgroups-per-CU variants): (isf_conv_cu_plan struct, the int32 buffer it points
+    into).  One plan serves every 256-column layer on the rulebook."""
+    cap8 = int(variant) in CU_CAP8_VARIANTS
+    key = "_cu_plan8" if cap8 else "_cu_plan"
+    if getattr(rb, key, None) is None:
         lib = _lib.load()
         K = rb.nbr.numel() // rb.stride
         n = ctypes.c_size_t(0)
         _lib.check(lib.isf_sparse_conv_cu_plan_ints(rb.num_out, ctypes.byref(n)), "isf_sparse_conv_cu_plan_ints")
         buf = torch.zeros((n.value,), dtype=torch.int32, device=rb.nbr.device)
         plan = _lib.ConvCuPlan()
+        plan.variant = 9 if cap8 else 0       # read by the planner: decides the unit shape
         _lib.check(lib.isf_sparse_conv_cu_plan(_lib.ptr(rb.nbr), rb.stride, K, rb.num_out, _lib.ptr(buf),
                                                ctypes.byref(plan), _lib.stream()), "isf_sparse_conv_cu_plan")
-        rb._cu_plan = (plan, buf)
-    return rb._cu_plan
+        setattr(rb, key, (plan, buf))
+    return getattr(rb, key)
 
 
-def cu_plan_units(rb):
+def cu_plan_units(rb, variant=0):
     """The plan's unit table as a CPU tensor [num_units, 2] = (first 16-row group, groups) and the group masks [groups]."""
-    plan, buf = cu_plan(rb)
+    plan, buf = cu_plan(rb, variant)
     base = buf.data_ptr()
     n = int(buf[(plan.num_units - base) // 4].item())
     uo = (plan.units - base) // 4
@@ -367,14 +374,15 @@ def sparse_conv_forward_cu(features, packed16, K, c_in, c_out, rb, scale=None, s
                            variant=0):
     """sparse_conv_forward_f16x3 (mode 0) on the one-workgroup-per-CU kernel of the 256-column layers
     (isf_sparse_conv_forward_cu; c_out = 256, c_in in {128, 256}); bit-identical results.  variant: isf_conv_cu_plan
-    .variant (0 production; 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2: valid results;
-    1 / 2 / 3 timing knock-outs)."""
+    .variant (0 round 4's shape; 4 / 5 = 4 waves at prefetch depth 1 / 2, 6 / 7 = 8 waves at depth 1 / 2; 8 = 8 waves with the
+    assembly multiply phase; 9 / 10 = two 4-wave workgroups per CU over units of <= 8 groups: valid results; 1 / 2 / 3,
+    11-15 timing knock-outs)."""
     _lib.require_cuda(features)
     xs = to_split(features)
     rs = None if residual is None else to_split(residual)
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=features.device)
-    plan, _buf = cu_plan(rb)
-    plan = _lib.ConvCuPlan(plan.group_masks, plan.units, plan.num_units, plan.max_units, plan.num_out, int(variant))
+    plan, _buf = cu_plan(rb, variant)
+    plan = _lib.ConvCuPlan(plan.group_masks, plan.units, plan.num_units, plan.max_units, plan.num_out, int(variant), plan.cap)
     _lib.check(_lib.load().isf_sparse_conv_forward_cu(
         _lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, c_out, _lib.ptr(rb.nbr), rb.stride, rb.num_out,
         _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(rs), int(bool(relu)), _lib.ptr(ys), ctypes.byref(plan),
@@ -599,10 +607,26 @@ class _TransposedRulebook:
 _PACKED_PAIRS = {}   # id(weight parameter) -> (version, data_ptr, packed forward filters, packed transposed filters, weakref)
 
 
+# The cache below is keyed on (parameter identity, Tensor._version, data_ptr).  torch.optim steps, load_state_dict and
+# every in-place op on the parameter bump _version; writes through `.data` (p.data.copy_(), EMA swaps, fp16 copy-back of
+# older mmcv optim wrappers) do NOT -- after such an update call drop_packed_pairs() (or set PACKED_PAIR_CACHE = False for
+# the run: 5 more launches per layer and step), otherwise forward and dX keep multiplying with the old filters.
+PACKED_PAIR_CACHE = True
+
+
+def drop_packed_pairs():
+    """Forget every cached (forward, transposed) packed-filter pair: call after updating sparse-conv weights through
+    `.data` (which does not bump Tensor._version, the cache's change detector)."""
+    _PACKED_PAIRS.clear()
+
+
 def _packed_pair(weight, w, K, c_in, c_out):
     """(packed filters of the forward conv, packed per-tap TRANSPOSED filters of the dX conv) of a weight parameter,
     packed once per parameter version: the forward pass packs both, the backward pass finds its half here instead of
     transposing + packing again (5 launches per layer and step)."""
+    if not PACKED_PAIR_CACHE:
+        wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*weight.shape[:-2], c_out, c_in)
+        return pack_filters_f16x3(w), pack_filters_f16x3(wt)
     key = id(weight)
     hit = _PACKED_PAIRS.get(key)
     # the weak reference tells a live parameter from a new tensor that reuses a dead one's id / address / version 0

@@ -684,7 +684,8 @@ def test_cu_unit_kernel_bit_identical_to_tile_kernel(dev, cin):
             assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm, ks)
             got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb)          # no epilogue terms
             assert torch.equal(got, sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb)), (n, subm, ks)
-            for variant in (4, 5, 6, 7, 8, 9):          # 4 / 8 waves x prefetch depth 1 / 2; 8 / 9 = assembly multiply phase
+            for variant in (4, 5, 6, 7, 8, 9, 10):      # 4 / 8 waves x prefetch depth 1 / 2; 8 = assembly multiply phase; 9 / 10 =
+                                                        # two 4-wave workgroups per CU over units of <= 8 groups, depth 1 / 2
                 got = sp.sparse_conv_forward_cu(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, variant=variant)
                 assert torch.equal(got, ref), (n, subm, ks, variant)
             # the plan: device == host walk; groups covered once; masks = taps with a neighbour per 16-row group
@@ -698,6 +699,10 @@ def test_cu_unit_kernel_bit_identical_to_tile_kernel(dev, cin):
             work = np.array([bin(int(v)).count("1") for v in want_masks], np.int32)
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             assert np.array_equal(units.numpy(), sp.cu_plan_host(work, cus)), (n, subm, ks)
+            # the 8-group plan of the two-workgroups-per-CU shape: every group once, in order, 1..8 groups per unit
+            u8 = sp.cu_plan_units(rb, variant=9)[0].numpy()
+            assert u8[0, 0] == 0 and (u8[:, 1] >= 1).all() and (u8[:, 1] <= 8).all()
+            assert np.array_equal(u8[1:, 0], (u8[:, 0] + u8[:, 1])[:-1]) and u8[-1, 0] + u8[-1, 1] == ng
     with pytest.raises(Exception):
         sp.sparse_conv_forward_cu(T(np.zeros((10, 64), np.float32), dev), p16, 27, 64, 64, rb)   # narrow: not built
 

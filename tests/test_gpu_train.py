@@ -316,6 +316,33 @@ def test_two_ranks_of_the_real_forward_share_one_gpu(dev):
     assert cfg["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"                 # what RCCL needs on this image (dmabuf IPC)
 
 
+def test_bench_under_torch_distributed_run_with_one_rccl_rank(dev):
+    """the driver's multi-GPU command line with N = 1 -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P bench.py --gpus 1 ...` -- takes the collective path end to
+    end on this GPU: RCCL init (backend "nccl"), the barriers around the timed region, the max-reduce of the clock, ONE
+    final line naming the collectives; so the only untested difference on an 8-GPU node is N."""
+    import json
+    import subprocess
+    import sys
+    from isfusion_amd import launch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(launch.free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--points", "40000", "--batch", "2", "--no-cfg3", "--no-cfg4", "--no-cfg5", "--no-pipelined",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    final = [l for l in lines if "metric" in l and "leg" not in l]
+    assert len(final) == 1 and lines[-1] is final[0]            # the contract's line is the LAST line
+    line = final[0]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["collectives"].startswith("RCCL "), line["config"]
+    assert line["config"]["parallelism"] == "dp1" and "roofline" in line and len(json.dumps(line)) < 2048
+
+
 def test_two_ranks_train_side_by_side_with_ddp_over_gloo(dev):
     """the DDP training step of tools/train_step.py with two ranks on ONE device (gloo all-reduce, NaiveSyncBatchNorm's
     statistics exchange with world size 2): the multi-rank training path runs end to end with the real kernels before an
@@ -360,6 +387,25 @@ def test_fused_bn1d_relu_matches_the_stock_modules(dev, c, n, relu, with_res):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6, (float((a - b).abs().max()), float(b.abs().max()))
     for a, b in zip(outs[0], outs[2]):
         assert torch.equal(a, b)                       # ordered two-level sums: the same bits on a second run
+
+
+def test_fused_bn1d_keeps_precision_when_the_mean_dwarfs_the_spread(dev):
+    """the fused statistics are sums about the batch's first row (isf_bn1d_stats_pivot / _apply_pivot), so
+    channels with |mean| >> std keep the accuracy of torch's two-pass batch_norm (plain E[x^2] - E[x]^2 in fp32 loses all
+    digits of a variance of 1e-4 next to a mean of 1e3); momentum = None (cumulative average) routes to the stock path."""
+    from isfusion_amd import norm
+    torch.manual_seed(5)
+    n, c = 40000, 32
+    x = (torch.randn(n, c, device=dev, dtype=torch.float64) * 1e-2 + 1e3).float()
+    bn = torch.nn.BatchNorm1d(c, eps=1e-5).to(dev).train()
+    ref = torch.nn.functional.batch_norm(x.double(), None, None, bn.weight.double(), bn.bias.double(), True, 0.1, 1e-5)
+    y = norm.bn1d_relu(bn, x.clone().requires_grad_(), relu=False)
+    assert float((y.double() - ref).abs().max()) < 5e-2          # x itself carries 6e-5 of fp32 rounding = 6e-3 sigma
+    var_ref = x.double().var(0, unbiased=True)
+    assert float(((bn.running_var.double() - 0.9) / 0.1 / var_ref - 1).abs().max()) < 1e-3
+    bn2 = torch.nn.BatchNorm1d(c, momentum=None).to(dev).train()
+    y2 = norm.bn1d_relu(bn2, x.clone().requires_grad_(), relu=False)   # stock path: torch's cumulative average
+    assert torch.allclose(bn2.running_mean, x.mean(0), rtol=1e-5)
 
 
 def test_fused_sync_bn_on_two_ranks_matches_the_reference_composition(dev):

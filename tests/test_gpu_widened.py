@@ -782,6 +782,13 @@ def test_sparse_encoder_matches_reference_module_tree_golden(dev, golden, name):
         out2, enc_feats = enc.forward_modules(_T(feats, dev), _T(coors, dev), B)
     assert np.abs(out2.cpu().numpy().reshape(-1)[g[name + ".idx"]] - g[name + ".val"]).max() < 1e-3
     assert [int(t.features.shape[0]) for t in enc_feats] == g[name + ".stage_voxels"].tolist()
+    # the drop-in forward() on the fused path: same BEV tensor, and encode_features is the reference's per-stage list,
+    # computed only when somebody reads it (mmdet3d/models/middle_encoders/sparse_encoder.py:131-138)
+    with torch.no_grad():
+        out3, lazy, kw = enc(_T(feats, dev), _T(coors, dev), B)
+    assert torch.equal(out3, out) and kw == {} and "not computed" in repr(lazy)
+    assert [int(t.features.shape[0]) for t in lazy] == g[name + ".stage_voxels"].tolist() and len(lazy) == len(enc_feats)
+    assert torch.equal(lazy[-1].features, enc_feats[-1].features)
 
 
 @pytest.mark.parametrize("name,seed,B,P", [("b2", 41, 2, 3000), ("b1", 43, 1, 5000)])
