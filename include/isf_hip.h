@@ -86,6 +86,17 @@ int isf_hard_voxelize(const float* points, int num_points, int num_features,
                       const float voxel_size_host[3], const float coors_range_host[6],
                       int max_points, int max_voxels, float* voxels, int32_t* coors,
                       int32_t* num_points_per_voxel, int* voxel_num_host, isf_stream_t stream);
+/* The same voxelization WITHOUT the host read-back (round 6: device-resident count): the outputs are sized for max_voxels
+ * and need NOT be zeroed; rows [0, *voxel_num_device) are written completely (padding slots of a voxel as zeros), the
+ * rows behind them are left untouched; *voxel_num_device (device int32) = min(voxels found, max_voxels).  Nothing waits
+ * on the host: the caller reads the count when it needs it (the host mirror copies it to pinned memory behind the
+ * kernels and slices the outputs after the LiDAR branch has been queued -- detector.ISFusionPtsPath.extract_pts_feat).
+ * Replaces the same reference code as isf_hard_voxelize (mmdet3d/ops/voxel/src/voxelization_cuda.cu:231-373), whose
+ * `voxel_num` is a host-side .item() (voxelization_cuda.cu:366-371). */
+int isf_hard_voxelize_device(const float* points, int num_points, int num_features,
+                             const float voxel_size_host[3], const float coors_range_host[6],
+                             int max_points, int max_voxels, float* voxels, int32_t* coors,
+                             int32_t* num_points_per_voxel, int32_t* voxel_num_device, isf_stream_t stream);
 
 /* A3  DynamicScatter ------------------------------------------------------------------------------
  * replaces voxel_layer.dynamic_point_to_voxel_forward(feats, coors, reduce_type) ->

@@ -105,6 +105,8 @@ SIGNATURES = {
                                              _F6, c_void_p, c_void_p]),
     "isf_hard_voxelize": (c_int, [c_void_p, c_int, c_int, _F3, _F6, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_int_p, c_void_p]),
+    "isf_hard_voxelize_device": (c_int, [c_void_p, c_int, c_int, _F3, _F6, c_int, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
     "isf_dynamic_point_to_voxel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_void_p, c_int_p, c_void_p]),
     "isf_dynamic_point_to_voxel_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

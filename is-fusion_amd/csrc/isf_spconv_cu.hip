@@ -287,8 +287,12 @@ __global__ __launch_bounds__(64 * NW, CAP == 8 ? 2 : 1) void spconv_cu_kernel(
     int allowed = 0;
 #pragma unroll
     for (int i = 0; i < D - 1; ++i) allowed += inq[i];
-    if constexpr ((KNOCK & 4) != 0) {       // TIMING DIAGNOSTIC: no wait for the loads at all (results garbage): what is
-                                            // left of the memory cost is issue + contention, not exposed latency
+    if constexpr ((KNOCK & 4) != 0) {       // TIMING DIAGNOSTIC: no wait for the loads (results garbage): what is left of
+                                            // the memory cost is issue + contention, not exposed latency.  The fragment
+                                            // registers stay tied to the statement (hipcc must not reuse them while the
+                                            // loads it cannot see are in flight); vmcnt(63) waits for nothing
+      if constexpr (NF == 4) asm volatile("s_waitcnt vmcnt(63)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3])::"memory");
+      else asm volatile("s_waitcnt vmcnt(63)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(bn[2]), "+v"(bn[3]), "+v"(bn[4]), "+v"(bn[5]), "+v"(bn[6]), "+v"(bn[7])::"memory");
     } else if constexpr (D == 1) {          // nothing younger than G(t - 1) exists: drain
       if constexpr (NF == 4) ISF_CU_WAIT4_ALL(bn);
       else ISF_CU_WAIT8_ALL(bn);
@@ -627,7 +631,7 @@ int sparse_conv_forward_cu_impl(const void* xs, int c_in, const void* packed16, 
     case 9: ISF_CU_LAUNCH(CI, 4, 1, 0, true, 8, false); break;                                                                 \
     case 10: ISF_CU_LAUNCH(CI, 8, 2, 0, true, 16, true); break;                                                                \
     case 11: ISF_CU_LAUNCH(CI, 8, 1, 24, true, 16, false); break;                                                               \
-    case 12: ISF_CU_LAUNCH(CI, 8, 1, 8, true, 16, false); break;                                                               \
+    case 12: ISF_CU_LAUNCH(CI, 8, 1, 4, true, 16, false); break;                                                               \
     case 13: ISF_CU_LAUNCH(CI, 8, 1, 16, true, 16, false); break;                                                               \
     case 14: ISF_CU_LAUNCH(CI, 8, 2, 0, true, 16, false); break;                                                                \
     case 15: ISF_CU_LAUNCH(CI, 4, 2, 0, true, 8, true); break;                                                                \

@@ -10,7 +10,6 @@
 // All of it is HBM/L2-bound integer work: O(P * max_points) atomics worst case, O(P) typical.
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "isf_common.h"
 
@@ -83,10 +82,9 @@ __global__ void hv_pack_bytes_kernel(const unsigned char* __restrict__ seen, siz
   bits[w] = v;
 }
 
-// points of a cell = one segment of the point indices STABLY sorted by the cell's rank (hipcub radix sort over the
-// rank's bits): inside a segment the indices ascend, so a cell's T smallest point indices -- what the reference's
+// points of a cell = one segment of the point indices STABLY sorted by the cell's rank (radix sort over the rank's bits,
+// hv_stable_sort below): inside a segment the indices ascend, so a cell's T smallest point indices -- what the reference's
 // sequential scan keeps (voxelization_cpu.cpp:54-69) -- are the first T of its segment.  Deterministic, no atomics.
-// (rocprim radix sort, the engine under hipcub::DeviceRadixSort.)
 // History: v1 atomicMin bubble insertion (720 us per 300 k points in pillars), v2 count -> scan -> fill -> select with
 // one atomic per point per pass (90 + 16 + 90 + 55 us: the pillar grid's hot cells serialise the atomics).
 __global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
@@ -99,7 +97,143 @@ __global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, V
   if (voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx, cy, cz))
     key = (uint32_t)occ_lookup(cbits, cprefix, ((unsigned long long)cz * g.gy + cy) * g.gx + cx);
   keys[i] = key;
-  idx[i] = i;
+  if (idx) idx[i] = i;     // (the sort below takes the identity permutation implicitly)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The stable sort itself (round 6; hand-written, replaces rocprim::radix_sort_pairs -- 8 launches, 270 us per two-sample
+// forward, one of them 214 us: a library tuned for arrays a thousand times larger).  LSD radix sort, `bits` (<= 10) key
+// bits per pass, WAVE MULTI-SPLIT ranking: a wave owns a tile of kRsTile consecutive elements and walks it in order, 64 at
+// a time; `bits` ballots tell every lane which lanes hold the same digit (mask &= my bit ? ballot : ~ballot), so its rank
+// among them is a popcount and the group's first lane keeps the wave's running count of the digit in LDS -- no atomics,
+// no sorting network, stable by construction (lanes, sub-tiles and tiles are all taken in index order).
+//   count pass   per (digit, tile) counts                -> hist [digits][tiles]   (digit-major: the order of the output)
+//   row scan     per digit: exclusive prefix over its tiles, and its total
+//   scatter pass out[first position of the digit + hist[digit][tile] + running count in the tile + rank in the sub-tile]
+constexpr int kRsTile = 1024;     // elements per wave (16 sub-tiles): 293 waves for 300 k points
+constexpr int kRsWaves = 4;       // waves (tiles) per workgroup
+
+template <bool SCATTER>
+__global__ __launch_bounds__(64 * kRsWaves) void hv_radix_pass_kernel(const uint32_t* __restrict__ keys_in,
+                                                                      const int* __restrict__ vals_in /* nullptr: identity */,
+                                                                      int n, int shift, int bits, int tiles,
+                                                                      uint32_t* __restrict__ hist,
+                                                                      const uint32_t* __restrict__ totals /* [digits] */,
+                                                                      uint32_t* __restrict__ keys_out, int* __restrict__ vals_out) {
+  __shared__ uint32_t cnt_s[kRsWaves][1024];
+  __shared__ uint32_t dbase_s[1024];                 // SCATTER: first output position of every digit
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * kRsWaves + wave;
+  const int nd = 1 << bits;
+  if (SCATTER) {                                     // exclusive prefix of the digit totals (<= 1024 values: one wave)
+    if (wave == 0) {
+      uint32_t run = 0u;
+      for (int b0 = 0; b0 < nd; b0 += 64) {
+        const uint32_t v = totals[b0 + lane];
+        uint32_t x = v;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const uint32_t o = __shfl_up(x, dlt, 64);
+          if (lane >= dlt) x += o;
+        }
+        dbase_s[b0 + lane] = run + x - v;
+        run += __shfl(x, 63, 64);
+      }
+    }
+    __syncthreads();
+  }
+  if (tile >= tiles) return;
+  volatile uint32_t* cnt = cnt_s[wave];
+  for (int d = lane; d < nd; d += 64) cnt[d] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  // the tile's keys (and values) are requested up front: kRsTile / 64 independent loads in flight per lane instead of one
+  // exposed round trip per sub-tile (147 waves walking 32 dependent round trips each made a pass 50 us)
+  constexpr int NSUB = kRsTile / 64;
+  uint32_t kreg[NSUB];
+  int vreg[NSUB];
+#pragma unroll
+  for (int sub = 0; sub < NSUB; ++sub) {
+    const int i = tile * kRsTile + sub * 64 + lane;
+    kreg[sub] = i < n ? keys_in[i] : 0u;
+    vreg[sub] = (SCATTER && i < n) ? (vals_in ? vals_in[i] : i) : 0;
+  }
+#pragma unroll
+  for (int sub = 0; sub < NSUB; ++sub) {
+    const int i = tile * kRsTile + sub * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t key = kreg[sub];
+    const uint32_t d = (key >> shift) & (uint32_t)(nd - 1);
+    unsigned long long m = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int rank = __popcll(m & lt), group = __popcll(m);
+    uint32_t base = 0u;
+    if (valid) base = cnt[d];                       // every lane of a digit group reads the count before ...
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) cnt[d] = base + (uint32_t)group;   // ... its first lane advances it (one address per group)
+    __builtin_amdgcn_wave_barrier();
+    if (SCATTER && valid) {
+      const uint32_t pos = dbase_s[d] + hist[(size_t)d * tiles + tile] + base + (uint32_t)rank;
+      keys_out[pos] = key;
+      vals_out[pos] = vreg[sub];
+    }
+  }
+  if (!SCATTER)
+    for (int d = lane; d < nd; d += 64) hist[(size_t)d * tiles + tile] = cnt[d];
+}
+
+// per digit (one wave each): exclusive prefix of its row of per-tile counts in place (coalesced, ceil(tiles / 64) rounds)
+// and the digit's total; the scatter pass turns the totals into the digits' first output positions itself.  (A single
+// workgroup scanning all digits x tiles entries with a chunk per thread was 100 us of dependent, uncoalesced loads.)
+__global__ __launch_bounds__(256) void hv_radix_rowscan_kernel(uint32_t* __restrict__ hist, int nd, int tiles,
+                                                               uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= nd) return;
+  uint32_t* row = hist + (size_t)d * tiles;
+  uint32_t run = 0u;
+  for (int b0 = 0; b0 < tiles; b0 += 64) {
+    const int t = b0 + lane;
+    const uint32_t v = t < tiles ? row[t] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+      const uint32_t o = __shfl_up(x, dlt, 64);
+      if (lane >= dlt) x += o;
+    }
+    if (t < tiles) row[t] = run + x - v;
+    run += __shfl(x, 63, 64);
+  }
+  if (lane == 0) totals[d] = run;
+}
+
+// (keys, 0 .. n - 1) stably sorted by the low `key_bits` bits of the keys -> (keys_sorted, idx_sorted); keys_tmp / idx_tmp:
+// scratch of n entries each, hist: (1 << 10) * tiles entries.  The sorted data always ends in keys_sorted / idx_sorted.
+static int hv_stable_sort(const uint32_t* keys, uint32_t* keys_tmp, uint32_t* keys_sorted, int* idx_tmp, int* idx_sorted,
+                          uint32_t* hist /* 1024 * (tiles + 1) */, int n, int key_bits, hipStream_t st) {
+  const int passes = (key_bits + 9) / 10, bits = (key_bits + passes - 1) / passes;
+  const int tiles = ceil_div(n, kRsTile), blocks = ceil_div(tiles, kRsWaves);
+  const uint32_t* kin = keys;
+  const int* vin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    // ping-pong so that the LAST pass writes the caller's output buffers
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    uint32_t* kout = to_out ? keys_sorted : keys_tmp;
+    int* vout = to_out ? idx_sorted : idx_tmp;
+    uint32_t* totals = hist + (size_t)1024 * tiles;
+    hipLaunchKernelGGL(hv_radix_pass_kernel<false>, dim3(blocks), dim3(64 * kRsWaves), 0, st, kin, vin, n, p * bits, bits, tiles,
+                       hist, totals, kout, vout);
+    hipLaunchKernelGGL(hv_radix_rowscan_kernel, dim3(ceil_div(1 << bits, 4)), dim3(256), 0, st, hist, 1 << bits, tiles, totals);
+    hipLaunchKernelGGL(hv_radix_pass_kernel<true>, dim3(blocks), dim3(64 * kRsWaves), 0, st, kin, vin, n, p * bits, bits, tiles,
+                       hist, totals, kout, vout);
+    kin = kout;
+    vin = vout;
+  }
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
 }
 
 // first sorted position of every cell
@@ -135,7 +269,7 @@ __global__ void hv_gather_kernel(const float* __restrict__ points, int C, const 
                                  int T, const unsigned long long* __restrict__ pbits,
                                  const uint32_t* __restrict__ pprefix, int max_voxels,
                                  float* __restrict__ voxels, int32_t* __restrict__ coors,
-                                 int32_t* __restrict__ num_points) {
+                                 int32_t* __restrict__ num_points, int fill_empty) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (long long)(*nrows) * T) return;
   const int r = (int)(tid / T), t = (int)(tid % T);
@@ -147,6 +281,9 @@ __global__ void hv_gather_kernel(const float* __restrict__ points, int C, const 
     const float* p = points + (size_t)pi * C;
     float* o = voxels + ((size_t)vid * T + t) * C;
     for (int k = 0; k < C; ++k) o[k] = p[k];
+  } else if (fill_empty) {                       // the caller did not zero the output: write the padding slots here
+    float* o = voxels + ((size_t)vid * T + t) * C;
+    for (int k = 0; k < C; ++k) o[k] = 0.f;
   }
   if (t == 0) {
     int n = 0;
@@ -159,13 +296,23 @@ __global__ void hv_gather_kernel(const float* __restrict__ points, int C, const 
   }
 }
 
+__global__ void hv_publish_count_kernel(const int* __restrict__ total, int max_voxels, int32_t* __restrict__ out) {
+  *out = *total < max_voxels ? *total : max_voxels;
+}
+
+// voxel_num_dev != nullptr: DEVICE-RESIDENT COUNT -- no host read-back (the caller sized the outputs for max_voxels and
+// did not zero them: rows [0, *voxel_num_dev) are written completely, padding slots included; the rest is untouched)
 int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float vs[3],
                        const float range[6], int max_points, int max_voxels, float* voxels,
-                       int32_t* coors, int32_t* num_points, int* voxel_num_host, hipStream_t st) {
+                       int32_t* coors, int32_t* num_points, int* voxel_num_host, hipStream_t st,
+                       int32_t* voxel_num_dev = nullptr) {
   const VoxGeom g = make_geom(vs, range);
   ISF_REQUIRE(g.gx > 0 && g.gy > 0 && g.gz > 0, ISF_ERR_ARG, "hard_voxelize: empty grid");
-  *voxel_num_host = 0;
-  if (P <= 0) return ISF_OK;
+  if (voxel_num_host) *voxel_num_host = 0;
+  if (P <= 0) {
+    if (voxel_num_dev) ISF_HIP_TRY(hipMemsetAsync(voxel_num_dev, 0, sizeof(int32_t), st));
+    return ISF_OK;
+  }
   const long long cells = (long long)g.gx * g.gy * g.gz;
   const int row_cap = (int)(cells < P ? cells : P);
   OccIndex cocc;  // occupied cells of this sample
@@ -194,28 +341,24 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
   ISF_TRY(occ_create(a, &pocc, 1, 1, 1, P, st));
   {
     uint32_t *keys = nullptr, *keys_sorted = nullptr, *start = nullptr;
-    int *idx = nullptr, *idx_sorted = nullptr;
+    int* idx_sorted = nullptr;
     ISF_TRY(a.alloc_n(&keys, (size_t)P));
     ISF_TRY(a.alloc_n(&keys_sorted, (size_t)P));
-    ISF_TRY(a.alloc_n(&idx, (size_t)P));
     ISF_TRY(a.alloc_n(&idx_sorted, (size_t)P));
     ISF_TRY(a.alloc_n(&start, (size_t)row_cap + 1));
     const uint32_t none = (uint32_t)row_cap;           // ranks are < row_cap
     int key_bits = 1;
     while ((1ull << key_bits) <= (unsigned long long)none) ++key_bits;
     hipLaunchKernelGGL(hv_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, cocc.bits,
-                       cocc.prefix, none, keys, idx);
+                       cocc.prefix, none, keys, (int*)nullptr);
     ISF_LAUNCH_CHECK();
-    // Onesweep radix sort forced (rocprim's default picks a merge sort below 1 M items: 21 launches, 115 us here)
-    using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                                  rocprim::default_config, 4096>;
-    size_t temp_bytes = 0;
-    ISF_HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, temp_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)P,
-                                                      0u, (unsigned)key_bits, st));
-    void* temp = nullptr;
-    ISF_TRY(a.alloc(&temp, temp_bytes));
-    ISF_HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(temp, temp_bytes, keys, keys_sorted, idx, idx_sorted, (size_t)P, 0u,
-                                                      (unsigned)key_bits, st));
+    uint32_t* keys_tmp = nullptr;
+    int* idx_tmp = nullptr;
+    uint32_t* hist = nullptr;
+    ISF_TRY(a.alloc_n(&keys_tmp, (size_t)P));
+    ISF_TRY(a.alloc_n(&idx_tmp, (size_t)P));
+    ISF_TRY(a.alloc_n(&hist, (size_t)1024 * (ceil_div(P, kRsTile) + 1)));
+    ISF_TRY(hv_stable_sort(keys, keys_tmp, keys_sorted, idx_tmp, idx_sorted, hist, P, key_bits, st));
     hipLaunchKernelGGL(hv_segment_heads_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, keys_sorted, P, none, start);
     hipLaunchKernelGGL(hv_segment_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, keys_sorted, idx_sorted, P,
                        start, none, max_points, slots);
@@ -226,8 +369,13 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
   ISF_TRY(occ_scan(a, pocc, st));
   hipLaunchKernelGGL(hv_gather_kernel, dim3(ceil_div((long long)row_cap * max_points, 256)), dim3(256),
                      0, st, points, C, slots, cocc.total, cell_coors, max_points, pocc.bits,
-                     pocc.prefix, max_voxels, voxels, coors, num_points);
+                     pocc.prefix, max_voxels, voxels, coors, num_points, voxel_num_dev ? 1 : 0);
   ISF_LAUNCH_CHECK();
+  if (voxel_num_dev) {
+    hipLaunchKernelGGL(hv_publish_count_kernel, dim3(1), dim3(1), 0, st, pocc.total, max_voxels, voxel_num_dev);
+    ISF_LAUNCH_CHECK();
+    return ISF_OK;
+  }
   int total = 0;
   ISF_TRY(read_int(pocc.total, &total, st));
   *voxel_num_host = total < max_voxels ? total : max_voxels;
@@ -278,6 +426,22 @@ int isf_hard_voxelize(const float* points, int num_points, int num_features,
   return isf::hard_voxelize_impl(a, points, num_points, num_features, voxel_size_host,
                                  coors_range_host, max_points, max_voxels, voxels, coors,
                                  num_points_per_voxel, voxel_num_host, isf::as_stream(stream));
+}
+
+int isf_hard_voxelize_device(const float* points, int num_points, int num_features,
+                             const float voxel_size_host[3], const float coors_range_host[6],
+                             int max_points, int max_voxels, float* voxels, int32_t* coors,
+                             int32_t* num_points_per_voxel, int32_t* voxel_num_device, isf_stream_t stream) {
+  ISF_REQUIRE(num_points >= 0 && num_features >= 3 && max_points > 0 && max_voxels > 0 &&
+                  voxel_num_device && voxel_size_host && coors_range_host,
+              ISF_ERR_ARG, "hard_voxelize_device: bad arguments");
+  ISF_REQUIRE(num_points == 0 || (points && voxels && coors && num_points_per_voxel), ISF_ERR_ARG,
+              "hard_voxelize_device: null pointer");
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
+  ISF_TRY(a.reset());
+  return isf::hard_voxelize_impl(a, points, num_points, num_features, voxel_size_host,
+                                 coors_range_host, max_points, max_voxels, voxels, coors,
+                                 num_points_per_voxel, nullptr, isf::as_stream(stream), voxel_num_device);
 }
 
 }  // extern "C"

@@ -101,6 +101,22 @@ class ISFusionPtsPath(nn.Module):
             coors.append(torch.nn.functional.pad(c, (1, 0), mode="constant", value=i))
         return torch.cat(voxels, 0), torch.cat(num_points, 0), torch.cat(coors, 0)
 
+    @torch.no_grad()
+    def voxelize_async(self, points):
+        """The pillar voxelization of every sample QUEUED on the current stream, no host wait (device-resident counts:
+        isf_hard_voxelize_device) -> a callable that returns voxelize()'s triple; call it after other host work."""
+        pend = [self.pts_pillar_layer.forward_async(res) for res in points]
+
+        def finish():
+            voxels, coors, num_points = [], [], []
+            for i, p in enumerate(pend):
+                v, c, n = p.result()
+                voxels.append(v)
+                num_points.append(n)
+                coors.append(torch.nn.functional.pad(c, (1, 0), mode="constant", value=i))
+            return torch.cat(voxels, 0), torch.cat(num_points, 0), torch.cat(coors, 0)
+        return finish
+
     def isfusion(self, pts, pts_feats, img_feats, img_metas, batch_size, pillars=None, **kwargs):
         """isfusion.py:83-101.  pillars: a (pillars, num_points, coors) triple voxelized ahead of time
         (extract_pts_feat does it on a side stream while the LiDAR branch runs)."""
@@ -131,9 +147,16 @@ class ISFusionPtsPath(nn.Module):
         if side is None:
             side = self._side_streams[pts[0].device] = torch.cuda.Stream(device=pts[0].device)
         side.wait_stream(main)                       # the points are ready on the main stream
+        # Round 6: the pillar kernels are queued FIRST, on the side stream, with their counts left on the device
+        # (voxelize_async); the LiDAR branch -- whose own host waits keep this thread busy for most of its duration -- is
+        # queued next, and only then are the pillar counts looked at: they arrived long ago, nothing waits, and the
+        # 270-450 us the GPU used to idle per forward between the branch and Point-to-Grid are gone
+        # (profiles/r05_v2_timeline_gaps_cfg3.txt: copyBuffer -> copyBuffer).
+        with torch.cuda.stream(side):
+            finish = self.voxelize_async(pts)
         x = self._lidar(pts)
         with torch.cuda.stream(side):
-            pil = self.voxelize(pts, voxel_type="pillar")
+            pil = finish()                           # slices + concatenation, on the stream that produced them
         main.wait_stream(side)
         for t in pil:
             t.record_stream(main)                    # allocated on the side stream, consumed on the main one
@@ -184,15 +207,18 @@ class ISFusionPtsPath(nn.Module):
             if side is None:
                 side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)
+            with torch.cuda.stream(side):
+                finish = self.voxelize_async(pts)    # queued first, counts on the device (see extract_pts_feat)
             self._lidar(pts, out=x)
             with torch.cuda.stream(side):
-                pil = self.voxelize(pts, voxel_type="pillar")
+                pil = finish()
             main.wait_stream(side)
             for t in pil:
                 t.record_stream(main)
         else:
-            self._lidar(pts, out=x)
-            pil = self.voxelize(pts, voxel_type="pillar")
+            finish = self.voxelize_async(pts)        # same stream, in front of the branch: its counts are in host memory
+            self._lidar(pts, out=x)                  # long before the branch's own host waits are over
+            pil = finish()
         ops.p2g_sample(pil[0], pil[2], img_feats[1], None, None, None, img_metas[0]["input_shape"], B,
                        self.fusion_encoder.bev_size, self.fusion_encoder.num_views, cam=cam, out=img_bev)
         g.replay()

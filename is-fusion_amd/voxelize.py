@@ -60,6 +60,42 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
     return voxels[:m], coors[:m], num[:m]
 
 
+class PendingVoxels:
+    """Hard voxelization queued without a host wait (isf_hard_voxelize_device): capacity-sized outputs, the voxel count in
+    device memory and on its way to pinned host memory.  `result()` -- call it when something else has kept the host busy
+    in between -- waits for that copy (normally long finished) and returns the reference's (voxels[:M], coors[:M],
+    num_points[:M])."""
+
+    def __init__(self, voxels, coors, num, count_host, event):
+        self.voxels, self.coors, self.num, self._count_host, self._event = voxels, coors, num, count_host, event
+
+    def result(self):
+        self._event.synchronize()
+        m = int(self._count_host[0])
+        return self.voxels[:m], self.coors[:m], self.num[:m]
+
+
+def hard_voxelize_async(points, voxel_size, coors_range, max_points, max_voxels):
+    """hard_voxelize with a DEVICE-RESIDENT count: every kernel is queued on the current stream, nothing waits on the host
+    (the reference reads voxel_num back synchronously, voxelization_cuda.cu:366-371).  The outputs are allocated at
+    capacity and not zero-filled -- the kernel writes the padding slots of every voxel it emits.  -> PendingVoxels."""
+    _lib.require_cuda(points)
+    points = points.contiguous().float()
+    voxels = points.new_empty((max_voxels, max_points, points.size(1)))
+    coors = points.new_empty((max_voxels, 3), dtype=torch.int32)
+    num = points.new_empty((max_voxels,), dtype=torch.int32)
+    count = points.new_empty((1,), dtype=torch.int32)
+    _lib.check(_lib.load().isf_hard_voxelize_device(
+        _lib.ptr(points), points.size(0), points.size(1), _lib.f3(voxel_size), _lib.f6(coors_range), int(max_points),
+        int(max_voxels), _lib.ptr(voxels), _lib.ptr(coors), _lib.ptr(num), _lib.ptr(count), _lib.stream()),
+        "isf_hard_voxelize_device")
+    count_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+    count_host.copy_(count, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingVoxels(voxels, coors, num, count_host, ev)
+
+
 def voxelization(points, voxel_size, coors_range, max_points=35, max_voxels=20000, deterministic=True):
     """Functional form (voxelize.py:10-76).  ``deterministic=False`` selects the same deterministic kernel:
     the non-deterministic CUDA variant exists only to dodge the O(P^2) kernel this build does not have."""
@@ -88,6 +124,12 @@ class Voxelization(nn.Module):
         max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
         return voxelization(input, self.voxel_size, self.point_cloud_range, self.max_num_points, max_voxels,
                             self.deterministic)
+
+    def forward_async(self, input):
+        """forward() queued without a host wait -> PendingVoxels (hard voxelization only)."""
+        max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
+        assert self.max_num_points != -1 and max_voxels != -1, "dynamic voxelization has no count to wait for"
+        return hard_voxelize_async(input, self.voxel_size, self.point_cloud_range, self.max_num_points, max_voxels)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range="

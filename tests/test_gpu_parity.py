@@ -36,6 +36,15 @@ def test_voxelize_golden_reference_vectors(dev, golden, case):
     assert np.array_equal(c.cpu().numpy(), g[case + "_coors"])
     assert np.array_equal(n.cpu().numpy(), g[case + "_num"])
     assert np.array_equal(v.cpu().numpy(), g[case + "_voxels"])
+    if Tm != -1:
+        # the same through the device-resident count (isf_hard_voxelize_device: no host read-back, outputs not zeroed by
+        # the caller -- fill them with garbage first: the kernel must write every padding slot of the voxels it emits)
+        from isfusion_amd.voxelize import hard_voxelize_async
+        junk = torch.full((MV * Tm * pts.shape[1] + 4 * MV,), float("nan"), device=dev)
+        del junk                                   # the caching allocator hands the poisoned block to the next empty()
+        v2, c2, n2 = hard_voxelize_async(pts, vs, rg, Tm, MV).result()
+        assert np.array_equal(c2.cpu().numpy(), g[case + "_coors"]) and np.array_equal(n2.cpu().numpy(), g[case + "_num"])
+        assert np.array_equal(v2.cpu().numpy(), g[case + "_voxels"])
 
 
 def test_voxelize_vs_oracle_synthetic(dev, oracle_mod):
@@ -57,6 +66,14 @@ def test_voxelize_vs_oracle_synthetic(dev, oracle_mod):
     assert v.shape[1:] == (12, 5) and c.shape[1] == 3 and n.max() <= 12
     v, c, n = m.voxelization(torch.zeros((0, 5), device=dev), [0.6, 0.6, 8.0], RG, 12, 100)
     assert v.shape == (0, 12, 5) and c.shape == (0, 3)
+    v, c, n = layer.forward_async(torch.zeros((0, 5), device=dev)).result()
+    assert v.shape == (0, 12, 5) and c.shape == (0, 3) and n.shape == (0,)
+    pend = [layer.forward_async(T(pts[i * 30000:(i + 1) * 30000], dev)) for i in range(3)]   # several in flight
+    for i, pd in enumerate(pend):
+        ov, oc, on = oracle_mod.hard_voxelize(pts[i * 30000:(i + 1) * 30000], [0.6, 0.6, 8.0], RG, 12, 60000)
+        v, c, n = pd.result()
+        assert np.array_equal(c.cpu().numpy(), oc) and np.array_equal(n.cpu().numpy(), on)
+        assert np.array_equal(v.cpu().numpy(), ov)
 
 
 def test_dynamic_voxelize_batched(dev, oracle_mod):
