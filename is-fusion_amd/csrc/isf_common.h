@@ -261,6 +261,13 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st, const uint32_t* lmask = nullptr /* line-compressed table's masks instead of nbr */);
+// isf_spconv_deep.hip (round 6): the deep layers' 4-wave two-group launches with LDS-DMA gathers and one hand-scheduled
+// instruction stream per step; the tile kernel's plan / order / query semantics; bit-identical to it
+bool sparse_conv_deep_supported(int c_in, int c_out);
+int sparse_conv_forward_deep_impl(bool balance, bool table, const uint4* xs, int c_in, const uint4* wpk, const float* winv,
+                                  int K, int c_out, const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
+                                  const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
+                                  const int32_t* order, Conv16LaunchInfo* query);
 // isf_spconv_cu.hip: the same convolution for the 256-column layers as one workgroup per compute unit over units of equal
 // matrix work (plan built once per rulebook); bit-identical to sparse_conv_forward_f16x3_impl
 struct ConvCuPlan {

@@ -22,6 +22,7 @@
 //   16-row group does not use are skipped by that wave (wave-uniform branch);
 //   epilogue: LDS transpose, y = act(acc*scale + shift + residual), rows written once in split format.
 #include "isf_spconv16.h"
+#include "isf_spconv16_mult.h"
 
 #include <stdlib.h>
 
@@ -30,6 +31,7 @@
 
 namespace isf {
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // phase trace (MODE bit 2048): dwords per wave record = kPhaseHdr + kPhaseStep * kPhaseMaxSteps
 constexpr int kPhaseHdr = 8, kPhaseMaxSteps = kMaxTaps * 8, kPhaseStep = 8;
@@ -102,6 +104,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   // (profiles/r02_call3_sharing.txt).  MODE bit 16 switches it off everywhere (bit-equality reference).
   constexpr bool SHARE = (MODE & 16) == 0 && NT <= 4 && (CIN >= 64 || NT == 2);
   constexpr int KCH = Conv16Step<CIN, NT>::KCH;
+  // the multiply section in hand-scheduled assembly (isf_spconv16_mult.h) for the deep layers' 4-wave shape; MODE bit 16
+  // ("no neighbour sharing": the deep layers do not share anyway) keeps hipcc's section -- the bit-equality reference
+  constexpr bool ASMM = (MODE & (16 | 65536 | 262144)) == 0 && (RG == 2 || RG == 1) && NT == 8 && KCH == 1 &&
+                        (NW == 4 || NW == 8) && (MODE & 1) == 0;
   using S = Conv16Smem<NT, RG, KCH, NW>;
   constexpr int NTHR = 64 * NW;
   constexpr int TM = S::TM;
@@ -430,6 +436,42 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     // column tiles [i0, i1) of this step's products (i = kc * NT + nt); B fragments one tile ahead
     auto multiply = [&](int i0, int i1) {
       if (!((wmask >> tap) & 1u)) return;
+      if constexpr (ASMM) {
+        // the hand-scheduled section (isf_spconv16_mult.h): the whole step's products, B fragments through a[0:31]
+        const unsigned vb = bbuf_addr + (unsigned)((s & 1) * (NT * 128) + lane) * 16u;
+        const int n0 = (int)((rgm[0] >> tap) & 1u), n1 = (int)((rgm[RG > 1 ? 1 : 0] >> tap) & 1u);
+        const i32x4 a0h = *reinterpret_cast<const i32x4*>(&a_cur[0][0][0]), a0l = *reinterpret_cast<const i32x4*>(&a_cur[0][0][1]);
+        const i32x4 a1h = *reinterpret_cast<const i32x4*>(&a_cur[RG > 1 ? 1 : 0][0][0]),
+                    a1l = *reinterpret_cast<const i32x4*>(&a_cur[RG > 1 ? 1 : 0][0][1]);
+        constexpr int R1 = RG > 1 ? 1 : 0, T7 = NT > 7 ? 7 : 0, T6 = NT > 7 ? 6 : 0, T5 = NT > 7 ? 5 : 0, T4 = NT > 7 ? 4 : 0,
+                      T3 = NT > 7 ? 3 : 0, T2 = NT > 7 ? 2 : 0, T1 = NT > 7 ? 1 : 0;
+        if constexpr (RG == 1) {            // one row group per wave: the pair pipeline without the case split
+          asm volatile(ISF_TM_TEXT_RG1
+                       : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][T1]), [c02] "+v"(acc[0][T2]), [c03] "+v"(acc[0][T3]),
+                         [c04] "+v"(acc[0][T4]), [c05] "+v"(acc[0][T5]), [c06] "+v"(acc[0][T6]), [c07] "+v"(acc[0][T7])
+                       : [a0h] "v"(a0h), [a0l] "v"(a0l), [vb] "v"(vb)
+                       : ISF_TM_CLOBBERS);
+          return;
+        }
+        if constexpr (NW == 8) {            // 128 registers per wave: one column tile per fragment buffer, a[0:15]
+          asm volatile(ISF_TN_TEXT
+                       : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][T1]), [c02] "+v"(acc[0][T2]), [c03] "+v"(acc[0][T3]),
+                         [c04] "+v"(acc[0][T4]), [c05] "+v"(acc[0][T5]), [c06] "+v"(acc[0][T6]), [c07] "+v"(acc[0][T7]),
+                         [c10] "+v"(acc[R1][0]), [c11] "+v"(acc[R1][T1]), [c12] "+v"(acc[R1][T2]), [c13] "+v"(acc[R1][T3]),
+                         [c14] "+v"(acc[R1][T4]), [c15] "+v"(acc[R1][T5]), [c16] "+v"(acc[R1][T6]), [c17] "+v"(acc[R1][T7])
+                       : [a0h] "v"(a0h), [a0l] "v"(a0l), [a1h] "v"(a1h), [a1l] "v"(a1l), [vb] "v"(vb), [n0] "s"(n0), [n1] "s"(n1)
+                       : ISF_TN_CLOBBERS);
+          return;
+        }
+        asm volatile(ISF_TM_TEXT
+                     : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][T1]), [c02] "+v"(acc[0][T2]), [c03] "+v"(acc[0][T3]),
+                       [c04] "+v"(acc[0][T4]), [c05] "+v"(acc[0][T5]), [c06] "+v"(acc[0][T6]), [c07] "+v"(acc[0][T7]),
+                       [c10] "+v"(acc[R1][0]), [c11] "+v"(acc[R1][T1]), [c12] "+v"(acc[R1][T2]), [c13] "+v"(acc[R1][T3]),
+                       [c14] "+v"(acc[R1][T4]), [c15] "+v"(acc[R1][T5]), [c16] "+v"(acc[R1][T6]), [c17] "+v"(acc[R1][T7])
+                     : [a0h] "v"(a0h), [a0l] "v"(a0l), [a1h] "v"(a1h), [a1l] "v"(a1l), [vb] "v"(vb), [n0] "s"(n0), [n1] "s"(n1)
+                     : ISF_TM_CLOBBERS);
+        return;
+      }
       const uint4* b = bbuf + (s & 1) * (KCH * NT * 128) + lane;
       bool need[RG];
 #pragma unroll
@@ -565,6 +607,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   }
   if (PHASE && lane == 0) ph[7] = ph_top;
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  // the last MFMAs were issued from assembly: hipcc's hazard recogniser has not seen them (XDL write -> VALU / LDS read)
+  if constexpr (ASMM) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
   if (TRACE) t_loop = wall_clock64();
 
@@ -734,6 +778,10 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                          const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
                          Conv16LaunchInfo* query) {
+  // mode bit 32768 (opt-in, bit-identical, measured 8 % slower: profiles/r06_deep.txt): the deep layers' 4-wave launches on
+  // isf_spconv_deep.hip (LDS-DMA gathers + one instruction stream per step)
+  const bool use_deep = (mode & 32768) != 0;
+  mode &= ~32768;
 #define ISF_ARGS16 (mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
   // mode bits 4096 / 8192 (round 5 experiment, valid results, bit-identical): the 256-COLUMN layers as ONE column block
   // -- a workgroup owns all 256 output columns of its rows, so a row is gathered ONCE per tap and chunk instead of once per
@@ -793,6 +841,11 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
     return launch16<CIN, (NT == 8 ? NT : 2), 2, 8>(ISF_ARGS16);
   if constexpr (NT == 8 && CIN >= 128) {
     if (cout == 256 && n_out <= 96 * conv16_device_cus()) return launch16<CIN, NT, 1, 4>(ISF_ARGS16);
+  }
+  if constexpr (NT == 8 && CIN >= 128) {
+    if (use_deep && (mode & ~(32 | 1024)) == 0 && sparse_conv_deep_supported(CIN, cout))
+      return sparse_conv_forward_deep_impl((mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, CIN, wpk, winv, K, cout,
+                                           nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
   }
   return launch16<CIN, NT, 2, 4>(ISF_ARGS16);
 #undef ISF_ARGS16
@@ -1130,7 +1183,7 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  const int m = mode & ~(32 | 4096 | 8192 | 65536 | 131072 | 262144);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
+  const int m = mode & ~(32 | 4096 | 8192 | 32768 | 65536 | 131072 | 262144);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
                                                // column block for the 256-column layers (4 x 32-row / 8 x 16-row waves)
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "

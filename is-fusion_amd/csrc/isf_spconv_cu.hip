@@ -33,7 +33,7 @@ __device__ uint4 g_zero_line_cu[8];   // 128 zero bytes: what a row without a ne
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int kCuRows = 16 * kCuCapGroups;       // 256
+
 static constexpr int kCuCout = 256;
 static constexpr int kCuDepth = 1;                      // production prefetch depth (steps)
 static constexpr int kCuWavesProd = 4;                  // production workgroup: 4 waves x 64 columns

@@ -512,6 +512,38 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
 
 
+@pytest.mark.parametrize("cin,cout", [(256, 256), (128, 256), (128, 128)])
+def test_conv_assembly_multiply_section_reproduces_the_compiler_bits(dev, cin, cout):
+    """round 6: the multiply section of the deep layers' 4-wave shape is hand-scheduled assembly (isf_spconv16_mult.h:
+    column tiles in pairs, B fragments through a[0:31] two pairs ahead, one straight-line stream per (row group has the
+    tap) case).  Mode 16 keeps hipcc's section: the same products in the same order per accumulator, so the outputs are
+    equal bit for bit -- on sparse random geometry (most 16-row groups lack most taps: all three cases run), SubM and
+    strided, with and without the epilogue terms, at sizes above the small-launch bound (two-group tiles)."""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin * 3 + cout)
+    B, shape = 2, [12, 96, 96]
+    for n in (30000, 90000):
+        idx = _random_geometry(rng, B, shape, n)
+        x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+        for subm, ks, st, pd in ((True, [3, 3, 3], [1, 1, 1], [1, 1, 1]), (False, [3, 3, 3], [2, 2, 2], [1, 1, 1])):
+            K = int(np.prod(ks))
+            rb = sp.build_rulebook(T(idx, dev), B, shape, ks, st, pd, subm)
+            w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (*ks, cin, cout)).astype(np.float32), dev)
+            res = T(rng.normal(0, 1, (rb.num_out, cout)).astype(np.float32), dev)
+            sc = T(rng.random(cout, dtype=np.float32) + 0.5, dev)
+            sh = T(rng.normal(0, 0.2, cout).astype(np.float32), dev)
+            p16 = sp.pack_filters_f16x3(w)
+            got = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True)
+            ref = sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=16)
+            assert ref.abs().max() > 0.5 and torch.equal(got, ref), (n, subm)
+            assert torch.equal(sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb),
+                               sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, mode=16)), (n, subm)
+            # mode 32768: the deep layers on isf_spconv_deep.hip (LDS-DMA gathers, a step's products and the next step's
+            # loads in one hand-scheduled instruction stream; opt-in)
+            assert torch.equal(sp.sparse_conv_forward_f16x3(x, p16, K, cin, cout, rb, sc, sh, res, relu=True, mode=32768),
+                               ref), (n, subm)
+
+
 def test_conv_one_column_block_variants_reproduce_the_two_block_bits(dev):
     """round 5: the 256-column layers with ONE column block per workgroup (conv mode 4096: 4 waves x 32 rows, 8192: 8 waves
     x 16 rows; encoder diagnostic 262144 / 524288) gather a row once per tap and chunk instead of once per column block;
