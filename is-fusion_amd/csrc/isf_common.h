@@ -261,6 +261,10 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st, const uint32_t* lmask = nullptr /* line-compressed table's masks instead of nbr */);
+// tile order of a launch of several rounds: the tiles of an XCD band by band in y (z-neighbour rows stay in its L2)
+bool conv16_band_order_applies(const Conv16LaunchInfo& info);
+int conv16_band_order_impl(const int32_t* coors4, int n_out, const Conv16LaunchInfo& info, int band, int32_t* order /* [parts * tiles] */,
+                           hipStream_t st);
 // isf_spconv_deep.hip (round 6): the deep layers' 4-wave two-group launches with LDS-DMA gathers and one hand-scheduled
 // instruction stream per step; the tile kernel's plan / order / query semantics; bit-identical to it
 bool sparse_conv_deep_supported(int c_in, int c_out);

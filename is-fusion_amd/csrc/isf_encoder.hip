@@ -175,7 +175,8 @@ static int build_cu_plan(Arena& a, const int32_t* nbr, int stride, int K, int n_
 // permutation of uniform tiles (conv16_tile_order_impl); *order stays nullptr when neither applies.
 static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int32_t* nbr, int stride, int n_out,
                             int mode, bool dma, const int32_t** order, hipStream_t sg, const uint32_t* lmask = nullptr,
-                            bool* is_table = nullptr, bool tables = true) {
+                            bool* is_table = nullptr, bool tables = true,
+                            const int32_t* coors_out = nullptr /* [n_out][4] (b, z, y, x) of the output rows */, int band = 0) {
   *order = nullptr;
   if (is_table) *is_table = false;
   Conv16LaunchInfo info;
@@ -197,7 +198,17 @@ static int build_tile_order(Arena& a, const isf_conv_layer& ly, int K, const int
     *is_table = true;
     return ISF_OK;
   }
-  if (!conv16_order_applies(info)) return ISF_OK;
+  if (!conv16_order_applies(info)) {
+    // a launch of several rounds: its tiles band by band in y (conv16_band_order_kernel), so that the rows the dz = +-1
+    // taps gather are still in the XCD's L2
+    if (band > 0 && coors_out && conv16_band_order_applies(info)) {
+      int32_t* ord = nullptr;
+      ISF_TRY(a.alloc_n(&ord, (size_t)conv16_order_parts(info) * conv16_order_tiles(info)));
+      ISF_TRY(conv16_band_order_impl(coors_out, n_out, info, band, ord, sg));
+      *order = ord;
+    }
+    return ISF_OK;
+  }
   const size_t n = (size_t)conv16_order_parts(info) * conv16_order_tiles(info);
   int32_t *work = nullptr, *ord = nullptr;
   ISF_TRY(a.alloc_n(&work, n));
@@ -239,13 +250,18 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
                                                            // tile tables instead of uniform tiles + LPT order
   const bool line_tables = (diagnostic & 256 * 64) == 0;   // bit 16384: full neighbour tables for the narrow layers too
   const bool mailbox = (diagnostic & 131072) == 0;         // bit 131072: data-dependent counts through hipMemcpyAsync + sync
+  // band order of the launches of several rounds (conv16_band_order_kernel): OPT-IN with bit 16777216 -- measured slower on
+  // the benchmark's scenes (one dominant ground plane per frame: 64 -> 32 0.135 -> 0.154, 32 -> 32 0.27 -> 0.29, 64 -> 64
+  // 0.694 -> 0.709 ms per step, profiles/r06_band_order.txt): row order already keeps a plane's y-neighbours together
+  const bool band_order = (diagnostic & 16777216) != 0;
+  auto band_of = [&](const int shape[3]) -> int { return band_order ? std::max(8, shape[1] / 45) : 0; };
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   const int cu_cap = conv_cu_variant_cap((diagnostic >> 10) & 15);   // unit shape of the requested kernel variant
@@ -253,7 +269,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216));
   // bits 262144 / 524288: the 256-column layers as one column block (conv mode 4096 / 8192; isf_spconv16.hip)
   const int wide_cols = (diagnostic & 262144 ? 4096 : 0) | (diagnostic & 524288 ? 8192 : 0);
   const int stagger = ((diagnostic & 1048576) ? 65536 : 0) | ((diagnostic & 2097152) ? 131072 : 0) | ((diagnostic & 4194304) ? 262144 : 0) |
@@ -384,7 +400,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_cu = ConvCuPlan();
         if (want_order) {
           ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask,
-                                   &L.cache_order_is_table, tile_tables));
+                                   &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
         }
@@ -399,7 +415,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
           ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask,
-                                   &L.cache_order_is_table, tile_tables));
+                                   &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
           ISF_TRY(stream_wait_stream(a, st, sg));
@@ -454,7 +470,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       }
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
       if (want_order)
-        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask, &order_is_table, tile_tables));
+        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask, &order_is_table, tile_tables,
+                                 Nx.coors, band_of(Nx.shape)));
       if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg, cu_cap));
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_cu = ConvCuPlan();

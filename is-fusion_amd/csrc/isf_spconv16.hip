@@ -1083,6 +1083,56 @@ int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out,
   return ISF_OK;
 }
 
+// ------------------------------------------------------------------------------------------- band order (round 6)
+// A launch of SEVERAL rounds (levels 0 / 1: 2 700 tiles on 768 slots) hands its tiles out in row order = (b, z, y, x)
+// order: the ~96 tiles an XCD has in flight are one stretch of ONE z-plane, and the rows their dz = +-1 taps gather --
+// the same (y, x) region of the neighbouring planes, ~10 k rows away -- were fetched a few hundred tiles ago or will be a
+// few hundred tiles later: the dense planes of a level-1 sweep are 2.5 MB each, three of them do not stay in an XCD's 4-MB
+// L2, and every input row comes in from the fabric three times (measured FETCH per 64 -> 64 launch 394 MB against 196
+// algorithmic, profiles/r05_v2_traffic.json).  This order deals an XCD's tiles BAND BY BAND instead: all tiles (of every
+// plane of the part) whose first row lies in y-band 0, then band 1, ...; the z-neighbours of a tile are then a few tiles
+// away in time, its y-neighbours one band later -- both inside the in-flight window.  A permutation of the launch's own
+// tiles (read through `order` like the LPT tables): results are bit-identical.
+__global__ __launch_bounds__(256) void conv16_band_order_kernel(const int32_t* __restrict__ coors4, int n_out, Conv16Plan plan,
+                                                                int TM, int band, int32_t* __restrict__ order) {
+  extern __shared__ unsigned long long bkey[];
+  const int tiles = plan.full + plan.half, part = blockIdx.x;
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    int row0 = 0, row_end = 0;
+    bool half = false;
+    unsigned long long k = ~0ull;                       // empty tiles go last
+    if (conv16_tile_rows(plan, TM, n_out, part, t, row0, row_end, half)) {
+      const int4 c = reinterpret_cast<const int4*>(coors4)[row0];     // (b, z, y, x)
+      k = ((unsigned long long)(unsigned)(c.z / band) << 40) | ((unsigned long long)(unsigned)c.x << 32) |
+          ((unsigned long long)(unsigned)c.y << 20) | (unsigned long long)(unsigned)t;
+    }
+    bkey[t] = k;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < tiles; t += 256) {
+    const unsigned long long k = bkey[t];
+    int rank = 0;
+    for (int u = 0; u < tiles; ++u) rank += bkey[u] < k || (bkey[u] == k && u < t);
+    order[(size_t)part * tiles + rank] = t;
+  }
+}
+
+bool conv16_band_order_applies(const Conv16LaunchInfo& i) {
+  const int t = i.full + i.half;
+  return i.half == 0 && t > 2 * i.wgs_per_cu * i.cus_per_xcd && t <= 6000;
+}
+
+int conv16_band_order_impl(const int32_t* coors4, int n_out, const Conv16LaunchInfo& info, int band, int32_t* order,
+                           hipStream_t st) {
+  ISF_REQUIRE(conv16_band_order_applies(info) && band > 0 && coors4 && order, ISF_ERR_ARG, "band order: bad arguments");
+  const int parts = conv16_order_parts(info), tiles = conv16_order_tiles(info);
+  const Conv16Plan plan{info.full, info.half, info.part_rows};
+  hipLaunchKernelGGL(conv16_band_order_kernel, dim3(parts), dim3(256), (size_t)tiles * 8, st, coors4, n_out, plan, info.TM, band,
+                     order);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st) {
   unsigned* amax = nullptr;
   ISF_TRY(a.alloc_n(&amax, 64));
