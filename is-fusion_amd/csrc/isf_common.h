@@ -224,7 +224,8 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                    const float* shift, const void* residual, int relu, void* ys,
                                    int mode /* 0 | 1 single-pass f16 | timing diagnostics */, hipStream_t st,
-                                   const int32_t* order = nullptr, struct Conv16LaunchInfo* query = nullptr);
+                                   const int32_t* order = nullptr, struct Conv16LaunchInfo* query = nullptr,
+                                   const int32_t* rowmap = nullptr /* sorted launch: position -> output row (conv_row_sort_impl) */);
 // How a launch of that kernel is cut into tiles (query != nullptr: filled instead of launching), and the per-part tile
 // order that evens out the work of the tiles sharing a CU (conv16_tile_order_impl; nullptr = slot j works on tile j).
 struct Conv16LaunchInfo {
@@ -261,6 +262,16 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st, const uint32_t* lmask = nullptr /* line-compressed table's masks instead of nbr */);
+// isf_voxelize.hip: hand-written stable LSD radix sort (wave multi-split): idx_sorted = stable order of the keys' low bits
+int stable_sort_u32_impl(Arena& a, const uint32_t* keys, int n, int key_bits, int* idx_sorted, hipStream_t st);
+// ROW SORT of a deep SubM launch (round 6): the positions of a launch's part are dealt to its rows in the order of their
+// TAP MASKS, so that the rows of a tile (and of a 16-row group) want the same taps -- a tile walks popcount(OR of its rows'
+// masks) taps, a group multiplies through popcount(OR of its 16 masks): -15 % steps and -17 % MFMAs at level 3 on the
+// benchmark geometry (CPU census: profiles/r06_row_sort.txt).  rowmap [stride]: position -> row; nbr_sorted [K][stride]:
+// the neighbour table by position.  The conv kernel computes positions and reads / writes residual and output rows
+// through rowmap; every output row is still computed by the same products in the same order: bit-identical.
+int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int n_out, int part_rows, int32_t* rowmap,
+                       int32_t* nbr_sorted, hipStream_t st);
 // tile order of a launch of several rounds: the tiles of an XCD band by band in y (z-neighbour rows stay in its L2)
 bool conv16_band_order_applies(const Conv16LaunchInfo& info);
 int conv16_band_order_impl(const int32_t* coors4, int n_out, const Conv16LaunchInfo& info, int band, int32_t* order /* [parts * tiles] */,

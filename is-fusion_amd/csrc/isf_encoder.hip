@@ -159,6 +159,9 @@ struct LevelState {
   bool cache_order_is_table;
   const uint32_t* cache_lmask;  // non-null: cache_nbr is LINE-COMPRESSED (lines [ks0 * ks1][stride]) with these tap masks
   ConvCuPlan cache_cu;          // unit plan of cache_nbr for the one-workgroup-per-CU kernel (n_out == 0: not built)
+  const int32_t* cache_rowmap;  // ROW SORT of cache_nbr (conv_row_sort_impl): position -> row, or nullptr
+  const int32_t* cache_nbr_sorted;   // cache_nbr by position
+  int cache_sort_part_rows;     // the launch plan's rows per part the sort was cut for
 };
 
 // unit plan of one neighbour table (isf_spconv_cu.hip), built behind it on the geometry stream
@@ -250,7 +253,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
@@ -262,6 +265,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // 0.694 -> 0.709 ms per step, profiles/r06_band_order.txt): row order already keeps a plane's y-neighbours together
   const bool band_order = (diagnostic & 16777216) != 0;
   auto band_of = [&](const int shape[3]) -> int { return band_order ? std::max(8, shape[1] / 45) : 0; };
+  // row sort of the deep SubM launches (conv_row_sort_impl): rows of a tile / a 16-row group with the same tap mask;
+  // bit 33554432 switches it off (A/B; results are bit-identical either way)
+  const bool row_sort = (diagnostic & 33554432) == 0;
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   const int cu_cap = conv_cu_variant_cap((diagnostic >> 10) & 15);   // unit shape of the requested kernel variant
@@ -269,7 +275,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432));
   // bits 262144 / 524288: the 256-column layers as one column block (conv mode 4096 / 8192; isf_spconv16.hip)
   const int wide_cols = (diagnostic & 262144 ? 4096 : 0) | (diagnostic & 524288 ? 8192 : 0);
   const int stagger = ((diagnostic & 1048576) ? 65536 : 0) | ((diagnostic & 2097152) ? 131072 : 0) | ((diagnostic & 4194304) ? 262144 : 0) |
@@ -300,6 +306,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.cache_order_is_table = false;
   L.cache_cu = ConvCuPlan();
   L.cache_lmask = nullptr;
+  L.cache_rowmap = L.cache_nbr_sorted = nullptr;
+  L.cache_sort_part_rows = 0;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
   bool use16 = precision != 1;
   for (int i = 0; i < num_layers; ++i)
@@ -368,6 +376,36 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       }
       return true;
     };
+    // ROW SORT (round 6): a deep SubM layer on the tile kernel computes its rows in the order of their tap masks
+    const bool sort_ok = row_sort && use16 && !dma && !cu && srows == 0 && ly.conv_type == ISF_CONV_SUBM && ly.c_out >= 128 &&
+                         K == 27 && conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0 && L.n >= 4096;
+    const int32_t* rowmap = nullptr;
+    auto ensure_row_sort = [&](const int32_t* table, int tstride, int rows, bool* built) -> int {
+      *built = false;
+      if (!sort_ok) return ISF_OK;
+      Conv16LaunchInfo info;
+      ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
+                                             nullptr, 0, nullptr, conv_mode, sg, nullptr, &info));
+      if (L.cache_rowmap && L.cache_sort_part_rows == info.part_rows) return ISF_OK;
+      if (L.cache_rowmap) return ISF_OK;       // sorted for another plan: this layer keeps the plain table
+      int32_t *rm = nullptr, *ns = nullptr;
+      ISF_TRY(a.alloc_n(&rm, (size_t)tstride));
+      ISF_TRY(a.alloc_n(&ns, (size_t)K * tstride));
+      ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg));
+      L.cache_rowmap = rm;
+      L.cache_nbr_sorted = ns;
+      L.cache_sort_part_rows = info.part_rows;
+      *built = true;
+      return ISF_OK;
+    };
+    auto sort_applies = [&](const int32_t* table, int tstride, int rows) -> bool {   // this layer's plan == the sort's plan
+      if (!sort_ok || !L.cache_rowmap) return false;
+      Conv16LaunchInfo info;
+      if (sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
+                                         nullptr, 0, nullptr, conv_mode, sg, nullptr, &info) != ISF_OK)
+        return false;
+      return info.part_rows == L.cache_sort_part_rows;
+    };
     if (ly.conv_type == ISF_CONV_SUBM) {
       const bool hit = L.cache_nbr && L.cache_ks[0] == ly.ksize[0] && L.cache_ks[1] == ly.ksize[1] &&
                        L.cache_ks[2] == ly.ksize[2];
@@ -398,8 +436,15 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_order_cin = L.cache_order_cout = 0;
         L.cache_order_is_table = false;
         L.cache_cu = ConvCuPlan();
+        L.cache_rowmap = L.cache_nbr_sorted = nullptr;
+        L.cache_sort_part_rows = 0;
+        {
+          bool built = false;
+          if (!L.cache_lmask) ISF_TRY(ensure_row_sort(nbr, stride, n_out, &built));
+        }
         if (want_order) {
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask,
+          ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out, conv_mode,
+                                   dma, &L.cache_order, sg, L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
@@ -413,8 +458,14 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
+        if (!L.cache_lmask) {   // an earlier layer of the level did not sort (another kernel): sort now
+          bool built = false;
+          ISF_TRY(ensure_row_sort(nbr, stride, n_out, &built));
+          if (built) ISF_TRY(stream_wait_stream(a, st, sg));
+        }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
-          ISF_TRY(build_tile_order(a, ly, K, nbr, stride, n_out, conv_mode, dma, &L.cache_order, sg, L.cache_lmask,
+          ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out, conv_mode,
+                                   dma, &L.cache_order, sg, L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
@@ -427,6 +478,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       }
       cu_plan = L.cache_cu;
       lmask = L.cache_lmask;
+      if (!lmask && sort_applies(nbr, stride, n_out)) {   // positions instead of rows: the sorted table + the row map
+        nbr = const_cast<int32_t*>(L.cache_nbr_sorted);
+        rowmap = L.cache_rowmap;
+      }
       ISF_REQUIRE(!lmask || dma, ISF_ERR_UNSUPPORTED, "sparse_encoder: layer %d cannot read a line-compressed table", i);
       stg = L.cache_stage;
       if (want_order) {
@@ -476,6 +531,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       if (stats) stats->pairs[i] = -(long long)i - 1;
       Nx.cache_cu = ConvCuPlan();
       Nx.cache_lmask = nullptr;
+      Nx.cache_rowmap = Nx.cache_nbr_sorted = nullptr;
+      Nx.cache_sort_part_rows = 0;
       Nx.cache_nbr = nullptr;
       Nx.cache_order = nullptr;
       Nx.cache_order_cin = Nx.cache_order_cout = 0;
@@ -509,7 +566,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                              ly.shift, res, ly.relu, y,
                                              conv_mode | (order_is_table ? 1024 : 0) | (ly.c_out == 256 && conv_mode == (conv_mode & 32) ? wide_cols : 0) |
                                                  (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0),
-                                             st, order));
+                                             st, order, nullptr, rowmap));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))
       ISF_TRY(sparse_conv_forward_packed_impl(reinterpret_cast<const float*>(x), n_in, ly.c_in, ly.packed, K,
                                               ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,

@@ -280,7 +280,8 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
                                                 int col0 /* first output channel of this workgroup */, int cout,
                                                 float winv, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const uint4* __restrict__ residual,
-                                                uint4* __restrict__ ys, int n_out, int relu, int groups = RG) {
+                                                uint4* __restrict__ ys, int n_out, int relu, int groups = RG,
+                                                const int32_t* __restrict__ rowmap = nullptr /* position -> row */) {
   using E = Conv16Epi<NT, RG>;
   constexpr int EPN = E::EPN, RS = E::RS;
   const int col = lane & 15, kg = lane >> 4;
@@ -304,10 +305,11 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
           res_lo[it] = make_uint4(0, 0, 0, 0);
           if (i < 16 * UNITS && grow < n_out) {
             const int unit = (col0 + ps * (16 * EPN)) / 8 + i % UNITS;
+            const int gm = rowmap ? rowmap[grow] : grow;      // the row this position of the (sorted) launch computes
             if (F16IO) {
-              res_hi[it] = residual[(size_t)grow * (cout >> 3) + unit];
+              res_hi[it] = residual[(size_t)gm * (cout >> 3) + unit];
             } else {
-              const size_t o = split_hi_index((size_t)grow, cout >> 3, unit);
+              const size_t o = split_hi_index((size_t)gm, cout >> 3, unit);
               res_hi[it] = residual[o];
               res_lo[it] = residual[o + 4];
             }
@@ -344,10 +346,11 @@ __device__ __forceinline__ void conv16_epilogue(const f32x4 (&acc)[RG][NT], floa
           }
           uint4 hi, lo;
           split8(v, hi, lo);
+          const int gm = rowmap ? rowmap[grow] : grow;
           if (F16IO) {
-            ys[(size_t)grow * (cout >> 3) + (gc >> 3)] = hi;   // round-to-nearest f16 of the fp32 result
+            ys[(size_t)gm * (cout >> 3) + (gc >> 3)] = hi;   // round-to-nearest f16 of the fp32 result
           } else {
-            const size_t o = split_hi_index((size_t)grow, cout >> 3, gc >> 3);
+            const size_t o = split_hi_index((size_t)gm, cout >> 3, gc >> 3);
             ys[o] = hi;
             ys[o + 4] = lo;
           }

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, Conv16Plan plan, const int32_t* __restrict__ order,
-    long long* __restrict__ trace) {
+    long long* __restrict__ trace, const int32_t* __restrict__ rowmap /* nullptr | position -> output row (sorted launch) */) {
   // MODE bit 512: per-workgroup trace (isf_sparse_conv_trace): 8 x int64 per workgroup -- constant-clock time stamps at
   // entry / after the prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half << 32
   constexpr bool TRACE = (MODE & 512) != 0;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
   conv16_epilogue<NT, RG, F16IO>(acc, tile_l, lane, row0 + wave * (half_tile ? WR / 2 : WR), cb * BN, cout, *w_inv_scale,
-                                 scale, shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG);
+                                 scale, shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG, rowmap);
   if (TRACE) {
     __syncthreads();
     if (tid == 0) {
@@ -714,7 +714,7 @@ template <int CIN, int NT, int RG, int NW, int MODE = 0>
 static int launch16(bool balance, bool table /* `order` is a tile table (conv16_table_part), not a permutation */, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                     const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                     const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
-                    Conv16LaunchInfo* query, long long* trace = nullptr) {
+                    Conv16LaunchInfo* query, long long* trace = nullptr, const int32_t* rowmap = nullptr) {
   using S = Conv16Smem<NT, RG, Conv16Step<CIN, NT>::KCH, NW>;
   auto kern = spconv_f16x3_kernel<CIN, NT, RG, NW, MODE>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};   // of this instantiation on this device family
@@ -741,7 +741,7 @@ static int launch16(bool balance, bool table /* `order` is a tile table (conv16_
     return ISF_OK;
   }
   hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K,
-                     cout, scale, shift, residual, ys, n_out, relu, plan, order, trace);
+                     cout, scale, shift, residual, ys, n_out, relu, plan, order, trace, rowmap);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -777,12 +777,12 @@ template <int CIN, int NT>
 static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                          const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
-                         Conv16LaunchInfo* query) {
+                         Conv16LaunchInfo* query, const int32_t* rowmap = nullptr) {
   // mode bit 32768 (opt-in, bit-identical, measured 8 % slower: profiles/r06_deep.txt): the deep layers' 4-wave launches on
   // isf_spconv_deep.hip (LDS-DMA gathers + one instruction stream per step)
   const bool use_deep = (mode & 32768) != 0;
   mode &= ~32768;
-#define ISF_ARGS16 (mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
+#define ISF_ARGS16 (mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, nullptr, rowmap
   // mode bits 4096 / 8192 (round 5 experiment, valid results, bit-identical): the 256-COLUMN layers as ONE column block
   // -- a workgroup owns all 256 output columns of its rows, so a row is gathered ONCE per tap and chunk instead of once per
   // column block.  The phase trace (profiles/r05_att_256.txt) shows the step bound by the vector-memory issue path (a
@@ -790,7 +790,7 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
   // the step time): per MFMA this halves the gather instructions.  4096: 4 waves x 32 rows (two workgroups per CU:
   // 64 KiB weight stage); 8192: 8 waves x 16 rows.  Tile-order tables belong to the two-block launch plan: ignored.
   if constexpr (NT == 8 && CIN >= 128) {
-    if ((mode & (4096 | 8192)) && cout == 256 && (mode & ~(32 | 1024 | 4096 | 8192)) == 0) {
+    if ((mode & (4096 | 8192)) && cout == 256 && (mode & ~(32 | 1024 | 4096 | 8192)) == 0 && !rowmap) {
       if (mode & 8192)
         return launch16<CIN, 16, 1, 8>(false, false, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual,
                                        relu, ys, st, nullptr, query);
@@ -843,7 +843,7 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
     if (cout == 256 && n_out <= 96 * conv16_device_cus()) return launch16<CIN, NT, 1, 4>(ISF_ARGS16);
   }
   if constexpr (NT == 8 && CIN >= 128) {
-    if (use_deep && (mode & ~(32 | 1024)) == 0 && sparse_conv_deep_supported(CIN, cout))
+    if (use_deep && !rowmap && (mode & ~(32 | 1024)) == 0 && sparse_conv_deep_supported(CIN, cout))
       return sparse_conv_forward_deep_impl((mode & 32) == 0, (mode & 1024) != 0 && order != nullptr, xs, CIN, wpk, winv, K, cout,
                                            nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
   }
@@ -855,12 +855,12 @@ template <int CIN>
 static int dispatch16(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                       const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                       const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
-                      Conv16LaunchInfo* query) {
+                      Conv16LaunchInfo* query, const int32_t* rowmap) {
   switch (cout) {
-    case 32:  return launch16_rows<CIN, 2>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
-    case 64:  return launch16_rows<CIN, 4>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
+    case 32:  return launch16_rows<CIN, 2>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, rowmap);
+    case 64:  return launch16_rows<CIN, 4>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, rowmap);
     case 128:
-    case 256: return launch16_rows<CIN, 8>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query);
+    case 256: return launch16_rows<CIN, 8>(mode, xs, wpk, winv, K, cout, nbr, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, rowmap);
   }
   return ISF_ERR_UNSUPPORTED;
 }
@@ -869,7 +869,7 @@ static int dispatch16(int mode, const uint4* xs, const uint4* wpk, const float* 
 int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed16, int K, int c_out,
                                    const int32_t* nbr, int nbr_stride, int n_out, const float* scale,
                                    const float* shift, const void* residual, int relu, void* ys, int mode,
-                                   hipStream_t st, const int32_t* order, Conv16LaunchInfo* query) {
+                                   hipStream_t st, const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap) {
   if (n_out <= 0) {
     if (query) *query = Conv16LaunchInfo{0, 0, 0, 0, 0, 0, 0};
     return ISF_OK;
@@ -885,10 +885,10 @@ int sparse_conv_forward_f16x3_impl(const void* xs, int c_in, const void* packed1
   const uint4* r = reinterpret_cast<const uint4*>(residual);
   uint4* y = reinterpret_cast<uint4*>(ys);
   switch (c_in) {
-    case 32:  return dispatch16<32>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
-    case 64:  return dispatch16<64>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
-    case 128: return dispatch16<128>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
-    case 256: return dispatch16<256>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query);
+    case 32:  return dispatch16<32>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap);
+    case 64:  return dispatch16<64>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap);
+    case 128: return dispatch16<128>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap);
+    case 256: return dispatch16<256>(mode, x, w, winv, K, c_out, nbr, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap);
   }
   return ISF_ERR_UNSUPPORTED;
 }
@@ -1079,6 +1079,49 @@ int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out,
     hipLaunchKernelGGL(conv16_tile_work_kernel, dim3(parts * tiles), dim3(256), 0, st, nbr, nbr_stride, K, n_out, plan,
                        info.TM, work);
   hipLaunchKernelGGL(conv16_tile_order_kernel, dim3(parts), dim3(64), 0, st, work, tiles, info.cus_per_xcd, order);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+// ------------------------------------------------------------------------------------------- row sort (round 6)
+__global__ __launch_bounds__(256) void conv_row_key_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K, int n_out,
+                                                           int part_rows, uint32_t* __restrict__ keys) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_out) return;
+  uint32_t m = 0u;
+  for (int k = 0; k < K; ++k) m |= (nbr[(size_t)k * nbr_stride + r] >= 0 ? 1u : 0u) << k;
+  // 16 bits of the mask decide the order: eight taps of the plane above (k = 19 .. 26) and eight of the plane below
+  // (k = 1 .. 8) -- on the benchmark geometry as good as all 27 (tile-taps 7 298 -> 6 217 against 6 190, CPU census in
+  // profiles/r06_row_sort.txt) and one radix pass less.  Rows stay inside their part (= their XCD's row range).
+  const uint32_t m16 = K == 27 ? (((m >> 19) & 0xffu) << 8) | ((m >> 1) & 0xffu) : (m & 0xffffu);
+  keys[r] = ((uint32_t)(r / part_rows) << 16) | m16;
+}
+
+__global__ __launch_bounds__(256) void conv_row_permute_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K, int n_out,
+                                                               int32_t* __restrict__ rowmap /* in: [n_out]; padded to the stride */,
+                                                               int32_t* __restrict__ nbr_sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nbr_stride) return;
+  const int r = i < n_out ? rowmap[i] : -1;
+  if (i >= n_out) rowmap[i] = i;                         // positions behind the rows: never read (kept in range)
+  for (int k = 0; k < K; ++k) nbr_sorted[(size_t)k * nbr_stride + i] = r >= 0 ? nbr[(size_t)k * nbr_stride + r] : -1;
+}
+
+int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int n_out, int part_rows, int32_t* rowmap,
+                       int32_t* nbr_sorted, hipStream_t st) {
+  ISF_REQUIRE(nbr && rowmap && nbr_sorted && n_out > 0 && K >= 1 && K <= kMaxTaps && part_rows > 0 && nbr_stride >= n_out,
+              ISF_ERR_ARG, "conv_row_sort: bad arguments");
+  const int parts = ceil_div(n_out, part_rows);
+  ISF_REQUIRE(parts <= 32, ISF_ERR_ARG, "conv_row_sort: %d parts", parts);
+  int part_bits = 0;
+  while ((1 << part_bits) < parts) ++part_bits;
+  uint32_t* keys = nullptr;
+  ISF_TRY(a.alloc_n(&keys, (size_t)n_out));
+  hipLaunchKernelGGL(conv_row_key_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, part_rows, keys);
+  ISF_LAUNCH_CHECK();
+  ISF_TRY(stable_sort_u32_impl(a, keys, n_out, 16 + part_bits, rowmap, st));
+  hipLaunchKernelGGL(conv_row_permute_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out,
+                     rowmap, nbr_sorted);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

@@ -236,6 +236,19 @@ static int hv_stable_sort(const uint32_t* keys, uint32_t* keys_tmp, uint32_t* ke
   return ISF_OK;
 }
 
+// the same sort for other callers (the row sort of the deep conv launches, isf_spconv16.hip): idx_sorted [n] = the stable
+// order of the low `key_bits` bits of keys [n]; scratch from the arena
+int stable_sort_u32_impl(Arena& a, const uint32_t* keys, int n, int key_bits, int* idx_sorted, hipStream_t st) {
+  ISF_REQUIRE(keys && idx_sorted && n > 0 && key_bits >= 1 && key_bits <= 32, ISF_ERR_ARG, "stable_sort: bad arguments");
+  uint32_t *keys_tmp = nullptr, *keys_sorted = nullptr, *hist = nullptr;
+  int* idx_tmp = nullptr;
+  ISF_TRY(a.alloc_n(&keys_tmp, (size_t)n));
+  ISF_TRY(a.alloc_n(&keys_sorted, (size_t)n));
+  ISF_TRY(a.alloc_n(&idx_tmp, (size_t)n));
+  ISF_TRY(a.alloc_n(&hist, (size_t)1024 * (ceil_div(n, kRsTile) + 1)));
+  return hv_stable_sort(keys, keys_tmp, keys_sorted, idx_tmp, idx_sorted, hist, n, key_bits, st);
+}
+
 // first sorted position of every cell
 __global__ void hv_segment_heads_kernel(const uint32_t* __restrict__ keys, int P, uint32_t none,
                                         uint32_t* __restrict__ start) {

@@ -510,6 +510,10 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         assert torch.isfinite(got).all() and got.abs().max().item() > 0.1
         assert torch.equal(got, want), n
         assert torch.equal(lb(pl, conv_diag=48), want), n      # and without neighbour sharing
+        # round 6: the deep SubM layers compute their rows in the order of their tap masks (conv_row_sort_impl: a tile / a
+        # 16-row group of like rows walks fewer taps); every row still gets the same products in the same order, so the
+        # un-sorted launch (diagnostic 33554432) gives the same bits
+        assert torch.equal(lb(pl, conv_diag=33554432), want), n
         # round 6 (opt-in, diagnostic 16777216): the launches of several rounds (levels 0 / 1) hand their tiles out band by
         # band in y (conv16_band_order_kernel) -- a permutation of the same tiles
         assert torch.equal(lb(pl, conv_diag=16777216), want), n
