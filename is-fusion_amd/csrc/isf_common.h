@@ -258,7 +258,8 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
                                  int nbr_stride, int n_out, const float* scale, const float* shift,
                                  const void* residual, int relu, void* ys, int mode, hipStream_t st,
                                  const int32_t* order = nullptr, Conv16LaunchInfo* query = nullptr,
-                                 const uint32_t* lmask = nullptr /* line-compressed table: nbr = lines */, int nx = 0);
+                                 const uint32_t* lmask = nullptr /* line-compressed table: nbr = lines */, int nx = 0,
+                                 const int32_t* rowmap = nullptr /* sorted launch: position -> output row */);
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st, const uint32_t* lmask = nullptr /* line-compressed table's masks instead of nbr */);
@@ -272,6 +273,11 @@ int stable_sort_u32_impl(Arena& a, const uint32_t* keys, int n, int key_bits, in
 // through rowmap; every output row is still computed by the same products in the same order: bit-identical.
 int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int n_out, int part_rows, int32_t* rowmap,
                        int32_t* nbr_sorted, hipStream_t st);
+// the same for a LINE-COMPRESSED table (lines [num_lines][stride] + 27-bit masks [stride]): the keys come from the masks;
+// full_key: all 27 mask bits decide (the finest level, whose rows have few and varied neighbours) instead of 16
+int conv_row_sort_lines_impl(Arena& a, const int32_t* lines, const uint32_t* lmask, int nbr_stride, int num_lines, int n_out,
+                             int part_rows, bool full_key, int32_t* rowmap, int32_t* lines_sorted, uint32_t* lmask_sorted,
+                             hipStream_t st);
 // tile order of a launch of several rounds: the tiles of an XCD band by band in y (z-neighbour rows stay in its L2)
 bool conv16_band_order_applies(const Conv16LaunchInfo& info);
 int conv16_band_order_impl(const int32_t* coors4, int n_out, const Conv16LaunchInfo& info, int band, int32_t* order /* [parts * tiles] */,

@@ -161,6 +161,7 @@ struct LevelState {
   ConvCuPlan cache_cu;          // unit plan of cache_nbr for the one-workgroup-per-CU kernel (n_out == 0: not built)
   const int32_t* cache_rowmap;  // ROW SORT of cache_nbr (conv_row_sort_impl): position -> row, or nullptr
   const int32_t* cache_nbr_sorted;   // cache_nbr by position
+  const uint32_t* cache_lmask_sorted;   // cache_lmask by position (line-compressed tables)
   int cache_sort_part_rows;     // the launch plan's rows per part the sort was cut for
 };
 
@@ -253,7 +254,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
@@ -268,6 +269,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // row sort of the deep SubM launches (conv_row_sort_impl): rows of a tile / a 16-row group with the same tap mask;
   // bit 33554432 switches it off (A/B; results are bit-identical either way)
   const bool row_sort = (diagnostic & 33554432) == 0;
+  // ... of the NARROW layers too (LDS-DMA kernel, line-compressed tables): opt-in with bit 67108864 -- 33 % fewer tile-taps at
+  // level 0 on paper, no gain measured (64 -> 64 0.703 -> 0.719, 32 -> 32 0.272 -> 0.276 ms per step: those layers are bound
+  // by their gathers, and like rows are further apart), profiles/r06_row_sort.txt
+  const bool narrow_sort = (diagnostic & 67108864) != 0;
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   const int cu_cap = conv_cu_variant_cap((diagnostic >> 10) & 15);   // unit shape of the requested kernel variant
@@ -275,7 +280,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864));
   // bits 262144 / 524288: the 256-column layers as one column block (conv mode 4096 / 8192; isf_spconv16.hip)
   const int wide_cols = (diagnostic & 262144 ? 4096 : 0) | (diagnostic & 524288 ? 8192 : 0);
   const int stagger = ((diagnostic & 1048576) ? 65536 : 0) | ((diagnostic & 2097152) ? 131072 : 0) | ((diagnostic & 4194304) ? 262144 : 0) |
@@ -307,6 +312,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   L.cache_cu = ConvCuPlan();
   L.cache_lmask = nullptr;
   L.cache_rowmap = L.cache_nbr_sorted = nullptr;
+  L.cache_lmask_sorted = nullptr;
   L.cache_sort_part_rows = 0;
   // precision: f16x3 split MFMA when every layer was packed for it (and not overridden), else fp32 MFMA
   bool use16 = precision != 1;
@@ -376,22 +382,39 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       }
       return true;
     };
-    // ROW SORT (round 6): a deep SubM layer on the tile kernel computes its rows in the order of their tap masks
-    const bool sort_ok = row_sort && use16 && !dma && !cu && srows == 0 && ly.conv_type == ISF_CONV_SUBM && ly.c_out >= 128 &&
-                         K == 27 && conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0 && L.n >= 4096;
+    // ROW SORT (round 6): a SubM layer computes its rows in the order of their tap masks (deep layers on the tile kernel,
+    // narrow layers on the LDS-DMA kernel, full or line-compressed table)
+    const bool sort_ok = row_sort && use16 && !cu && srows == 0 && ly.conv_type == ISF_CONV_SUBM && K == 27 &&
+                         conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0 && L.n >= 4096 &&
+                         (dma ? narrow_sort : ly.c_out >= 128);
     const int32_t* rowmap = nullptr;
+    auto launch_info = [&](const int32_t* table, int tstride, int rows, Conv16LaunchInfo* info) -> int {
+      if (dma)
+        return sparse_conv_forward_dma_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
+                                            nullptr, 0, nullptr, conv_mode, sg, nullptr, info);
+      return sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
+                                            nullptr, 0, nullptr, conv_mode, sg, nullptr, info);
+    };
     auto ensure_row_sort = [&](const int32_t* table, int tstride, int rows, bool* built) -> int {
       *built = false;
-      if (!sort_ok) return ISF_OK;
+      if (!sort_ok || L.cache_rowmap) return ISF_OK;   // (sorted for another plan: this layer keeps the plain table)
       Conv16LaunchInfo info;
-      ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
-                                             nullptr, 0, nullptr, conv_mode, sg, nullptr, &info));
-      if (L.cache_rowmap && L.cache_sort_part_rows == info.part_rows) return ISF_OK;
-      if (L.cache_rowmap) return ISF_OK;       // sorted for another plan: this layer keeps the plain table
+      ISF_TRY(launch_info(table, tstride, rows, &info));
       int32_t *rm = nullptr, *ns = nullptr;
       ISF_TRY(a.alloc_n(&rm, (size_t)tstride));
-      ISF_TRY(a.alloc_n(&ns, (size_t)K * tstride));
-      ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg));
+      if (L.cache_lmask) {
+        const int nl = ly.ksize[0] * ly.ksize[1];
+        uint32_t* lms = nullptr;
+        ISF_TRY(a.alloc_n(&ns, (size_t)nl * tstride));
+        ISF_TRY(a.alloc_n(&lms, (size_t)tstride));
+        // the input level's rows have few, varied neighbours (6 of 27 on the benchmark geometry): all 27 bits decide
+        ISF_TRY(conv_row_sort_lines_impl(a, table, L.cache_lmask, tstride, nl, rows, info.part_rows, L.coors == coors0, rm, ns,
+                                         lms, sg));
+        L.cache_lmask_sorted = lms;
+      } else {
+        ISF_TRY(a.alloc_n(&ns, (size_t)K * tstride));
+        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg));
+      }
       L.cache_rowmap = rm;
       L.cache_nbr_sorted = ns;
       L.cache_sort_part_rows = info.part_rows;
@@ -401,9 +424,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     auto sort_applies = [&](const int32_t* table, int tstride, int rows) -> bool {   // this layer's plan == the sort's plan
       if (!sort_ok || !L.cache_rowmap) return false;
       Conv16LaunchInfo info;
-      if (sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
-                                         nullptr, 0, nullptr, conv_mode, sg, nullptr, &info) != ISF_OK)
-        return false;
+      if (launch_info(table, tstride, rows, &info) != ISF_OK) return false;
       return info.part_rows == L.cache_sort_part_rows;
     };
     if (ly.conv_type == ISF_CONV_SUBM) {
@@ -437,14 +458,16 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_order_is_table = false;
         L.cache_cu = ConvCuPlan();
         L.cache_rowmap = L.cache_nbr_sorted = nullptr;
+        L.cache_lmask_sorted = nullptr;
         L.cache_sort_part_rows = 0;
         {
           bool built = false;
-          if (!L.cache_lmask) ISF_TRY(ensure_row_sort(nbr, stride, n_out, &built));
+          ISF_TRY(ensure_row_sort(nbr, stride, n_out, &built));
         }
         if (want_order) {
           ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out, conv_mode,
-                                   dma, &L.cache_order, sg, L.cache_lmask,
+                                   dma, &L.cache_order, sg,
+                                   (L.cache_lmask && sort_applies(nbr, stride, n_out)) ? L.cache_lmask_sorted : L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
@@ -458,14 +481,15 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(build_stage_tables(a, nbr, stride, K, &L.cache_stage, sg));
           ISF_TRY(stream_wait_stream(a, st, sg));
         }
-        if (!L.cache_lmask) {   // an earlier layer of the level did not sort (another kernel): sort now
+        {   // an earlier layer of the level did not sort (another kernel): sort now
           bool built = false;
           ISF_TRY(ensure_row_sort(nbr, stride, n_out, &built));
           if (built) ISF_TRY(stream_wait_stream(a, st, sg));
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
           ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out, conv_mode,
-                                   dma, &L.cache_order, sg, L.cache_lmask,
+                                   dma, &L.cache_order, sg,
+                                   (L.cache_lmask && sort_applies(nbr, stride, n_out)) ? L.cache_lmask_sorted : L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
           L.cache_order_cout = ly.c_out;
@@ -478,8 +502,9 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       }
       cu_plan = L.cache_cu;
       lmask = L.cache_lmask;
-      if (!lmask && sort_applies(nbr, stride, n_out)) {   // positions instead of rows: the sorted table + the row map
+      if (sort_applies(nbr, stride, n_out)) {   // positions instead of rows: the sorted table + the row map
         nbr = const_cast<int32_t*>(L.cache_nbr_sorted);
+        if (lmask) lmask = L.cache_lmask_sorted;
         rowmap = L.cache_rowmap;
       }
       ISF_REQUIRE(!lmask || dma, ISF_ERR_UNSUPPORTED, "sparse_encoder: layer %d cannot read a line-compressed table", i);
@@ -532,6 +557,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       Nx.cache_cu = ConvCuPlan();
       Nx.cache_lmask = nullptr;
       Nx.cache_rowmap = Nx.cache_nbr_sorted = nullptr;
+      Nx.cache_lmask_sorted = nullptr;
       Nx.cache_sort_part_rows = 0;
       Nx.cache_nbr = nullptr;
       Nx.cache_order = nullptr;
@@ -560,7 +586,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                           ly.relu, y, cu_plan, st));
     else if (dma)
       ISF_TRY(sparse_conv_forward_dma_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale, ly.shift,
-                                           res, ly.relu, y, conv_mode, st, order, nullptr, lmask, nx));
+                                           res, ly.relu, y, conv_mode, st, order, nullptr, lmask, nx, rowmap));
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y,

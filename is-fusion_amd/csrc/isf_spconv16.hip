@@ -1126,6 +1126,49 @@ int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int 
   return ISF_OK;
 }
 
+__global__ __launch_bounds__(256) void conv_row_key_lines_kernel(const uint32_t* __restrict__ lmask, int n_out, int part_rows,
+                                                                 int key_bits /* 16 | 27 */, uint32_t* __restrict__ keys) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_out) return;
+  const uint32_t m = lmask[r] & 0x7ffffffu;
+  const uint32_t mk = key_bits == 27 ? m : ((((m >> 19) & 0xffu) << 8) | ((m >> 1) & 0xffu));
+  keys[r] = ((uint32_t)(r / part_rows) << key_bits) | mk;
+}
+
+__global__ __launch_bounds__(256) void conv_row_permute_lines_kernel(const int32_t* __restrict__ lines,
+                                                                     const uint32_t* __restrict__ lmask, int nbr_stride,
+                                                                     int num_lines, int n_out, int32_t* __restrict__ rowmap,
+                                                                     int32_t* __restrict__ lines_sorted,
+                                                                     uint32_t* __restrict__ lmask_sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nbr_stride) return;
+  const int r = i < n_out ? rowmap[i] : -1;
+  if (i >= n_out) rowmap[i] = i;
+  lmask_sorted[i] = r >= 0 ? lmask[r] : 0u;
+  for (int l = 0; l < num_lines; ++l) lines_sorted[(size_t)l * nbr_stride + i] = r >= 0 ? lines[(size_t)l * nbr_stride + r] : -1;
+}
+
+int conv_row_sort_lines_impl(Arena& a, const int32_t* lines, const uint32_t* lmask, int nbr_stride, int num_lines, int n_out,
+                             int part_rows, bool full_key, int32_t* rowmap, int32_t* lines_sorted, uint32_t* lmask_sorted,
+                             hipStream_t st) {
+  ISF_REQUIRE(lines && lmask && rowmap && lines_sorted && lmask_sorted && n_out > 0 && num_lines >= 1 && num_lines <= 9 &&
+                  part_rows > 0 && nbr_stride >= n_out, ISF_ERR_ARG, "conv_row_sort_lines: bad arguments");
+  const int parts = ceil_div(n_out, part_rows);
+  ISF_REQUIRE(parts <= 32, ISF_ERR_ARG, "conv_row_sort_lines: %d parts", parts);
+  int part_bits = 0;
+  while ((1 << part_bits) < parts) ++part_bits;
+  const int key_bits = full_key ? 27 : 16;
+  uint32_t* keys = nullptr;
+  ISF_TRY(a.alloc_n(&keys, (size_t)n_out));
+  hipLaunchKernelGGL(conv_row_key_lines_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, st, lmask, n_out, part_rows, key_bits, keys);
+  ISF_LAUNCH_CHECK();
+  ISF_TRY(stable_sort_u32_impl(a, keys, n_out, key_bits + part_bits, rowmap, st));
+  hipLaunchKernelGGL(conv_row_permute_lines_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st, lines, lmask, nbr_stride,
+                     num_lines, n_out, rowmap, lines_sorted, lmask_sorted);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 // ------------------------------------------------------------------------------------------- band order (round 6)
 // A launch of SEVERAL rounds (levels 0 / 1: 2 700 tiles on 768 slots) hands its tiles out in row order = (b, z, y, x)
 // order: the ~96 tiles an XCD has in flight are one stretch of ONE z-plane, and the rows their dz = +-1 taps gather --

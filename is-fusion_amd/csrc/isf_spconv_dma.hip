@@ -66,7 +66,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     int nbr_stride, const uint4* __restrict__ wpk,
     const float* __restrict__ w_inv_scale, int K, int cout, const float* __restrict__ scale,
     const float* __restrict__ shift, const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
-    Conv16Plan plan, const int32_t* __restrict__ order) {
+    Conv16Plan plan, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ rowmap /* nullptr | sorted launch: position -> output row (conv_row_sort_impl) */) {
   constexpr bool HALF = (MODE & 1) != 0, F16IO = (MODE & 256) != 0;
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   using S = ConvDmaSmem<NT, NW, RG>;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
   conv16_epilogue<NT, RG, F16IO>(acc, tile_l, lane, row0w, cb * BN, cout, *w_inv_scale, scale, shift, residual, ys,
-                                 row_end, relu, half_tile ? RG / 2 : RG);
+                                 row_end, relu, half_tile ? RG / 2 : RG, rowmap);
 }
 
 bool sparse_conv_dma_supported(int c_in, int c_out) {
@@ -338,7 +339,7 @@ template <int CIN, int NT, int MODE, bool LINES, int NW = 4, int RG = 2>
 static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                       const int32_t* nbr, const uint32_t* lmask, int nx, int nbr_stride, int n_out, const float* scale,
                       const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
-                      const int32_t* order, Conv16LaunchInfo* query) {
+                      const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap) {
   using S = ConvDmaSmem<NT, NW, RG>;
   auto kern = spconv_dma_kernel<CIN, NT, NW, MODE, RG, LINES>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};
@@ -362,7 +363,7 @@ static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const flo
     return ISF_OK;
   }
   hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, lmask, nx, nbr_stride, wpk,
-                     winv, K, cout, scale, shift, residual, ys, n_out, relu, plan, order);
+                     winv, K, cout, scale, shift, residual, ys, n_out, relu, plan, order, rowmap);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -371,9 +372,9 @@ template <int CIN, int NT>
 static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                         const int32_t* nbr, const uint32_t* lmask, int nx, int nbr_stride, int n_out, const float* scale,
                         const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
-                        const int32_t* order, Conv16LaunchInfo* query) {
+                        const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap) {
   const bool balance = (mode & 32) == 0;
-#define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, lmask, nx, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query
+#define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, lmask, nx, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, rowmap
   if (lmask) {
     switch (mode & ~32) {
       case 0: return launch_dma<CIN, NT, 0, true>(ISF_ARGS_DMA);
@@ -394,7 +395,8 @@ static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float
 int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16, int K, int c_out, const int32_t* nbr,
                                  int nbr_stride, int n_out, const float* scale, const float* shift,
                                  const void* residual, int relu, void* ys, int mode, hipStream_t st,
-                                 const int32_t* order, Conv16LaunchInfo* query, const uint32_t* lmask, int nx) {
+                                 const int32_t* order, Conv16LaunchInfo* query, const uint32_t* lmask, int nx,
+                                 const int32_t* rowmap) {
   if (n_out <= 0) {
     if (query) *query = Conv16LaunchInfo{0, 0, 0, 0, 0, 0, 0};
     return ISF_OK;
@@ -409,7 +411,7 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
   const uint4* x = reinterpret_cast<const uint4*>(xs);
   const uint4* r = reinterpret_cast<const uint4*>(residual);
   uint4* y = reinterpret_cast<uint4*>(ys);
-#define ISF_CALL_DMA(CI, NTT) dispatch_dma<CI, NTT>(mode, x, w, winv, K, c_out, nbr, lmask, nx, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query)
+#define ISF_CALL_DMA(CI, NTT) dispatch_dma<CI, NTT>(mode, x, w, winv, K, c_out, nbr, lmask, nx, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap)
   if (c_in == 32) return c_out == 32 ? ISF_CALL_DMA(32, 2) : ISF_CALL_DMA(32, 4);
   return c_out == 32 ? ISF_CALL_DMA(64, 2) : ISF_CALL_DMA(64, 4);
 #undef ISF_CALL_DMA
