@@ -272,7 +272,9 @@ int stable_sort_u32_impl(Arena& a, const uint32_t* keys, int n, int key_bits, in
 // the neighbour table by position.  The conv kernel computes positions and reads / writes residual and output rows
 // through rowmap; every output row is still computed by the same products in the same order: bit-identical.
 int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int n_out, int part_rows, int32_t* rowmap,
-                       int32_t* nbr_sorted, hipStream_t st);
+                       int32_t* nbr_sorted, hipStream_t st,
+                       int key_mode = 1 /* 1: 6 coarse bits (which ky rows of the planes above / below hold a neighbour), one radix
+                                           pass; 2: coarse | the nine in-plane taps, two passes */);
 // the same for a LINE-COMPRESSED table (lines [num_lines][stride] + 27-bit masks [stride]): the keys come from the masks;
 // full_key: all 27 mask bits decide (the finest level, whose rows have few and varied neighbours) instead of 16
 int conv_row_sort_lines_impl(Arena& a, const int32_t* lines, const uint32_t* lmask, int nbr_stride, int num_lines, int n_out,

@@ -254,7 +254,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
@@ -273,6 +273,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // level 0 on paper, no gain measured (64 -> 64 0.703 -> 0.719, 32 -> 32 0.272 -> 0.276 ms per step: those layers are bound
   // by their gathers, and like rows are further apart), profiles/r06_row_sort.txt
   const bool narrow_sort = (diagnostic & 67108864) != 0;
+  const int sort_key_mode = (diagnostic & 134217728) ? 2 : 1;   // bit 134217728: the two-pass key (coarse | in-plane taps): A/B
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   const int cu_cap = conv_cu_variant_cap((diagnostic >> 10) & 15);   // unit shape of the requested kernel variant
@@ -280,7 +281,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728));
   // bits 262144 / 524288: the 256-column layers as one column block (conv mode 4096 / 8192; isf_spconv16.hip)
   const int wide_cols = (diagnostic & 262144 ? 4096 : 0) | (diagnostic & 524288 ? 8192 : 0);
   const int stagger = ((diagnostic & 1048576) ? 65536 : 0) | ((diagnostic & 2097152) ? 131072 : 0) | ((diagnostic & 4194304) ? 262144 : 0) |
@@ -413,7 +414,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_lmask_sorted = lms;
       } else {
         ISF_TRY(a.alloc_n(&ns, (size_t)K * tstride));
-        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg));
+        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg, sort_key_mode));
       }
       L.cache_rowmap = rm;
       L.cache_nbr_sorted = ns;
@@ -549,6 +550,20 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                            stride, pair_counts + i, sg));
       }
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
+      // ROW SORT of a deep strided convolution's own table (its rows want 10 of 27 taps, in many patterns: -12 % tile-taps,
+      // -26 % MFMA blocks at level 3 on the benchmark geometry, profiles/r06_row_sort.txt)
+      if (row_sort && use16 && !dma && !cu && srows == 0 && !lmask && ly.c_out >= 128 && K == 27 &&
+          conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0 && Nx.n >= 4096) {
+        Conv16LaunchInfo info;
+        ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, Nx.n, nullptr, nullptr,
+                                               nullptr, 0, nullptr, conv_mode, sg, nullptr, &info));
+        int32_t *rm = nullptr, *ns = nullptr;
+        ISF_TRY(a.alloc_n(&rm, (size_t)stride));
+        ISF_TRY(a.alloc_n(&ns, (size_t)K * stride));
+        ISF_TRY(conv_row_sort_impl(a, nbr, stride, K, Nx.n, info.part_rows, rm, ns, sg, 1));
+        nbr = ns;
+        rowmap = rm;
+      }
       if (want_order)
         ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask, &order_is_table, tile_tables,
                                  Nx.coors, band_of(Nx.shape)));

@@ -1085,16 +1085,21 @@ int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out,
 
 // ------------------------------------------------------------------------------------------- row sort (round 6)
 __global__ __launch_bounds__(256) void conv_row_key_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K, int n_out,
-                                                           int part_rows, uint32_t* __restrict__ keys) {
+                                                           int part_rows, int key_mode, uint32_t* __restrict__ keys) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= n_out) return;
   uint32_t m = 0u;
   for (int k = 0; k < K; ++k) m |= (nbr[(size_t)k * nbr_stride + r] >= 0 ? 1u : 0u) << k;
-  // 16 bits of the mask decide the order: eight taps of the plane above (k = 19 .. 26) and eight of the plane below
-  // (k = 1 .. 8) -- on the benchmark geometry as good as all 27 (tile-taps 7 298 -> 6 217 against 6 190, CPU census in
-  // profiles/r06_row_sort.txt) and one radix pass less.  Rows stay inside their part (= their XCD's row range).
-  const uint32_t m16 = K == 27 ? (((m >> 19) & 0xffu) << 8) | ((m >> 1) & 0xffu) : (m & 0xffffu);
-  keys[r] = ((uint32_t)(r / part_rows) << 16) | m16;
+  // What decides the order (CPU census of the benchmark geometry, profiles/r06_row_sort.txt): for each of the two
+  // neighbouring planes (kz = 0 / kz = 2), WHICH OF ITS THREE ky ROWS holds a neighbour at all -- 6 bits that say which
+  // tap lines a tile will have to walk -- then (key_mode 2) the nine in-plane taps.  Tile-taps at level 3: 7 298 unsorted,
+  // 6 190 by all 27 bits in numeric order, 5 836 by the 6 coarse bits alone (ONE radix pass), 5 748 by coarse | in-plane.
+  // Rows stay inside their part (= their XCD's row range).
+  const uint32_t top = (m >> 18) & 0x1ffu, bot = m & 0x1ffu;
+  const uint32_t coarse = ((top & 7u) ? 8u : 0u) | ((top & 0x38u) ? 16u : 0u) | ((top & 0x1c0u) ? 32u : 0u) |
+                          ((bot & 7u) ? 1u : 0u) | ((bot & 0x38u) ? 2u : 0u) | ((bot & 0x1c0u) ? 4u : 0u);
+  const uint32_t part = (uint32_t)(r / part_rows);
+  keys[r] = key_mode == 2 ? ((part << 15) | (coarse << 9) | ((m >> 9) & 0x1ffu)) : ((part << 6) | coarse);
 }
 
 __global__ __launch_bounds__(256) void conv_row_permute_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K, int n_out,
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(256) void conv_row_permute_kernel(const int32_t* __
 }
 
 int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int n_out, int part_rows, int32_t* rowmap,
-                       int32_t* nbr_sorted, hipStream_t st) {
+                       int32_t* nbr_sorted, hipStream_t st, int key_mode) {
   ISF_REQUIRE(nbr && rowmap && nbr_sorted && n_out > 0 && K >= 1 && K <= kMaxTaps && part_rows > 0 && nbr_stride >= n_out,
               ISF_ERR_ARG, "conv_row_sort: bad arguments");
   const int parts = ceil_div(n_out, part_rows);
@@ -1117,9 +1122,11 @@ int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int 
   while ((1 << part_bits) < parts) ++part_bits;
   uint32_t* keys = nullptr;
   ISF_TRY(a.alloc_n(&keys, (size_t)n_out));
-  hipLaunchKernelGGL(conv_row_key_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, part_rows, keys);
+  ISF_REQUIRE(K == 27 && (key_mode == 1 || key_mode == 2), ISF_ERR_ARG, "conv_row_sort: %d taps, key mode %d", K, key_mode);
+  hipLaunchKernelGGL(conv_row_key_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, part_rows,
+                     key_mode, keys);
   ISF_LAUNCH_CHECK();
-  ISF_TRY(stable_sort_u32_impl(a, keys, n_out, 16 + part_bits, rowmap, st));
+  ISF_TRY(stable_sort_u32_impl(a, keys, n_out, (key_mode == 2 ? 15 : 6) + part_bits, rowmap, st));
   hipLaunchKernelGGL(conv_row_permute_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out,
                      rowmap, nbr_sorted);
   ISF_LAUNCH_CHECK();

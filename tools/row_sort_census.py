@@ -122,3 +122,64 @@ for name,c,sh,parts in (("L1",c1,s1,8),("L0",c0,shape,8)):
     full=evalkey(m,lambda s:s,parts)
     pairs=sum(bin(int(x)).count('1') for x in m)
     print(name,"rows",len(m),"pairs/row %.1f"%(pairs/len(m)),"unsorted tile-taps, group-taps",none,"16b",z16,"full",full, "tiles",int(np.ceil(len(m)/128)))
+
+print("--- strided conv outputs (taps = inputs present in the 3x3x3 window at stride 2)")
+def stridemasks(cin, shape_in, cout, ks=(3,3,3), st=(2,2,2), pd=(1,1,1)):
+    key=lambda a: ((a[:,0]*shape_in[0]+a[:,1])*shape_in[1]+a[:,2])*shape_in[2]+a[:,3]
+    kin=np.sort(key(cin))
+    m=np.zeros(len(cout),np.uint32); t=0
+    for kz in range(ks[0]):
+      for ky in range(ks[1]):
+        for kx in range(ks[2]):
+            n=cout.copy()
+            n[:,1]=cout[:,1]*st[0]-pd[0]+kz; n[:,2]=cout[:,2]*st[1]-pd[1]+ky; n[:,3]=cout[:,3]*st[2]-pd[2]+kx
+            ok=(n[:,1]>=0)&(n[:,1]<shape_in[0])&(n[:,2]>=0)&(n[:,2]<shape_in[1])&(n[:,3]>=0)&(n[:,3]<shape_in[2])
+            kk=key(n); pos=np.searchsorted(kin,kk); pos[pos>=len(kin)]=len(kin)-1
+            m|=((ok&(kin[pos]==kk)).astype(np.uint32)<<t); t+=1
+    return m
+for name,ci,si,co,parts in (("L2->L3 (128->256)",c2,s2,c3,4),("L1->L2 (64->128)",c1,s1,c2,8)):
+    m=stridemasks(ci,si,co)
+    pairs=sum(bin(int(x)).count('1') for x in m)
+    print(name,"rows",len(m),"pairs/row %.1f"%(pairs/len(m)),"unsorted",steps(m),"full sort",evalkey(m,lambda s:s,parts),"tiles",int(np.ceil(len(m)/128)))
+
+print("--- ordering variants at L3 (4 parts): frequency-ordered bits, greedy")
+m=submasks(c3,s3)
+freq=[int(((m>>np.uint32(t))&1).sum()) for t in range(27)]
+order_rare_ms=sorted(range(27),key=lambda t:freq[t])          # rare bits most significant? perm_bits puts order[0] at bit 0 (LSB)
+print("freq",freq)
+print("common bits LSB.. rare MSB", evalkey(m,lambda s:perm_bits(s,sorted(range(27),key=lambda t:-freq[t]))))
+print("rare bits LSB.. common MSB", evalkey(m,lambda s:perm_bits(s,order_rare_ms)))
+
+print("--- one-pass keys (<= 10 bits incl. part bits: 4 parts -> 8 key bits; 8 parts -> 7 key bits)")
+def k16(s): return ((((s>>19)&0xff).astype(np.uint64))<<8)|((s>>1)&0xff).astype(np.uint64)
+for name,c,sh,parts,kb in (("L3",c3,s3,4,8),("L2",c2,s2,8,7),("L4",c4,s4,4,8)):
+    m=submasks(c,sh)
+    f=lambda x: np.array([bin(int(v)).count('1') for v in x]).astype(np.uint64)
+    # a: 4 bits popcount(z+ 9) | 4 bits popcount(z- 9)
+    a=evalkey(m,lambda s:(np.minimum(f((s>>18)&0x1ff),15)<<4)|np.minimum(f(s&0x1ff),15),parts)
+    # b: z+ edge pattern: (any of row ky=0, ky=1, ky=2 in z+ ; same z-) 3+3 bits + 2 bits in-plane corner info
+    def rows3(x): return (((x&0x7)!=0).astype(np.uint64))|((((x>>3)&0x7)!=0).astype(np.uint64)<<1)|((((x>>6)&0x7)!=0).astype(np.uint64)<<2)
+    b=evalkey(m,lambda s:(rows3((s>>18)&0x1ff)<<3)|rows3(s&0x1ff),parts)
+    # c: top kb bits of the 16-bit key
+    cc=evalkey(m,lambda s:k16(s)>>np.uint64(16-kb),parts)
+    # d: centre column taps: z+ (ky=1: 3 bits) z- (ky=1: 3 bits) + z+ centre, ...
+    print(name,"unsorted",steps(m),"16b",evalkey(m,k16,parts),"| popc(z+),popc(z-) 8b",a,"| 3 rows z+,z- 6b",b,"| top",kb,"bits of 16b",cc)
+
+print("--- coarse6 + detail")
+for name,c,sh,parts in (("L3",c3,s3,4),("L2",c2,s2,8),("L4",c4,s4,4)):
+    m=submasks(c,sh)
+    co=lambda s:(rows3((s>>18)&0x1ff)<<3)|rows3(s&0x1ff)
+    a=evalkey(m,lambda s:(co(s)<<np.uint64(16))|k16(s),parts)
+    b=evalkey(m,lambda s:(co(s)<<np.uint64(9))|((s>>9)&0x1ff).astype(np.uint64),parts)   # coarse + in-plane 9 bits
+    # coarse by columns too: 3 rows + 3 cols per plane = 12 bits
+    def cols3(x): return (((x&0x49)!=0).astype(np.uint64))|(((x&0x92)!=0).astype(np.uint64)<<1)|(((x&0x124)!=0).astype(np.uint64)<<2)
+    c12=evalkey(m,lambda s:(rows3((s>>18)&0x1ff)<<9)|(rows3(s&0x1ff)<<6)|(cols3((s>>18)&0x1ff)<<3)|cols3(s&0x1ff),parts)
+    print(name,"coarse6|k16",a,"coarse6|inplane9",b,"rows+cols 12b",c12)
+
+print("--- strided with coarse keys")
+for name,ci,si,co_,parts in (("L2->L3",c2,s2,c3,4),("L1->L2",c1,s1,c2,8)):
+    m=stridemasks(ci,si,co_)
+    co=lambda s:(rows3((s>>18)&0x1ff)<<3)|rows3(s&0x1ff)
+    co9=lambda s:(rows3((s>>18)&0x1ff)<<6)|(rows3((s>>9)&0x1ff)<<3)|rows3(s&0x1ff)
+    print(name,"unsorted",steps(m),"full27",evalkey(m,lambda s:s,parts),"coarse6",evalkey(m,co,parts),"coarse9 (3 planes x 3 rows)",evalkey(m,co9,parts),
+          "coarse9|k16", evalkey(m,lambda s:(co9(s)<<np.uint64(16))|k16(s),parts))
