@@ -254,7 +254,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
@@ -273,7 +273,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // level 0 on paper, no gain measured (64 -> 64 0.703 -> 0.719, 32 -> 32 0.272 -> 0.276 ms per step: those layers are bound
   // by their gathers, and like rows are further apart), profiles/r06_row_sort.txt
   const bool narrow_sort = (diagnostic & 67108864) != 0;
-  const int sort_key_mode = (diagnostic & 134217728) ? 2 : 1;   // bit 134217728: the two-pass key (coarse | in-plane taps): A/B
+  constexpr int sort_min_rows = 4096;   // (configs[2] at B = 2: 7.05 ms sorted from 4 096 rows up, 7.10 from 32 768, 7.10 unsorted)
+  // key of the sort: 1 = six coarse bits (one radix pass), 3 = sixteen taps of the planes above / below (two passes; measured
+  // better on the 256-column levels: 1.13 vs 1.15 ms per step, worse on the 128-column one: 0.79 vs 0.75);
+  // bit 134217728: coarse | in-plane taps everywhere (A/B)
+  const bool sort_key_ab = (diagnostic & 134217728) != 0;
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
   const int cu_cap = conv_cu_variant_cap((diagnostic >> 10) & 15);   // unit shape of the requested kernel variant
@@ -281,11 +285,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456));
   // bits 262144 / 524288: the 256-column layers as one column block (conv mode 4096 / 8192; isf_spconv16.hip)
   const int wide_cols = (diagnostic & 262144 ? 4096 : 0) | (diagnostic & 524288 ? 8192 : 0);
   const int stagger = ((diagnostic & 1048576) ? 65536 : 0) | ((diagnostic & 2097152) ? 131072 : 0) | ((diagnostic & 4194304) ? 262144 : 0) |
-                      ((diagnostic & 8388608) ? 32768 : 0);   // bit 8388608: the deep layers on isf_spconv_deep.hip (opt-in: LDS-DMA gathers + one instruction stream per step; bit-identical, 8 % slower)   // bit 4194304: gathered rows two steps ahead (A2 loop); bit 2097152: round 4's issue phase in the deep layers (A/B)
+                      ((diagnostic & 8388608) ? 32768 : 0) | ((diagnostic & 268435456) ? 64 : 0);   // bit 8388608: the deep layers on isf_spconv_deep.hip (opt-in: LDS-DMA gathers + one instruction stream per step; bit-identical, 8 % slower)   // bit 4194304: gathered rows two steps ahead (A2 loop); bit 2097152: round 4's issue phase in the deep layers (A/B)
     // bit 1048576: staggered issue phases in the deep layers' workgroups
   const bool f16io = precision == 2;
   const int stage_opt = opt ? opt->stage_rows : 0;
@@ -386,7 +390,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     // ROW SORT (round 6): a SubM layer computes its rows in the order of their tap masks (deep layers on the tile kernel,
     // narrow layers on the LDS-DMA kernel, full or line-compressed table)
     const bool sort_ok = row_sort && use16 && !cu && srows == 0 && ly.conv_type == ISF_CONV_SUBM && K == 27 &&
-                         conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0 && L.n >= 4096 &&
+                         conv_mode == (conv_mode & 32) && wide_cols == 0 && (stagger & ~64) == 0 && L.n >= sort_min_rows &&
                          (dma ? narrow_sort : ly.c_out >= 128);
     const int32_t* rowmap = nullptr;
     auto launch_info = [&](const int32_t* table, int tstride, int rows, Conv16LaunchInfo* info) -> int {
@@ -394,7 +398,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         return sparse_conv_forward_dma_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
                                             nullptr, 0, nullptr, conv_mode, sg, nullptr, info);
       return sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
-                                            nullptr, 0, nullptr, conv_mode, sg, nullptr, info);
+                                            nullptr, 0, nullptr, conv_mode | (ly.c_out >= 128 ? stagger : 0), sg, nullptr, info);
     };
     auto ensure_row_sort = [&](const int32_t* table, int tstride, int rows, bool* built) -> int {
       *built = false;
@@ -414,7 +418,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_lmask_sorted = lms;
       } else {
         ISF_TRY(a.alloc_n(&ns, (size_t)K * tstride));
-        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg, sort_key_mode));
+        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg, sort_key_ab ? 2 : (ly.c_out == 256 ? 3 : 1)));
       }
       L.cache_rowmap = rm;
       L.cache_nbr_sorted = ns;
@@ -466,8 +470,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(ensure_row_sort(nbr, stride, n_out, &built));
         }
         if (want_order) {
-          ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out, conv_mode,
-                                   dma, &L.cache_order, sg,
+          ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out,
+                                   conv_mode | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &L.cache_order, sg,
                                    (L.cache_lmask && sort_applies(nbr, stride, n_out)) ? L.cache_lmask_sorted : L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
@@ -488,8 +492,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           if (built) ISF_TRY(stream_wait_stream(a, st, sg));
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
-          ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out, conv_mode,
-                                   dma, &L.cache_order, sg,
+          ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out,
+                                   conv_mode | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &L.cache_order, sg,
                                    (L.cache_lmask && sort_applies(nbr, stride, n_out)) ? L.cache_lmask_sorted : L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
@@ -553,10 +557,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       // ROW SORT of a deep strided convolution's own table (its rows want 10 of 27 taps, in many patterns: -12 % tile-taps,
       // -26 % MFMA blocks at level 3 on the benchmark geometry, profiles/r06_row_sort.txt)
       if (row_sort && use16 && !dma && !cu && srows == 0 && !lmask && ly.c_out >= 128 && K == 27 &&
-          conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0 && Nx.n >= 4096) {
+          conv_mode == (conv_mode & 32) && wide_cols == 0 && (stagger & ~64) == 0 && Nx.n >= sort_min_rows) {
         Conv16LaunchInfo info;
         ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, Nx.n, nullptr, nullptr,
-                                               nullptr, 0, nullptr, conv_mode, sg, nullptr, &info));
+                                               nullptr, 0, nullptr, conv_mode | stagger, sg, nullptr, &info));
         int32_t *rm = nullptr, *ns = nullptr;
         ISF_TRY(a.alloc_n(&rm, (size_t)stride));
         ISF_TRY(a.alloc_n(&ns, (size_t)K * stride));
@@ -565,7 +569,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         rowmap = rm;
       }
       if (want_order)
-        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode, dma, &order, sg, lmask, &order_is_table, tile_tables,
+        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &order, sg, lmask, &order_is_table, tile_tables,
                                  Nx.coors, band_of(Nx.shape)));
       if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg, cu_cap));
       if (stats) stats->pairs[i] = -(long long)i - 1;

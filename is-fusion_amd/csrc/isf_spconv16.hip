@@ -778,6 +778,9 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
                          const int32_t* nbr, int nbr_stride, int n_out, const float* scale, const float* shift,
                          const uint4* residual, int relu, uint4* ys, hipStream_t st, const int32_t* order,
                          Conv16LaunchInfo* query, const int32_t* rowmap = nullptr) {
+  // mode bit 64 (A/B): the 128-column layers of the large levels on the 4-wave 128-row tile instead of the 8-wave 256-row one
+  const bool narrow_tiles = (mode & 64) != 0;
+  mode &= ~64;
   // mode bit 32768 (opt-in, bit-identical, measured 8 % slower: profiles/r06_deep.txt): the deep layers' 4-wave launches on
   // isf_spconv_deep.hip (LDS-DMA gathers + one instruction stream per step)
   const bool use_deep = (mode & 32768) != 0;
@@ -837,7 +840,7 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
   if constexpr (NT == 8) {   // small launches: one 16-row group per wave (see conv16_device_cus above)
     if (cout == 128 && n_out >= 8 * 256 && n_out <= 256 * conv16_device_cus()) return launch16<CIN, NT, 1, 8>(ISF_ARGS16);
   }
-  if (NT == 8 && cout == 128 && n_out >= 8 * 256)
+  if (NT == 8 && cout == 128 && n_out >= 8 * 256 && !narrow_tiles)
     return launch16<CIN, (NT == 8 ? NT : 2), 2, 8>(ISF_ARGS16);
   if constexpr (NT == 8 && CIN >= 128) {
     if (cout == 256 && n_out <= 96 * conv16_device_cus()) return launch16<CIN, NT, 1, 4>(ISF_ARGS16);
@@ -1099,7 +1102,9 @@ __global__ __launch_bounds__(256) void conv_row_key_kernel(const int32_t* __rest
   const uint32_t coarse = ((top & 7u) ? 8u : 0u) | ((top & 0x38u) ? 16u : 0u) | ((top & 0x1c0u) ? 32u : 0u) |
                           ((bot & 7u) ? 1u : 0u) | ((bot & 0x38u) ? 2u : 0u) | ((bot & 0x1c0u) ? 4u : 0u);
   const uint32_t part = (uint32_t)(r / part_rows);
-  keys[r] = key_mode == 2 ? ((part << 15) | (coarse << 9) | ((m >> 9) & 0x1ffu)) : ((part << 6) | coarse);
+  const uint32_t m16 = (((m >> 19) & 0xffu) << 8) | ((m >> 1) & 0xffu);   // key_mode 3: eight taps above, eight below
+  keys[r] = key_mode == 2 ? ((part << 15) | (coarse << 9) | ((m >> 9) & 0x1ffu))
+                          : (key_mode == 3 ? ((part << 16) | m16) : ((part << 6) | coarse));
 }
 
 __global__ __launch_bounds__(256) void conv_row_permute_kernel(const int32_t* __restrict__ nbr, int nbr_stride, int K, int n_out,
@@ -1122,11 +1127,11 @@ int conv_row_sort_impl(Arena& a, const int32_t* nbr, int nbr_stride, int K, int 
   while ((1 << part_bits) < parts) ++part_bits;
   uint32_t* keys = nullptr;
   ISF_TRY(a.alloc_n(&keys, (size_t)n_out));
-  ISF_REQUIRE(K == 27 && (key_mode == 1 || key_mode == 2), ISF_ERR_ARG, "conv_row_sort: %d taps, key mode %d", K, key_mode);
+  ISF_REQUIRE(K == 27 && key_mode >= 1 && key_mode <= 3, ISF_ERR_ARG, "conv_row_sort: %d taps, key mode %d", K, key_mode);
   hipLaunchKernelGGL(conv_row_key_kernel, dim3(ceil_div(n_out, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out, part_rows,
                      key_mode, keys);
   ISF_LAUNCH_CHECK();
-  ISF_TRY(stable_sort_u32_impl(a, keys, n_out, (key_mode == 2 ? 15 : 6) + part_bits, rowmap, st));
+  ISF_TRY(stable_sort_u32_impl(a, keys, n_out, (key_mode == 2 ? 15 : key_mode == 3 ? 16 : 6) + part_bits, rowmap, st));
   hipLaunchKernelGGL(conv_row_permute_kernel, dim3(ceil_div(nbr_stride, 256)), dim3(256), 0, st, nbr, nbr_stride, K, n_out,
                      rowmap, nbr_sorted);
   ISF_LAUNCH_CHECK();
@@ -1326,7 +1331,7 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  const int m = mode & ~(32 | 4096 | 8192 | 32768 | 65536 | 131072 | 262144);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
+  const int m = mode & ~(32 | 64 | 4096 | 8192 | 32768 | 65536 | 131072 | 262144);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
                                                // column block for the 256-column layers (4 x 32-row / 8 x 16-row waves)
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "
