@@ -4,12 +4,13 @@
 // (663 MB/sample) to map voxels back to points.  Here:
 //   mark bitmap -> popcount scan            voxel id = rank, sorted (b,z,y,x) order, no sort, no canvas
 //   count / scan / order                    points grouped by voxel (counting sort: 1 int atomic per point)
-//   mean        thread per voxel            exact 2^-24 fixed-point int64 sums -> order independent
-//   layer 1     128 sorted points / block   11 features -> Linear+BN+ReLU (fp32 VALU, weights through SGPRs)
-//                                           -> per-voxel max
-//   layer 2     64 sorted points / wave     h1 recomputed (never stored: 307 MB at P=1.2M), [h1 | vmax1[voxel]]
-//                                           (128) x W2^T on the f16 matrix cores with the hi/lo split
-//                                           arithmetic of isf_spconv16.hip (fp32-class accuracy), BN+ReLU,
+//   mean        wave per 64 sorted points   exact 2^-24 fixed-point int64 sums -> order independent; segmented scan over
+//                                           the lanes, the wave holding a voxel's first record follows its run
+//   layer 1     64 sorted points / wave     11 features -> Linear+BN+ReLU on the f16 matrix cores (hi/lo split, fp32-class),
+//                                           TRANSPOSED: out^T = W x in^T, so the result's C/D registers are ...
+//   layer 2     64 sorted points / wave     ... the B operand of layer 2: h1 recomputed (never stored: 307 MB at
+//                                           P=1.2M), [h1 | vmax1[voxel]] (128) x W2^T with W2's fragments in LDS,
+//                                           persistent workgroups, the next tile's loads in flight, BN+ReLU,
 //                                           per-voxel max
 // Because a voxel's points are contiguous after the counting sort, the per-voxel max is a segmented
 // reduction inside the wave (channel per lane, 256-byte row stores); only segments cut by a wave boundary
@@ -25,26 +26,43 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 static constexpr int kC = 64;  // c1 == c2 == 64 (config); other widths -> ISF_ERR_UNSUPPORTED
 static constexpr int kL1Threads = 128;
-static constexpr int kLdsStride = kC + 1;
 static constexpr double kFix = 16777216.0;  // 2^24 fixed point for the exact coordinate sums
 
 struct VfeGeom {
   float vx, vy, vz, ox, oy, oz;  // voxel size, centre offsets (vs/2 + range_min)
 };
 
+// hi = f16(x), lo = f16(x - hi), two values per register: v_cvt_pk_f16_f32 and one v_fma_mix{lo,hi}_f16 per value (the
+// mixed-precision FMA takes hi as an f16 operand: f16(fma(hi, -1, x)), x - hi being exact in fp32) -- three
+// instructions per pair where convert / convert back / subtract / convert took seven.
+__device__ __forceinline__ void vfe_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(x0), "v"(x1));
+}
+
 __device__ __forceinline__ void vfe_split8(const f32x8 v, uint4& hi, uint4& lo) {
-  const h8 h = __builtin_convertvector(v, h8);
-  const f32x8 r = v - __builtin_convertvector(h, f32x8);
-  const h8 l = __builtin_convertvector(r, h8);
-  hi = *reinterpret_cast<const uint4*>(&h);
-  lo = *reinterpret_cast<const uint4*>(&l);
+  vfe_split2(v[0], v[1], hi.x, lo.x);
+  vfe_split2(v[2], v[3], hi.y, lo.y);
+  vfe_split2(v[4], v[5], hi.z, lo.z);
+  vfe_split2(v[6], v[7], hi.w, lo.w);
 }
 
 // ------------------------------------------------------------------------------------------ weight prep
-// w2p[kc][nt][hi|lo][lane][8] = split(w2[16nt + (lane&15)][32kc + 8(lane>>4) + jj] * 2^sw), kc = 0..3
-// sc2[o] = scale2[o] * 2^-sw
-// w1p[nt][hi|lo][lane][4] = split(w1[16nt + (lane&15)][4(lane>>4) + jj] * 2^sw1) (zero for k >= F): B fragments of
+// The two layers run TRANSPOSED on the matrix cores: out^T[channel][point] = W[channel][k] x in^T[k][point], so the
+// C/D registers of layer 1 (lane (n, g) = (lane & 15, lane >> 4): point n of the group, channels 16 ct + 4 g + t) ARE
+// the B operand of layer 2 -- no trip through LDS, no per-point register rows.  The reduction index of layer 2 is
+// permuted to fit: slot (g, jj) of 32-channel chunk c < 2 holds layer-1 channel 16 (2c + (jj >> 2)) + 4 g + (jj & 3);
+// chunks 2, 3 (the voxel's layer-1 max) keep the natural order 64 + 32 (c - 2) + 8 g + jj.
+// w2p[c][ct][hi|lo][lane][8] = split(w2[16 ct + (lane & 15)][vfe_k2(c, lane >> 4, jj)] * 2^sw): A fragments of
+// v_mfma_f32_16x16x32_f16;  sc2[o] = scale2[o] * 2^-sw
+// w1p[ct][hi|lo][lane][4] = split(w1[16 ct + (lane & 15)][4 (lane >> 4) + jj] * 2^sw1) (zero for k >= F): A fragments of
 // v_mfma_f32_16x16x16_f16;  sc1[o] = scale1[o] * 2^-sw1
+__host__ __device__ constexpr int vfe_k2(int c, int g, int jj) {
+  return c < 2 ? 16 * (2 * c + (jj >> 2)) + 4 * g + (jj & 3) : 64 + 32 * (c - 2) + 8 * g + jj;
+}
 __global__ void vfe_prep_kernel(const float* __restrict__ w1, int F, const float* __restrict__ w2,
                                 const float* __restrict__ scale1, const float* __restrict__ scale2,
                                 uint2* __restrict__ w1p, float* __restrict__ sc1,
@@ -99,11 +117,11 @@ __global__ void vfe_prep_kernel(const float* __restrict__ w1, int F, const float
     f32x8 v;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
-      v[jj] = w2[(size_t)(16 * nt + (lane & 15)) * (2 * kC) + 32 * kc + 8 * (lane >> 4) + jj] * s;
+      v[jj] = w2[(size_t)(16 * nt + (lane & 15)) * (2 * kC) + vfe_k2(kc, lane >> 4, jj)] * s;
     uint4 hi, lo;
     vfe_split8(v, hi, lo);
-    w2p[(size_t)(kc * 4 + nt) * 128 + lane] = hi;
-    w2p[(size_t)(kc * 4 + nt) * 128 + 64 + lane] = lo;
+    w2p[(size_t)(kc * 4 + nt) * 128 + lane] = hi;        // = [(c * 4 + ct) * 2 + 0][lane]
+    w2p[(size_t)(kc * 4 + nt) * 128 + 64 + lane] = lo;   //   [(c * 4 + ct) * 2 + 1][lane]
   }
 }
 
@@ -124,6 +142,8 @@ __global__ __launch_bounds__(256) void vfe_count_kernel(const int32_t* __restric
     v = occ_lookup(bits, prefix, (((unsigned long long)c.x * D + c.y) * H + c.z) * W + c.w);
   pt2vox[i] = v;
   if (v >= 0) {
+    // (75 us at 1.2 M shuffled points, 43 of them this returning atomic: 28 G/s, the same at workgroup scope; the loads
+    // and stores around it take 30: profiles/r06_vfe.txt)
     const uint32_t s = atomicAdd(&cnt[v], 1u);
     slot[i] = (int32_t)s;
     if (s == 0) reinterpret_cast<int4*>(voxel_coors)[v] = c;  // exactly one point per voxel draws slot 0
@@ -156,23 +176,77 @@ __global__ __launch_bounds__(256) void vfe_order_kernel(const float* __restrict_
   o[1] = make_float4(r[4], r[5], r[6], r[7]);
 }
 
+// Per-voxel means of the sorted records, one wave per 64 records: exact 2^-24 fixed-point sums (order independent) by
+// a segmented scan over the wave's lanes; a voxel belongs to the wave that holds its FIRST record, which follows a run
+// that leaves its 64 records through the next waves' records until the voxel changes (the long runs are the few voxels
+// next to the sensor).  (Round 5: one thread per voxel walking its records -- 32-byte strides, a wave as slow as its
+// longest voxel: 45 us at 1.2 M points.)
 template <int CIN>
 __global__ __launch_bounds__(256) void vfe_mean_kernel(const float* __restrict__ recs,
                                                        const uint32_t* __restrict__ start, int N,
                                                        float4* __restrict__ mean4) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= N) return;
-  const uint32_t j0 = start[v], j1 = start[v + 1];
-  long long sx = 0, sy = 0, sz = 0;
-  for (uint32_t j = j0; j < j1; ++j) {
-    const float* p = recs + (size_t)j * kRec;
-    sx += __double2ll_rn((double)p[0] * kFix);
-    sy += __double2ll_rn((double)p[1] * kFix);
-    sz += __double2ll_rn((double)p[2] * kFix);
+  const int lane = threadIdx.x & 63;
+  const long long j0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const long long nv = start[N];   // number of in-range points = records
+  if (j0 >= nv) return;
+  auto load = [&](long long j, int& v, long long& sx, long long& sy, long long& sz) {
+    v = -1;
+    sx = sy = sz = 0;
+    if (j < nv) {
+      const float4 a = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
+      v = __float_as_int(recs[(size_t)j * kRec + kRec - 1]);
+      sx = __double2ll_rn((double)a.x * kFix);
+      sy = __double2ll_rn((double)a.y * kFix);
+      sz = __double2ll_rn((double)a.z * kFix);
+    }
+  };
+  auto write = [&](int v, long long sx, long long sy, long long sz) {
+    const uint32_t cnt = start[v + 1] - start[v];
+    const double d = kFix * (double)cnt;
+    mean4[v] = make_float4((float)((double)sx / d), (float)((double)sy / d), (float)((double)sz / d), (float)cnt);
+  };
+  int v;
+  long long sx, sy, sz;
+  load(j0 + lane, v, sx, sy, sz);
+  const int vprev = j0 > 0 ? __float_as_int(recs[(size_t)(j0 - 1) * kRec + kRec - 1]) : -1;
+  const int vnext = j0 + 64 < nv ? __float_as_int(recs[(size_t)(j0 + 64) * kRec + kRec - 1]) : -1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int ov = __shfl_up(v, d, 64);
+    const long long ox = __shfl_up(sx, d, 64), oy = __shfl_up(sy, d, 64), oz = __shfl_up(sz, d, 64);
+    if (lane >= d && ov == v) {
+      sx += ox;
+      sy += oy;
+      sz += oz;
+    }
   }
-  const double d = kFix * (double)(j1 - j0);
-  mean4[v] = make_float4((float)((double)sx / d), (float)((double)sy / d), (float)((double)sz / d),
-                         (float)(j1 - j0));
+  const int v0 = __builtin_amdgcn_readlane(v, 0), v63 = __builtin_amdgcn_readlane(v, 63);
+  const int vn = __shfl_down(v, 1, 64);
+  const bool end = v >= 0 && (lane == 63 || vn != v);
+  const bool owned = !(v == v0 && vprev == v0);          // the run began in this wave
+  const bool leaves = lane == 63 && v >= 0 && vnext == v;   // ... and goes on past it
+  if (end && owned && !leaves) write(v, sx, sy, sz);
+  // wave-uniform: the last run leaves the wave and is ours
+  const bool follow = v63 >= 0 && vnext == v63 && !(v63 == v0 && vprev == v0);
+  if (!follow) return;
+  long long tx = __shfl(sx, 63, 64), ty = __shfl(sy, 63, 64), tz = __shfl(sz, 63, 64);
+  for (long long j = j0 + 64; j < nv; j += 64) {
+    int w;
+    long long ax, ay, az;
+    load(j + lane, w, ax, ay, az);
+    if (w != v63) ax = ay = az = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      ax += __shfl_xor(ax, d, 64);
+      ay += __shfl_xor(ay, d, 64);
+      az += __shfl_xor(az, d, 64);
+    }
+    tx += ax;
+    ty += ay;
+    tz += az;
+    if (__builtin_amdgcn_readlane(w, 63) != v63) break;
+  }
+  if (lane == 0) write(v63, tx, ty, tz);
 }
 
 // ------------------------------------------------------------------------------------------ per-point math
@@ -190,79 +264,102 @@ __device__ __forceinline__ void vfe_point_features(const float* __restrict__ p, 
   f[CIN + 5] = __fsub_rn(p[2], __fadd_rn(__fmul_rn((float)c.y, g.vz), g.oz));
 }
 
-// Layer 1 on the matrix cores: the wave's 64 points x F (<= 16) features times W1^T [16 x 64] as 4 row groups x
-// 4 column tiles of v_mfma_f32_16x16x16_f16 in the same hi/lo split arithmetic as everywhere else (fp32-class).
-// The per-lane features go through a 4 KiB wave-private LDS staging area ([point][16 hi | 16 lo] halves) to reach
-// the A-fragment layout; the result stays in the C/D layout: acc[rg][nt][t] = sum for point 16 rg + 4 (lane>>4) + t,
-// channel 16 nt + (lane & 15), before BatchNorm.  (The VALU version cost 704 FMAs per point fed by 44 scalar
+// Layer 1 on the matrix cores, transposed: W1 [64 x 16] (A, 4 channel tiles) times the wave's features^T [16 x 64]
+// (B, 4 point groups of 16) as v_mfma_f32_16x16x16_f16 in the same hi/lo split arithmetic as everywhere else
+// (fp32-class).  The per-lane features go through a 4 KiB wave-private LDS staging area ([point][16 hi | 16 lo] halves)
+// to reach the B-fragment layout; the result stays in the C/D layout: c1[ct][t] = sum for channel 16 ct + 4 (lane >> 4)
+// + t of point 16 pg + (lane & 15), before BatchNorm.  (The VALU version cost 704 FMAs per point fed by 44 scalar
 // weight loads per wave.)
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 
 template <int F>
-__device__ __forceinline__ void vfe_layer1_mfma(const float (&f)[F], bool valid, const uint2* __restrict__ w1p,
-                                                char* __restrict__ stage, int lane, f32x4 (&acc)[4][4]) {
+__device__ __forceinline__ void vfe_stage_features(const float (&f)[F], bool valid, char* __restrict__ stage, int lane) {
   static_assert(F <= 16, "layer-1 features must fit one K = 16 MFMA");
-  {
-    _Float16 hi[16], lo[16];
+  uint32_t hi[8], lo[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float x = (k < F && valid) ? f[k < F ? k : 0] : 0.f;
-      hi[k] = (_Float16)x;
-      lo[k] = (_Float16)(x - (float)hi[k]);
-    }
-    uint4* sp = reinterpret_cast<uint4*>(stage + lane * 64);
-    sp[0] = *reinterpret_cast<const uint4*>(&hi[0]);
-    sp[1] = *reinterpret_cast<const uint4*>(&hi[8]);
-    sp[2] = *reinterpret_cast<const uint4*>(&lo[0]);
-    sp[3] = *reinterpret_cast<const uint4*>(&lo[8]);
+  for (int k = 0; k < 16; k += 2) {
+    const float x0 = (k < F && valid) ? f[k < F ? k : 0] : 0.f;
+    const float x1 = (k + 1 < F && valid) ? f[k + 1 < F ? k + 1 : 0] : 0.f;
+    if (k < F) vfe_split2(x0, x1, hi[k / 2], lo[k / 2]);
+    else hi[k / 2] = lo[k / 2] = 0u;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  const int col = lane & 15, kq = lane >> 4;
-  uint2 ah[4], al[4];
+  uint4* sp = reinterpret_cast<uint4*>(stage + lane * 64);
+  sp[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  sp[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+  sp[2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  sp[3] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+}
+
+struct VfeW1 {   // this lane's A fragments of W1, loaded once per wave
+  h4v hi[4], lo[4];
+  __device__ __forceinline__ void load(const uint2* __restrict__ w1p, int lane) {
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) {
-    const char* base = stage + (16 * rg + col) * 64 + kq * 8;
-    ah[rg] = *reinterpret_cast<const uint2*>(base);
-    al[rg] = *reinterpret_cast<const uint2*>(base + 32);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const uint2 bhu = w1p[(nt * 2 + 0) * 64 + lane];
-    const uint2 blu = w1p[(nt * 2 + 1) * 64 + lane];
-    const h4v bh = *reinterpret_cast<const h4v*>(&bhu);
-    const h4v bl = *reinterpret_cast<const h4v*>(&blu);
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const h4v a_h = *reinterpret_cast<const h4v*>(&ah[rg]);
-      const h4v a_l = *reinterpret_cast<const h4v*>(&al[rg]);
-      f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-      c = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l, bh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, bl, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h, bh, c, 0, 0, 0);
-      acc[rg][nt] = c;
+    for (int ct = 0; ct < 4; ++ct) {
+      const uint2 h = w1p[(ct * 2 + 0) * 64 + lane], l = w1p[(ct * 2 + 1) * 64 + lane];
+      hi[ct] = *reinterpret_cast<const h4v*>(&h);
+      lo[ct] = *reinterpret_cast<const h4v*>(&l);
     }
+  }
+};
+
+// point group pg of the staged wave: c1[ct] (4 channel tiles)
+__device__ __forceinline__ void vfe_layer1_group(const char* __restrict__ stage, int pg, int lane, const VfeW1& w,
+                                                 f32x4 (&c1)[4]) {
+  const char* base = stage + (16 * pg + (lane & 15)) * 64 + (lane >> 4) * 8;
+  const uint2 xh2 = *reinterpret_cast<const uint2*>(base), xl2 = *reinterpret_cast<const uint2*>(base + 32);
+  const h4v xh = *reinterpret_cast<const h4v*>(&xh2), xl = *reinterpret_cast<const h4v*>(&xl2);
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(w.hi[ct], xl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(w.lo[ct], xh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16f16(w.hi[ct], xh, c, 0, 0, 0);
+    c1[ct] = c;
   }
 }
 
-// C/D-layout layer-1 sums -> relu(BN) -> fp32 tile [point - 32 half][kLdsStride] for the points of row groups 2 half
-// and 2 half + 1.  The tiles hold HALF a wave's points (8.3 KiB per wave instead of 16.6): LDS is what bounds the
-// occupancy of the two VFE kernels (round 2: 8 waves per CU; now 18).
-static constexpr int kHalfPts = 32;
-__device__ __forceinline__ void vfe_layer1_store_tile(const f32x4 (&acc)[4][4], const float* __restrict__ sc1,
-                                                      const float* __restrict__ shift1, float* __restrict__ tile,
-                                                      int lane, int half) {
-  const int col = lane & 15, kq = lane >> 4;
+// channel tiles 2 c, 2 c + 1 only (layer 2 takes layer 1 a 32-channel chunk at a time)
+__device__ __forceinline__ void vfe_layer1_pair(const char* __restrict__ stage, int pg, int lane, const VfeW1& w, int c,
+                                                f32x4 (&c1)[2]) {
+  const char* base = stage + (16 * pg + (lane & 15)) * 64 + (lane >> 4) * 8;
+  const uint2 xh2 = *reinterpret_cast<const uint2*>(base), xl2 = *reinterpret_cast<const uint2*>(base + 32);
+  const h4v xh = *reinterpret_cast<const h4v*>(&xh2), xl = *reinterpret_cast<const h4v*>(&xl2);
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const float sc = sc1[16 * nt + col], sh = shift1[16 * nt + col];
-#pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        tile[(16 * r2 + 4 * kq + t) * kLdsStride + 16 * nt + col] =
-            fmaxf(fmaf(half ? acc[2 + r2][nt][t] : acc[r2][nt][t], sc, sh), 0.f);
+  for (int k = 0; k < 2; ++k) {
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    a = __builtin_amdgcn_mfma_f32_16x16x16f16(w.hi[2 * c + k], xl, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x16f16(w.lo[2 * c + k], xh, a, 0, 0, 0);
+    a = __builtin_amdgcn_mfma_f32_16x16x16f16(w.hi[2 * c + k], xh, a, 0, 0, 0);
+    c1[k] = a;
   }
+}
+
+// this lane's sixteen BatchNorm scales / shifts: channel 16 ct + 4 (lane >> 4) + t
+struct VfeBn {
+  float4 sc[4], sh[4];
+  __device__ __forceinline__ void load(const float* __restrict__ scale, const float* __restrict__ shift, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      sc[ct] = *reinterpret_cast<const float4*>(scale + 16 * ct + 4 * (lane >> 4));
+      sh[ct] = *reinterpret_cast<const float4*>(shift + 16 * ct + 4 * (lane >> 4));
+    }
+  }
+  __device__ __forceinline__ f32x4 relu(const f32x4 x, int ct) const {
+    return f32x4{fmaxf(fmaf(x[0], sc[ct].x, sh[ct].x), 0.f), fmaxf(fmaf(x[1], sc[ct].y, sh[ct].y), 0.f),
+                 fmaxf(fmaf(x[2], sc[ct].z, sh[ct].z), 0.f), fmaxf(fmaf(x[3], sc[ct].w, sh[ct].w), 0.f)};
+  }
+};
+
+// C/D-layout values of ONE point group -> fp32 tile [16 points][kTileStride]: this lane's four consecutive channels of a
+// tile go out as one ds_write_b128 (16 writes per wave and group; the [32][65] tile of round 5 took 64 conflicting
+// ds_write_b32 per half).  The segmented max reads it back channel per lane (consecutive words: conflict free).
+static constexpr int kTilePts = 16;
+static constexpr int kTileStride = kC + 4;                      // rows 16-byte aligned, 272 bytes apart
+static constexpr int kTileBytes = kTilePts * kTileStride * 4;   // 4352
+__device__ __forceinline__ void vfe_store_tile(const f32x4 (&a)[4], float* __restrict__ tile, int lane) {
+  float* row = tile + (lane & 15) * kTileStride + 4 * (lane >> 4);
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) *reinterpret_cast<f32x4*>(row + 16 * ct) = a[ct];
 }
 
 // Segmented per-voxel max over the 64 voxel-sorted points of one wave; lane = channel.  `val(p)` yields this lane's
@@ -272,57 +369,66 @@ __device__ __forceinline__ void vfe_layer1_store_tile(const f32x4 (&acc)[4][4], 
 // boundary -- or whose neighbour across the boundary belongs to another voxel (`vprev`, `vnext`: the voxel ids of
 // records j0-1 and j0+64) -- is written with one 256-byte row store; a run cut by the boundary uses integer
 // atomicMax on the zero-initialised destination (identical result for non-negative floats).
-// fill(half) puts the points [32 half, 32 half + 32) into the wave's tile before val() reads them (val(p): p in 0..63).
+// fill(pg) puts the points [16 pg, 16 pg + 16) into the wave's tile before val() reads them (val(p): p in 0..63).
 // split_dst != nullptr: whole rows go there in the SPLIT activation format of the sparse-conv kernels (isf_common.h:
 // per 32 channels 4 x 8 f16 hi then 4 x 8 f16 lo) instead of fp32 into dst -- lane = channel stores its two halves;
 // rows cut by a wave boundary still accumulate in dst (fp32 atomicMax) and are converted by vfe_cut_rows_split_kernel.
 __device__ __forceinline__ void vfe_store_split(_Float16* __restrict__ split_dst, int row, int lane, float m) {
-  const _Float16 hi = (_Float16)m;
-  const _Float16 lo = (_Float16)(m - (float)hi);
-  _Float16* p = split_dst + (size_t)row * (2 * kC) + (lane >> 5) * 64 + (lane & 31);
-  p[0] = hi;
-  p[32] = lo;
+  uint32_t hi, lo;   // low halves: f16(m), f16(m - hi)
+  asm("v_cvt_f16_f32 %0, %2\n\t"
+      "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]"
+      : "=&v"(hi), "=&v"(lo)
+      : "v"(m));
+  // (row: wave-uniform -> scalar base, 32-bit lane offset)
+  char* base = reinterpret_cast<char*>(split_dst + (size_t)row * (2 * kC));
+  unsigned short* p = reinterpret_cast<unsigned short*>(base + (uint32_t)(((lane >> 5) * 64 + (lane & 31)) * 2));
+  p[0] = (unsigned short)hi;
+  p[32] = (unsigned short)lo;
 }
 
+// The control flow is scalar: the run ends of the wave's 64 points are one 64-bit mask (ballot of "my voxel differs from
+// the next lane's"), bit p tested with a constant index inside the unrolled point loop -- one VALU max, one scalar test
+// and one branch per point (round 5 read every point's voxel id back with v_readlane and compared it twice).
 template <typename FillFn, typename ValFn>
 __device__ __forceinline__ void vfe_segmented_max(int myvox, int vprev, int vnext, int lane, float* __restrict__ dst,
                                                   FillFn fill, ValFn val, _Float16* __restrict__ split_dst = nullptr) {
-  int run = -1, first = 0;
+  const int nxt = __shfl_down(myvox, 1, 64);
+  // invalid points (voxel -1) only follow the last valid one: they never end a run and what they add to m is dropped
+  const unsigned long long ends = __ballot(myvox >= 0 && (lane == 63 || nxt != myvox));
+  const int v0 = __builtin_amdgcn_readlane(myvox, 0), v63 = __builtin_amdgcn_readlane(myvox, 63);
+  // runs cut by the wave's boundaries accumulate with atomicMax (on rows zeroed by vfe_zero_cut_rows_kernel)
+  unsigned long long cut = 0;
+  if (v0 >= 0 && vprev == v0) cut |= ends & (0ull - ends);   // the first run's end
+  if (v63 >= 0 && vnext == v63) cut |= 1ull << 63;
   float m = 0.f;
-  auto flush = [&](int last) {   // run covers points [first, last]
-    if (run < 0) return;
-    const bool whole = (first > 0 || vprev != run) && (last < 63 || vnext != run);
-    if (whole) {
-      if (split_dst) vfe_store_split(split_dst, run, lane, m);
-      else dst[(size_t)run * kC + lane] = m;
-    } else if (m > 0.f) {
-      atomicMax(reinterpret_cast<int*>(dst) + (size_t)run * kC + lane, __float_as_int(m));
-    }
-  };
 #pragma unroll
   for (int c = 0; c < 64; c += 16) {
-    if (c % kHalfPts == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous half has been read
-      fill(c / kHalfPts);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous group has been read
+    fill(c / kTilePts);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     float vals[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) vals[q] = val(c + q);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int v = __builtin_amdgcn_readlane(myvox, c + q);
-      if (v < 0) continue;   // past the last valid point (only at the very end of the sorted list)
-      if (v != run) {
-        flush(c + q - 1);
-        run = v;
-        first = c + q;
+      m = fmaxf(m, vals[q]);
+      if ((ends >> (c + q)) & 1ull) {   // wave-uniform
+        const int run = __builtin_amdgcn_readlane(myvox, c + q);
+        if ((cut >> (c + q)) & 1ull) {
+          if (m > 0.f) {
+            char* base = reinterpret_cast<char*>(dst + (size_t)run * kC);
+            atomicMax(reinterpret_cast<int*>(base + (uint32_t)(lane * 4)), __float_as_int(m));
+          }
+        } else if (split_dst) {
+          vfe_store_split(split_dst, run, lane, m);
+        } else {
+          char* base = reinterpret_cast<char*>(dst + (size_t)run * kC);
+          *reinterpret_cast<float*>(base + (uint32_t)(lane * 4)) = m;
+        }
         m = 0.f;
       }
-      m = fmaxf(m, vals[q]);
     }
   }
-  flush(63);
 }
 
 // The segmented max writes a voxel's row with ONE store when the voxel's run of records lies inside a wave, and with
@@ -365,174 +471,229 @@ __device__ __forceinline__ int vfe_record_voxel(const float* __restrict__ recs, 
   return (j >= 0 && j < (long long)n) ? __float_as_int(recs[(size_t)j * kRec + kRec - 1]) : -1;
 }
 
+// one sorted record per lane -> the staged layer-1 features of a wave's 64 points; returns the record's voxel id
+struct VfeRecord {
+  float4 a, b;   // {x, y, z, f3}, {f4, -, -, voxel id}
+  bool live;     // false past the last valid record
+  // Every load of the VFE kernels is UNCONDITIONAL (addresses clamped into the buffers, the voxel id patched afterwards):
+  // a load inside a divergent branch makes the compiler wait for all outstanding loads at the join (it cannot count
+  // them), which is exactly what the tile pipeline of layer 2 must not do.  What a dead lane computes from the clamped
+  // row never leaves its own matrix column, and the segmented max skips it.
+  __device__ __forceinline__ void load(const float* __restrict__ recs, uint32_t j, uint32_t n_valid) {
+    const uint32_t jc = j < n_valid ? j : n_valid - 1;
+    a = reinterpret_cast<const float4*>(recs + (size_t)jc * kRec)[0];
+    b = reinterpret_cast<const float4*>(recs + (size_t)jc * kRec)[1];
+    live = j < n_valid;
+  }
+  // (not evaluated inside load(): the first use of a loaded value is where the wave waits for it)
+  __device__ __forceinline__ int voxel() const { return live ? __float_as_int(b.w) : -1; }   // -1: no point
+  __device__ __forceinline__ int row() const { return __float_as_int(b.w); }   // always a row that exists
+};
+
+template <int CIN>
+__device__ __forceinline__ void vfe_stage_record(const VfeRecord& r, int4 c, float4 mean, VfeGeom g,
+                                                 char* __restrict__ stage, int lane) {
+  const float rec[kRec] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+  float f[CIN + 6];
+  vfe_point_features<CIN>(rec, c, mean, g, f);
+  vfe_stage_features<CIN + 6>(f, r.voxel() >= 0, stage, lane);
+}
+
 template <int CIN>
 __global__ __launch_bounds__(kL1Threads) void vfe_layer1_kernel(
     const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
     const float4* __restrict__ mean4, VfeGeom g, const uint2* __restrict__ w1p, const float* __restrict__ sc1,
     const float* __restrict__ shift1, float* __restrict__ vmax1) {
-  __shared__ __attribute__((aligned(16))) float tile[(kL1Threads / 64) * kHalfPts * kLdsStride];
+  __shared__ __attribute__((aligned(16))) char smem[(kL1Threads / 64) * (4096 + kTileBytes)];
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const long long wj0 = (long long)blockIdx.x * kL1Threads + wave * 64;
   const uint32_t nv = (uint32_t)*n_valid;
-  if (wj0 >= (long long)nv) return;   // wave-uniform; the tile is wave-private, no block barrier below
+  if (wj0 >= (long long)nv) return;   // wave-uniform; the LDS areas are wave-private, no block barrier below
   const uint32_t j = (uint32_t)wj0 + lane;
-  int v = -1;
-  float f[CIN + 6];
-#pragma unroll
-  for (int k = 0; k < CIN + 6; ++k) f[k] = 0.f;
-  if (j < nv) {
-    float rec[kRec];
-    *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
-    *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
-    v = __float_as_int(rec[kRec - 1]);
-    vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
-  }
-  float* wt = tile + wave * kHalfPts * kLdsStride;   // >= the 4 KiB layer-1 staging area
-  f32x4 acc[4][4];
-  vfe_layer1_mfma<CIN + 6>(f, v >= 0, w1p, reinterpret_cast<char*>(wt), lane, acc);
+  char* stage = smem + wave * (4096 + kTileBytes);
+  float* wt = reinterpret_cast<float*>(stage + 4096);
+  VfeRecord r;
+  r.load(recs, j, nv);
+  const int v = r.voxel();
+  const int4 c = reinterpret_cast<const int4*>(voxel_coors)[r.row()];
+  const float4 m = mean4[r.row()];
+  VfeW1 w1;
+  w1.load(w1p, lane);
+  VfeBn bn;
+  bn.load(sc1, shift1, lane);
+  vfe_stage_record<CIN>(r, c, m, g, stage, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   vfe_segmented_max(v, vfe_record_voxel(recs, wj0 - 1, nv), vfe_record_voxel(recs, wj0 + 64, nv), lane, vmax1,
-                    [&](int half) { vfe_layer1_store_tile(acc, sc1, shift1, wt, lane, half); },
-                    [&](int p) { return wt[(p % kHalfPts) * kLdsStride + lane]; });
+                    [&](int pg) {   // layer 1 of one point group, just in time: sixteen live sums instead of sixty-four
+                      f32x4 h1[4];
+                      vfe_layer1_group(stage, pg, lane, w1, h1);
+#pragma unroll
+                      for (int ct = 0; ct < 4; ++ct) h1[ct] = bn.relu(h1[ct], ct);
+                      vfe_store_tile(h1, wt, lane);
+                    },
+                    [&](int p) { return wt[(p % kTilePts) * kTileStride + lane]; });
 }
 
 // ------------------------------------------------------------------------------------------ layer 2 (MFMA)
-// One wave = 64 sorted points = 4 MFMA row groups; K = 128 = [h1 (64) | vmax1[voxel] (64)] in two halves.
-// LDS per wave, 8.3 KiB: the A tile of ONE 32-channel chunk, split format [unit 4][hi|lo][point 64][8 halves] = 8 KiB
-// (conflict free for both the point-per-lane writes and the ds_read_b128 fragment reads; the four chunks of K = 128 go
-// through it one after the other, each with its B fragments loaded once), reused as the fp32 [32 points][65] tiles of
-// the layer-1 hand-over and of the output (two point halves each).
-static constexpr int kL2Waves = 2;
-static constexpr int kL2WaveBytes = kHalfPts * kLdsStride * 4;  // 8320 >= 8192
+// One wave = 64 sorted points = 4 point groups; K = 128 = [h1 (64) | vmax1[voxel] (64)] in four 32-channel chunks.
+// Layer 1 is recomputed (its [P, 64] output never goes to HBM) and handed to layer 2 in registers (see vfe_k2).
+// Workgroups are persistent (two per CU): W2's 32 KiB of A fragments sit in LDS, loaded once, and every wave walks
+// over its share of the 64-point tiles with the loads of the NEXT tile in flight: its records are requested at the top
+// of a tile, its voxel coordinates / means after the first two chunks, its features are staged before the segmented
+// max; the voxel-max rows of chunk 2 are requested before layer 1, those of chunk 3 before chunk 2 multiplies.  (At
+// two waves per SIMD nothing else hides a load: with every load waited for where it was issued the parts of a tile
+// simply added up -- records 21 us, voxel-max rows 17, layer 1 12, layer 2 24, tile + segmented max 41 of 126 us at
+// 1.2 M points: profiles/r06_vfe.txt.)  LDS per wave: staging area 4 KiB, one [16][68] fp32 tile for the segmented
+// max, the wave's 64 voxel ids.
+// (Round 5's version turned the layer-1 output into one point per lane -- 64 + 64 registers of rows, 128 ds_reads, four
+// 8-KiB trips through an A tile: 204 registers, 181 us.)
+static constexpr int kL2Waves = 4;
+static constexpr int kL2WaveBytes = 4096 + kTileBytes + 256;    // 8704
+static constexpr int kL2W2Bytes = 4 * 4 * 2 * 64 * 16;          // 32768
+static constexpr int kL2Lds = kL2W2Bytes + kL2Waves * kL2WaveBytes;
 
 template <int CIN>
-__global__ __launch_bounds__(64 * kL2Waves) void vfe_layer2_kernel(
+__global__ __launch_bounds__(64 * kL2Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) void vfe_layer2_kernel(
     const float* __restrict__ recs, const int32_t* __restrict__ voxel_coors, const int* __restrict__ n_valid,
     const float4* __restrict__ mean4, VfeGeom g, const uint2* __restrict__ w1p, const float* __restrict__ sc1,
     const float* __restrict__ shift1, const float* __restrict__ vmax1, const uint4* __restrict__ w2p,
     const float* __restrict__ sc2, const float* __restrict__ shift2, float* __restrict__ out,
     _Float16* __restrict__ out_split) {
-  __shared__ __attribute__((aligned(16))) char smem[kL2Waves * kL2WaveBytes];
-  __shared__ int vox_s[kL2Waves * 64];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t j0 = (blockIdx.x * kL2Waves + wave) * 64;
+  uint4* w2s = reinterpret_cast<uint4*>(smem);   // [(c * 4 + ct) * 2 + hi|lo][lane]
+  for (int i = threadIdx.x; i < kL2W2Bytes / 16; i += 64 * kL2Waves) w2s[i] = w2p[i];
+  __syncthreads();   // the only block barrier; everything below is wave-private
+  char* stage = smem + kL2W2Bytes + wave * kL2WaveBytes;
+  float* ftile = reinterpret_cast<float*>(stage + 4096);   // [16][68]
+  int* vox = reinterpret_cast<int*>(stage + 4096 + kTileBytes);
+  const int n = lane & 15, kg = lane >> 4;
   const uint32_t nv = (uint32_t)*n_valid;
-  if (j0 >= nv) return;  // wave-uniform; no block-level barrier below
-  uint4* atile = reinterpret_cast<uint4*>(smem + wave * kL2WaveBytes);  // [unit][hi|lo][pt] uint4
-  float* ftile = reinterpret_cast<float*>(smem + wave * kL2WaveBytes);  // [pt][65]
-  int* vox = vox_s + wave * 64;
-  const int col = lane & 15, kg = lane >> 4;
-
-  const uint32_t j = j0 + lane;
-  int v = -1;
-  float h[kC];
-  {
-    float f[CIN + 6];
-#pragma unroll
-    for (int k = 0; k < CIN + 6; ++k) f[k] = 0.f;
-    if (j < nv) {
-      float rec[kRec];
-      *reinterpret_cast<float4*>(rec) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[0];
-      *reinterpret_cast<float4*>(rec + 4) = reinterpret_cast<const float4*>(recs + (size_t)j * kRec)[1];
-      v = __float_as_int(rec[kRec - 1]);
-      vfe_point_features<CIN>(rec, reinterpret_cast<const int4*>(voxel_coors)[v], mean4[v], g, f);
-    }
-    // layer 1 recomputed on the matrix cores (its output [P, 64] never goes to HBM), through the fp32 tile (32 points
-    // at a time) back to one-point-per-lane registers for the split-format A tile of layer 2
-    f32x4 acc1[4][4];
-    vfe_layer1_mfma<CIN + 6>(f, v >= 0, w1p, reinterpret_cast<char*>(ftile), lane, acc1);
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      vfe_layer1_store_tile(acc1, sc1, shift1, ftile, lane, half);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      if ((lane >> 5) == half) {
-#pragma unroll
-        for (int o = 0; o < kC; ++o) h[o] = ftile[(lane & 31) * kLdsStride + o];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
-  }
-  vox[lane] = v;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // chunk q of K = 128 (q = 2 * half + kc: 32 channels of x, this lane's point) -> A tile -> 48 MFMAs
-  auto chunk = [&](const float (&x)[kC], int half, int kc) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f32x8 vv;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) vv[q] = x[(4 * kc + u) * 8 + q];
-      uint4 hi, lo;
-      vfe_split8(vv, hi, lo);
-      atile[(u * 2 + 0) * 64 + lane] = hi;
-      atile[(u * 2 + 1) * 64 + lane] = lo;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    uint4 ah[4], al[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      ah[rg] = atile[(kg * 2 + 0) * 64 + rg * 16 + col];
-      al[rg] = atile[(kg * 2 + 1) * 64 + rg * 16 + col];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the tile may be overwritten by the next chunk
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const uint4 bhu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + lane];
-      const uint4 blu = w2p[(size_t)((half * 2 + kc) * 4 + nt) * 128 + 64 + lane];
-      const h8 bh = *reinterpret_cast<const h8*>(&bhu);
-      const h8 bl = *reinterpret_cast<const h8*>(&blu);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const h8 a_h = *reinterpret_cast<const h8*>(&ah[rg]);
-        const h8 a_l = *reinterpret_cast<const h8*>(&al[rg]);
-        acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, bh, acc[rg][nt], 0, 0, 0);
-        acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bl, acc[rg][nt], 0, 0, 0);
-        acc[rg][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, bh, acc[rg][nt], 0, 0, 0);
-      }
-    }
-  };
-
-  // half 0: h1
-  chunk(h, 0, 0);
-  chunk(h, 0, 1);
-  // half 1: the voxel's layer-1 max (map_voxel_center_to_point gather, voxel_encoder.py:541-544)
-  {
-    float r[kC];
-    if (v >= 0) {
-      const float4* src = reinterpret_cast<const float4*>(vmax1 + (size_t)v * kC);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float4 t4 = src[q];
-        r[4 * q + 0] = t4.x; r[4 * q + 1] = t4.y; r[4 * q + 2] = t4.z; r[4 * q + 3] = t4.w;
-      }
-    } else {
-#pragma unroll
-      for (int o = 0; o < kC; ++o) r[o] = 0.f;
-    }
-    chunk(r, 1, 0);
-    chunk(r, 1, 1);
-  }
-  // accumulators (col = lane&15 -> channel, row = 4*(lane>>4)+t -> point) -> fp32 tile [pt - 32 half][65], half by half
+  const uint32_t stride = gridDim.x * kL2Waves * 64;
+  uint32_t j0 = (blockIdx.x * kL2Waves + wave) * 64;
+  if (j0 >= nv) return;
+  VfeW1 w1;
+  w1.load(w1p, lane);
+  VfeBn bn;
+  bn.load(sc1, shift1, lane);
   const float sc = sc2[lane], sh = shift2[lane];
-  vfe_segmented_max(vox[lane], vfe_record_voxel(recs, (long long)j0 - 1, nv),
-                    vfe_record_voxel(recs, (long long)j0 + 64, nv), lane, out,
-                    [&](int half) {
+
+  int v;
+  {   // prologue: the first tile's records, staged
+    VfeRecord r;
+    r.load(recs, j0 + lane, nv);
+    v = r.voxel();
+    const int4 c = reinterpret_cast<const int4*>(voxel_coors)[r.row()];
+    const float4 m = mean4[r.row()];
+    vfe_stage_record<CIN>(r, c, m, g, stage, lane);
+  }
+
+  for (;;) {
+    const uint32_t jn = j0 + stride;
+    const bool more = jn < nv;   // wave-uniform
+    VfeRecord rn;
+    rn.load(recs, jn + lane, nv);   // (1) the next tile's records (the last tile re-reads the last record)
+    vox[lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int vp[4];
 #pragma unroll
-                      for (int r2 = 0; r2 < 2; ++r2)
+    for (int pg = 0; pg < 4; ++pg) vp[pg] = vox[16 * pg + n];
+    // the voxel's layer-1 max (map_voxel_center_to_point gather, voxel_encoder.py:541-544): this lane's eight channels
+    // 32 c + 8 kg .. + 8 of the row of point 16 pg + n's voxel
+    auto vmax_rows = [&](int c, f32x8 (&r)[4]) {
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
+      for (int pg = 0; pg < 4; ++pg) {
+        const float4* src = reinterpret_cast<const float4*>(vmax1 + (size_t)(vp[pg] < 0 ? 0 : vp[pg]) * kC + 32 * c + 8 * kg);
+        const float4 r0 = src[0], r1 = src[1];
+        r[pg] = f32x8{r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      }
+    };
+    f32x8 vm2[4];
+    vmax_rows(0, vm2);   // (2) requested before layer 1
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[4][4];   // [point group][channel tile]
 #pragma unroll
-                          for (int t = 0; t < 4; ++t)
-                            ftile[(r2 * 16 + 4 * kg + t) * kLdsStride + nt * 16 + col] =
-                                half ? acc[2 + r2][nt][t] : acc[r2][nt][t];
-                    },
-                    [&](int p) { return fmaxf(fmaf(ftile[(p % kHalfPts) * kLdsStride + lane], sc, sh), 0.f); }, out_split);
+    for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto chunk = [&](int c, const uint4 (&bh)[4], const uint4 (&bl)[4]) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const uint4 ahu = w2s[((c * 4 + ct) * 2 + 0) * 64 + lane];
+        const uint4 alu = w2s[((c * 4 + ct) * 2 + 1) * 64 + lane];
+        const h8 a_h = *reinterpret_cast<const h8*>(&ahu);
+        const h8 a_l = *reinterpret_cast<const h8*>(&alu);
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+          const h8 b_h = *reinterpret_cast<const h8*>(&bh[pg]);
+          const h8 b_l = *reinterpret_cast<const h8*>(&bl[pg]);
+          acc[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_l, acc[pg][ct], 0, 0, 0);
+          acc[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l, b_h, acc[pg][ct], 0, 0, 0);
+          acc[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h, b_h, acc[pg][ct], 0, 0, 0);
+        }
+      }
+    };
+    // chunks 0, 1: layer 1's channel tiles 2 c, 2 c + 1 of every point group -> B fragments -> 48 MFMAs
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 bh[4], bl[4];
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) {
+        f32x4 c1[2];
+        vfe_layer1_pair(stage, pg, lane, w1, c, c1);
+        const f32x4 a = bn.relu(c1[0], 2 * c), b = bn.relu(c1[1], 2 * c + 1);
+        vfe_split8(f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}, bh[pg], bl[pg]);
+      }
+      chunk(c, bh, bl);
+    }
+    // (3) the next tile's voxel coordinates and means (its records have arrived under the multiplies above)
+    __builtin_amdgcn_sched_barrier(0);
+    int vrow = rn.row();
+    asm volatile("" : "+v"(vrow));   // the wait for the records belongs here, not where the compiler would extend the index
+    const int vn = rn.live ? vrow : -1;
+    const int4 cn = reinterpret_cast<const int4*>(voxel_coors)[vrow];
+    const float4 mn = mean4[vrow];
+    {
+      f32x8 vm3[4];
+      vmax_rows(1, vm3);   // (4) requested before chunk 2 multiplies
+      __builtin_amdgcn_sched_barrier(0);
+      uint4 bh[4], bl[4];
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) vfe_split8(vm2[pg], bh[pg], bl[pg]);
+      chunk(2, bh, bl);
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) vfe_split8(vm3[pg], bh[pg], bl[pg]);
+      chunk(3, bh, bl);
+    }
+    // (5) the next tile's features into the staging area (layer 1 of this tile has read it)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" : "+v"(rn.a.x), "+v"(rn.a.y), "+v"(rn.a.z), "+v"(rn.a.w), "+v"(rn.b.x));   // (nothing of it earlier)
+    vfe_stage_record<CIN>(rn, cn, mn, g, stage, lane);
+
+    // accumulators (lane (n, kg): channels 16 ct + 4 kg + t of point 16 pg + n) -> fp32 tile, one point group at a
+    // time; BatchNorm + ReLU where the segmented max reads them back channel per lane
+    vfe_segmented_max(v, vfe_record_voxel(recs, (long long)j0 - 1, nv), vfe_record_voxel(recs, (long long)j0 + 64, nv),
+                      lane, out,
+                      [&](int pg) {
+                        switch (pg) {   // constant after unrolling
+                          case 0: vfe_store_tile(acc[0], ftile, lane); break;
+                          case 1: vfe_store_tile(acc[1], ftile, lane); break;
+                          case 2: vfe_store_tile(acc[2], ftile, lane); break;
+                          default: vfe_store_tile(acc[3], ftile, lane); break;
+                        }
+                      },
+                      [&](int p) { return fmaxf(fmaf(ftile[(p % kTilePts) * kTileStride + lane], sc, sh), 0.f); },
+                      out_split);
+    if (!more) break;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    v = vn;
+    j0 = jn;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -595,7 +756,7 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(scan_u32_exclusive(a, cnt, start, (size_t)N, st));  // start[N] = number of in-range points
   hipLaunchKernelGGL(vfe_order_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, pt2vox, slot, P, start,
                      recs);
-  hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(N, 256)), dim3(256), 0, st, recs, start, N, mean4);
+  hipLaunchKernelGGL(vfe_mean_kernel<CIN>, dim3(ceil_div(P, 256)), dim3(256), 0, st, recs, start, N, mean4);
   const int* n_valid = reinterpret_cast<const int*>(start + N);
   // rows of the voxels cut by a 64-record boundary start from zero (atomicMax), every other row is stored whole
   static_assert(kRec == 8 && kC == 64, "vfe_zero_cut_rows_kernel indexes records / rows with these sizes");
@@ -603,9 +764,18 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
                      voxel_feats);
   hipLaunchKernelGGL(vfe_layer1_kernel<CIN>, dim3(ceil_div(P, kL1Threads)), dim3(kL1Threads), 0, st, recs,
                      voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1);
-  hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(ceil_div(P, 64 * kL2Waves)), dim3(64 * kL2Waves), 0, st, recs,
-                     voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1, w2p, sc2, shift2, voxel_feats,
-                     reinterpret_cast<_Float16*>(voxel_feats_split));
+  {
+    static bool lds_set[2] = {false, false};   // per instantiation; the attribute is idempotent, a race is harmless
+    if (!lds_set[CIN - 4]) {
+      ISF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&vfe_layer2_kernel<CIN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kL2Lds));
+      lds_set[CIN - 4] = true;
+    }
+    const int tiles = ceil_div(P, 64 * kL2Waves);
+    hipLaunchKernelGGL(vfe_layer2_kernel<CIN>, dim3(tiles < 512 ? tiles : 512), dim3(64 * kL2Waves), kL2Lds, st, recs,
+                       voxel_coors, n_valid, mean4, g, w1p, sc1, shift1, vmax1, w2p, sc2, shift2, voxel_feats,
+                       reinterpret_cast<_Float16*>(voxel_feats_split));
+  }
   if (voxel_feats_split)
     hipLaunchKernelGGL(vfe_cut_rows_split_kernel, dim3(ceil_div(ceil_div(P, 64), 4)), dim3(256), 0, st, recs, n_valid,
                        voxel_feats, reinterpret_cast<_Float16*>(voxel_feats_split));

@@ -168,6 +168,38 @@ def test_dynamic_vfe_fused_vs_oracle(dev, oracle_mod):
     assert np.abs(ovf).max() > 0.5
 
 
+def test_dynamic_vfe_voxels_longer_than_a_wave(dev, oracle_mod):
+    """Voxels of 1 ... 700 points: the runs of the voxel-sorted records cross one, two, ten 64-record boundaries -- the
+    cut-row accumulation of the layer kernels and the follow-the-run path of the mean kernel (isf_vfe.hip), and runs that
+    end exactly on a boundary."""
+    import isfusion_amd as m
+    from isfusion_amd.norm import fold_bn
+    rng = np.random.default_rng(7)
+    lb = m.LidarBranch().randomize_weights_(5).randomize_bn_(6).eval()
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 700, 3, 64, 64, 1, 191, 320]
+    pts = []
+    for k, n in enumerate(sizes):   # one voxel each: cell (10 + 3k, 20 + k, 4 + k % 5) of the (x, y, z) grid
+        lo = np.array([RG[0] + (10 + 3 * k) * VS[0], RG[1] + (20 + k) * VS[1], RG[2] + (4 + k % 5) * VS[2]])
+        p = np.concatenate([lo + rng.uniform(0.05, 0.95, (n, 3)) * np.array(VS), rng.random((n, 2))], 1)
+        pts.append(p)
+    pts = np.concatenate(pts).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    coors = np.concatenate([np.zeros((len(pts), 1), np.int32), oracle_mod.dynamic_voxelize(pts, VS, RG)], 1)
+    assert len(np.unique(coors, axis=0)) == len(sizes)
+    vfe = lb.pts_voxel_encoder
+    bn1 = [t.numpy() for t in fold_bn(vfe.vfe_layers[0].norm)]
+    bn2 = [t.numpy() for t in fold_bn(vfe.vfe_layers[1].norm)]
+    ovf, ovc, _ = oracle_mod.dynamic_vfe(pts, coors, VS, RG, vfe.vfe_layers[0].linear.weight.detach().numpy(), bn1,
+                                         vfe.vfe_layers[1].linear.weight.detach().numpy(), bn2)
+    lb = lb.to(dev)
+    vf, vc = lb.pts_voxel_encoder(T(pts, dev), T(coors, dev))
+    assert np.array_equal(vc.cpu().numpy(), ovc)
+    err = np.abs(vf.cpu().numpy() - ovf).max()
+    assert err < 1e-4, err
+    vf2, _ = lb.pts_voxel_encoder(T(pts, dev), T(coors, dev))   # order independent => run to run identical
+    assert torch.equal(vf, vf2)
+
+
 def test_dynamic_vfe_composed_path_matches_fused(dev, oracle_mod):
     lb, pl, pts, coors, ovf, ovc, _ = _vfe_case(oracle_mod, dev, P=8000, B=2, seed=3)
     vfe = lb.pts_voxel_encoder
