@@ -625,6 +625,42 @@ int isf_decode_boxes(const float* heatmap, const float* query_score, const int64
                      int num_classes, int num_proposals, int ld, const float* coder, float* boxes, float* scores,
                      int32_t* labels, int32_t* counts, isf_stream_t stream);
 
+/* 8f #1  proposal initialisation / prediction outputs of the detection head ------------------------------------
+ * isf_head_query_init replaces the tensor ops of TransFusionHeadV2.forward_single between the top-k and the first
+ *   decoder layer (dense_heads/transfusion_head_v2.py:806-842): query_labels = top // HW, query_pos = bev_pos[top % HW],
+ *   query = feature column + class_encoding(one_hot(label)), the first layer's self_posembed(query_pos) as a row of a
+ *   per-cell table, query + position, and query_heatmap_score = heatmap.gather(top % HW) (:888-890).
+ *   top_index / top_raw [B, P] int32 as isf_instance_topk writes them; feat_tok [B*HW, E] token-major;
+ *   tok_of_cell [HW] int64 (BEV cell -> token row inside a sample) or NULL = identity; class_table [classes, E] =
+ *   class_encoding.weight[:, c] + bias; qpe_table [HW, E] or NULL (then qpe / x are not written); bev_pos [HW, 2];
+ *   masked [B, classes * HW] = the suppressed heat-map.  Outputs: query / qpe / x [B*P, E], query_pos [B, P, 2],
+ *   top_index64 / query_labels [B, P] int64, query_score [B, classes, P].
+ * isf_head_scatter_predictions replaces the per-output transposes of FFN.forward's results (:505-590), `center +=
+ *   query_pos` (:883) and `query_pos = center.detach().clone()` (:885): output h = columns [col0[h], col0[h] +
+ *   channels[h]) of the token-major block src[h] [B*P, src_ld[h]] -> dst[h] [B, channels[h], P]; center_head (or -1)
+ *   gets query_pos [B, P, 2] added and is copied to query_pos_next [B, P, 2] (or NULL).  The four arrays and src / dst
+ *   are HOST arrays of num_heads (<= 8) entries.  Both asynchronous. */
+int isf_head_query_init(const int32_t* top_index, const int32_t* top_raw, int batch_size, int num_proposals, int hw,
+                        int embed, int num_classes, const float* feat_tok, const int64_t* tok_of_cell,
+                        const float* class_table, const float* qpe_table, const float* bev_pos, const float* masked,
+                        float* query, float* qpe, float* x, float* query_pos, int64_t* top_index64,
+                        int64_t* query_labels, float* query_score, isf_stream_t stream);
+int isf_head_scatter_predictions(int num_heads, const float* const* src, const int* src_ld, const int* col0,
+                                 const int* channels, float* const* dst, int center_head, const float* query_pos,
+                                 float* query_pos_next, int batch_size, int num_proposals, isf_stream_t stream);
+
+/* A12/A13  the mined instances' features and positions ---------------------------------------------------------
+ * replaces the tensor ops of ISFusionEncoder.instance_fusion after the top-k (middle_encoders/fusion_encoder.py:
+ *   1133-1141: x_ins = x_scene.gather(top), query_pos = bev_pos.gather(top)) and InsContextAtt.forward's preamble
+ *   (:800-812: positions / bev_size, query_pos_embed, features + embedding).
+ * top [B, Q] int32: flat cells y'*S + x' of the TRANSPOSED map (isf_instance_topk on the transposed heat-map);
+ * scene [B, E, S, S] in the un-transposed orientation (cell x'*S + y'); qpe_table [S*S, E] = query_pos_embed of every
+ * create_2D_grid cell.  Outputs: top64 / cell64 [B, Q] int64 (the transposed / un-transposed cell), tokens, qpe,
+ * tokens_pos = tokens + qpe [B*Q, E], query_pos [B, Q, 2] = (x' + .5, y' + .5), ref = query_pos / S.  Asynchronous. */
+int isf_instance_gather(const int32_t* top, int batch_size, int num_instances, int bev_size, int embed,
+                        const float* scene, const float* qpe_table, int64_t* top64, int64_t* cell64, float* tokens,
+                        float* qpe, float* tokens_pos, float* query_pos, float* ref, isf_stream_t stream);
+
 /* 8f #2  sparse convolution backward ------------------------------------------------------------------------
  * replaces sparse_conv_ext.indice_conv_backward_fp32(features, filters, out_bp, indice_pairs, indice_num, inverse,
  *   subm) -> [input_bp, filters_bp]   (spconv_ops.h:363-456; SparseConvFunction.backward, functional.py:38-52).

@@ -116,15 +116,13 @@ class ISFusionEncoder(nn.Module):
             hm = self.heatmap_head_3(self.heatmap_head_2(self.heatmap_head_1(self.conv_heatmap(out))))
             x_scene_t = self.conv_scene(out).permute(0, 1, 3, 2).contiguous()
             q = self.conv_ins(bev_feats)
-        top_idx = ops.instance_topk(hm, self.instance_num, self.nms_kernel_size,
-                                    (8, 9) if self.num_views == 6 else (1, 2))
-        self.last_top_idx = top_idx   # [B, instance_num] flat cell (of the transposed map) of every mined instance
-        # cell n' = y'*S + x' of the transposed map is cell x'*S + y' of the un-transposed one
-        idx_t = (top_idx % S) * S + torch.div(top_idx, S, rounding_mode="floor")
-        x_ins, _ = ops.gather_instances(x_scene_t, idx_t, S)
-        _, query_pos = ops.gather_instances(x_scene_t, top_idx, S)
-        # query_pos = (x' + .5, y' + .5) of cell top_idx = y'*S + x' = create_2D_grid cell x'*S + y' = idx_t
-        x_ins = ops.ins_context_att(self.instance_att, x_ins, query_pos, x_scene_t, S, query_cells=idx_t)
+        top32, _, _ = ops.instance_topk(hm, self.instance_num, self.nms_kernel_size,
+                                        (8, 9) if self.num_views == 6 else (1, 2), as_int32=True)
+        # cell n' = y'*S + x' of the transposed map is cell x'*S + y' of the un-transposed one; query_pos = (x' + .5,
+        # y' + .5) = create_2D_grid's position of that cell: features, positions, position embedding in one launch
+        mined = ops.mined_instances(self.instance_att, top32, x_scene_t, S)
+        self.last_top_idx = mined["top"]   # [B, instance_num] flat cell (of the transposed map) of every mined instance
+        x_ins = ops.ins_context_att(self.instance_att, None, None, x_scene_t, S, mined=mined)
         ret = ops.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, S)
         return ret, hm
 

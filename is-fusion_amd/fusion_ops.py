@@ -351,8 +351,10 @@ def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, i
 
 
 # ----------------------------------------------------------------------------------------------------- A12
-def instance_topk(heatmap, k=200, nms_kernel=3, pool1_classes=(8, 9), return_masked=False):
-    """fusion_encoder.py:1100-1131 -> top index % (H*W) [B, k] int64 (and the suppressed map when asked)."""
+def instance_topk(heatmap, k=200, nms_kernel=3, pool1_classes=(8, 9), return_masked=False, as_int32=False):
+    """fusion_encoder.py:1100-1131 -> top index % (H*W) [B, k] int64 (and the suppressed map when asked).
+    as_int32: -> (top, raw, masked | None) with the kernel's own int32 index tensors (what isf_instance_gather /
+    isf_head_query_init take), no conversion launches."""
     _lib.require_cuda(heatmap)
     assert nms_kernel == 3
     hm = heatmap.float().contiguous()
@@ -366,9 +368,59 @@ def instance_topk(heatmap, k=200, nms_kernel=3, pool1_classes=(8, 9), return_mas
     _lib.check(_lib.load().isf_instance_topk(_lib.ptr(hm), B, K, H, W, k, mask, _lib.ptr(top), _lib.ptr(raw),
                                              _lib.ptr(masked) if masked is not None else None, _lib.stream()),
                "isf_instance_topk")
+    if as_int32:
+        return top, raw, masked
     if return_masked:
         return top.long(), raw.long(), masked
     return top.long()
+
+
+def head_query_init(top_index, top_raw, feat_tok, tok_of_cell, class_table, qpe_table, bev_pos, masked, num_classes):
+    """TransFusionHeadV2.forward_single between the top-k and the first decoder layer in one launch
+    (transfusion_head_v2.py:806-842, :888-890; isf_head_query_init).  top_index / top_raw [B, P] int32 ->
+    query, qpe, x = query + qpe [B*P, E], query_pos [B, P, 2], top_index / query_labels [B, P] int64,
+    query_heatmap_score [B, classes, P]."""
+    _lib.require_cuda(feat_tok)
+    B, P = top_index.shape
+    E = feat_tok.shape[1]
+    HW = bev_pos.shape[-2]
+    dev = feat_tok.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    query, qpe, x = (torch.empty((B * P, E), **f32) for _ in range(3))
+    query_pos = torch.empty((B, P, 2), **f32)
+    top64 = torch.empty((B, P), dtype=torch.int64, device=dev)
+    labels = torch.empty((B, P), dtype=torch.int64, device=dev)
+    score = torch.empty((B, num_classes, P), **f32)
+    assert feat_tok.is_contiguous() and class_table.is_contiguous() and masked.is_contiguous() and bev_pos.is_contiguous()
+    assert qpe_table is None or qpe_table.is_contiguous()
+    _lib.check(_lib.load().isf_head_query_init(
+        _lib.ptr(top_index), _lib.ptr(top_raw), B, P, HW, E, num_classes, _lib.ptr(feat_tok),
+        _lib.ptr(tok_of_cell) if tok_of_cell is not None else None, _lib.ptr(class_table),
+        _lib.ptr(qpe_table) if qpe_table is not None else None, _lib.ptr(bev_pos), _lib.ptr(masked), _lib.ptr(query),
+        _lib.ptr(qpe), _lib.ptr(x), _lib.ptr(query_pos), _lib.ptr(top64), _lib.ptr(labels), _lib.ptr(score), _lib.stream()),
+        "isf_head_query_init")
+    return query, qpe, x, query_pos, top64, labels, score
+
+
+def head_scatter_predictions(blocks, B, P, query_pos):
+    """blocks: [(name, src [B*P, ld] fp32, col0, channels)] -> {name: [B, channels, P]} with `center` offset by
+    query_pos [B, P, 2], and the new query positions [B, P, 2] (transfusion_head_v2.py:883-885;
+    isf_head_scatter_predictions): one launch for every output of a decoder layer."""
+    n = len(blocks)
+    dev = blocks[0][1].device
+    out = {name: torch.empty((B, ch, P), dtype=torch.float32, device=dev) for name, _, _, ch in blocks}
+    center = [i for i, b in enumerate(blocks) if b[0] == "center"]
+    qnext = torch.empty((B, P, 2), dtype=torch.float32, device=dev) if center else None
+    vp = ctypes.c_void_p
+    src = (vp * n)(*[_lib.ptr(b[1]) for b in blocks])
+    dst = (vp * n)(*[_lib.ptr(out[b[0]]) for b in blocks])
+    ld = (ctypes.c_int * n)(*[b[1].stride(0) for b in blocks])
+    col0 = (ctypes.c_int * n)(*[b[2] for b in blocks])
+    ch = (ctypes.c_int * n)(*[b[3] for b in blocks])
+    _lib.check(_lib.load().isf_head_scatter_predictions(
+        n, src, ld, col0, ch, dst, center[0] if center else -1, _lib.ptr(query_pos) if center else None,
+        _lib.ptr(qnext) if center else None, B, P, _lib.stream()), "isf_head_scatter_predictions")
+    return out, qnext
 
 
 def decode_boxes(heatmap, query_score, query_labels, center, height, dim, rot, vel, cell, origin, post_center_range,
@@ -582,16 +634,10 @@ def _pos_embed(mod, xy):
     return out.view(*xy.shape[:-1], -1)
 
 
-def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None):
-    """InsContextAtt.forward (fusion_encoder.py:795-830), eval mode.  x_ins [B, E, Q], query_pos [B, Q, 2] (x, y),
-    scene [B, E, H, W] = the reference's `x_scene.permute(0, 1, 3, 2)` (:806; the caller holds the map in that
-    orientation already) -> [B, E, Q].  query_cells [B, Q] long (optional): the queries sit on cell centres of the
-    create_2D_grid lattice, query_pos = bev_pos[query_cells] -- then their position embedding is a row of a per-cell
-    table computed once (the same MLP on the same inputs) instead of two GEMMs + glue per forward."""
-    _lib.require_cuda(scene)
-    dev = scene.device
-    B, E, Q = x_ins.shape
+def _ins_context_pack(mod, dev, bev_size):
+    """per-module cache of InsContextAtt: position tables of the create_2D_grid lattice + packed weights"""
     c = _cache(mod, dev)
+    E = mod.layers[0].self_attn.out_proj.in_features
     if "key_pos" not in c:
         g = torch.linspace(0, bev_size - 1, bev_size, device=dev) + 0.5
         bx, by = torch.meshgrid(g, g, indexing="ij")
@@ -613,6 +659,48 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None):
                 aw=PackedLinear(ca.attention_weights.weight, ca.attention_weights.bias),
                 oproj=PackedLinear(ca.output_proj.weight, ca.output_proj.bias),
                 l1=PackedLinear(l.linear1.weight, l.linear1.bias), l2=PackedLinear(l.linear2.weight, l.linear2.bias)))
+    return c
+
+
+def mined_instances(mod, top32, scene, bev_size):
+    """fusion_encoder.py:1133-1141 + the preamble of InsContextAtt.forward (:800-812) in one launch
+    (isf_instance_gather): top32 [B, Q] int32 = cells of the transposed map as isf_instance_topk returns them, scene
+    [B, E, S, S] the un-transposed map, mod = the InsContextAtt module (its query_pos_embed table).  -> dict(top [B, Q]
+    int64, cells [B, Q] int64, tokens / qpe / tokens_pos [B*Q, E], query_pos [B, Q, 2], ref [B*Q, 2])."""
+    _lib.require_cuda(scene)
+    dev = scene.device
+    B, Q = top32.shape
+    E = scene.shape[1]
+    assert scene.shape[2] == bev_size and scene.shape[3] == bev_size
+    c = _ins_context_pack(mod, dev, bev_size)
+    scene = scene.float().contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    r = dict(top=torch.empty((B, Q), dtype=torch.int64, device=dev), cells=torch.empty((B, Q), dtype=torch.int64, device=dev),
+             tokens=torch.empty((B * Q, E), **f32), qpe=torch.empty((B * Q, E), **f32),
+             tokens_pos=torch.empty((B * Q, E), **f32), query_pos=torch.empty((B, Q, 2), **f32),
+             ref=torch.empty((B * Q, 2), **f32))
+    _lib.check(_lib.load().isf_instance_gather(_lib.ptr(top32), B, Q, bev_size, E, _lib.ptr(scene),
+                                               _lib.ptr(c["query_pos_table"]), _lib.ptr(r["top"]), _lib.ptr(r["cells"]),
+                                               _lib.ptr(r["tokens"]), _lib.ptr(r["qpe"]), _lib.ptr(r["tokens_pos"]),
+                                               _lib.ptr(r["query_pos"]), _lib.ptr(r["ref"]), _lib.stream()),
+               "isf_instance_gather")
+    return r
+
+
+def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None, mined=None):
+    """InsContextAtt.forward (fusion_encoder.py:795-830), eval mode.  x_ins [B, E, Q], query_pos [B, Q, 2] (x, y),
+    scene [B, E, H, W] = the reference's `x_scene.permute(0, 1, 3, 2)` (:806; the caller holds the map in that
+    orientation already) -> [B, E, Q].  query_cells [B, Q] long (optional): the queries sit on cell centres of the
+    create_2D_grid lattice, query_pos = bev_pos[query_cells] -- then their position embedding is a row of a per-cell
+    table computed once (the same MLP on the same inputs) instead of two GEMMs + glue per forward.  mined = the dict of
+    mined_instances() (then x_ins / query_pos / query_cells are not read)."""
+    _lib.require_cuda(scene)
+    dev = scene.device
+    c = _ins_context_pack(mod, dev, bev_size)
+    if mined is not None:
+        (B, Q), E = mined["top"].shape, scene.shape[1]
+    else:
+        B, E, Q = x_ins.shape
     H, W = scene.shape[2:]
     ck = ("cell_index", B, H * W)
     if ck not in c:
@@ -620,15 +708,20 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None):
     cell = c[ck]
     # read channels-first inside the GEMM (no token copy) when the kernel's 4-row groups stay inside a sample
     scene = scene.float().contiguous() if (H * W) % 4 == 0 else to_tokens(scene.float())
-    out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
-    ref = (query_pos / bev_size).reshape(B * Q, 2).contiguous()
-    if query_cells is not None:
-        qpe = c["query_pos_table"][query_cells.reshape(-1)]
+    qk_first = None
+    if mined is not None:   # mined_instances() has gathered tokens, positions and embeddings already
+        out, ref, qpe, qk_first = mined["tokens"], mined["ref"], mined["qpe"], mined["tokens_pos"]
     else:
-        qpe = _pos_embed(mod.query_pos_embed, ref.view(B, Q, 2)).reshape(B * Q, E)
+        out = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
+        ref = (query_pos / bev_size).reshape(B * Q, 2).contiguous()
+        if query_cells is not None:
+            qpe = c["query_pos_table"][query_cells.reshape(-1)]
+        else:
+            qpe = _pos_embed(mod.query_pos_embed, ref.view(B, Q, 2)).reshape(B * Q, E)
     for l, p in zip(mod.layers, c["layers"]):
         nhead, npts = l.cross_attn.n_heads, l.cross_attn.n_points
-        qk_in = out + qpe
+        qk_in = qk_first if qk_first is not None else out + qpe
+        qk_first = None
         qk = linear(qk_in, p["qk"])
         v = linear(out, p["v"])
         # q = columns [0, E), k = columns [E, 2E) of qk (row stride 2E); v has row stride E, and the C entry takes

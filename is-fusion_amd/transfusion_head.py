@@ -124,6 +124,7 @@ class TransFusionHeadV2(nn.Module):
             c["hm1"] = PackedConvBN(self.heatmap_head[1], None, relu=False)   # 128 -> 10 (columns zero-padded to 32)
             bev_pos = self._bev_pos(device)
             c["bev_pos"] = bev_pos
+            c["bev_pos_tok"] = bev_pos[0].contiguous()                            # [HW, 2] for isf_head_query_init
             c["layers"] = []
             E = self.shared_conv.out_channels
             for l in self.decoder:
@@ -234,27 +235,29 @@ class TransFusionHeadV2(nn.Module):
                 dense_heatmap = self.heatmap_head[1](self.heatmap_head[0](lidar_feat))
                 feat_tok = ops.to_tokens(lidar_feat)
         pool1 = (8, 9) if self.test_cfg["dataset"] == "nuScenes" else (1, 2)
-        top_index, top_raw, masked = ops.instance_topk(dense_heatmap, self.num_proposals, self.nms_kernel_size, pool1,
-                                                       return_masked=True)
-        self.query_labels = top_class = torch.div(top_raw, HW, rounding_mode="floor")
-        self.last_top_index = top_index   # BEV cell of every proposal (for inspection)
-        bev_pos = c["bev_pos"].expand(B, -1, -1)
-        query_pos = bev_pos.gather(1, top_index[:, :, None].expand(-1, -1, 2))                      # [B, P, 2]
-        rows = top_index if tok_of_cell is None else tok_of_cell[top_index]
-        rows = (rows + torch.arange(B, device=dev)[:, None] * HW).reshape(-1)
-        query = feat_tok[rows]                                                                       # [B*P, E]
-        # class_encoding(one_hot) = column `class` of the 1x1 conv + bias
+        top32, raw32, masked = ops.instance_topk(dense_heatmap, self.num_proposals, self.nms_kernel_size, pool1,
+                                                 return_masked=True, as_int32=True)
+        # labels, positions, query = feature column + class_encoding(one_hot) (= column `class` of the 1x1 conv + bias),
+        # the first layer's position embedding (the proposals sit on cell centres: a row of the per-cell table), query +
+        # position and the proposals' heat-map scores: one launch (isf_head_query_init)
         ce = self.class_encoding
-        query = query + (ce.weight[:, :, 0].t()[top_class.reshape(-1)] + ce.bias)
+        ctab = c.get("class_table")
+        if ctab is None:
+            ctab = c["class_table"] = (ce.weight[:, :, 0].t() + ce.bias).detach().float().contiguous()
+        query, qpe0, x0, query_pos, top_index, top_class, q_score = ops.head_query_init(
+            top32, raw32, feat_tok, tok_of_cell, ctab, c["layers"][0]["qpe_table"], c["bev_pos_tok"], masked,
+            self.num_classes)
+        self.query_labels = top_class
+        self.last_top_index = top_index   # BEV cell of every proposal (for inspection)
         P = self.num_proposals
         ret_dicts = []
         for i, (l, p) in enumerate(zip(self.decoder, c["layers"])):
             if i == 0:   # = self_posembed(query_pos): the proposals sit on cell centres; later layers use refined centres
-                qpe = p["qpe_table"][top_index.reshape(-1)]
+                qpe, x = qpe0, x0
             else:
                 qpe = ops._pos_embed(l.self_posembed, query_pos).reshape(B * P, E)
+                x = query + qpe
             # self attention: q = k = v = query + pos (:98-101)
-            x = query + qpe
             qkv = ops.linear(x, p["s_qkv"])
             att = ops.attention(qkv, qkv[:, E:], qkv[:, 2 * E:], B, P, P, E, l.nhead, ldkv=3 * E)
             query = ops.linear(att, p["s_out"], residual=query, ln=l.norm1)
@@ -271,19 +274,19 @@ class TransFusionHeadV2(nn.Module):
             query = ops.linear(h, p["l2"], residual=query, ln=l.norm3)
             pp = c["pred"][i] if self.dense_conv == "hip" else None
             if pp is not None:
-                res = {}
+                blocks = []
                 for grp in pp:
-                    o = ops.linear(ops.linear(query, grp["l1"], act=ops.ACT_RELU), grp["l2"]).view(B, P, -1)
-                    for n, a, b in grp["cols"]:
-                        res[n] = o[:, :, a:b].transpose(1, 2).contiguous()
+                    o = ops.linear(ops.linear(query, grp["l1"], act=ops.ACT_RELU), grp["l2"])       # [B*P, columns]
+                    blocks += [(n, o, a, b - a) for n, a, b in grp["cols"]]
+                # every output as [B, c, P], center += query_pos, the next layer's positions: one launch
+                res, query_pos = ops.head_scatter_predictions(blocks, B, P, query_pos.contiguous())
                 res = {n: res[n] for n in self.prediction_heads[i].heads}      # the reference's key order
             else:
                 res = self.prediction_heads[i](query.view(B, P, E).transpose(1, 2).contiguous())       # [B, E, P]
-            res["center"] = res["center"] + query_pos.permute(0, 2, 1)
+                res["center"] = res["center"] + query_pos.permute(0, 2, 1)
+                query_pos = res["center"].detach().clone().permute(0, 2, 1)
             ret_dicts.append(res)
-            query_pos = res["center"].detach().clone().permute(0, 2, 1)
-        ret_dicts[0]["query_heatmap_score"] = masked.view(B, self.num_classes, HW).gather(
-            2, top_index[:, None, :].expand(-1, self.num_classes, -1))
+        ret_dicts[0]["query_heatmap_score"] = q_score
         ret_dicts[0]["dense_heatmap"] = dense_heatmap
         if not self.auxiliary:
             return [ret_dicts[-1]]
