@@ -690,7 +690,7 @@ def mined_instances(mod, top32, scene, bev_size):
 def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None, mined=None):
     """InsContextAtt.forward (fusion_encoder.py:795-830), eval mode.  x_ins [B, E, Q], query_pos [B, Q, 2] (x, y),
     scene [B, E, H, W] = the reference's `x_scene.permute(0, 1, 3, 2)` (:806; the caller holds the map in that
-    orientation already) -> [B, E, Q].  query_cells [B, Q] long (optional): the queries sit on cell centres of the
+    orientation already) -> [B, E, Q] (token-major [B*Q, E] with mined=).  query_cells [B, Q] long (optional): the queries sit on cell centres of the
     create_2D_grid lattice, query_pos = bev_pos[query_cells] -- then their position embedding is a row of a per-cell
     table computed once (the same MLP on the same inputs) instead of two GEMMs + glue per forward.  mined = the dict of
     mined_instances() (then x_ins / query_pos / query_cells are not read)."""
@@ -736,6 +736,8 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size, query_cells=None, mi
         out = linear(t2, p["oproj"], residual=out, ln=l.norm1)
         h = linear(out, p["l1"], act=ACT_RELU)
         out = linear(h, p["l2"], residual=out, ln=l.norm3)
+    if mined is not None:
+        return out   # token-major [B*Q, E]: what instance_to_scene reads (the caller of mined= is the encoder)
     return out.view(B, Q, E).transpose(1, 2).contiguous()
 
 
@@ -753,10 +755,12 @@ def channel_attention(query_scene, query_ins):
 
 def instance_to_scene(mod, query, x_ins, scene_feats, bev_size):
     """Instane2SceneAtt.forward (fusion_encoder.py:480-502), eval mode: query [B, E, H, W] = conv_ins(bev),
-    x_ins [B, E, Q], scene_feats [B, E, H, W] (the Grid-to-Region output)."""
+    x_ins [B, E, Q] (or token-major [B*Q, E], as ins_context_att(mined=...) returns it), scene_feats [B, E, H, W] (the
+    Grid-to-Region output)."""
     _lib.require_cuda(query)
     B, E, H, W = query.shape
-    Q = x_ins.size(2)
+    tokens = x_ins.dim() == 2
+    Q = x_ins.size(0) // B if tokens else x_ins.size(2)
     c = _cache(mod, query.device)
     if "q" not in c:
         a = mod.multihead_attn
@@ -766,7 +770,7 @@ def instance_to_scene(mod, query, x_ins, scene_feats, bev_size):
         c["out"] = PackedLinear(a.out_proj.weight, a.out_proj.bias)
     fused_io = (H * W) % 4 == 0
     xq = query.float().contiguous() if fused_io else to_tokens(query.float())   # read channels-first in the GEMMs
-    xk = x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
+    xk = x_ins if tokens else x_ins.transpose(1, 2).reshape(B * Q, E).contiguous()
     qp = linear(xq, c["q"])
     kv = linear(xk, c["kv"])
     att = attention(qp, kv, kv[:, E:], B, H * W, Q, E, mod.nhead, ldkv=2 * E)   # k | v share rows of kv

@@ -293,7 +293,8 @@ class TransFusionHeadV2(nn.Module):
         new_res = {}
         for key in ret_dicts[0].keys():
             if key not in ("dense_heatmap", "dense_heatmap_old", "query_heatmap_score"):
-                new_res[key] = torch.cat([r[key] for r in ret_dicts], dim=-1)
+                # (one decoder layer, the shipped head: the tensor itself -- torch.cat of one tensor is a copy launch)
+                new_res[key] = torch.cat([r[key] for r in ret_dicts], dim=-1) if len(ret_dicts) > 1 else ret_dicts[0][key]
             else:
                 new_res[key] = ret_dicts[0][key]
         return [new_res]
