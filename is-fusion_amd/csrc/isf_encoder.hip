@@ -274,9 +274,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // by their gathers, and like rows are further apart), profiles/r06_row_sort.txt
   const bool narrow_sort = (diagnostic & 67108864) != 0;
   constexpr int sort_min_rows = 4096;   // (configs[2] at B = 2: 7.05 ms sorted from 4 096 rows up, 7.10 from 32 768, 7.10 unsorted)
-  // key of the sort: 1 = six coarse bits (one radix pass), 3 = sixteen taps of the planes above / below (two passes; measured
-  // better on the 256-column levels: 1.13 vs 1.15 ms per step, worse on the 128-column one: 0.79 vs 0.75);
-  // bit 134217728: coarse | in-plane taps everywhere (A/B)
+  // key of the sort: 1 = six coarse bits (one radix pass) everywhere.  Sixteen taps of the planes above / below (key 3,
+  // two passes) made the 256-column launches 0.8 % faster (1.131 vs 1.140 ms per step) and their fabric traffic 37 % larger
+  // (FETCH_SIZE 226 -> 311 MB per launch: finer key groups scatter a tile's rows over the grid) -- not kept;
+  // bit 134217728: coarse | in-plane taps (key 2; A/B)
   const bool sort_key_ab = (diagnostic & 134217728) != 0;
   const bool cu_units = (diagnostic & 512) != 0;     // bit 512 (opt-in; measured slower): the 256-column
                                                      // layers on the one-workgroup-per-CU kernel
@@ -418,7 +419,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         L.cache_lmask_sorted = lms;
       } else {
         ISF_TRY(a.alloc_n(&ns, (size_t)K * tstride));
-        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg, sort_key_ab ? 2 : (ly.c_out == 256 ? 3 : 1)));
+        ISF_TRY(conv_row_sort_impl(a, table, tstride, K, rows, info.part_rows, rm, ns, sg, sort_key_ab ? 2 : 1));
       }
       L.cache_rowmap = rm;
       L.cache_nbr_sorted = ns;

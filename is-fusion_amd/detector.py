@@ -155,12 +155,19 @@ class ISFusionPtsPath(nn.Module):
         with torch.cuda.stream(side):
             finish = self.voxelize_async(pts)
         x = self._lidar(pts)
+        img_bev = None
         with torch.cuda.stream(side):
             pil = finish()                           # slices + concatenation, on the stream that produced them
+            if "p2g_cam" in kwargs and kwargs.get("p2g_out") is None:
+                # Point-to-Grid needs the pillars and the camera features only: on the side stream too, under the tail
+                # of the LiDAR branch (its last launches are still running when the host gets here)
+                img_bev = self.fusion_encoder.img_fv_to_bev(
+                    [img_feats[1]], len(pts), pts_metas=dict(pillars=pil[0], pillar_coors=pil[2]), img_metas=img_metas,
+                    **kwargs)
         main.wait_stream(side)
-        for t in pil:
+        for t in pil + ((img_bev,) if img_bev is not None else ()):
             t.record_stream(main)                    # allocated on the side stream, consumed on the main one
-        feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), pillars=pil, **kwargs)
+        feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), pillars=pil, img_bev=img_bev, **kwargs)
         return (feats, ins_heatmap) if return_heatmap else feats
 
     def _forward_pts_graph(self, pts, img_feats, img_metas, **kwargs):

@@ -179,7 +179,9 @@ class ISFusionEncoder(nn.Module):
             return self.forward_eval(img_mlvl_feats, lidar_feats, bs, **kwargs)
 
     def forward_eval(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
-        img_bev = self.img_fv_to_bev([img_mlvl_feats[1]], bs, **kwargs)
+        img_bev = kwargs.pop("img_bev", None)     # Point-to-Grid already run by the caller (detector: on its side stream)
+        if img_bev is None:
+            img_bev = self.img_fv_to_bev([img_mlvl_feats[1]], bs, **kwargs)
         return self.forward_tail(img_bev, lidar_feats, bs, **kwargs)
 
     def forward_tail(self, img_bev, lidar_feats, bs, **kwargs):
