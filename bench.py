@@ -890,10 +890,11 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    pipelined = None
-    if world == 1 and not args.no_pipelined and not args.lib:
-        pipelined = pipelined_leg(lb, frame_sets, args.steps, max(2, args.warmup // 2), 2, precision=precision,
-                                  conv_diag=args.conv_diag, **stage_kw)
+    # (the two-batches-in-flight leg runs LAST, after every other leg: the four extra streams it leaves behind -- two launch
+    # streams + the library's geometry side streams -- make every later launch on torch's default stream slower; measured on
+    # the configs[2] leg, same box, alternating: 6.71 / 6.75 ms on its own or without this leg before it, 6.92 / 6.92 with it:
+    # gpurun_out/r06_cfg3_ctx)
+    want_pipelined = world == 1 and not args.no_pipelined and not args.lib
     diag = (args.conv_diag & 15) != 0 or ((args.conv_diag >> 10) & 3) != 0   # timing diagnostics: results are garbage (16 = sharing off, 32 = uniform tiles: valid)
     assert diag or args.lib or torch.isfinite(out).all()
 
@@ -980,30 +981,16 @@ def main():
                                         "parameter-change scan"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            cdt, n0 = cpu_baseline(args.cpu_points, 1234 + 1000 * CFG_ID)
-            import oracle
-            cores = oracle.num_threads()
-            n0_full = st.num_in[0] / args.batch
-            line["cpu_baseline"] = {
-                "value": round(1.0 / cdt * (n0 / n0_full), 4), "unit": "frames/s (300k-pt-frame equivalent)",
-                "cores": cores, "kind": "port",
-                "sample": f"oracle (C port, oracle/isf_oracle.c; the conv loop runs OpenMP over the pairs of a tap "
-                          f"on {cores} host threads, the other stages are scalar) on 1 frame of {args.cpu_points} "
-                          f"points ({n0} voxels) took {cdt:.2f} s; scaled linearly by level-0 voxels to a "
-                          f"{args.points}-pt frame ({int(n0_full)} voxels)",
-                "sample_seconds": round(cdt, 2)}
         # ---- secondary legs.  Each is printed on ITS OWN earlier line ({"leg": name, ...}); the final line carries short
         # scalar copies of their headline numbers in front of the nested objects and stays under 2 KB, so that a reader who
         # keeps only the top-level keys / the tail of the output still sees every configuration.
         legs = {}
         cfg3_count = None
-        if pipelined is not None:
-            legs["pipelined"] = pipelined
         if world == 1 and not args.no_cfg3:
             # BASELINE configs[2] (full HSF + IGF forward, batch 2) measured by the same process, after the headline's
             # timed region: a driver-observed number for the second configuration
-            del lb, out, frame_sets, frames
+            if not want_pipelined:
+                del lb, out, frame_sets, frames
             torch.cuda.empty_cache()
             c3 = fusion_leg(args, rank, world, dev, 2, args.cfg3_steps, max(3, args.warmup), False)
             legs["cfg3"] = {k: c3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype",
@@ -1019,6 +1006,24 @@ def main():
         if world == 1 and not args.no_cfg4:
             torch.cuda.empty_cache()
             legs["cfg4_train"] = train_leg(args, rank, world, dev)
+        if want_pipelined:
+            torch.cuda.empty_cache()
+            legs["pipelined"] = pipelined_leg(lb, frame_sets, args.steps, max(2, args.warmup // 2), 2, precision=precision,
+                                              conv_diag=args.conv_diag, **stage_kw)
+        # the CPU baseline after every GPU leg (128 OpenMP threads on the host the launch thread runs on)
+        if world == 1 and not args.no_cpu_baseline:
+            cdt, n0 = cpu_baseline(args.cpu_points, 1234 + 1000 * CFG_ID)
+            import oracle
+            cores = oracle.num_threads()
+            n0_full = st.num_in[0] / args.batch
+            line["cpu_baseline"] = {
+                "value": round(1.0 / cdt * (n0 / n0_full), 4), "unit": "frames/s (300k-pt-frame equivalent)",
+                "cores": cores, "kind": "port",
+                "sample": f"oracle (C port, oracle/isf_oracle.c; the conv loop runs OpenMP over the pairs of a tap "
+                          f"on {cores} host threads, the other stages are scalar) on 1 frame of {args.cpu_points} "
+                          f"points ({n0} voxels) took {cdt:.2f} s; scaled linearly by level-0 voxels to a "
+                          f"{args.points}-pt frame ({int(n0_full)} voxels)",
+                "sample_seconds": round(cdt, 2)}
         if cfg3_count is not None:      # after every timed leg (the profiler slows the launches that follow it)
             legs["cfg3"]["launches_per_forward"] = cfg3_count()
         final = compact_line(line, legs)
