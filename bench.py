@@ -276,6 +276,8 @@ def main_fusion(args):
     assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.launch_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -783,6 +785,8 @@ def main():
     ap.add_argument("--lib", default="",
                     help="A/B and probe builds: load this build of libisf_hip.so instead of the in-tree one (results are "
                          "not checked for finiteness: knock-out builds produce garbage)")
+    ap.add_argument("--launch-stream", action="store_true",
+                    help="run every leg on a private (non-NULL) HIP stream instead of torch's default stream")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the two-batches-in-flight leg appended as \"pipelined\"")
     ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in range(1, 8)] + [16384, 32768, 49152, 65536, 131072, 262144, 524288, 262144 + 32, 262144 + 64, 1048576, 2097152, 4194304, 8388608, 16777216, 33554432, 67108864, 134217728, 268435456] + [512 + 1024 * v for v in range(1, 16)],
@@ -832,6 +836,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (libisf_hip.so has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.launch_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     # under a launcher (torch.distributed.run exports MASTER_PORT) the collective path runs even with ONE rank: RCCL
     # init, the barriers around the timed region, the max-reduce of the clock -- so that the only thing a multi-GPU run
     # adds to a tested path is N (tests/test_gpu_train.py)
