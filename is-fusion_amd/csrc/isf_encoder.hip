@@ -340,9 +340,11 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     x = xs0;
     x_in0 = xs0;
   }
-  unsigned long long* pair_counts = nullptr;
-  ISF_TRY(a.alloc_n(&pair_counts, 32));
-  ISF_HIP_TRY(hipMemsetAsync(pair_counts, 0, 32 * sizeof(unsigned long long), sg));
+  unsigned long long* pair_counts = nullptr;   // per-rulebook pair totals: statistics only (8 + 1 launches a caller without
+  if (stats) {                                   // `stats` does not pay for)
+    ISF_TRY(a.alloc_n(&pair_counts, 32));
+    ISF_HIP_TRY(hipMemsetAsync(pair_counts, 0, 32 * sizeof(unsigned long long), sg));
+  }
   std::vector<hipEvent_t> ev;
   if (time_layers && stats) {
     ev.resize((size_t)num_layers * 2);
@@ -446,12 +448,12 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           ISF_TRY(a.alloc_n(&nbr, (size_t)nl * stride));
           ISF_TRY(a.alloc_n(&lm, (size_t)stride));
           ISF_TRY(launch_nbr_lines(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nbr, lm, stride,
-                                   pair_counts + i, sg));
+                                   stats ? pair_counts + i : nullptr, sg));
           L.cache_lmask = lm;
         } else {
           ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
           ISF_TRY(launch_nbr(a, L.coors, L.n, L.shape, ly.ksize, ly.stride, ly.padding, true, L.occ, nullptr, nbr,
-                             stride, pair_counts + i, sg));
+                             stride, stats ? pair_counts + i : nullptr, sg));
         }
         L.cache_nbr = nbr;
         L.cache_stride = stride;
@@ -547,12 +549,12 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         ISF_TRY(a.alloc_n(&nbr, (size_t)ly.ksize[0] * ly.ksize[1] * stride));
         ISF_TRY(a.alloc_n(&lm, (size_t)stride));
         ISF_TRY(launch_nbr_lines(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nbr, lm, stride,
-                                 pair_counts + i, sg));
+                                 stats ? pair_counts + i : nullptr, sg));
         lmask = lm;
       } else {
         ISF_TRY(a.alloc_n(&nbr, (size_t)K * stride));
         ISF_TRY(launch_nbr(a, Nx.coors, Nx.n, L.shape, ly.ksize, ly.stride, ly.padding, false, L.occ, nullptr, nbr,
-                           stride, pair_counts + i, sg));
+                           stride, stats ? pair_counts + i : nullptr, sg));
       }
       if (srows > 0) ISF_TRY(build_stage_tables(a, nbr, stride, K, &stg, sg));
       // ROW SORT of a deep strided convolution's own table (its rows want 10 of 27 taps, in many patterns: -12 % tile-taps,
