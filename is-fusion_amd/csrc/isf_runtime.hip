@@ -294,9 +294,29 @@ __global__ __launch_bounds__(1024) void occ_scan_sums_kernel(uint32_t* __restric
   if (threadIdx.x == 0) *total = (int)carry_s;
 }
 
+// Offset of a block = sum of the totals of the blocks before it.  Up to kLookBehindBlocks blocks every block adds them up
+// itself (SUMS = true: `block_sums` holds raw totals; the last block also writes the grand total) -- the single-workgroup scan
+// in between is one launch more than the few KiB of L2 reads it saves; larger grids (level 0: 5 000 blocks) keep it.
+static constexpr int kLookBehindBlocks = 2048;
+__device__ __forceinline__ uint32_t scan_look_behind(const uint32_t* __restrict__ block_sums, uint32_t* lds) {
+  uint32_t s = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += kScanThreads) s += block_sums[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  uint32_t t = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) t += lds[w];
+  __syncthreads();
+  return t;
+}
+
+template <bool SUMS>
 __global__ __launch_bounds__(kScanThreads) void occ_write_prefix_kernel(
     const unsigned long long* __restrict__ bits, size_t nwords,
-    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ prefix) {
+    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ prefix, int* __restrict__ total) {
   __shared__ uint32_t lds[kScanThreads / 64];
   const size_t w0 = (size_t)blockIdx.x * kWordsPerBlock + (size_t)threadIdx.x * kWordsPerThread;
   uint32_t pc[kWordsPerThread];
@@ -304,7 +324,9 @@ __global__ __launch_bounds__(kScanThreads) void occ_write_prefix_kernel(
   for (int i = 0; i < kWordsPerThread; ++i) pc[i] = (w0 + i < nwords) ? __popcll(bits[w0 + i]) : 0;
   uint32_t c = pc[0] + pc[1] + pc[2] + pc[3];
   uint32_t tot;
-  uint32_t ex = block_exclusive_scan(c, lds, &tot) + block_offsets[blockIdx.x];
+  const uint32_t base = SUMS ? scan_look_behind(block_offsets, lds) : block_offsets[blockIdx.x];
+  uint32_t ex = block_exclusive_scan(c, lds, &tot) + base;
+  if (SUMS && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = (int)(base + tot);
 #pragma unroll
   for (int i = 0; i < kWordsPerThread; ++i) {
     if (w0 + i < nwords) prefix[w0 + i] = ex;
@@ -466,9 +488,14 @@ int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st) {
   ISF_TRY(a.alloc_n(&sums, (size_t)nblocks + 1));
   hipLaunchKernelGGL(occ_block_count_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, occ.bits,
                      occ.nwords, sums);
-  hipLaunchKernelGGL(occ_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks, occ.total);
-  hipLaunchKernelGGL(occ_write_prefix_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, occ.bits,
-                     occ.nwords, sums, occ.prefix);
+  if (nblocks <= kLookBehindBlocks) {
+    hipLaunchKernelGGL(occ_write_prefix_kernel<true>, dim3(nblocks), dim3(kScanThreads), 0, st, occ.bits, occ.nwords, sums,
+                       occ.prefix, occ.total);
+  } else {
+    hipLaunchKernelGGL(occ_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks, occ.total);
+    hipLaunchKernelGGL(occ_write_prefix_kernel<false>, dim3(nblocks), dim3(kScanThreads), 0, st, occ.bits, occ.nwords, sums,
+                       occ.prefix, occ.total);
+  }
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -487,6 +514,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_u32_block_kernel(const uint
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+template <bool SUMS>
 __global__ __launch_bounds__(kScanThreads) void scan_u32_write_kernel(const uint32_t* __restrict__ in, size_t n,
                                                                       const uint32_t* __restrict__ block_offsets,
                                                                       uint32_t* __restrict__ out) {
@@ -496,7 +524,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_u32_write_kernel(const uint
 #pragma unroll
   for (int i = 0; i < kWordsPerThread; ++i) v[i] = (i0 + i < n) ? in[i0 + i] : 0;
   uint32_t tot;
-  uint32_t ex = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], lds, &tot) + block_offsets[blockIdx.x];
+  const uint32_t base = SUMS ? scan_look_behind(block_offsets, lds) : block_offsets[blockIdx.x];
+  uint32_t ex = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], lds, &tot) + base;
 #pragma unroll
   for (int i = 0; i < kWordsPerThread; ++i) {
     if (i0 + i < n) out[i0 + i] = ex;
@@ -516,8 +545,12 @@ int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hi
   ISF_TRY(a.alloc_n(&sums, (size_t)nblocks + 1));
   ISF_TRY(a.alloc_n(&total, 64));
   hipLaunchKernelGGL(scan_u32_block_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, in, n, sums);
-  hipLaunchKernelGGL(occ_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks, total);
-  hipLaunchKernelGGL(scan_u32_write_kernel, dim3(nblocks), dim3(kScanThreads), 0, st, in, n, sums, out);
+  if (nblocks <= kLookBehindBlocks) {
+    hipLaunchKernelGGL(scan_u32_write_kernel<true>, dim3(nblocks), dim3(kScanThreads), 0, st, in, n, sums, out);
+  } else {
+    hipLaunchKernelGGL(occ_scan_sums_kernel, dim3(1), dim3(1024), 0, st, sums, nblocks, total);
+    hipLaunchKernelGGL(scan_u32_write_kernel<false>, dim3(nblocks), dim3(kScanThreads), 0, st, in, n, sums, out);
+  }
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
