@@ -300,6 +300,18 @@ int isf_sparse_conv_phase_trace(const void* features_split, int num_in, int c_in
                                 const float* shift, const void* residual_split, int relu, void* out_split,
                                 const int32_t* order, long long* trace, size_t trace_bytes, int* grid_blocks,
                                 int* waves_per_block, int* dwords_per_wave, isf_stream_t stream);
+
+/* DIAGNOSTIC: the per-workgroup trace of the NARROW layers' kernel (isf_sparse_conv_forward_dma / _dma_lines; c_in,
+ * c_out in {32, 64}): one production launch with 12 int64 per workgroup -- constant-clock (100 MHz) stamps at entry / after
+ * the prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half tile << 32, then wave 0's
+ * shader-clock cycles summed over the steps: at the per-step vmcnt(0), at the barrier, in the section that reads the
+ * transit / weight buffers and issues the next step's loads, in the multiply section.  table / mask: the dense neighbour
+ * table (mask NULL, taps_per_line ignored) or the line-compressed one.  tools/conv_trace.py --level 0 | 1. */
+int isf_sparse_conv_dma_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                              int taps_per_line, int c_out, const int32_t* table, const uint32_t* mask, int nbr_stride,
+                              int num_out, const float* scale, const float* shift, const void* residual_split, int relu,
+                              void* out_split, long long* trace, int trace_capacity_blocks, int* grid_blocks,
+                              isf_stream_t stream);
 /* The same convolution for the NARROW layers (c_in, c_out in {32, 64}) with the gathered rows brought in by LDS-DMA
  * (isf_spconv_dma.hip; mode 0 | 1 | 257, +32; order: NULL or isf_sparse_conv_tile_order's table).  A gather instruction of
  * isf_sparse_conv_forward_f16x3 loads straight into the MFMA operand layout -- four different rows = four cache lines per

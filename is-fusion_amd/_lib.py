@@ -215,6 +215,9 @@ SIGNATURES = {
                                  c_int, c_int, c_void_p, c_void_p]),
     "isf_decode_boxes": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_float)]
                          + [c_void_p] * 5),
+    "isf_sparse_conv_dma_trace": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                         ctypes.POINTER(c_int), c_void_p]),
     "isf_instance_gather": (c_int, [c_void_p, c_int, c_int, c_int, c_int] + [c_void_p] * 10),
     "isf_head_query_init": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 14),
     "isf_head_scatter_predictions": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int),

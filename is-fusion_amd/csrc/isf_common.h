@@ -259,7 +259,8 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
                                  const void* residual, int relu, void* ys, int mode, hipStream_t st,
                                  const int32_t* order = nullptr, Conv16LaunchInfo* query = nullptr,
                                  const uint32_t* lmask = nullptr /* line-compressed table: nbr = lines */, int nx = 0,
-                                 const int32_t* rowmap = nullptr /* sorted launch: position -> output row */);
+                                 const int32_t* rowmap = nullptr /* sorted launch: position -> output row */,
+                                 long long* trace = nullptr /* mode 512: per-workgroup trace (isf_sparse_conv_dma_trace) */);
 int conv16_tile_order_impl(const int32_t* nbr, int nbr_stride, int K, int n_out, const Conv16LaunchInfo& info,
                            int32_t* work /* [parts * tiles] scratch */, int32_t* order /* [parts * tiles] */,
                            hipStream_t st, const uint32_t* lmask = nullptr /* line-compressed table's masks instead of nbr */);

@@ -45,6 +45,13 @@ namespace isf {
 #endif
 __device__ uint4 g_zero_line[8];   // 128 zero bytes: what a row without a neighbour reads
 
+constexpr int kDmaTraceWords = 12;
+__device__ __forceinline__ unsigned long long dma_shader_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+
 template <int NT, int NW, int RG = 2>
 struct ConvDmaSmem {
   static constexpr int TM = 16 * RG * NW;
@@ -67,8 +74,15 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     const float* __restrict__ w_inv_scale, int K, int cout, const float* __restrict__ scale,
     const float* __restrict__ shift, const uint4* __restrict__ residual, uint4* __restrict__ ys, int n_out, int relu,
     Conv16Plan plan, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ rowmap /* nullptr | sorted launch: position -> output row (conv_row_sort_impl) */) {
-  constexpr bool HALF = (MODE & 1) != 0, F16IO = (MODE & 256) != 0;
+    const int32_t* __restrict__ rowmap /* nullptr | sorted launch: position -> output row (conv_row_sort_impl) */,
+    long long* __restrict__ trace /* MODE bit 512: kDmaTraceWords int64 per workgroup (isf_sparse_conv_dma_trace) */) {
+  constexpr bool HALF = (MODE & 1) != 0, F16IO = (MODE & 256) != 0, TRACE = (MODE & 512) != 0;
+  // TRACE (diagnostic instantiations only): constant-clock stamps at entry / after the prologue / after the loop / at
+  // exit, and wave 0's shader-clock account of the loop: cycles at the per-step vmcnt(0), at the barrier, in the section
+  // that reads the transit / weights and issues the next step's loads, in the multiply section
+  long long t_entry = 0, t_pro = 0, t_loop = 0;
+  unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mul = 0;
+  if (TRACE) t_entry = wall_clock64();
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   using S = ConvDmaSmem<NT, NW, RG>;
   constexpr int NTHR = 64 * NW, TM = S::TM, WR = 16 * RG;
@@ -249,6 +263,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       }
     }
   };
+  if (TRACE) t_pro = wall_clock64();
   if (nsteps > 0) {
     if constexpr (LINES) load_line(line_of(__ffs(rem) - 1), base_nxt);
     else load_idx(__ffs(rem) - 1, idx_nxt);
@@ -258,9 +273,13 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   }
   for (int s = 0; s < nsteps; ++s) {
     const int tap_s = tap;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (TRACE) c0 = dma_shader_clock();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's A(s) rows and its share of B(s) have landed
+    if (TRACE) c1 = dma_shader_clock();
     if constexpr ((ISF_DMA_KNOCKOUT & 8) == 0)
       __syncthreads();                    // B(s) complete for every wave; everyone is done reading buffer (s+1)&1
+    if (TRACE) c2 = dma_shader_clock();
     uint4 a_cur[RG][2];
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
@@ -292,6 +311,12 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       stage_B(tap, ch, (s + 1) & 1);
     }
 #endif
+    if (TRACE) {
+      c3 = dma_shader_clock();
+      c_wait += c1 - c0;
+      c_bar += c2 - c1;
+      c_issue += c3 - c2;
+    }
     if (((wmask >> tap_s) & 1u) && (ISF_DMA_KNOCKOUT & 4) == 0) {
       bool need[RG];
 #pragma unroll
@@ -319,13 +344,27 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
         }
       }
     }
+    if (TRACE) c_mul += dma_shader_clock() - c3;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
+  if (TRACE) t_loop = wall_clock64();
 
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
   conv16_epilogue<NT, RG, F16IO>(acc, tile_l, lane, row0w, cb * BN, cout, *w_inv_scale, scale, shift, residual, ys,
                                  row_end, relu, half_tile ? RG / 2 : RG, rowmap);
+  if (TRACE) {
+    __syncthreads();
+    if (tid == 0) {
+      unsigned hw_id, xcc_id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+      long long* t = trace + (size_t)blockIdx.x * kDmaTraceWords;
+      t[0] = t_entry; t[1] = t_pro; t[2] = t_loop; t[3] = wall_clock64();
+      t[4] = nsteps; t[5] = hw_id; t[6] = xcc_id; t[7] = (long long)row0 | ((long long)half_tile << 32);
+      t[8] = (long long)c_wait; t[9] = (long long)c_bar; t[10] = (long long)c_issue; t[11] = (long long)c_mul;
+    }
+  }
 }
 
 bool sparse_conv_dma_supported(int c_in, int c_out) {
@@ -339,7 +378,7 @@ template <int CIN, int NT, int MODE, bool LINES, int NW = 4, int RG = 2>
 static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                       const int32_t* nbr, const uint32_t* lmask, int nx, int nbr_stride, int n_out, const float* scale,
                       const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
-                      const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap) {
+                      const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap, long long* trace) {
   using S = ConvDmaSmem<NT, NW, RG>;
   auto kern = spconv_dma_kernel<CIN, NT, NW, MODE, RG, LINES>;
   static std::atomic<int> wgs_per_cu{0}, cus_per_xcd{0};
@@ -363,7 +402,7 @@ static int launch_dma(bool balance, const uint4* xs, const uint4* wpk, const flo
     return ISF_OK;
   }
   hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, lmask, nx, nbr_stride, wpk,
-                     winv, K, cout, scale, shift, residual, ys, n_out, relu, plan, order, rowmap);
+                     winv, K, cout, scale, shift, residual, ys, n_out, relu, plan, order, rowmap, trace);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -372,17 +411,19 @@ template <int CIN, int NT>
 static int dispatch_dma(int mode, const uint4* xs, const uint4* wpk, const float* winv, int K, int cout,
                         const int32_t* nbr, const uint32_t* lmask, int nx, int nbr_stride, int n_out, const float* scale,
                         const float* shift, const uint4* residual, int relu, uint4* ys, hipStream_t st,
-                        const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap) {
+                        const int32_t* order, Conv16LaunchInfo* query, const int32_t* rowmap, long long* trace) {
   const bool balance = (mode & 32) == 0;
-#define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, lmask, nx, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, rowmap
+#define ISF_ARGS_DMA balance, xs, wpk, winv, K, cout, nbr, lmask, nx, nbr_stride, n_out, scale, shift, residual, relu, ys, st, order, query, rowmap, trace
   if (lmask) {
     switch (mode & ~32) {
+      case 512: return launch_dma<CIN, NT, 512, true>(ISF_ARGS_DMA);   // trace (isf_sparse_conv_dma_trace)
       case 0: return launch_dma<CIN, NT, 0, true>(ISF_ARGS_DMA);
       case 1: return launch_dma<CIN, NT, 1, true>(ISF_ARGS_DMA);
       case 257: return launch_dma<CIN, NT, 257, true>(ISF_ARGS_DMA);
     }
   } else {
     switch (mode & ~32) {
+      case 512: return launch_dma<CIN, NT, 512, false>(ISF_ARGS_DMA);
       case 0: return launch_dma<CIN, NT, 0, false>(ISF_ARGS_DMA);
       case 1: return launch_dma<CIN, NT, 1, false>(ISF_ARGS_DMA);
       case 257: return launch_dma<CIN, NT, 257, false>(ISF_ARGS_DMA);
@@ -396,7 +437,7 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
                                  int nbr_stride, int n_out, const float* scale, const float* shift,
                                  const void* residual, int relu, void* ys, int mode, hipStream_t st,
                                  const int32_t* order, Conv16LaunchInfo* query, const uint32_t* lmask, int nx,
-                                 const int32_t* rowmap) {
+                                 const int32_t* rowmap, long long* trace) {
   if (n_out <= 0) {
     if (query) *query = Conv16LaunchInfo{0, 0, 0, 0, 0, 0, 0};
     return ISF_OK;
@@ -411,7 +452,7 @@ int sparse_conv_forward_dma_impl(const void* xs, int c_in, const void* packed16,
   const uint4* x = reinterpret_cast<const uint4*>(xs);
   const uint4* r = reinterpret_cast<const uint4*>(residual);
   uint4* y = reinterpret_cast<uint4*>(ys);
-#define ISF_CALL_DMA(CI, NTT) dispatch_dma<CI, NTT>(mode, x, w, winv, K, c_out, nbr, lmask, nx, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap)
+#define ISF_CALL_DMA(CI, NTT) dispatch_dma<CI, NTT>(mode, x, w, winv, K, c_out, nbr, lmask, nx, nbr_stride, n_out, scale, shift, r, relu, y, st, order, query, rowmap, trace)
   if (c_in == 32) return c_out == 32 ? ISF_CALL_DMA(32, 2) : ISF_CALL_DMA(32, 4);
   return c_out == 32 ? ISF_CALL_DMA(64, 2) : ISF_CALL_DMA(64, 4);
 #undef ISF_CALL_DMA
@@ -448,6 +489,28 @@ int isf_sparse_conv_forward_dma_lines(const void* features_split, int num_in, in
   return isf::sparse_conv_forward_dma_impl(features_split, c_in, packed16, num_taps, c_out, lines, nbr_stride, num_out,
                                            scale, shift, residual_split, relu, out_split, mode, isf::as_stream(stream),
                                            nullptr, nullptr, mask, taps_per_line);
+}
+
+int isf_sparse_conv_dma_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
+                              int taps_per_line, int c_out, const int32_t* table, const uint32_t* mask, int nbr_stride,
+                              int num_out, const float* scale, const float* shift, const void* residual_split, int relu,
+                              void* out_split, long long* trace, int trace_capacity_blocks, int* grid_blocks,
+                              isf_stream_t stream) {
+  ISF_REQUIRE(num_in >= 0 && num_out > 0 && features_split && packed16 && table && out_split && trace && grid_blocks &&
+                  trace_capacity_blocks > 0 && ((scale == nullptr) == (shift == nullptr)), ISF_ERR_ARG,
+              "sparse_conv_dma_trace: bad arguments");
+  isf::Conv16LaunchInfo info;
+  ISF_TRY(isf::sparse_conv_forward_dma_impl(features_split, c_in, packed16, num_taps, c_out, table, nbr_stride, num_out,
+                                            scale, shift, residual_split, relu, out_split, 512, isf::as_stream(stream),
+                                            nullptr, &info, mask, taps_per_line, nullptr, nullptr));
+  const int blocks = 8 * (info.full + (info.half < 0 ? 0 : info.half));   // conv16_grid_blocks
+  ISF_REQUIRE(blocks <= trace_capacity_blocks, ISF_ERR_ARG,
+              "sparse_conv_dma_trace: the launch has %d workgroups, the trace buffer holds %d", blocks,
+              trace_capacity_blocks);
+  *grid_blocks = blocks;
+  return isf::sparse_conv_forward_dma_impl(features_split, c_in, packed16, num_taps, c_out, table, nbr_stride, num_out,
+                                           scale, shift, residual_split, relu, out_split, 512, isf::as_stream(stream),
+                                           nullptr, nullptr, mask, taps_per_line, nullptr, trace);
 }
 
 }  // extern "C"

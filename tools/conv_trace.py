@@ -1,6 +1,7 @@
 """tools/conv_trace.py -- where the time of ONE deep sparse-conv launch goes, per workgroup (isf_sparse_conv_trace).
 
     python tools/conv_trace.py [--level 3] [--batch 4] [--points 300000] [--reps 5]
+    python tools/conv_trace.py --level 0 | 1      # the NARROW layers' LDS-DMA kernel (isf_sparse_conv_dma_trace, round 6)
 
 Builds the benchmark geometry (B synthetic sweeps -> voxels -> the three strided levels), runs the production launch of
 the level's SubM layer (level 3: 256 -> 256, level 2: 128 -> 128) with the per-workgroup trace on, with tiles in
@@ -75,9 +76,50 @@ def describe(name, tr):
     return span
 
 
+def main_narrow(args, rb, dev):
+    """levels 0 / 1: 32 -> 32 / 64 -> 64 on the LDS-DMA kernel; the per-workgroup record carries wave 0's cycle account"""
+    import numpy as np
+    import torch
+    from isfusion_amd import spconv
+    C = 32 if args.level == 0 else 64
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(rb.num_in, C, generator=g).to(dev)
+    w = (torch.randn(3, 3, 3, C, C, generator=g) * (1.0 / (9 * C)) ** 0.5).to(dev)
+    packed = spconv.pack_filters_f16x3(w)
+    xs = spconv.to_split(x)
+    scale, shift = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    res = spconv.to_split(torch.randn(rb.num_out, C, generator=g).to(dev))
+    print(f"level {args.level}: {rb.num_out} rows, {C} -> {C}, {'dense table' if args.dense_table else 'line table'}")
+    spans = []
+    for r in range(args.reps + 2):
+        ys, tr = spconv.sparse_conv_dma_trace(xs, packed, 27, C, C, rb, scale, shift, res, True, lines=not args.dense_table)
+        torch.cuda.synchronize()
+        if r >= 2:
+            spans.append((tr[:, 3].max() - tr[tr[:, 3] != 0][:, 0].min()).item() * TICK_US)
+    print(f"-- launch span over {args.reps} runs: " + " ".join(f"{s:.1f}" for s in spans) + " us")
+    t = tr.cpu().numpy()
+    describe("narrow launch", t[:, :8])
+    t = t[t[:, 3] != 0]
+    cyc = t[:, 8:12].astype(np.float64)
+    steps = np.maximum(t[:, 4].astype(np.float64), 1)
+    tot = cyc.sum(1)
+    names = ("vmcnt(0) wait", "barrier", "read + issue", "multiply")
+    print("   wave 0 of every workgroup, shader-clock cycles of the loop: " +
+          ", ".join(f"{n} {100 * cyc[:, i].sum() / tot.sum():.1f} %" for i, n in enumerate(names)))
+    print("   cycles per step (mean over workgroups): " +
+          ", ".join(f"{n} {np.mean(cyc[:, i] / steps):.0f}" for i, n in enumerate(names)) +
+          f"; total {np.mean(tot / steps):.0f}")
+    loop_us = (t[:, 2] - t[:, 1]) * TICK_US
+    print(f"   loop wall time per step {np.mean(loop_us / steps):.3f} us = {np.mean(loop_us / steps) * 1e3:.0f} ns; "
+          f"cycles / wall => shader clock ~ {np.mean(tot / np.maximum(loop_us, 1e-9)) / 1e3:.2f} GHz")
+    if args.dump:
+        np.savez(args.dump, narrow=t)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--level", type=int, default=3, choices=[2, 3])
+    ap.add_argument("--level", type=int, default=3, choices=[0, 1, 2, 3])
+    ap.add_argument("--dense-table", action="store_true", help="levels 0 / 1: the dense neighbour table instead of lines")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--points", type=int, default=300000)
     ap.add_argument("--reps", type=int, default=5)
@@ -90,6 +132,8 @@ def main():
     dev = torch.device("cuda", 0)
     pts = [torch.from_numpy(p).to(dev) for p in bench.make_frames(0, 1, args.batch, args.points, 0)]
     rb = level_rulebooks(pts, args.batch, args.level)
+    if args.level < 2:
+        return main_narrow(args, rb, dev)
     C = 256 if args.level == 3 else 128
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(rb.num_in, C, generator=g).to(dev)
