@@ -877,7 +877,7 @@ def main():
     # events ride on every `stride`-th step of the timed region (an odd stride: both rotating frame sets are
     # sampled); the other steps run exactly as a caller runs them.
     nl = len(lb.conv_layer_table())
-    stride = max(1, args.steps // 5) | 1
+    stride = max(1, args.steps // 3) | 1   # three sampled steps (round 5: five; each costs the step ~0.3 ms)
     samples = []   # (ms, num_in, num_out, pairs) per layer of every sampled step
     t0 = time.perf_counter()
     for step in range(args.steps):
