@@ -719,7 +719,15 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(a.alloc_n(&sc2, (size_t)kC));
   ISF_TRY(a.alloc_n(&w1p, (size_t)4 * 2 * 64));
   ISF_TRY(a.alloc_n(&w2p, (size_t)4 * 4 * 128));
-  hipLaunchKernelGGL(vfe_prep_kernel, dim3(1), dim3(256), 0, st, w1, F, w2, scale1, scale2, w1p, sc1, w2p, sc2);
+  // one 256-thread workgroup, 14 us of latency: on the workspace's side stream, beside the index scan and the counting
+  // sort; the layer kernels wait for it
+  hipStream_t sprep = nullptr;
+  ISF_TRY(side_stream(a, &sprep));
+  ISF_TRY(stream_wait_stream(a, sprep, st));   // the weights are ready where the caller's stream stands
+  hipLaunchKernelGGL(vfe_prep_kernel, dim3(1), dim3(256), 0, sprep, w1, F, w2, scale1, scale2, w1p, sc1, w2p, sc2);
+  hipEvent_t prep_done;
+  ISF_TRY(pooled_event(a, &prep_done));
+  ISF_HIP_TRY(hipEventRecord(prep_done, sprep));
   // The one host round trip of the VFE: N sizes every per-voxel buffer.  The read-back is followed by an event, and
   // everything that does not need N -- the point -> voxel map and the per-voxel point counts (75 us of GPU work at
   // 1.2 M points, counters allocated for the worst case of one voxel per point) -- is queued behind it BEFORE the host
@@ -749,6 +757,7 @@ static int vfe_run(Arena& a, const float* points, const int32_t* coors4, int P, 
   ISF_TRY(wait_int(a, n_ticket, st, &N));
   *n_host = N;
   if (occ_out) *occ_out = occ;
+  ISF_HIP_TRY(hipStreamWaitEvent(st, prep_done, 0));   // (before any return: the packed weights live in this call's arena)
   if (N == 0) return ISF_OK;   // vfe_count_kernel has marked every point -1
   ISF_TRY(a.alloc_n(&start, (size_t)N + 2));
   ISF_TRY(a.alloc_n(&mean4, (size_t)N));
