@@ -302,10 +302,11 @@ int isf_sparse_conv_phase_trace(const void* features_split, int num_in, int c_in
                                 int* waves_per_block, int* dwords_per_wave, isf_stream_t stream);
 
 /* DIAGNOSTIC: the per-workgroup trace of the NARROW layers' kernel (isf_sparse_conv_forward_dma / _dma_lines; c_in,
- * c_out in {32, 64}): one production launch with 12 int64 per workgroup -- constant-clock (100 MHz) stamps at entry / after
+ * c_out in {32, 64}): one production launch with 16 int64 per workgroup -- constant-clock (100 MHz) stamps at entry / after
  * the prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half tile << 32, then wave 0's
  * shader-clock cycles summed over the steps: at the per-step vmcnt(0), at the barrier, in the section that reads the
- * transit / weight buffers and issues the next step's loads, in the multiply section.  table / mask: the dense neighbour
+ * transit / weight buffers and issues the next step's loads, in the multiply section; [12], [13]: of the third, the fragment
+ * reads' LDS round trip and the index arithmetic + weight run (the rest: the row gathers).  table / mask: the dense neighbour
  * table (mask NULL, taps_per_line ignored) or the line-compressed one.  tools/conv_trace.py --level 0 | 1. */
 int isf_sparse_conv_dma_trace(const void* features_split, int num_in, int c_in, const void* packed16, int num_taps,
                               int taps_per_line, int c_out, const int32_t* table, const uint32_t* mask, int nbr_stride,

@@ -45,7 +45,7 @@ namespace isf {
 #endif
 __device__ uint4 g_zero_line[8];   // 128 zero bytes: what a row without a neighbour reads
 
-constexpr int kDmaTraceWords = 12;
+constexpr int kDmaTraceWords = 16;
 __device__ __forceinline__ unsigned long long dma_shader_clock() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
   // exit, and wave 0's shader-clock account of the loop: cycles at the per-step vmcnt(0), at the barrier, in the section
   // that reads the transit / weights and issues the next step's loads, in the multiply section
   long long t_entry = 0, t_pro = 0, t_loop = 0;
-  unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mul = 0;
+  unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mul = 0, c_rd = 0, c_adv = 0;
   if (TRACE) t_entry = wall_clock64();
   static_assert(!F16IO || HALF, "f16 storage implies single-pass f16 arithmetic");
   using S = ConvDmaSmem<NT, NW, RG>;
@@ -297,12 +297,19 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
     // buffer); the rows follow once the transit has been read
     const bool more = s + 1 < nsteps;
 #if ISF_DMA_EARLY_B
+    unsigned long long ca = 0, cb = 0;
+    if (TRACE) ca = dma_shader_clock();   // (waits for the fragment reads: their LDS round trip on its own)
     if (more) {
       advance();
       stage_B(tap, ch, (s + 1) & 1);
     }
+    if (TRACE) cb = dma_shader_clock();
     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the transit has been read, the next rows may overwrite it
     if (more) issue_A(tap, ch, idx_cur);
+    if (TRACE) {
+      c_rd += ca - c2;
+      c_adv += cb - ca;
+    }
 #else   // probe builds (tools/probes/build_side_lib.sh isf_spconv_dma.hip ISF_DMA_EARLY_B=0): round 4's order, for A/B
     __builtin_amdgcn_s_waitcnt(0xC07F);
     if (more) {
@@ -363,6 +370,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_dma_kernel(
       t[0] = t_entry; t[1] = t_pro; t[2] = t_loop; t[3] = wall_clock64();
       t[4] = nsteps; t[5] = hw_id; t[6] = xcc_id; t[7] = (long long)row0 | ((long long)half_tile << 32);
       t[8] = (long long)c_wait; t[9] = (long long)c_bar; t[10] = (long long)c_issue; t[11] = (long long)c_mul;
+      t[12] = (long long)c_rd; t[13] = (long long)c_adv; t[14] = 0; t[15] = 0;   // of c_issue: fragment reads, index + weight run
     }
   }
 }

@@ -422,8 +422,9 @@ def sparse_conv_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, 
 def sparse_conv_dma_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,
                           lines=True):
     """DIAGNOSTIC (isf_sparse_conv_dma_trace): one production launch of a narrow layer (c_in, c_out in {32, 64}) on split
-    rows `xs` -> (out_split, trace int64 [workgroups, 12]): the eight columns of sparse_conv_trace + wave 0's shader-clock
-    cycles at the per-step vmcnt(0) / at the barrier / in the read-and-issue section / in the multiply section."""
+    rows `xs` -> (out_split, trace int64 [workgroups, 16]): the eight columns of sparse_conv_trace + wave 0's shader-clock
+    cycles at the per-step vmcnt(0) / at the barrier / in the read-and-issue section / in the multiply section, and of the
+    read-and-issue section: the fragment reads' LDS round trip, index arithmetic + weight run (the rest: the row gathers)."""
     _lib.require_cuda(xs)
     lib = _lib.load()
     ys = torch.empty(rb.num_out * c_out * 4, dtype=torch.uint8, device=xs.device)
@@ -433,14 +434,14 @@ def sparse_conv_dma_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=No
         if lt is not None:
             table, mask, nx = lt[0], lt[1], 3
     cap = 8 * 1024
-    trace = torch.zeros((cap * 12,), dtype=torch.int64, device=xs.device)
+    trace = torch.zeros((cap * 16,), dtype=torch.int64, device=xs.device)
     n = ctypes.c_int(0)
     _lib.check(lib.isf_sparse_conv_dma_trace(_lib.ptr(xs), rb.num_in, c_in, _lib.ptr(packed16), K, nx, c_out, _lib.ptr(table),
                                              _lib.ptr(mask) if mask is not None else None, stride, rb.num_out,
                                              _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual_split), int(bool(relu)),
                                              _lib.ptr(ys), _lib.ptr(trace), cap, ctypes.byref(n), _lib.stream()),
                "isf_sparse_conv_dma_trace")
-    return ys, trace[:n.value * 12].view(n.value, 12)
+    return ys, trace[:n.value * 16].view(n.value, 16)
 
 
 def sparse_conv_phase_trace(xs, packed16, K, c_in, c_out, rb, scale=None, shift=None, residual_split=None, relu=False,

@@ -109,6 +109,9 @@ def main_narrow(args, rb, dev):
     print("   cycles per step (mean over workgroups): " +
           ", ".join(f"{n} {np.mean(cyc[:, i] / steps):.0f}" for i, n in enumerate(names)) +
           f"; total {np.mean(tot / steps):.0f}")
+    rd, adv = t[:, 12].astype(np.float64), t[:, 13].astype(np.float64)
+    print(f"   of read + issue, cycles per step: fragment reads (LDS round trip) {np.mean(rd / steps):.0f}, index arithmetic + "
+          f"weight run {np.mean(adv / steps):.0f}, row gathers {np.mean((cyc[:, 2] - rd - adv) / steps):.0f}")
     loop_us = (t[:, 2] - t[:, 1]) * TICK_US
     print(f"   loop wall time per step {np.mean(loop_us / steps):.3f} us = {np.mean(loop_us / steps) * 1e3:.0f} ns; "
           f"cycles / wall => shader clock ~ {np.mean(tot / np.maximum(loop_us, 1e-9)) / 1e3:.2f} GHz")
