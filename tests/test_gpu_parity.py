@@ -742,6 +742,34 @@ def test_dma_gather_kernel_bit_identical_to_gather_kernel(dev, cin, cout):
         sp.sparse_conv_forward_dma(T(np.zeros((10, 128), np.float32), dev), p16, 27, 128, 128, rb)   # wide: not built
 
 
+@pytest.mark.parametrize("cin", [32, 64])
+def test_dma_kernel_trace_instantiation_computes_the_same_bits(dev, cin):
+    """isf_sparse_conv_dma_trace (the diagnostic instantiation of the narrow layers' kernel: tools/conv_trace.py --level
+    0 | 1) == the production launch bit for bit, with the line-compressed and the dense table; its record is sane: one
+    row per workgroup, stamps in order, steps <= 27 * chunks, the four cycle sums add up to a positive loop time"""
+    from isfusion_amd import spconv as sp
+    rng = np.random.default_rng(cin)
+    B, shape, n = 2, [12, 64, 64], 20000
+    idx = _random_geometry(rng, B, shape, n)
+    rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    x = T(rng.normal(0, 1, (n, cin)).astype(np.float32), dev)
+    w = T(rng.normal(0, (1.0 / (9 * cin)) ** 0.5, (3, 3, 3, cin, cin)).astype(np.float32), dev)
+    res = T(rng.normal(0, 1, (rb.num_out, cin)).astype(np.float32), dev)
+    sc = T(rng.random(cin, dtype=np.float32) + 0.5, dev)
+    sh = T(rng.normal(0, 0.2, cin).astype(np.float32), dev)
+    p16 = sp.pack_filters_f16x3(w)
+    ref = sp.sparse_conv_forward_dma(x, p16, 27, cin, cin, rb, sc, sh, res, relu=True)
+    xs, rs = sp.to_split(x), sp.to_split(res)
+    for lines in (True, False):
+        ys, tr = sp.sparse_conv_dma_trace(xs, p16, 27, cin, cin, rb, sc, sh, rs, True, lines=lines)
+        assert torch.equal(sp.from_split(ys, (rb.num_out, cin)), ref), lines
+        t = tr.cpu().numpy()
+        t = t[t[:, 3] != 0]
+        assert len(t) >= n // 128 and (t[:, 0] <= t[:, 1]).all() and (t[:, 1] <= t[:, 2]).all() and (t[:, 2] <= t[:, 3]).all()
+        assert (t[:, 4] >= 1).all() and (t[:, 4] <= 27 * (cin // 32)).all()
+        assert (t[:, 8:12].sum(1) > 0).all() and (t[:, 12] + t[:, 13] <= t[:, 10]).all()
+
+
 @pytest.mark.parametrize("cin", [128, 256])
 def test_cu_unit_kernel_bit_identical_to_tile_kernel(dev, cin):
     """isf_sparse_conv_forward_cu (256-column layers: one 8-wave workgroup per compute unit over units of equal matrix
