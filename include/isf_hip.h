@@ -98,6 +98,18 @@ int isf_hard_voxelize_device(const float* points, int num_points, int num_featur
                              int max_points, int max_voxels, float* voxels, int32_t* coors,
                              int32_t* num_points_per_voxel, int32_t* voxel_num_device, isf_stream_t stream);
 
+/* The samples of a batch in ONE pass (round 6; replaces the per-sample loop of ISFusionDetector.voxelize,
+ * mmdet3d/models/detectors/isfusion.py:148-176: `for res in points: voxel_layer(res)` + cat + F.pad with the sample index):
+ * points = the samples one behind the other, sample b = rows [point_offsets_host[b], point_offsets_host[b + 1]) (HOST array of
+ * batch_size + 1 entries, batch_size <= 16).  Per sample exactly isf_hard_voxelize_device's result (same voxels, same order,
+ * max_voxels each); the samples' voxels are written one behind the other: voxels [rows, max_points, C], coors4 [rows, 4] =
+ * (sample, z, y, x), num_points_per_voxel [rows], buffers sized batch_size * max_voxels rows; voxel_num_device
+ * [batch_size + 1] = voxels kept per sample, then their sum (= rows written).  Asynchronous, no host read-back. */
+int isf_hard_voxelize_batched_device(const float* points, const int64_t* point_offsets_host, int batch_size,
+                                     int num_features, const float voxel_size_host[3], const float coors_range_host[6],
+                                     int max_points, int max_voxels, float* voxels, int32_t* coors4,
+                                     int32_t* num_points_per_voxel, int32_t* voxel_num_device, isf_stream_t stream);
+
 /* A3  DynamicScatter ------------------------------------------------------------------------------
  * replaces voxel_layer.dynamic_point_to_voxel_forward(feats, coors, reduce_type) ->
  *   [reduced_feats, out_coors, coors_map int32, reduce_count int32]

@@ -107,6 +107,8 @@ SIGNATURES = {
                                   c_void_p, c_int_p, c_void_p]),
     "isf_hard_voxelize_device": (c_int, [c_void_p, c_int, c_int, _F3, _F6, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
+    "isf_hard_voxelize_batched_device": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64), c_int, c_int, _F3, _F6, c_int,
+                                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isf_dynamic_point_to_voxel_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                                    c_void_p, c_void_p, c_void_p, c_int_p, c_void_p]),
     "isf_dynamic_point_to_voxel_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -43,7 +43,22 @@ int dynamic_voxelize_impl(const float* points, int P, int C, const float vs[3], 
 // ------------------------------------------------------------------------------------------- A2
 static constexpr int kEmpty = 0x7f7f7f7f;  // hipMemset byte pattern 0x7f; larger than any point index
 
-__global__ void hv_mark_cells_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+// The samples of a batch voxelized in ONE pass (isf_hard_voxelize_batched_device): the points are concatenated, sample b owns
+// the point indices [off[b], off[b + 1]) and the grid planes [b * gz, (b + 1) * gz) of a grid stacked along z.  Point indices
+// ascend with the sample, so "rank of a cell's first point" numbers sample 0's voxels first, then sample 1's ...
+static constexpr int kHvMaxBatch = 16;
+struct HvBatch {
+  int n;
+  int off[kHvMaxBatch + 1];
+};
+__device__ __forceinline__ int hv_sample_of(const HvBatch& hb, int i) {
+  int b = 0;
+#pragma unroll
+  for (int k = 1; k < kHvMaxBatch; ++k) b += (k < hb.n && i >= hb.off[k]) ? 1 : 0;
+  return b;
+}
+
+__global__ void hv_mark_cells_kernel(const float* __restrict__ points, int P, int C, VoxGeom g, HvBatch hb,
                                      unsigned long long* __restrict__ cbits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
@@ -51,6 +66,7 @@ __global__ void hv_mark_cells_kernel(const float* __restrict__ points, int P, in
   if (!voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx,
                       cy, cz))
     return;
+  cz += hv_sample_of(hb, i) * g.gz;
   const unsigned long long cell = ((unsigned long long)cz * g.gy + cy) * g.gx + cx;
   const unsigned long long bit = 1ull << (cell & 63);
   unsigned long long* p = cbits + (cell >> 6);
@@ -59,7 +75,7 @@ __global__ void hv_mark_cells_kernel(const float* __restrict__ points, int P, in
 
 // byte-map marking for small grids (pillars: 32 k cells): plain byte stores instead of device-scope atomicOr on a few
 // hundred hot words (memory-side atomics serialise per address: 257 us for 300 k points), then one pack pass
-__global__ void hv_mark_bytes_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+__global__ void hv_mark_bytes_kernel(const float* __restrict__ points, int P, int C, VoxGeom g, HvBatch hb,
                                      unsigned char* __restrict__ seen) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
@@ -67,6 +83,7 @@ __global__ void hv_mark_bytes_kernel(const float* __restrict__ points, int P, in
   if (!voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx,
                       cy, cz))
     return;
+  cz += hv_sample_of(hb, i) * g.gz;
   seen[((size_t)cz * g.gy + cy) * g.gx + cx] = 1;
 }
 
@@ -87,7 +104,7 @@ __global__ void hv_pack_bytes_kernel(const unsigned char* __restrict__ seen, siz
 // sequential scan keeps (voxelization_cpu.cpp:54-69) -- are the first T of its segment.  Deterministic, no atomics.
 // History: v1 atomicMin bubble insertion (720 us per 300 k points in pillars), v2 count -> scan -> fill -> select with
 // one atomic per point per pass (90 + 16 + 90 + 55 us: the pillar grid's hot cells serialise the atomics).
-__global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, VoxGeom g,
+__global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, VoxGeom g, HvBatch hb,
                                const unsigned long long* __restrict__ cbits, const uint32_t* __restrict__ cprefix,
                                uint32_t none, uint32_t* __restrict__ keys, int* __restrict__ idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,7 +112,8 @@ __global__ void hv_keys_kernel(const float* __restrict__ points, int P, int C, V
   int cx, cy, cz;
   uint32_t key = none;   // points outside the grid sort behind every cell (none = row capacity > any rank)
   if (voxel_of_point(points + (size_t)i * C, g.vx, g.vy, g.vz, g.x0, g.y0, g.z0, g.gx, g.gy, g.gz, cx, cy, cz))
-    key = (uint32_t)occ_lookup(cbits, cprefix, ((unsigned long long)cz * g.gy + cy) * g.gx + cx);
+    key = (uint32_t)occ_lookup(cbits, cprefix,
+                               ((unsigned long long)(cz + hv_sample_of(hb, i) * g.gz) * g.gy + cy) * g.gx + cx);
   keys[i] = key;
   if (idx) idx[i] = i;     // (the sort below takes the identity permutation implicitly)
 }
@@ -277,18 +295,46 @@ __global__ void hv_mark_first_kernel(const int* __restrict__ slots, const int* _
   atomicOr(pbits + (first >> 6), 1ull << (first & 63));
 }
 
+// number of set bits before position x of an occupancy index over point indices (x <= number of positions)
+__device__ __forceinline__ int hv_rank_before(const unsigned long long* __restrict__ bits, const uint32_t* __restrict__ prefix,
+                                              int x, int npos, const int* __restrict__ total) {
+  if (x >= npos) return *total;
+  const unsigned long long w = bits[x >> 6];
+  return (int)prefix[x >> 6] + __popcll(w & ((1ull << (x & 63)) - 1ull));
+}
+
+// batched (hb.n > 1 or coors4 output): voxel ids are local to the sample (id among ALL first points - first points of the
+// earlier samples), capped per sample, and the samples' voxels are written one behind the other (row = voxels kept by the
+// earlier samples + local id) with (sample, z, y, x) coordinates -- what the reference's per-sample loop + cat + pad produce
 __global__ void hv_gather_kernel(const float* __restrict__ points, int C, const int* __restrict__ slots,
                                  const int* __restrict__ nrows, const int32_t* __restrict__ cell_coors4,
                                  int T, const unsigned long long* __restrict__ pbits,
                                  const uint32_t* __restrict__ pprefix, int max_voxels,
                                  float* __restrict__ voxels, int32_t* __restrict__ coors,
-                                 int32_t* __restrict__ num_points, int fill_empty) {
+                                 int32_t* __restrict__ num_points, int fill_empty, HvBatch hb, int gz, int batched,
+                                 const int* __restrict__ ptotal) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (long long)(*nrows) * T) return;
   const int r = (int)(tid / T), t = (int)(tid % T);
   const int* s = slots + (size_t)r * T;
-  const int vid = occ_lookup(pbits, pprefix, (unsigned long long)s[0]);
-  if (vid < 0 || vid >= max_voxels) return;
+  int vid = occ_lookup(pbits, pprefix, (unsigned long long)s[0]);
+  int b = 0;
+  if (batched) {
+    b = hv_sample_of(hb, s[0]);
+    const int npos = hb.off[hb.n];
+    int row0 = 0, before = 0;   // voxels kept by the earlier samples; first points of the earlier samples
+    for (int k = 0; k < b; ++k) {
+      const int nxt = hv_rank_before(pbits, pprefix, hb.off[k + 1], npos, ptotal);
+      const int cnt = nxt - before;
+      row0 += cnt < max_voxels ? cnt : max_voxels;
+      before = nxt;
+    }
+    vid -= before;
+    if (vid < 0 || vid >= max_voxels) return;
+    vid += row0;
+  } else if (vid < 0 || vid >= max_voxels) {
+    return;
+  }
   const int pi = s[t];
   if (pi != kEmpty) {
     const float* p = points + (size_t)pi * C;
@@ -302,10 +348,17 @@ __global__ void hv_gather_kernel(const float* __restrict__ points, int C, const 
     int n = 0;
     for (int k = 0; k < T; ++k) n += (s[k] != kEmpty);
     num_points[vid] = n;
-    const int4 c = reinterpret_cast<const int4*>(cell_coors4)[r];  // (0, z, y, x)
-    coors[(size_t)vid * 3 + 0] = c.y;
-    coors[(size_t)vid * 3 + 1] = c.z;
-    coors[(size_t)vid * 3 + 2] = c.w;
+    const int4 c = reinterpret_cast<const int4*>(cell_coors4)[r];  // (0, z, y, x); batched: z = sample * gz + z
+    if (batched) {
+      coors[(size_t)vid * 4 + 0] = b;
+      coors[(size_t)vid * 4 + 1] = c.y - b * gz;
+      coors[(size_t)vid * 4 + 2] = c.z;
+      coors[(size_t)vid * 4 + 3] = c.w;
+    } else {
+      coors[(size_t)vid * 3 + 0] = c.y;
+      coors[(size_t)vid * 3 + 1] = c.z;
+      coors[(size_t)vid * 3 + 2] = c.w;
+    }
   }
 }
 
@@ -313,33 +366,56 @@ __global__ void hv_publish_count_kernel(const int* __restrict__ total, int max_v
   *out = *total < max_voxels ? *total : max_voxels;
 }
 
+// batched: out[b] = voxels kept of sample b, out[n] = their sum (= rows written)
+__global__ void hv_publish_counts_kernel(const unsigned long long* __restrict__ pbits, const uint32_t* __restrict__ pprefix,
+                                         const int* __restrict__ total, HvBatch hb, int max_voxels,
+                                         int32_t* __restrict__ out) {
+  int before = 0, sum = 0;
+  for (int b = 0; b < hb.n; ++b) {
+    const int nxt = hv_rank_before(pbits, pprefix, hb.off[b + 1], hb.off[hb.n], total);
+    const int cnt = nxt - before < max_voxels ? nxt - before : max_voxels;
+    out[b] = cnt;
+    sum += cnt;
+    before = nxt;
+  }
+  out[hb.n] = sum;
+}
+
 // voxel_num_dev != nullptr: DEVICE-RESIDENT COUNT -- no host read-back (the caller sized the outputs for max_voxels and
 // did not zero them: rows [0, *voxel_num_dev) are written completely, padding slots included; the rest is untouched)
+// batch != nullptr (with voxel_num_dev): the samples of a batch in one pass -- `points` holds them one behind the other,
+// coors is [rows, 4] = (sample, z, y, x), voxel_num_dev has n + 1 entries (per sample, then the sum); see HvBatch
 int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float vs[3],
                        const float range[6], int max_points, int max_voxels, float* voxels,
                        int32_t* coors, int32_t* num_points, int* voxel_num_host, hipStream_t st,
-                       int32_t* voxel_num_dev = nullptr) {
+                       int32_t* voxel_num_dev = nullptr, const HvBatch* batch = nullptr) {
   const VoxGeom g = make_geom(vs, range);
   ISF_REQUIRE(g.gx > 0 && g.gy > 0 && g.gz > 0, ISF_ERR_ARG, "hard_voxelize: empty grid");
   if (voxel_num_host) *voxel_num_host = 0;
+  HvBatch hb;
+  for (int k = 0; k <= kHvMaxBatch; ++k) hb.off[k] = P;
+  hb.n = 1;
+  hb.off[0] = 0;
+  if (batch) hb = *batch;
+  const int nb = hb.n;
   if (P <= 0) {
-    if (voxel_num_dev) ISF_HIP_TRY(hipMemsetAsync(voxel_num_dev, 0, sizeof(int32_t), st));
+    if (voxel_num_dev) ISF_HIP_TRY(hipMemsetAsync(voxel_num_dev, 0, (batch ? nb + 1 : 1) * sizeof(int32_t), st));
     return ISF_OK;
   }
-  const long long cells = (long long)g.gx * g.gy * g.gz;
+  const long long cells = (long long)g.gx * g.gy * g.gz * nb;
   const int row_cap = (int)(cells < P ? cells : P);
   OccIndex cocc;  // occupied cells of this sample
   if (cells <= (1ll << 22)) {
-    ISF_TRY(occ_create(a, &cocc, 1, g.gz, g.gy, g.gx, st));   // zeroed incl. the padding words the scan reads
+    ISF_TRY(occ_create(a, &cocc, 1, g.gz * nb, g.gy, g.gx, st));   // zeroed incl. the padding words the scan reads
     unsigned char* seen = nullptr;
     ISF_TRY(a.alloc_n(&seen, (size_t)cells));
     ISF_HIP_TRY(hipMemsetAsync(seen, 0, (size_t)cells, st));
-    hipLaunchKernelGGL(hv_mark_bytes_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, seen);
+    hipLaunchKernelGGL(hv_mark_bytes_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, hb, seen);
     hipLaunchKernelGGL(hv_pack_bytes_kernel, dim3(ceil_div((long long)cocc.nwords, 256)), dim3(256), 0, st, seen,
                        (size_t)cells, cocc.nwords, cocc.bits);
   } else {
-    ISF_TRY(occ_create(a, &cocc, 1, g.gz, g.gy, g.gx, st));
-    hipLaunchKernelGGL(hv_mark_cells_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g,
+    ISF_TRY(occ_create(a, &cocc, 1, g.gz * nb, g.gy, g.gx, st));
+    hipLaunchKernelGGL(hv_mark_cells_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, hb,
                        cocc.bits);
   }
   ISF_LAUNCH_CHECK();
@@ -362,7 +438,7 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
     const uint32_t none = (uint32_t)row_cap;           // ranks are < row_cap
     int key_bits = 1;
     while ((1ull << key_bits) <= (unsigned long long)none) ++key_bits;
-    hipLaunchKernelGGL(hv_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, cocc.bits,
+    hipLaunchKernelGGL(hv_keys_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, hb, cocc.bits,
                        cocc.prefix, none, keys, (int*)nullptr);
     ISF_LAUNCH_CHECK();
     uint32_t* keys_tmp = nullptr;
@@ -382,10 +458,15 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
   ISF_TRY(occ_scan(a, pocc, st));
   hipLaunchKernelGGL(hv_gather_kernel, dim3(ceil_div((long long)row_cap * max_points, 256)), dim3(256),
                      0, st, points, C, slots, cocc.total, cell_coors, max_points, pocc.bits,
-                     pocc.prefix, max_voxels, voxels, coors, num_points, voxel_num_dev ? 1 : 0);
+                     pocc.prefix, max_voxels, voxels, coors, num_points, voxel_num_dev ? 1 : 0, hb, g.gz, batch ? 1 : 0,
+                     pocc.total);
   ISF_LAUNCH_CHECK();
   if (voxel_num_dev) {
-    hipLaunchKernelGGL(hv_publish_count_kernel, dim3(1), dim3(1), 0, st, pocc.total, max_voxels, voxel_num_dev);
+    if (batch)
+      hipLaunchKernelGGL(hv_publish_counts_kernel, dim3(1), dim3(1), 0, st, pocc.bits, pocc.prefix, pocc.total, hb,
+                         max_voxels, voxel_num_dev);
+    else
+      hipLaunchKernelGGL(hv_publish_count_kernel, dim3(1), dim3(1), 0, st, pocc.total, max_voxels, voxel_num_dev);
     ISF_LAUNCH_CHECK();
     return ISF_OK;
   }
@@ -455,6 +536,32 @@ int isf_hard_voxelize_device(const float* points, int num_points, int num_featur
   return isf::hard_voxelize_impl(a, points, num_points, num_features, voxel_size_host,
                                  coors_range_host, max_points, max_voxels, voxels, coors,
                                  num_points_per_voxel, nullptr, isf::as_stream(stream), voxel_num_device);
+}
+
+int isf_hard_voxelize_batched_device(const float* points, const int64_t* point_offsets_host, int batch_size,
+                                     int num_features, const float voxel_size_host[3], const float coors_range_host[6],
+                                     int max_points, int max_voxels, float* voxels, int32_t* coors4,
+                                     int32_t* num_points_per_voxel, int32_t* voxel_num_device, isf_stream_t stream) {
+  ISF_REQUIRE(point_offsets_host && batch_size >= 1 && batch_size <= isf::kHvMaxBatch && num_features >= 3 &&
+                  max_points > 0 && max_voxels > 0 && voxel_num_device && voxel_size_host && coors_range_host,
+              ISF_ERR_ARG, "hard_voxelize_batched_device: bad arguments (batch 1..%d)", isf::kHvMaxBatch);
+  isf::HvBatch hb;
+  hb.n = batch_size;
+  ISF_REQUIRE(point_offsets_host[0] == 0, ISF_ERR_ARG, "hard_voxelize_batched_device: offsets start at 0");
+  for (int b = 0; b <= isf::kHvMaxBatch; ++b) {
+    const int64_t o = point_offsets_host[b < batch_size ? b : batch_size];
+    ISF_REQUIRE(o >= 0 && o < (1ll << 31) && (b == 0 || b > batch_size || o >= point_offsets_host[b - 1]), ISF_ERR_ARG,
+                "hard_voxelize_batched_device: bad offsets");
+    hb.off[b] = (int)o;
+  }
+  const int P = hb.off[batch_size];
+  ISF_REQUIRE(P == 0 || (points && voxels && coors4 && num_points_per_voxel), ISF_ERR_ARG,
+              "hard_voxelize_batched_device: null pointer");
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
+  ISF_TRY(a.reset());
+  return isf::hard_voxelize_impl(a, points, P, num_features, voxel_size_host, coors_range_host, max_points, max_voxels,
+                                 voxels, coors4, num_points_per_voxel, nullptr, isf::as_stream(stream), voxel_num_device,
+                                 &hb);
 }
 
 }  // extern "C"

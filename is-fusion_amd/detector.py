@@ -105,6 +105,10 @@ class ISFusionPtsPath(nn.Module):
     def voxelize_async(self, points):
         """The pillar voxelization of every sample QUEUED on the current stream, no host wait (device-resident counts:
         isf_hard_voxelize_device) -> a callable that returns voxelize()'s triple; call it after other host work."""
+        if 1 < len(points) <= 16 and self.__dict__.get("batched_pillars", True):
+            # round 6: one pass for the whole batch (isf_hard_voxelize_batched_device): half the launches of two samples,
+            # the concatenation and the sample column written by the kernel
+            return self.pts_pillar_layer.forward_batch_async(points).result
         pend = [self.pts_pillar_layer.forward_async(res) for res in points]
 
         def finish():

@@ -96,6 +96,50 @@ def hard_voxelize_async(points, voxel_size, coors_range, max_points, max_voxels)
     return PendingVoxels(voxels, coors, num, count_host, ev)
 
 
+class PendingBatchVoxels:
+    """hard_voxelize_batched_async's handle: result() -> (voxels [M, T, C], num_points [M], coors [M, 4] = (sample, z, y,
+    x)), M = the samples' voxels one behind the other -- the triple ISFusionDetector.voxelize returns for pillars."""
+
+    def __init__(self, voxels, coors4, num, count_host, event, batch_size):
+        self.voxels, self.coors4, self.num = voxels, coors4, num
+        self._count_host, self._event, self.batch_size = count_host, event, batch_size
+
+    def result(self):
+        self._event.synchronize()
+        m = int(self._count_host[self.batch_size])
+        return self.voxels[:m], self.num[:m], self.coors4[:m]
+
+    def counts(self):
+        self._event.synchronize()
+        return [int(v) for v in self._count_host[:self.batch_size]]
+
+
+def hard_voxelize_batched_async(points_list, voxel_size, coors_range, max_points, max_voxels):
+    """The samples of a batch voxelized in one pass (isf_hard_voxelize_batched_device): per sample exactly
+    hard_voxelize_async's voxels in the same order, concatenated, with (sample, z, y, x) coordinates; one set of launches
+    for the batch instead of one per sample, nothing waits on the host.  -> PendingBatchVoxels."""
+    B = len(points_list)
+    _lib.require_cuda(*points_list)
+    pts = torch.cat([p.contiguous().float() for p in points_list], 0) if B > 1 else points_list[0].contiguous().float()
+    offs = [0]
+    for p in points_list:
+        offs.append(offs[-1] + p.size(0))
+    rows = B * int(max_voxels)
+    voxels = pts.new_empty((rows, max_points, pts.size(1)))
+    coors4 = pts.new_empty((rows, 4), dtype=torch.int32)
+    num = pts.new_empty((rows,), dtype=torch.int32)
+    count = pts.new_empty((B + 1,), dtype=torch.int32)
+    _lib.check(_lib.load().isf_hard_voxelize_batched_device(
+        _lib.ptr(pts), (ctypes.c_int64 * (B + 1))(*offs), B, pts.size(1), _lib.f3(voxel_size), _lib.f6(coors_range),
+        int(max_points), int(max_voxels), _lib.ptr(voxels), _lib.ptr(coors4), _lib.ptr(num), _lib.ptr(count), _lib.stream()),
+        "isf_hard_voxelize_batched_device")
+    count_host = torch.empty((B + 1,), dtype=torch.int32, pin_memory=True)
+    count_host.copy_(count, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingBatchVoxels(voxels, coors4, num, count_host, ev, B)
+
+
 def voxelization(points, voxel_size, coors_range, max_points=35, max_voxels=20000, deterministic=True):
     """Functional form (voxelize.py:10-76).  ``deterministic=False`` selects the same deterministic kernel:
     the non-deterministic CUDA variant exists only to dodge the O(P^2) kernel this build does not have."""
@@ -130,6 +174,12 @@ class Voxelization(nn.Module):
         max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
         assert self.max_num_points != -1 and max_voxels != -1, "dynamic voxelization has no count to wait for"
         return hard_voxelize_async(input, self.voxel_size, self.point_cloud_range, self.max_num_points, max_voxels)
+
+    def forward_batch_async(self, inputs):
+        """the samples of a batch in one pass -> PendingBatchVoxels (hard voxelization only, <= 16 samples)"""
+        max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
+        assert self.max_num_points != -1 and max_voxels != -1, "dynamic voxelization has no count to wait for"
+        return hard_voxelize_batched_async(inputs, self.voxel_size, self.point_cloud_range, self.max_num_points, max_voxels)
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range="

@@ -76,6 +76,32 @@ def test_voxelize_vs_oracle_synthetic(dev, oracle_mod):
         assert np.array_equal(v.cpu().numpy(), ov)
 
 
+def test_hard_voxelize_batched_equals_the_per_sample_loop(dev, oracle_mod):
+    """isf_hard_voxelize_batched_device: the samples of a batch in one pass == the oracle's hard voxelization of every
+    sample, concatenated, with the sample index in front of the coordinates (what the reference's loop + cat + F.pad
+    build, isfusion.py:148-176).  Samples of different sizes, an empty one, one whose voxels exceed max_voxels (capped per
+    sample: the later samples' rows move up), pillar and fine grids; outputs poisoned before the call."""
+    from isfusion_amd import synthetic
+    from isfusion_amd.voxelize import hard_voxelize_batched_async
+    sizes = [40000, 0, 70000, 25000, 3]
+    pl = [synthetic.lidar_sweeps(50 + i, max(n, 1))[:n] for i, n in enumerate(sizes)]
+    pl[2][:300, 1] += 200.0   # out-of-range rows
+    for vs, Tm, MV in (([0.6, 0.6, 8.0], 20, 30000), ([0.6, 0.6, 8.0], 12, 900), ([0.3, 0.3, 4.0], 5, 4000)):
+        for B in (5, 2, 1):
+            junk = torch.full((B * MV * Tm * 5 + 64,), float("nan"), device=dev)
+            del junk
+            pend = hard_voxelize_batched_async([T(p, dev) for p in pl[:B]], vs, RG, Tm, MV)
+            v, n, c = pend.result()
+            exp = [oracle_mod.hard_voxelize(p, vs, RG, Tm, MV) for p in pl[:B]]
+            assert pend.counts() == [len(e[2]) for e in exp], (vs, MV, B)
+            ev = np.concatenate([e[0] for e in exp])
+            ec = np.concatenate([np.concatenate([np.full((len(e[1]), 1), b, np.int32), e[1]], 1) for b, e in enumerate(exp)])
+            en = np.concatenate([e[2] for e in exp])
+            assert c.dtype == torch.int32 and np.array_equal(c.cpu().numpy(), ec), (vs, MV, B)
+            assert np.array_equal(n.cpu().numpy(), en) and np.array_equal(v.cpu().numpy(), ev), (vs, MV, B)
+    assert any(len(oracle_mod.hard_voxelize(p, [0.6, 0.6, 8.0], RG, 12, 900)[2]) == 900 for p in pl)   # the cap was hit
+
+
 def test_dynamic_voxelize_batched(dev, oracle_mod):
     from isfusion_amd.voxelize import dynamic_voxelize_batched
     from isfusion_amd import synthetic
