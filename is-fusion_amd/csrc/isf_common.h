@@ -96,6 +96,7 @@ struct OccIndex {
 };
 
 int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st, bool zero = true);
+size_t occ_bits_bytes(const OccIndex& occ);   // bytes occ_create(zero = true) clears
 // atomic-free marking through persistent byte maps (writes EVERY bitmap word: create with zero = false)
 int occ_mark_coords4_bytemap(Arena& a, const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
 int scan_u32_exclusive(Arena& a, const uint32_t* in, uint32_t* out, size_t n, hipStream_t st);
@@ -103,6 +104,9 @@ int occ_scan(Arena& a, const OccIndex& occ, hipStream_t st);                    
 int occ_mark_coords4(const OccIndex& occ, const int32_t* coors4, int n, hipStream_t st);
 // coords of all set bits in rank order -> out [total,4]
 int occ_compact_coords4(const OccIndex& occ, int32_t* out, hipStream_t st);
+// up to four byte fills in one launch; every buffer must be an arena allocation (256-byte aligned, padded to 256 bytes:
+// the fill works in 8-byte words)
+int fill_many(hipStream_t st, int n, void* const* ptrs, const size_t* bytes, const unsigned char* byte_values);
 int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream sync
 // A device int -> the host WITHOUT a copy command: a one-thread kernel writes (value, ticket) into pinned host memory
 // behind the producer on `st` and the host spins on the ticket.  hipMemcpyAsync D2H + synchronise costs a copy-engine

@@ -334,6 +334,10 @@ __global__ __launch_bounds__(kScanThreads) void occ_write_prefix_kernel(
   }
 }
 
+size_t occ_bits_bytes(const OccIndex& occ) {   // what occ_create's zero fill covers (for callers that batch their fills)
+  return round_up(occ.nwords, kWordsPerBlock) * sizeof(unsigned long long);
+}
+
 int occ_create(Arena& a, OccIndex* occ, int B, int D, int H, int W, hipStream_t st, bool zero) {
   occ->B = B; occ->D = D; occ->H = H; occ->W = W;
   occ->ncells = (unsigned long long)B * D * H * W;
@@ -478,6 +482,44 @@ int occ_mark_coords4_bytemap(Arena& a, const OccIndex& occ, const int32_t* coors
                        occ.H, occ.W, bm.fine, bm.coarse);
   hipLaunchKernelGGL(occ_bytemap_pack_kernel, dim3(ceil_div((long long)(alloc_words / 4), 256)), dim3(256), 0, st,
                      bm.fine, bm.coarse, alloc_words, occ.bits);
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
+// up to four byte fills in ONE launch (the memsets in front of a chain of small kernels are launches like any other)
+struct FillJobs {
+  unsigned long long* ptr[4];
+  unsigned long long words[4];   // 8-byte words (arena allocations are 256-byte aligned and padded)
+  unsigned long long value[4];
+  unsigned long long first[5];
+};
+__global__ __launch_bounds__(256) void fill_many_kernel(FillJobs j) {
+  const unsigned long long total = j.first[4];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) k += i >= j.first[q] ? 1 : 0;
+    j.ptr[k][i - j.first[k]] = j.value[k];
+  }
+}
+
+int fill_many(hipStream_t st, int n, void* const* ptrs, const size_t* bytes, const unsigned char* byte_values) {
+  ISF_REQUIRE(n >= 1 && n <= 4, ISF_ERR_ARG, "fill_many: %d jobs (1..4)", n);
+  FillJobs j;
+  unsigned long long at = 0;
+  for (int k = 0; k < 4; ++k) {
+    const bool on = k < n && bytes[k] > 0;
+    j.ptr[k] = on ? reinterpret_cast<unsigned long long*>(ptrs[k]) : nullptr;
+    j.words[k] = on ? (bytes[k] + 7) / 8 : 0;   // rounds up inside the allocation's 256-byte padding
+    j.value[k] = on ? 0x0101010101010101ull * byte_values[k] : 0;
+    j.first[k] = at;
+    at += j.words[k];
+  }
+  j.first[4] = at;
+  if (at == 0) return ISF_OK;
+  const unsigned long long blocks = (at + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(fill_many_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, j);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

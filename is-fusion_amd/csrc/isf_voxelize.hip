@@ -405,11 +405,21 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
   const long long cells = (long long)g.gx * g.gy * g.gz * nb;
   const int row_cap = (int)(cells < P ? cells : P);
   OccIndex cocc;  // occupied cells of this sample
-  if (cells <= (1ll << 22)) {
-    ISF_TRY(occ_create(a, &cocc, 1, g.gz * nb, g.gy, g.gx, st));   // zeroed incl. the padding words the scan reads
+  OccIndex pocc;  // bitmap over POINT indices: rank of a cell's first point = its voxel id
+  int* slots = nullptr;
+  ISF_TRY(a.alloc_n(&slots, (size_t)row_cap * max_points));
+  const bool bytes_path = cells <= (1ll << 22);
+  if (bytes_path) {
+    // the four fills of the pass -- cell index, byte map, point index (zero: incl. the padding words the scans read) and the
+    // slot table (kEmpty) -- in one launch
+    ISF_TRY(occ_create(a, &cocc, 1, g.gz * nb, g.gy, g.gx, st, false));
+    ISF_TRY(occ_create(a, &pocc, 1, 1, 1, P, st, false));
     unsigned char* seen = nullptr;
     ISF_TRY(a.alloc_n(&seen, (size_t)cells));
-    ISF_HIP_TRY(hipMemsetAsync(seen, 0, (size_t)cells, st));
+    void* fp[4] = {cocc.bits, seen, pocc.bits, slots};
+    const size_t fb[4] = {occ_bits_bytes(cocc), (size_t)cells, occ_bits_bytes(pocc), (size_t)row_cap * max_points * sizeof(int)};
+    const unsigned char fv[4] = {0, 0, 0, 0x7f};
+    ISF_TRY(fill_many(st, 4, fp, fb, fv));
     hipLaunchKernelGGL(hv_mark_bytes_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, points, P, C, g, hb, seen);
     hipLaunchKernelGGL(hv_pack_bytes_kernel, dim3(ceil_div((long long)cocc.nwords, 256)), dim3(256), 0, st, seen,
                        (size_t)cells, cocc.nwords, cocc.bits);
@@ -420,14 +430,13 @@ int hard_voxelize_impl(Arena& a, const float* points, int P, int C, const float 
   }
   ISF_LAUNCH_CHECK();
   ISF_TRY(occ_scan(a, cocc, st));
-  int* slots = nullptr;
   int32_t* cell_coors = nullptr;
-  ISF_TRY(a.alloc_n(&slots, (size_t)row_cap * max_points));
   ISF_TRY(a.alloc_n(&cell_coors, (size_t)row_cap * 4));
-  ISF_HIP_TRY(hipMemsetAsync(slots, 0x7f, (size_t)row_cap * max_points * sizeof(int), st));
+  if (!bytes_path) {
+    ISF_HIP_TRY(hipMemsetAsync(slots, 0x7f, (size_t)row_cap * max_points * sizeof(int), st));
+    ISF_TRY(occ_create(a, &pocc, 1, 1, 1, P, st));
+  }
   ISF_TRY(occ_compact_coords4(cocc, cell_coors, st));
-  OccIndex pocc;  // bitmap over POINT indices: rank of a cell's first point = its voxel id
-  ISF_TRY(occ_create(a, &pocc, 1, 1, 1, P, st));
   {
     uint32_t *keys = nullptr, *keys_sorted = nullptr, *start = nullptr;
     int* idx_sorted = nullptr;
