@@ -71,6 +71,9 @@ class Arena {
   int* mailbox_host = nullptr;
   int* mailbox_dev = nullptr;
   unsigned mailbox_seq = 0;
+  // kZeroInts ints that are ZERO between top-level calls: a kernel chain that counts into them puts the zeros back itself
+  // (its last reader), which saves the memset in front of the chain (zero_ints())
+  int* zero_pool = nullptr;
  private:
   struct Block { char* base; size_t cap; size_t off; };
   std::vector<Block> blocks_;
@@ -116,6 +119,8 @@ int read_int(const int* dev, int* host, hipStream_t st);  // async copy + stream
 int post_int(Arena& a, const int* dev, hipStream_t st, unsigned* ticket);
 int wait_int(Arena& a, unsigned ticket, hipStream_t st, int* value);
 int side_stream(Arena& a, hipStream_t* out);               // the workspace's non-blocking helper stream
+static constexpr int kZeroInts = 256;
+int zero_ints(Arena& a, int** out);                        // the workspace's self-restoring zero counters (kZeroInts)
 int stream_wait_stream(Arena& a, hipStream_t waiter, hipStream_t producer);  // event from the workspace's pool
 int pooled_event(Arena& a, hipEvent_t* out);               // recycled hipEventDisableTiming events
 

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(1024) void topk_partial_kernel(const unsigned long 
 
 // stage 2: one workgroup per sample over the chunks' winners
 __global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long long* __restrict__ partial, int slots,
-                                                          const int* __restrict__ cand_count, int n, int HW, int k,
+                                                          int* __restrict__ cand_count /* read, then zeroed again */, int n,
+                                                          int HW, int k,
                                                           int32_t* __restrict__ top_mod,
                                                           int32_t* __restrict__ top_raw) {
   __shared__ int hist[1024];
@@ -379,6 +380,8 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const unsigned long lo
   const int b = blockIdx.x, t = threadIdx.x;
   // the candidates are compacted to the front: only the first ceil(count / chunk) chunks have winners (typically 9 of 80)
   const int live = min(slots, ((cand_count[b] + kTopkChunk - 1) / kTopkChunk) * k);
+  __syncthreads();
+  if (t == 0) cand_count[b] = 0;   // the workspace's zero counters go back to zero (Arena::zero_pool): no memset next time
   const int kk = topk_block_select(partial + (size_t)b * slots, live, k, sel, sel2, hist, wave_tot, &s_prefix, &s_need, &s_cnt);
   if (t < kk) {
     const int idx = 0x7FFFF - (int)(sel[t] & 0x7FFFF);
@@ -628,8 +631,12 @@ int isf_instance_topk(const float* heatmap, int batch_size, int num_classes, int
   unsigned long long* cand = nullptr;
   int* count = nullptr;
   ISF_TRY(a.alloc_n(&cand, (size_t)batch_size * n));
-  ISF_TRY(a.alloc_n(&count, (size_t)batch_size + 16));
-  ISF_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * batch_size, st));
+  if (batch_size <= kZeroInts) {
+    ISF_TRY(zero_ints(a, &count));     // zero on entry, zeroed again by topk_final_kernel: no memset launch
+  } else {
+    ISF_TRY(a.alloc_n(&count, (size_t)batch_size + 16));
+    ISF_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * batch_size, st));
+  }
   hipLaunchKernelGGL(nms_candidates_kernel, dim3(ceil_div(n, 256 * kNmsCellsPerThread), batch_size), dim3(256), 0, st, heatmap,
                      num_classes, height, width, pool1_class_mask, cand, count, masked_heatmap);
   ISF_LAUNCH_CHECK();

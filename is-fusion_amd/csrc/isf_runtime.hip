@@ -65,7 +65,7 @@ int Arena::alloc(void** out, size_t bytes) {
 }
 
 int Arena::release() {
-  if (!blocks_.empty() || bytemaps.fine || side || mailbox_host) ISF_HIP_TRY(hipDeviceSynchronize());
+  if (!blocks_.empty() || bytemaps.fine || side || mailbox_host || zero_pool) ISF_HIP_TRY(hipDeviceSynchronize());
   for (auto& b : blocks_) ISF_HIP_TRY(hipFree(b.base));
   blocks_.clear();
   if (bytemaps.fine) {
@@ -83,6 +83,10 @@ int Arena::release() {
   if (mailbox_host) {
     (void)hipHostFree(mailbox_host);
     mailbox_host = mailbox_dev = nullptr;
+  }
+  if (zero_pool) {
+    (void)hipFree(zero_pool);
+    zero_pool = nullptr;
   }
   return ISF_OK;
 }
@@ -120,6 +124,15 @@ Arena& arena_for_stream(hipStream_t st) {
   auto& slot = g_arenas[std::make_pair(dev, st)];
   if (!slot) slot.reset(new Arena());
   return *slot;
+}
+
+int zero_ints(Arena& a, int** out) {
+  if (!a.zero_pool) {
+    ISF_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a.zero_pool), kZeroInts * sizeof(int)));
+    ISF_HIP_TRY(hipMemset(a.zero_pool, 0, kZeroInts * sizeof(int)));   // once per workspace (synchronous)
+  }
+  *out = a.zero_pool;
+  return ISF_OK;
 }
 
 int side_stream(Arena& a, hipStream_t* out) {
