@@ -724,7 +724,8 @@ int isf_sparse_conv_backward_filter(const float* features, int num_in, int c_in,
  *   f16: only the hi halves are read and multiplied -- fp16 operands, fp32 accumulation: the arithmetic of the reference's
  *   indice_conv_backward<at::Half>, which is what its sparse convolutions run under autocast (functional.py:24
  *   custom_fwd(cast_inputs=torch.half)); the forward / dX counterpart is mode 1 of isf_sparse_conv_forward_f16x3 / _dma.
- *   All asynchronous. */
+ *   mode + 2: every tap's pair list is full (the rulebook of a dense grid, dense_train.py) -- larger reduction chunks (same
+ *   sums, chunk boundaries move; still deterministic).  All asynchronous. */
 int isf_pair_list_capacity(int num_in, int num_out);
 int isf_rulebook_pair_lists(const int32_t* nbr, int nbr_stride, int num_out, int num_taps, int capacity,
                             int32_t* indice_pairs, int32_t* indice_num, isf_stream_t stream);

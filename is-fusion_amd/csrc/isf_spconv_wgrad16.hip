@@ -500,8 +500,11 @@ int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in
                                           int capacity, int num_taps, const float* grad_inv_scale, float* grad_filters,
                                           int mode, isf_stream_t stream) {
   using namespace isf;
-  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && num_taps > 0 && grad_filters && (mode == 0 || mode == 1), ISF_ERR_ARG,
-              "sparse_conv_backward_filter_f16x3: bad arguments (mode 0 = f16x3 split, 1 = single-pass f16)");
+  ISF_REQUIRE(num_in >= 0 && num_out >= 0 && num_taps > 0 && grad_filters && mode >= 0 && mode <= 3, ISF_ERR_ARG,
+              "sparse_conv_backward_filter_f16x3: bad arguments (mode 0 = f16x3 split, 1 = single-pass f16, +2 = every tap "
+              "list is full (dense grid): larger chunks)");
+  const bool full_taps = (mode & 2) != 0;
+  mode &= 1;
   ISF_REQUIRE(sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
               "sparse_conv_backward_filter_f16x3: (Cin,Cout)=(%d,%d) not built (32 / 64 / 128 / 256)", c_in, c_out);
   hipStream_t st = as_stream(stream);
@@ -521,8 +524,10 @@ int isf_sparse_conv_backward_filter_f16x3(const void* features_split, int num_in
   const int blocks = (c_in / (BM * WM)) * (c_out / (BN * WN));
   // pairs per workgroup: ~3000 workgroups if every tap were full (the centre tap of a SubM layer is, the others hold
   // 0.2-0.6 of it), at least 256 pairs, at most what keeps the partial blocks under 256 MiB
-  long long chunk = ((long long)num_taps * capacity * blocks / 3000 + 127) / 128 * 128;
-  chunk = std::max<long long>(256, std::min<long long>(chunk, 16384));
+  // (+2, a dense grid's rulebook -- dense_train.py: every tap holds `capacity` pairs, so the 3000 are real: 254 chunks of 256
+  // pairs and 150 MB of partial blocks for a 128 -> 128 conv on 2 x 180 x 180 cells; three workgroups per CU, >= 512 pairs)
+  long long chunk = ((long long)num_taps * capacity * blocks / (full_taps ? 768 : 3000) + 127) / 128 * 128;
+  chunk = std::max<long long>(full_taps ? 512 : 256, std::min<long long>(chunk, 16384));
   while (((long long)capacity + chunk - 1) / chunk * (long long)elems * 4 > (256ll << 20) && chunk < (1 << 24)) chunk *= 2;
   const int chunk_pairs = (int)chunk, chunks = ceil_div(capacity, chunk_pairs);
   Arena& a = arena_for_stream(st);

@@ -128,8 +128,9 @@ class ISFusionEncoder(nn.Module):
 
     def forward_train(self, img_mlvl_feats, lidar_feats, bs, **kwargs):
         """training mode: the same data flow with gradients -- HIP forward kernels inside autograd
-        Functions (fusion_train.py), the 3x3 convolutions + BatchNorm (batch statistics) on stock PyTorch-ROCm as the
-        north_star prescribes, instance mining without gradient (indices), like the reference."""
+        Functions (fusion_train.py), the 3x3 convolutions + BatchNorm (batch statistics) on the sparse-conv kernels over the
+        dense grid (dense_train.py; `dense_conv="stock"`: PyTorch-ROCm / MIOpen, what north_star allows there), instance
+        mining without gradient (indices), like the reference."""
         from . import fusion_train as tr
         tr.pack_stock_convs(self)
         if kwargs.get("pts_backbone", None) is not None:
@@ -146,7 +147,16 @@ class ISFusionEncoder(nn.Module):
         img_bev = tr.p2g_sample(pm["pillars"], pm["pillar_coors"], img_mlvl_feats[1], kwargs["lidar2img"],
                                 kwargs["img_aug_matrix"], kwargs["lidar_aug_matrix"],
                                 kwargs["img_metas"][0]["input_shape"], bs, S, self.num_views, noise)
-        bev_feats = self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
+        from . import dense_train as dt
+        # 3x3 conv + BatchNorm stacks: the sparse-conv kernels over the dense grid with their own backward (dense_train.py);
+        # dense_conv = "stock": the nn modules (MIOpen)
+        if self.dense_conv == "hip":
+            stack = dt.conv_stack
+        else:
+            def stack(seq, t, transpose=False):
+                t = torch.cat(list(t), 1) if isinstance(t, (list, tuple)) else t
+                return seq(t.permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2) if transpose else seq(t)
+        bev_feats = stack(self.conv_fusion, [img_bev, lidar_feats])
         pts_backbone = kwargs.get("pts_backbone", None)
         x, ins_hm, feats = bev_feats, None, []
         for i in range(len(self.get_regions)):
@@ -154,10 +164,13 @@ class ISFusionEncoder(nn.Module):
             x = tr.sstv2_forward(self.grid2region_att[i], x, win, float(self.get_regions[i].pos_temperature))
             if i == 0:
                 scene_feats = x
-                out = bev_feats.permute(0, 1, 3, 2).contiguous()
-                ins_hm = self.heatmap_head_3(self.heatmap_head_2(self.heatmap_head_1(self.conv_heatmap(out))))
-                x_scene_t = self.conv_scene(out).permute(0, 1, 3, 2).contiguous()
-                q = self.conv_ins(bev_feats)
+                # the reference convolves the spatially transposed map (:1093, :1139): transposed taps on the un-transposed
+                # tokens instead (transpose=True), as the inference path does
+                t = stack(self.heatmap_head_2, stack(self.heatmap_head_1, stack(self.conv_heatmap, bev_feats, True), True),
+                          True)
+                ins_hm = self.heatmap_head_3(t.permute(0, 1, 3, 2))       # 64 -> 10 classes: stock conv
+                x_scene_t = stack(self.conv_scene, bev_feats, True)
+                q = stack(self.conv_ins, bev_feats)
                 with torch.no_grad():
                     top_idx = ops.instance_topk(ins_hm.detach(), self.instance_num, self.nms_kernel_size,
                                                 (8, 9) if self.num_views == 6 else (1, 2))

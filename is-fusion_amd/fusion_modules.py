@@ -239,7 +239,8 @@ class Instane2SceneAtt(nn.Module):
 
 class SECONDV2(nn.Module):
     """backbones/second.py:98-238: stock Conv2d(bias=False)+BN(eps 1e-3)+ReLU stacks, invoked stage-wise from the
-    fusion encoder.  Convolutions stay on PyTorch-ROCm (MIOpen)."""
+    fusion encoder.  dense_conv = "hip": on the sparse-conv kernels over the dense grid (inference: dense_conv.py, training:
+    dense_train.py); "stock": PyTorch-ROCm (MIOpen)."""
 
     def __init__(self, in_channels=128, out_channels=(128, 128, 256), layer_nums=(3, 5, 5), layer_strides=(2, 2, 2),
                  norm_cfg=dict(type="BN", eps=1e-3, momentum=0.01), conv_cfg=dict(type="Conv2d", bias=False), **kw):
@@ -290,14 +291,16 @@ class SECONDV2(nn.Module):
 
         def nchw(t):
             return t.to_nchw() if isinstance(t, SplitMap) else t
-        if self.training:      # training: stock Conv2d + BatchNorm (batch statistics) + ReLU with autograd
+        if self.training:      # training: conv + BatchNorm (batch statistics) + ReLU with autograd -- on the sparse-conv
+            from . import dense_train as dt      # kernels over the dense grid (dense_train.py), or the stock modules
+            run = dt.conv_stack if self.dense_conv == "hip" else (lambda seq, t: seq(t))
             if stage == "stage1":
-                feat = self.blocks[0](x[0] if isinstance(x, (list, tuple)) else x)
-                return self.ds_layer(feat), None, feat
+                feat = run(self.blocks[0], x[0] if isinstance(x, (list, tuple)) else x)
+                return run(self.ds_layer, feat), None, feat
             if stage == "stage2":
-                return None, None, self.blocks[1](x[0] if isinstance(x, (list, tuple)) else x)
-            x1 = self.blocks[0](x)
-            return x1, self.blocks[1](self.ds_layer(x1))
+                return None, None, run(self.blocks[1], x[0] if isinstance(x, (list, tuple)) else x)
+            x1 = run(self.blocks[0], x)
+            return x1, run(self.blocks[1], run(self.ds_layer, x1))
         if stage == "stage1":
             feat = self._run("b0", self.blocks[0], x[0] if isinstance(x, (list, tuple)) else x)
             return nchw(self._run("ds", self.ds_layer, feat)), None, nchw(feat)

@@ -259,7 +259,8 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
             y = F.layer_norm(x + linear(att, attn.out_proj), (d,), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
             h = F.gelu(linear(y, layer.linear1))
             x = F.layer_norm(y + linear(h, layer.linear2), (d,), layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
-    return ops.from_tokens(x, B, S, S)
+    # an NCHW VIEW of the token rows: the consumers (dense_train.conv_stack, to_tokens, flatten(2)) read rows again
+    return x.view(B, S, S, d).permute(0, 3, 1, 2)
 
 
 # ----------------------------------------------------------------------------------------------------- A13

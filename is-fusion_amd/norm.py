@@ -124,19 +124,40 @@ def bn1d_relu(mod, x, residual=None, relu=True):
     # quantities in backward ((sum g, sum g xhat) vs d / d(mean, meansqr)), both [2C], so a rank-local row count would
     # pair them up silently.  Synchronised: any row count >= 1 takes the fused kernels (count = all ranks' rows);
     # single-process BatchNorm1d keeps torch's n > 1 requirement
-    synced = isinstance(mod, NaiveSyncBatchNorm1d) and _needs_sync(mod)
-    ok = (FUSED_BN_TRAIN and mod.training and isinstance(mod, nn.BatchNorm1d) and x.dim() == 2 and x.is_cuda and
+    # (a BatchNorm2d on token rows -- dense_train.py: channels-last BatchNorm2d is BatchNorm1d over the tokens -- qualifies)
+    synced = isinstance(mod, (NaiveSyncBatchNorm1d, NaiveSyncBatchNorm2d)) and _needs_sync(mod)
+    ok = (FUSED_BN_TRAIN and mod.training and isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d)) and x.dim() == 2 and
+          x.is_cuda and
           x.dtype == torch.float32 and (x.shape[0] > 1 or (synced and x.shape[0] == 1)) and c % 4 == 0 and
           4 <= c <= 1024 and 256 % (c // 4) == 0 and torch.is_grad_enabled() and mod.momentum is not None)
     if not ok:
-        out = mod(x)
+        if isinstance(mod, nn.BatchNorm2d) and x.dim() == 2:      # token rows through a 2-d module: the same arithmetic
+            out = _bn2d_on_rows(mod, x, synced)
+        else:
+            out = mod(x)
         if residual is not None:
             out = out + residual
         return torch.relu(out) if relu else out
-    sync = isinstance(mod, NaiveSyncBatchNorm1d) and _needs_sync(mod)
+    sync = synced
     with torch.autocast("cuda", enabled=False):
         return _BN1dReLUFunction.apply(x, mod.weight, mod.bias, residual.float() if residual is not None else None,
                                        mod, relu, sync)
+
+
+def _bn2d_on_rows(mod, x, synced):
+    """nn.BatchNorm2d / naiveSyncBN2d semantics on [tokens, C] rows (the stock composition: eval mode, FUSED_BN_TRAIN off,
+    channel counts the fused kernels do not tile)"""
+    if synced:
+        return _sync_bn(mod, x, (0,))
+    use_batch = mod.training or not mod.track_running_stats
+    mom = mod.momentum
+    if mod.training and mod.track_running_stats and mod.num_batches_tracked is not None:
+        mod.num_batches_tracked.add_(1)
+        if mom is None:
+            mom = 1.0 / float(mod.num_batches_tracked)
+    return torch.nn.functional.batch_norm(x, mod.running_mean if mod.track_running_stats else None,
+                                          mod.running_var if mod.track_running_stats else None, mod.weight, mod.bias,
+                                          use_batch, 0.0 if mom is None else mom, mod.eps)
 
 
 def _needs_sync(mod):

@@ -421,3 +421,104 @@ def test_fused_sync_bn_on_two_ranks_matches_the_reference_composition(dev):
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("SYNC_BN_MAX_REL_ERR")]
     assert len(lines) == 1 and float(lines[0].split()[1]) < 5e-4, lines
+
+
+# ------------------------------------------------------------------------------- dense 3x3 conv + BN stacks, training
+def _stack_case(name):
+    nn = torch.nn
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    if name == "convmodule_768":          # conv_fusion: three 256-channel input groups
+        seq, cin, hw = nn.Sequential(nn.Conv2d(768, 128, 3, padding=1, bias=False), nn.BatchNorm2d(128), nn.ReLU()), 768, (12, 10)
+    elif name == "second_block":          # SECONDV2: stride-2 conv + two more, BN eps 1e-3 / momentum 0.01
+        mods = []
+        for i, (a, b, s) in enumerate([(128, 256, 2), (256, 256, 1), (256, 256, 1)]):
+            mods += [nn.Conv2d(a, b, 3, stride=s, padding=1, bias=False), nn.BatchNorm2d(b, eps=1e-3, momentum=0.01),
+                     nn.ReLU(inplace=True)]
+        seq, cin, hw = nn.Sequential(*mods), 128, (18, 14)
+    elif name == "narrow":                # heatmap_head_1 / 2: 128 -> 64 -> 64
+        seq = nn.Sequential(nn.Conv2d(128, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(),
+                            nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU())
+        cin, hw = 128, (16, 16)
+    else:                                 # a single Conv2d with bias (no BN, no ReLU)
+        seq, cin, hw = nn.Conv2d(64, 32, 3, padding=1, bias=True), 64, (9, 21)
+    for p in seq.parameters():
+        p.data = torch.randn(p.shape, generator=g) * (0.05 if p.dim() == 4 else 0.5) + (1.0 if p.dim() == 1 else 0.0)
+    x = torch.randn((2, cin) + hw, generator=g)
+    return seq, x
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("name", ["convmodule_768", "second_block", "narrow", "single_bias"])
+def test_dense_conv_stack_training_matches_float64_stock_modules(dev, name, transpose):
+    """dense_train.conv_stack (sparse-conv kernels over the dense grid: forward, dX over the transposed rulebook, dW on the
+    f16 matrix cores, fused BatchNorm on token rows) against the same nn modules in float64 on the CPU: output, input
+    gradient, every parameter gradient, BatchNorm running statistics.  transpose: the stack applied to the spatially
+    transposed map (fusion_encoder.py:1093), computed with transposed taps on the un-transposed tokens."""
+    import copy
+    from isfusion_amd import dense_train as dt
+    seq, x = _stack_case(name)
+    ref = copy.deepcopy(seq).double().train()
+    xr = x.double().requires_grad_()
+    yr = ref(xr.permute(0, 1, 3, 2)).permute(0, 1, 3, 2) if transpose else ref(xr)
+    w = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5)).double()
+    (yr * w).sum().backward()
+    net = seq.to(dev).train()
+    assert dt.usable(net), "the stack must run on the HIP kernels"
+    xg = x.to(dev).requires_grad_()
+    y = dt.conv_stack(net, xg, transpose)
+    assert y.shape == yr.shape
+    (y * w.float().to(dev)).sum().backward()
+    assert rel_err(y, yr.float()) < 2e-5
+    assert rel_err(xg.grad, xr.grad.float()) < 1e-4
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, n
+        assert rel_err(p.grad, q.grad.float()) < 2e-4, n
+    for (n, b), (_, c) in zip(net.named_buffers(), ref.named_buffers()):
+        assert rel_err(b.float(), c.float()) < 1e-5, n
+
+
+def test_dense_conv_stack_under_autocast_and_fallbacks(dev):
+    """under torch.autocast the stack computes in single-pass f16 (fp32 rows in and out: looser tolerance, finite
+    gradients); a stack the kernels do not tile (10 output channels) and ENABLED = False run the stock modules."""
+    import copy
+    from isfusion_amd import dense_train as dt
+    seq, x = _stack_case("narrow")
+    ref = copy.deepcopy(seq).double().train()
+    yr = ref(x.double())
+    net = seq.to(dev).train()
+    xg = x.to(dev).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = dt.conv_stack(net, xg)
+    assert y.dtype == torch.float32 and rel_err(y, yr.float()) < 2e-2
+    y.square().mean().backward()
+    assert torch.isfinite(xg.grad).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())
+    small = torch.nn.Conv2d(64, 10, 3, padding=1).to(dev)
+    assert not dt.usable(small)
+    xs = torch.randn(2, 64, 8, 8, device=dev)
+    assert torch.allclose(dt.conv_stack(small, xs), small(xs), atol=1e-6)
+    assert torch.allclose(dt.conv_stack(small, xs, True), small(xs.permute(0, 1, 3, 2)).permute(0, 1, 3, 2), atol=1e-5)
+    dt.ENABLED = False
+    try:
+        assert not dt.usable(net)
+    finally:
+        dt.ENABLED = True
+
+
+def test_dense_conv_stack_takes_a_list_of_maps_as_their_channel_concatenation(dev):
+    """conv_fusion's input (fusion_encoder.py:1163 torch.cat([img_bev, lidar_feats])) handed over as a list: written
+    token-major once per source, same result and gradients as the concatenated map"""
+    from isfusion_amd import dense_train as dt
+    seq, x = _stack_case("convmodule_768")
+    net = seq.to(dev).train()
+    xa = x.to(dev).requires_grad_()
+    ya = dt.conv_stack(net, xa)
+    ya.square().sum().backward()
+    ga = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    parts = [x[:, :256].to(dev).requires_grad_(), x[:, 256:].to(dev).requires_grad_()]
+    yb = dt.conv_stack(net, parts)
+    yb.square().sum().backward()
+    assert rel_err(yb, ya.cpu()) < 1e-6
+    assert rel_err(torch.cat([p.grad for p in parts], 1), xa.grad.cpu()) < 1e-6
+    for p, g in zip(net.parameters(), ga):
+        assert rel_err(p.grad, g.cpu()) < 1e-6

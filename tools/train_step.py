@@ -43,8 +43,13 @@ def main():
     ap.add_argument("--shared-device", action="store_true",
                     help="every rank uses cuda:0 (1-GPU box): proves that several processes of libisf_hip.so train side "
                          "by side; with --backend gloo")
+    ap.add_argument("--stock-dense", action="store_true",
+                    help="the dense 3x3 conv + BatchNorm stacks on the stock modules (MIOpen) instead of dense_train.py (A/B)")
     a = ap.parse_args()
     from isfusion_amd import launch, synthetic
+    if a.stock_dense:
+        from isfusion_amd import dense_train
+        dense_train.ENABLED = False
     if a.gpus > 0:
         launch.self_launch(a.gpus, a.backend)
     from isfusion_amd.detector import ISFusionPtsPath
