@@ -60,23 +60,36 @@ template <int KC /* K/32 */, int CT /* column tiles per chunk */, int RG /* row 
 __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16x3_kernel(const float* __restrict__ x, int M, int ldx,
                                                            const uint4* __restrict__ wp,
                                                            const float* __restrict__ w_inv_scale, int N,
-                                                           LinearEpilogue ep, float* __restrict__ y, int ldy) {
+                                                           LinearEpilogue ep, float* __restrict__ y, int ldy,
+                                                           int csplit) {
   constexpr int STEP_U4 = CT * 128;          // uint4 per staged step
   constexpr int PF = STEP_U4 / 256;          // uint4 per thread per step
   __shared__ uint4 bbuf[2][STEP_U4];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int col = lane & 15, kg = lane >> 4;
-  const int r0 = (blockIdx.x * 4 + wave) * 16 * RG;
   const int ntiles = N >> 4;
   const int nchunks = (ntiles + CT - 1) / CT;
+  // COLUMN SPLIT (csplit; launches with few row blocks and several column chunks -- the level-1 SST projections, 16 200 rows
+  // x 768 / 1024 columns: 254 workgroups = one wave per SIMD): one workgroup per (row block, column chunk).  Workgroups are
+  // dealt to the 8 XCDs round-robin, so the chunks of a row block take ids 8 apart: they run on ONE XCD, whose L2 then
+  // serves the block's input rows to all of them.
+  int rb = blockIdx.x, cbeg = 0, cend = nchunks;
+  if (csplit) {
+    const int g = blockIdx.x / (8 * nchunks), within = blockIdx.x - g * 8 * nchunks;
+    rb = g * 8 + (within & 7);
+    cbeg = within >> 3;
+    cend = cbeg + 1;
+    if (rb * 64 * RG >= M) return;
+  }
+  const int r0 = (rb * 4 + wave) * 16 * RG;
   // channels-first input: the workgroup's [K x 64 RG rows] tile is loaded with 16-byte loads along the rows (the
   // contiguous direction of [B, K, hw]) into LDS and read back transposed
   constexpr int XT_LD = 64 * RG + 4;
   extern __shared__ __attribute__((aligned(16))) float xt[];   // [K][XT_LD], only when ep.x_hw
   if (CF && ep.x_hw) {
     constexpr int QUADS = 16 * RG;   // row quads per tile
-    const int R0 = blockIdx.x * 64 * RG;
+    const int R0 = rb * 64 * RG;
     for (int idx = threadIdx.x; idx < KC * 32 * QUADS; idx += 256) {
       const int c = idx / QUADS, q = idx - c * QUADS;
       const int r = R0 + 4 * q;
@@ -133,11 +146,11 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
 #pragma unroll
     for (int i = 0; i < PF; ++i) bbuf[buf][threadIdx.x + 256 * i] = pf[i];
   };
-  fetch(0, 0);
+  fetch(cbeg, 0);
   commit(0);
   __syncthreads();
   int step = 0;
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int c0 = chunk * CT;
     f32x4 acc[RG][CT];
 #pragma unroll
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc, ++step) {
       const int buf = step & 1;
-      const bool more = !(chunk == nchunks - 1 && kc == KC - 1);
+      const bool more = !(chunk == cend - 1 && kc == KC - 1);
       if (more) fetch(kc == KC - 1 ? chunk + 1 : chunk, kc == KC - 1 ? 0 : kc + 1);
 #pragma unroll
       for (int nt = 0; nt < CT; ++nt) {
@@ -395,14 +408,26 @@ static int launch_linear(const float* x, int M, int ldx, const void* packed, int
     attr_set_ve = true;
   }
   // (the batched epilogue exists for one row group per wave only: with two it spills)
+  // (Small launches -- the 400-row Linears of the instance branch and the head, 27 of a full forward's 47 -- take 9-11 us on
+  // this kernel, ~4 us above an empty launch.  A variant that requests all of K at once (whole-K weights in LDS, one wait, no
+  // barrier in the loop; bit-identical) was built in round 6 and measured SLOWER, 15.6 us for 64 KiB of weights and 29 us
+  // for 128 KiB whether they came by LDS-DMA or through registers: its time follows the size of its straight-line code, i.e.
+  // instruction fetch of a once-executed unrolled body, not data.  Removed; gpurun_out/linear_census3/4.txt.)
+  // column split (see the kernel): several column chunks and fewer than four workgroups per CU without it; row-major input
+  // only -- a channels-first input tile is staged through LDS by every workgroup that reads it (16 200 x 256 -> 1024 from
+  // [B, C, hw]: 84 us whole rows, 130 us split, gpurun_out/linear_census2.txt)
 #define ISF_LIN(CT_, RG_, CF_, ROWS_, LDS_)                                                                             \
   do {                                                                                                                  \
+    const int rows_ = vepi ? 64 : ROWS_;                                                                                \
+    const int nrb_ = ceil_div(M, rows_), nch_ = ceil_div(ntiles, CT_);                                                  \
+    const int cs_ = (nch_ > 1 && nrb_ < 1024 && ep.x_hw == 0) ? 1 : 0;                                                  \
+    const dim3 grid_(cs_ ? ceil_div(nrb_, 8) * 8 * nch_ : nrb_);                                                        \
     if (vepi)                                                                                                           \
-      hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, 1, CF_, true>), dim3(ceil_div(M, 64)), block, LDS_, st, x, M, ldx, \
-                         wp, winv, N, ep, y, ldy);                                                                      \
+      hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, 1, CF_, true>), grid_, block, LDS_, st, x, M, ldx,               \
+                         wp, winv, N, ep, y, ldy, cs_);                                                                 \
     else                                                                                                                \
-      hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, RG_, CF_>), dim3(ceil_div(M, ROWS_)), block, LDS_, st, x, M, ldx,  \
-                         wp, winv, N, ep, y, ldy);                                                                      \
+      hipLaunchKernelGGL((linear_f16x3_kernel<KC, CT_, RG_, CF_>), grid_, block, LDS_, st, x, M, ldx,                   \
+                         wp, winv, N, ep, y, ldy, cs_);                                                                 \
   } while (0)
   if (wide_ln) {
     if (cf) ISF_LIN(16, 1, true, 64, lds1); else ISF_LIN(16, 1, false, 64, 0);

@@ -66,6 +66,28 @@ def test_linear_channels_first_io(dev, B, H, W, K, N):
     assert (y2 - F.linear(x.permute(0, 2, 3, 1), w, b).reshape(-1, N)).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N,flags", [(16200, 256, 768, "table"), (16200, 256, 1024, "relu"), (16200, 256, 256, "gelu"),
+                                         (5000, 128, 384, ""), (64800, 128, 256, "relu"), (16137, 256, 768, "")])
+def test_linear_column_split_launches_match_fp64(dev, M, K, N, flags):
+    """launches with several column chunks and fewer than 1024 row blocks deal (row block, column chunk) pairs to workgroups
+    (XCD-aware ids): every output element against float64, incl. a row count that leaves the last group of eight row
+    blocks partial"""
+    from isfusion_amd import fusion_ops as ops
+    x, w, b = rnd((M, K), 71), rnd((N, K), 72, K ** -0.5), rnd((N,), 73, 0.1)
+    tab = rnd((36, N), 74)
+    idx = torch.randint(0, 36, (M,), generator=torch.Generator().manual_seed(75)).int()
+    act = 1 if "relu" in flags else 2 if "gelu" in flags else 0
+    kw = dict(act=act)
+    if "table" in flags:
+        kw["table"], kw["index"] = tab.to(dev), idx.to(dev)
+    y = ops.linear(x.to(dev), ops.PackedLinear(w.to(dev), b.to(dev)), **kw).cpu().double()
+    z = F.linear(x.double(), w.double(), b.double())
+    if "table" in flags:
+        z = z + tab[idx.long()].double()
+    z = [z, F.relu(z), F.gelu(z)][act]
+    assert (y - z).abs().max().item() < 2e-5 * max(1.0, z.abs().max().item())
+
+
 def test_linear_rejects_bad_shapes(dev):
     from isfusion_amd import fusion_ops as ops
     from isfusion_amd._lib import IsfError
