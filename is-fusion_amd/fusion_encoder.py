@@ -86,7 +86,9 @@ class ISFusionEncoder(nn.Module):
         maps = [SplitMap.from_nchw(img_bev)]
         for off in range(0, lidar_feats.size(1), 256):
             maps.append(SplitMap.from_nchw(lidar_feats, off, min(256, lidar_feats.size(1) - off)))
-        return self._conv("conv_fusion")(maps).to_nchw()
+        m = self._conv("conv_fusion")(maps)
+        self.__dict__["_bev_split"] = m        # the instance branch convolves the same map: it takes the split form as it is
+        return m.to_nchw()
 
     def grid2region(self, level, bev):
         """A10/A11: SSTInputLayerV2 + SSTv2 on the dense [B, C, S, S] grid."""
@@ -100,7 +102,8 @@ class ISFusionEncoder(nn.Module):
         un-transposed tokens instead, so no transposed copy of the map is ever made."""
         S = self.bev_size
         if self.dense_conv == "hip":
-            m = SplitMap.from_nchw(bev_feats)
+            m = kwargs.get("bev_split")
+            m = m if m is not None else SplitMap.from_nchw(bev_feats)
             t = self._conv("heatmap_head_2")(self._conv("heatmap_head_1")(self._conv("conv_heatmap")(m, True), True),
                                              True)                                   # un-transposed orientation
             # 64 -> 10 channels: the same kernel with the output columns zero-padded to its narrowest tile (32), again
@@ -200,7 +203,9 @@ class ISFusionEncoder(nn.Module):
     def forward_tail(self, img_bev, lidar_feats, bs, **kwargs):
         """everything behind Point-to-Grid: shape-static for a given batch size (no pillar count in it), which is what
         ISFusionPtsPath captures in a HIP graph"""
+        self.__dict__["_bev_split"] = None
         bev_feats = self.fuse(img_bev, lidar_feats)
+        kwargs["bev_split"] = self.__dict__.pop("_bev_split", None)   # conv_fusion's output before its NCHW conversion
         pts_backbone = kwargs.get("pts_backbone", None)
         x = bev_feats
         ins_hm = None
