@@ -789,7 +789,7 @@ def main():
                     help="run every leg on a private (non-NULL) HIP stream instead of torch's default stream")
     ap.add_argument("--no-pipelined", action="store_true",
                     help="skip the two-batches-in-flight leg appended as \"pipelined\"")
-    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in range(1, 8)] + [16384, 32768, 49152, 65536, 131072, 262144, 524288, 262144 + 32, 262144 + 64, 1048576, 2097152, 4194304, 8388608, 16777216, 33554432, 67108864, 134217728, 268435456] + [512 + 1024 * v for v in range(1, 16)],
+    ap.add_argument("--conv-diag", type=int, default=0, choices=[0, 2, 4, 6, 8, 16, 32, 48, 64, 96, 128, 192, 256, 512, 704] + [1024 * v for v in range(1, 8)] + [16384, 32768, 49152, 65536, 131072, 262144, 524288, 262144 + 32, 262144 + 64, 1048576, 2097152, 4194304, 8388608, 16777216, 33554432, 67108864, 134217728, 268435456, 536870912] + [512 + 1024 * v for v in range(1, 16)],
                     help="DIAGNOSTIC ONLY: knock-out timing modes of the sparse-conv kernel (isf_encoder_options.diagnostic; "
                          "results are garbage, the line is labelled)")
     ap.add_argument("--stage-rows", type=int, default=0,

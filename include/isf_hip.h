@@ -230,6 +230,9 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
  * for the 256-column layers (4 x 32-row / 8 x 16-row waves), +65536 = staggered issue phases, +131072 = round 4's issue
  * phase (index reads inside the step, separate weight-DMA pieces), +262144 = gathered rows two steps ahead -- experiments
  * measured slower than the default, kept as tested opt-ins.
+ * Round 6, mode 0 / +32, c_out = 256 (other shapes ignore it): +524288 = CHUNK SPLIT -- a tile is computed by two workgroups,
+ * each over half of the 32-channel chunks; the second to arrive adds the other's accumulator tile and runs the epilogue.
+ * Deterministic, NOT the bits of mode 0 (the sum over chunks becomes (lower half) + (upper half)); measured slower; opt-in.
  * Workgroup shape (mode 0 / +32; chosen per launch from c_out and num_out, never changes a result): 4 waves x 32 rows and two
  * 128-column blocks for c_out = 256, 8 waves x 32 rows for c_out = 128 from 2048 rows up; launches the tile plan would cut
  * into half tiles only (c_out = 256: num_out <= 96 x CUs; c_out = 128: 2048 <= num_out <= 256 x CUs) run with 16 rows per
@@ -472,7 +475,9 @@ typedef struct isf_encoder_stats { /* filled on the host after the call (for roo
  *            8192); +1048576 = staggered issue phases inside the deep layers' workgroups (conv mode 65536); +4194304 = the
  *            gathered rows two steps ahead (conv mode 262144); +2097152 = round 4's issue phase (row-index reads inside the
  *            step, four separate weight-DMA pieces; conv mode 131072) -- the A/B partner of the default, which reads the
- *            indices one step ahead and stages a wave's weight share as one run. */
+ *            indices one step ahead and stages a wave's weight share as one run.
+ *            Round 6: +536870912 = the 256-column layers with the chunk split (conv mode 524288): valid, deterministic, not
+ *            the default's bits, measured slower (opt-in). */
 typedef struct isf_encoder_options {
   int precision;
   int diagnostic;

@@ -74,6 +74,12 @@ class Arena {
   // kZeroInts ints that are ZERO between top-level calls: a kernel chain that counts into them puts the zeros back itself
   // (its last reader), which saves the memset in front of the chain (zero_ints())
   int* zero_pool = nullptr;
+  // CHUNK-SPLIT convolutions (isf_spconv16.hip, conv mode bit 524288): the partial accumulator tiles the two workgroups of
+  // a tile exchange, and one arrival counter per tile (zero between launches: the second arriver puts the zero back)
+  float* ks_scratch = nullptr;
+  size_t ks_scratch_bytes = 0;
+  unsigned* ks_count = nullptr;
+  int ks_count_cap = 0;
  private:
   struct Block { char* base; size_t cap; size_t off; };
   std::vector<Block> blocks_;
@@ -121,6 +127,8 @@ int wait_int(Arena& a, unsigned ticket, hipStream_t st, int* value);
 int side_stream(Arena& a, hipStream_t* out);               // the workspace's non-blocking helper stream
 static constexpr int kZeroInts = 256;
 int zero_ints(Arena& a, int** out);                        // the workspace's self-restoring zero counters (kZeroInts)
+// the workspace's chunk-split buffers, grown on demand (a grow synchronises `st` first: earlier launches may still read them)
+int ksplit_buffers(Arena& a, size_t scratch_bytes, int counters, float** scratch, unsigned** count, hipStream_t st);
 int stream_wait_stream(Arena& a, hipStream_t waiter, hipStream_t producer);  // event from the workspace's pool
 int pooled_event(Arena& a, hipEvent_t* out);               // recycled hipEventDisableTiming events
 

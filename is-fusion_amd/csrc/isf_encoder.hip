@@ -254,7 +254,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                                 hipStream_t st, hipEvent_t geometry_ready = nullptr,
                                 const void* x0_split = nullptr /* x0 already in the split format (DynamicVFE wrote it) */) {
   const int precision = opt ? opt->precision : 0, diagnostic = opt ? opt->diagnostic : 0;
-  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
+  const int dg = diagnostic & ~(32 | 64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912);   // 256: isf_lidar_branch_forward's VFE hand-over, not the encoder's   // bits 32 (uniform conv tiles) and 64 (tiles in launch order) combine with the others
   const bool tile_order = (diagnostic & 64) == 0;
   const bool dma_gather = (diagnostic & 128) == 0;   // bit 128: the narrow layers on the gather kernel as well
   const bool tile_tables = (diagnostic & 32768) != 0;      // bit 32768 (opt-in; measured slower): equal-work
@@ -273,6 +273,14 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // level 0 on paper, no gain measured (64 -> 64 0.703 -> 0.719, 32 -> 32 0.272 -> 0.276 ms per step: those layers are bound
   // by their gathers, and like rows are further apart), profiles/r06_row_sort.txt
   const bool narrow_sort = (diagnostic & 67108864) != 0;
+  // CHUNK SPLIT of the 256-column layers (conv mode 524288, isf_spconv16.hip: two workgroups per tile, each over half of
+  // the 32-channel chunks, the second to arrive adds the other's accumulators and runs the epilogue): OPT-IN with bit
+  // 536870912.  Built on the reading that the small deep levels are ONE round of workgroups that ends with its longest tile
+  // (216 steps against an average of 136) -- and measured slower: 256 -> 256 0.223 -> 0.256 ms per launch, 1 030 -> 980
+  // frames/s (gpurun_out / profiles/EXPERIMENTS.md): the launch is bound by what its workgroups move through the CUs'
+  // vector-memory paths in total, not by its longest chain; a second prologue per tile and the exchange add to that.
+  // Deterministic (a + b == b + a), not the bits of the unsplit kernel (the sum over chunks is (lower half) + (upper half)).
+  const bool ksplit_on = (diagnostic & 536870912) != 0;
   constexpr int sort_min_rows = 4096;   // (configs[2] at B = 2: 7.05 ms sorted from 4 096 rows up, 7.10 from 32 768, 7.10 unsorted)
   // key of the sort: 1 = six coarse bits (one radix pass) everywhere.  Sixteen taps of the planes above / below (key 3,
   // two passes) made the 256-column launches 0.8 % faster (1.131 vs 1.140 ms per step) and their fabric traffic 37 % larger
@@ -286,7 +294,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
                   (dg == 0 || dg == 2 || dg == 4 || dg == 6 || dg == 8 || dg == 16) && !(precision == 2 && dg != 0),
               ISF_ERR_ARG, "sparse_encoder: options (precision %d, diagnostic %d)", precision, diagnostic);
   // precision 2: f16 storage + single-pass f16 arithmetic (mode 257 of the conv kernel)
-  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456));
+  const int conv_mode = precision == 2 ? (257 | (diagnostic & 32)) : (diagnostic & ~(64 | 128 | 256 | 512 | (15 << 10) | 16384 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576 | 2097152 | 4194304 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912));
   // bits 262144 / 524288: the 256-column layers as one column block (conv mode 4096 / 8192; isf_spconv16.hip)
   const int wide_cols = (diagnostic & 262144 ? 4096 : 0) | (diagnostic & 524288 ? 8192 : 0);
   const int stagger = ((diagnostic & 1048576) ? 65536 : 0) | ((diagnostic & 2097152) ? 131072 : 0) | ((diagnostic & 4194304) ? 262144 : 0) |
@@ -372,6 +380,8 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     const bool cu = use16 && cu_units && srows == 0 && conv_mode == 0 && sparse_conv_cu_supported(ly.c_in, ly.c_out);
     ConvCuPlan cu_plan;
     const bool want_order = use16 && tile_order && srows == 0 && !cu;
+    const int ksbit = (ksplit_on && use16 && !f16io && !cu && srows == 0 && dg == 0 && ly.c_out == 256 && ly.c_in >= 128 &&
+                       conv_mode == (conv_mode & 32) && wide_cols == 0 && stagger == 0) ? 524288 : 0;
     // narrow layers: LDS-DMA gathers (isf_spconv_dma.hip); the timing diagnostics and mode 16 exist on the gather kernel
     const bool dma = use16 && dma_gather && srows == 0 && dg == 0 && sparse_conv_dma_supported(ly.c_in, ly.c_out);
     const uint32_t* lmask = nullptr;   // non-null: `nbr` is the line-compressed table of this layer
@@ -401,7 +411,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         return sparse_conv_forward_dma_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
                                             nullptr, 0, nullptr, conv_mode, sg, nullptr, info);
       return sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, table, tstride, rows, nullptr, nullptr,
-                                            nullptr, 0, nullptr, conv_mode | (ly.c_out >= 128 ? stagger : 0), sg, nullptr, info);
+                                            nullptr, 0, nullptr, conv_mode | ksbit | (ly.c_out >= 128 ? stagger : 0), sg, nullptr, info);
     };
     auto ensure_row_sort = [&](const int32_t* table, int tstride, int rows, bool* built) -> int {
       *built = false;
@@ -474,7 +484,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         }
         if (want_order) {
           ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out,
-                                   conv_mode | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &L.cache_order, sg,
+                                   conv_mode | ksbit | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &L.cache_order, sg,
                                    (L.cache_lmask && sort_applies(nbr, stride, n_out)) ? L.cache_lmask_sorted : L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
@@ -496,7 +506,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         }
         if (want_order && (L.cache_order_cin != ly.c_in || L.cache_order_cout != ly.c_out)) {   // another launch shape
           ISF_TRY(build_tile_order(a, ly, K, sort_applies(nbr, stride, n_out) ? L.cache_nbr_sorted : nbr, stride, n_out,
-                                   conv_mode | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &L.cache_order, sg,
+                                   conv_mode | ksbit | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &L.cache_order, sg,
                                    (L.cache_lmask && sort_applies(nbr, stride, n_out)) ? L.cache_lmask_sorted : L.cache_lmask,
                                    &L.cache_order_is_table, tile_tables, L.coors, band_of(L.shape)));
           L.cache_order_cin = ly.c_in;
@@ -563,7 +573,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
           conv_mode == (conv_mode & 32) && wide_cols == 0 && (stagger & ~64) == 0 && Nx.n >= sort_min_rows) {
         Conv16LaunchInfo info;
         ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, Nx.n, nullptr, nullptr,
-                                               nullptr, 0, nullptr, conv_mode | stagger, sg, nullptr, &info));
+                                               nullptr, 0, nullptr, conv_mode | ksbit | stagger, sg, nullptr, &info));
         int32_t *rm = nullptr, *ns = nullptr;
         ISF_TRY(a.alloc_n(&rm, (size_t)stride));
         ISF_TRY(a.alloc_n(&ns, (size_t)K * stride));
@@ -572,7 +582,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
         rowmap = rm;
       }
       if (want_order)
-        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &order, sg, lmask, &order_is_table, tile_tables,
+        ISF_TRY(build_tile_order(a, ly, K, nbr, stride, Nx.n, conv_mode | ksbit | (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0), dma, &order, sg, lmask, &order_is_table, tile_tables,
                                  Nx.coors, band_of(Nx.shape)));
       if (cu && Nx.n > 0) ISF_TRY(build_cu_plan(a, nbr, stride, K, Nx.n, &cu_plan, sg, cu_cap));
       if (stats) stats->pairs[i] = -(long long)i - 1;
@@ -612,7 +622,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     else if (use16)
       ISF_TRY(sparse_conv_forward_f16x3_impl(x, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, n_out, ly.scale,
                                              ly.shift, res, ly.relu, y,
-                                             conv_mode | (order_is_table ? 1024 : 0) | (ly.c_out == 256 && conv_mode == (conv_mode & 32) ? wide_cols : 0) |
+                                             conv_mode | ksbit | (order_is_table ? 1024 : 0) | (ly.c_out == 256 && conv_mode == (conv_mode & 32) ? wide_cols : 0) |
                                                  (ly.c_out >= 128 && conv_mode == (conv_mode & 32) ? stagger : 0),
                                              st, order, nullptr, rowmap));
     else if (sparse_conv_mfma_supported(ly.c_in, ly.c_out))

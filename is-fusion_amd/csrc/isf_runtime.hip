@@ -65,7 +65,8 @@ int Arena::alloc(void** out, size_t bytes) {
 }
 
 int Arena::release() {
-  if (!blocks_.empty() || bytemaps.fine || side || mailbox_host || zero_pool) ISF_HIP_TRY(hipDeviceSynchronize());
+  if (!blocks_.empty() || bytemaps.fine || side || mailbox_host || zero_pool || ks_scratch || ks_count)
+    ISF_HIP_TRY(hipDeviceSynchronize());
   for (auto& b : blocks_) ISF_HIP_TRY(hipFree(b.base));
   blocks_.clear();
   if (bytemaps.fine) {
@@ -88,6 +89,12 @@ int Arena::release() {
     (void)hipFree(zero_pool);
     zero_pool = nullptr;
   }
+  if (ks_scratch) (void)hipFree(ks_scratch);
+  if (ks_count) (void)hipFree(ks_count);
+  ks_scratch = nullptr;
+  ks_count = nullptr;
+  ks_scratch_bytes = 0;
+  ks_count_cap = 0;
   return ISF_OK;
 }
 
@@ -132,6 +139,32 @@ int zero_ints(Arena& a, int** out) {
     ISF_HIP_TRY(hipMemset(a.zero_pool, 0, kZeroInts * sizeof(int)));   // once per workspace (synchronous)
   }
   *out = a.zero_pool;
+  return ISF_OK;
+}
+
+int ksplit_buffers(Arena& a, size_t scratch_bytes, int counters, float** scratch, unsigned** count, hipStream_t st) {
+  if (scratch_bytes > a.ks_scratch_bytes || counters > a.ks_count_cap) {
+    ISF_HIP_TRY(hipStreamSynchronize(st));     // launches that still use the old buffers are behind us on this stream
+    if (scratch_bytes > a.ks_scratch_bytes) {
+      if (a.ks_scratch) ISF_HIP_TRY(hipFree(a.ks_scratch));
+      a.ks_scratch = nullptr;
+      a.ks_scratch_bytes = 0;
+      const size_t want = round_up(scratch_bytes + scratch_bytes / 4, (size_t)1 << 20);
+      ISF_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a.ks_scratch), want));
+      a.ks_scratch_bytes = want;
+    }
+    if (counters > a.ks_count_cap) {
+      if (a.ks_count) ISF_HIP_TRY(hipFree(a.ks_count));
+      a.ks_count = nullptr;
+      a.ks_count_cap = 0;
+      const int want = (int)round_up((size_t)counters * 2, 4096);
+      ISF_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&a.ks_count), (size_t)want * sizeof(unsigned)));
+      ISF_HIP_TRY(hipMemset(a.ks_count, 0, (size_t)want * sizeof(unsigned)));   // once: the kernels restore the zeros
+      a.ks_count_cap = want;
+    }
+  }
+  *scratch = a.ks_scratch;
+  *count = a.ks_count;
   return ISF_OK;
 }
 

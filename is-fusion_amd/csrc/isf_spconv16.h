@@ -128,9 +128,10 @@ __host__ __device__ inline bool conv16_tile_rows(Conv16Plan plan, int TM, int n_
 // by conv16_tile_order_impl so that the tiles sharing a CU add up to about the same work).
 __device__ __forceinline__ bool conv16_tile_of_block(int ncb, Conv16Plan plan, int TM, int n_out, int& cb, int& row0,
                                                      int& row_end, bool& half,
-                                                     const int32_t* __restrict__ order = nullptr) {
-  const int xcd = blockIdx.x & 7;
-  int j = blockIdx.x >> 3;
+                                                     const int32_t* __restrict__ order = nullptr, int bid = -1) {
+  if (bid < 0) bid = (int)blockIdx.x;     // (chunk-split launches: the workgroup's id within its half of the grid)
+  const int xcd = bid & 7;
+  int j = bid >> 3;
   cb = ncb == 2 ? xcd & 1 : 0;
   const int part = ncb == 2 ? xcd >> 1 : xcd;
   if (plan.half < 0) {   // tile table: (first group, groups) per slot; a tile of <= TM / 32 groups runs as a half tile

@@ -74,7 +74,16 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
     const uint4* __restrict__ wpk, const float* __restrict__ w_inv_scale, int K, int cout,
     const float* __restrict__ scale, const float* __restrict__ shift, const uint4* __restrict__ residual,
     uint4* __restrict__ ys, int n_out, int relu, Conv16Plan plan, const int32_t* __restrict__ order,
-    long long* __restrict__ trace, const int32_t* __restrict__ rowmap /* nullptr | position -> output row (sorted launch) */) {
+    long long* __restrict__ trace, const int32_t* __restrict__ rowmap /* nullptr | position -> output row (sorted launch) */,
+    float* __restrict__ ks_scratch, unsigned* __restrict__ ks_count /* chunk-split launches (MODE bit 524288) */) {
+  // MODE bit 524288: CHUNK SPLIT.  A tile is computed by TWO workgroups -- blocks b and b + gridDim.x / 2 (ids 8 apart
+  // share an XCD, so these do too) -- each over half of the 32-channel chunks; both store their accumulator tile, the
+  // SECOND to arrive at the tile's counter adds the other's and runs the epilogue (a + b == b + a: the result does not
+  // depend on who arrives first; per output element: (chunks of the lower half, taps ascending) + (chunks of the upper
+  // half, taps ascending)).  Why: the 256-column layers live on the small deep levels -- 40 k rows at B = 4 x 300 k
+  // points = 636 workgroups on 768 slots, ONE round, whose duration is its longest tile's (27 taps x 8 chunks = 216
+  // steps of ~1.2 us) while the average tile has 136: 1 272 half-length workgroups refill the slots as they drain.
+  constexpr bool KSPLIT = (MODE & 524288) != 0;
   // MODE bit 512: per-workgroup trace (isf_sparse_conv_trace): 8 x int64 per workgroup -- constant-clock time stamps at
   // entry / after the prologue / after the multiply loop / at exit, steps, HW_ID, XCC_ID, first row | half << 32
   constexpr bool TRACE = (MODE & 512) != 0;
@@ -128,7 +137,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   const int ncb = cout / BN;
   int cb, row0, row_end;
   bool half_tile;   // every wave owns one 16-row group (rows row0 + 16 * wave ..) instead of RG
-  if (!conv16_tile_of_block(ncb, plan, TM, n_out, cb, row0, row_end, half_tile, order)) return;
+  const int ks_grid = KSPLIT ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const int ks_h = (KSPLIT && (int)blockIdx.x >= ks_grid) ? 1 : 0;       // which half of the chunks
+  const int bid = (int)blockIdx.x - ks_h * ks_grid;
+  if (!conv16_tile_of_block(ncb, plan, TM, n_out, cb, row0, row_end, half_tile, order, bid)) return;
   if constexpr (RG == 1) half_tile = false;   // one 16-row group per wave already: a short tile is a full tile with fewer rows
   const int ntiles_total = cout >> 4;
 
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   for (int w = 0; w < NW; ++w) wg_mask |= (unsigned)misc[w];
   wg_mask = __builtin_amdgcn_readfirstlane(wg_mask);
   const int ntaps = __popc(wg_mask);
-  const int nsteps = NOLOOP ? 0 : ntaps * NCG;
+  static_assert(!KSPLIT || (NCG % 2 == 0 && (MODE & (512 | 262144)) == 0), "chunk split: even chunk-group count, no trace / A2 loop");
+  const int nsteps = NOLOOP ? 0 : ntaps * (KSPLIT ? NCG / 2 : NCG);
   if (TRACE) t_pro = wall_clock64();
 
   f32x4 acc[RG][NT];
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
       if (s + 2 < nsteps) body(s + 2, A2s, A1);
     }
   }
-  Cursor cur{0u, -1, -1};
+  Cursor cur{0u, -1, KSPLIT ? ks_h * (NCG / 2) - 1 : -1};   // chunk split: this workgroup's first chunk group
   int idx_pre[RG];   // deep layers: row indices of the step after the current one (see the main loop)
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) idx_pre[rg] = -1;
@@ -612,6 +625,46 @@ __global__ __launch_bounds__(64 * NW, (NW >= 16 ? 1 : (NT * RG >= 16 ? 2 : 3))) 
   __syncthreads();  // all waves done with the weight buffers -> reuse as the epilogue transpose tile
   if (TRACE) t_loop = wall_clock64();
 
+  if constexpr (KSPLIT) {
+    // accumulator tiles in the C/D layout, one KiB per (row group, column tile) and wave: [tile][half][wave][rg][nt][lane].
+    // The exchange goes THROUGH the caches (system-scope stores / loads, sc0 sc1): a device-scope release fence here is a
+    // write-back of the XCD's whole L2 per workgroup (buffer_wbl2) -- measured: the launch 0.225 -> 0.49 ms.  Stores acked
+    // (s_waitcnt) before the arrival is counted; the counter is a device-scope atomic; the loads are issued behind it.
+    f32x4* mine = reinterpret_cast<f32x4*>(ks_scratch) + (((size_t)bid * 2 + ks_h) * NW + wave) * (RG * NT * 64) + lane;
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(mine + (rg * NT + nt) * 64), "v"(acc[rg][nt]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) misc[0] = (int)atomicAdd(ks_count + bid, 1u);
+    __syncthreads();
+    const int arrived = misc[0];
+    if (arrived == 0) return;              // first: the other workgroup of this tile finishes it
+    const f32x4* other = reinterpret_cast<const f32x4*>(ks_scratch) + (((size_t)bid * 2 + (ks_h ^ 1)) * NW + wave) * (RG * NT * 64) + lane;
+    f32x4 o[RG * NT];
+#pragma unroll
+    for (int k = 0; k < RG * NT; ++k)
+      asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(o[k]) : "v"(other + k * 64) : "memory");
+    static_assert(RG * NT == 8 || RG * NT == 16, "chunk split: 8 or 16 accumulator tiles per wave");
+    // the wait carries the loaded registers as operands, so that nothing that reads them is scheduled in front of it
+    if constexpr (RG * NT == 16)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(o[8]),
+                     "+v"(o[9]), "+v"(o[10]), "+v"(o[11]), "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[RG * NT - 1])
+                   : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])
+                   : : "memory");
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[rg][nt] = acc[rg][nt] + o[rg * NT + nt];
+    if (tid == 0) ks_count[bid] = 0u;      // the zero back for the next launch
+  }
+
   float* tile_l = reinterpret_cast<float*>(smem) + wave * (Conv16Epi<NT, RG>::wave_bytes / 4);
   conv16_epilogue<NT, RG, F16IO>(acc, tile_l, lane, row0 + wave * (half_tile ? WR / 2 : WR), cb * BN, cout, *w_inv_scale,
                                  scale, shift, residual, ys, row_end, relu, half_tile ? RG / 2 : RG, rowmap);
@@ -740,8 +793,15 @@ static int launch16(bool balance, bool table /* `order` is a tile table (conv16_
                               cus_per_xcd.load(std::memory_order_relaxed)};
     return ISF_OK;
   }
-  hipLaunchKernelGGL(kern, dim3(conv16_grid_blocks(plan)), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K,
-                     cout, scale, shift, residual, ys, n_out, relu, plan, order, trace, rowmap);
+  float* ks_scratch = nullptr;
+  unsigned* ks_count = nullptr;
+  int grid = conv16_grid_blocks(plan);
+  if constexpr ((MODE & 524288) != 0) {   // chunk split: two workgroups per tile, their exchange buffers from the workspace
+    ISF_TRY(ksplit_buffers(arena_for_stream(st), (size_t)grid * 2 * NW * RG * NT * 1024, grid, &ks_scratch, &ks_count, st));
+    grid *= 2;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), S::bytes, st, xs, nbr, nbr_stride, wpk, winv, K,
+                     cout, scale, shift, residual, ys, n_out, relu, plan, order, trace, rowmap, ks_scratch, ks_count);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -792,6 +852,15 @@ static int launch16_rows(int mode, const uint4* xs, const uint4* wpk, const floa
   // gather in the MFMA operand layout costs 64 address cycles, 12 resident waves x (3 gathers + 4 weight DMA pieces) =
   // the step time): per MFMA this halves the gather instructions.  4096: 4 waves x 32 rows (two workgroups per CU:
   // 64 KiB weight stage); 8192: 8 waves x 16 rows.  Tile-order tables belong to the two-block launch plan: ignored.
+  // mode bit 524288: CHUNK SPLIT for the 256-column layers (see the kernel); the workgroup shape follows the small-launch
+  // rule below (the choice does not change the arithmetic); other shapes / modes ignore the bit
+  if constexpr (NT == 8 && CIN >= 128) {
+    if ((mode & 524288) && cout == 256 && (mode & ~(32 | 1024 | 524288)) == 0) {
+      if (n_out <= 96 * conv16_device_cus()) return launch16<CIN, NT, 1, 4, 524288>(ISF_ARGS16);
+      return launch16<CIN, NT, 2, 4, 524288>(ISF_ARGS16);
+    }
+  }
+  mode &= ~524288;
   if constexpr (NT == 8 && CIN >= 128) {
     if ((mode & (4096 | 8192)) && cout == 256 && (mode & ~(32 | 1024 | 4096 | 8192)) == 0 && !rowmap) {
       if (mode & 8192)
@@ -1331,7 +1400,7 @@ int isf_sparse_conv_forward_f16x3(const void* features_split, int num_in, int c_
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3: null pointer");
-  const int m = mode & ~(32 | 64 | 4096 | 8192 | 32768 | 65536 | 131072 | 262144);   // bit 32 = uniform tiles (no full / half mix), combinable; 4096 / 8192 = one
+  const int m = mode & ~(32 | 64 | 4096 | 8192 | 32768 | 65536 | 131072 | 262144 | 524288);   // bit 32 = uniform tiles (no full / half mix), combinable; 524288 = chunk split (256-column layers); 4096 / 8192 = one
                                                // column block for the 256-column layers (4 x 32-row / 8 x 16-row waves)
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 2 || m == 4 || m == 6 || m == 8 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3: mode %d (0 default, 1 single-pass f16, 257 f16 storage, diagnostics 2 / 4 / 6 / "
@@ -1373,7 +1442,7 @@ int isf_sparse_conv_forward_f16x3_ordered(const void* features_split, int num_in
   if (num_out == 0) return ISF_OK;
   ISF_REQUIRE(features_split && packed16 && nbr && out_split && ((scale == nullptr) == (shift == nullptr)),
               ISF_ERR_ARG, "sparse_conv_forward_f16x3_ordered: null pointer");
-  const int m = mode & ~(32 | 65536 | 131072 | 262144);
+  const int m = mode & ~(32 | 65536 | 131072 | 262144 | 524288);
   ISF_REQUIRE(mode >= 0 && (m == 0 || m == 1 || m == 16 || m == 257), ISF_ERR_ARG,
               "sparse_conv_forward_f16x3_ordered: mode %d (0, 1, 16, 257, +32, +65536, +131072)", mode);
   return isf::sparse_conv_forward_f16x3_impl(features_split, c_in, packed16, num_taps, c_out, nbr, nbr_stride,

@@ -538,6 +538,57 @@ def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
     assert lb.last_stats.pairs[0] == pairs0 and lb.last_stats.pairs[1] == pairs0
 
 
+def test_chunk_split_of_the_256_column_layers(dev, oracle_mod):
+    """round 6 (opt-in: conv mode 524288 / encoder diagnostic 536870912; measured slower): a tile of a 256-column layer is
+    computed by two workgroups, each over half of the 32-channel chunks; the second to arrive adds the other's accumulator
+    tile (exchanged through system-scope stores / loads) and runs the epilogue.  Per output element the sum over chunks is
+    (lower half) + (upper half) instead of one running sum: not the bits of the unsplit kernel, but deterministic (a + b ==
+    b + a: no dependence on the arrival order), independent of the batch a frame is computed in, equal between the tile
+    shapes, and as close to the oracle."""
+    import isfusion_amd as m
+    from isfusion_amd import spconv as sp, synthetic
+    KS = 536870912
+    rng = np.random.default_rng(77)
+    B, shape = 2, [9, 40, 36]
+    for cin, cout in ((256, 256), (128, 256)):
+        for n in (2500, 9000, 23000):     # one-group tiles (<= 96 x CUs rows) and a ragged last tile; 23000: the densest
+            idx = _random_geometry(rng, B, shape, n)
+            feats = rng.normal(0, 1, (n, cin)).astype(np.float32)
+            w = rng.normal(0, (1.0 / (6 * cin)) ** 0.5, (3, 3, 3, cin, cout)).astype(np.float32)
+            scale, shift = rng.random(cout, dtype=np.float32) + 0.5, rng.normal(0, 0.2, cout).astype(np.float32)
+            res = rng.normal(0, 1, (n, cout)).astype(np.float32)
+            rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+            a = (T(feats, dev), sp.pack_filters_f16x3(T(w, dev)), 27, cin, cout, rb, T(scale, dev), T(shift, dev), T(res, dev))
+            plain = sp.sparse_conv_forward_f16x3(*a, relu=True)
+            got = sp.sparse_conv_forward_f16x3(*a, relu=True, mode=524288)
+            for _ in range(3):
+                assert torch.equal(sp.sparse_conv_forward_f16x3(*a, relu=True, mode=524288), got), (cin, cout, n)
+            assert torch.equal(sp.sparse_conv_forward_f16x3(*a, relu=True, mode=524288 + 32), got), (cin, cout, n)
+            assert (got - plain).abs().max().item() < 1e-4, (cin, cout, n)
+            assert not torch.equal(got, plain)
+            oidx, pairs, num = oracle_mod.get_indice_pairs(idx, B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], subm=True)
+            o1, o2 = lexsort4(rb.out_indices.cpu().numpy()), lexsort4(oidx)
+            want = oracle_mod.bn_act(oracle_mod.indice_conv(feats, w, pairs, num, len(oidx))[o2], scale, shift, res[o1], relu=True)
+            assert np.abs(got.cpu().numpy()[o1] - want).max() < 2e-4, (cin, cout, n)
+    # shapes the split is not built for ignore the bit
+    idx = _random_geometry(rng, B, shape, 3000)
+    rb = sp.build_rulebook(T(idx, dev), B, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], True)
+    f = T(rng.normal(0, 1, (3000, 128)).astype(np.float32), dev)
+    p = sp.pack_filters_f16x3(T(rng.normal(0, 0.05, (3, 3, 3, 128, 128)).astype(np.float32), dev))
+    assert torch.equal(sp.sparse_conv_forward_f16x3(f, p, 27, 128, 128, rb, mode=524288), sp.sparse_conv_forward_f16x3(f, p, 27, 128, 128, rb))
+    # the LiDAR branch with the split on: repeatable; a frame alone == the frame in a batch; tile plans do not matter
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 4)):
+        pl = [T(synthetic.lidar_sweeps(1300 + i, n), dev) for i in range(frames)]
+        got, ref = lb(pl, conv_diag=KS), lb(pl)
+        assert torch.isfinite(got).all() and got.abs().max().item() > 0.1
+        assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item()), n
+        assert not torch.equal(got, ref), n
+        assert torch.equal(lb(pl, conv_diag=KS), got) and torch.equal(lb(pl, conv_diag=KS + 32), got), n
+        assert torch.equal(lb(pl, conv_diag=KS + 64), got), n
+        assert torch.equal(lb(pl[:1], conv_diag=KS)[0], got[0]), n
+
+
 def test_conv_neighbour_sharing_reproduces_full_gather_bits(dev):
     """the conv kernel takes a row's fragment from the right-hand lane's registers when the indices match instead of
     gathering it again (isf_spconv16.hip, load_A): the shared fragment is the fragment the load would have returned, so
