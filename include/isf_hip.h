@@ -484,6 +484,11 @@ typedef struct isf_encoder_options {
   int stage_rows;  /* LDS-staged input rows per 128-row conv tile (isf_sparse_conv_forward_staged); 0 = the library's
                       per-layer default, -1 = staging off (every layer on the gather kernel) */
   int stage_mask;  /* with stage_rows > 0: bit i = layer i runs staged (tuning); 0 = every layer */
+  int bev_format;  /* spatial_features: 0 = fp32 [B, C*D, H, W] (the reference's layout, sparse_encoder.py:137-139);
+                      1 = the same map as split-format token matrices, one per 256-channel group: group g at byte offset
+                      g * B*H*W * 1024, [B*H*W, 256] in the split activation format (token = (b*H + y)*W + x, channel
+                      c*D + z) -- what the fusion encoder's convolutions read (isf_sparse_conv_forward_f16x3 over
+                      isf_dense_grid_rulebook): no isf_nchw_to_split pass.  Same byte count; precision 0 only */
 } isf_encoder_options;
 
 int isf_sparse_encoder_forward(const float* voxel_features, const int32_t* coors, int num_voxels,
@@ -587,6 +592,13 @@ int isf_p2g_forward(const float* pillars, int pillar_ld, int slots, const int32_
                     const float* img_nhwc, int batch_size, int num_cam, int feat_h, int feat_w, int channels,
                     const float* cam_params, int input_h, int input_w, int bev_size, float* out,
                     isf_stream_t stream);
+/* ... with the result as ONE split-format token matrix [B*bev*bev, 256] (token = (b*bev + y)*bev + x; channels == 256; the
+ * same bytes as the fp32 map, written completely): what conv_fusion reads (dense grid convolution on
+ * isf_sparse_conv_forward_f16x3) -- no isf_nchw_to_split pass, and a pillar's 256 values leave the wave as one KiB. */
+int isf_p2g_forward_split(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
+                          const float* img_nhwc, int batch_size, int num_cam, int feat_h, int feat_w, int channels,
+                          const float* cam_params, int input_h, int input_w, int bev_size, void* out_split,
+                          isf_stream_t stream);
 
 /* A12  instance mining: sigmoid + 3x3 NMS + top-k -------------------------------------------------------
  * replaces fusion_encoder.py:1100-1131.  heatmap [B, K, H, W] logits; classes with bit set in

@@ -44,15 +44,17 @@ class EncoderStats(ctypes.Structure):
 class EncoderOptions(ctypes.Structure):
     """struct isf_encoder_options: per-call precision (0 auto f16x3 / 1 fp32 MFMA / 2 single-pass f16) and timing
     diagnostic of the conv kernels (0 off)."""
-    _fields_ = [("precision", c_int), ("diagnostic", c_int), ("stage_rows", c_int), ("stage_mask", c_int)]
+    _fields_ = [("precision", c_int), ("diagnostic", c_int), ("stage_rows", c_int), ("stage_mask", c_int),
+                ("bev_format", c_int)]
 
 
-def encoder_options(precision=0, diagnostic=0, stage_rows=0, stage_mask=0):
+def encoder_options(precision=0, diagnostic=0, stage_rows=0, stage_mask=0, bev_format=0):
     """-> byref(isf_encoder_options) or None for the defaults.  stage_rows: LDS-staged input rows per conv tile
-    (0 = library default, -1 = off); stage_mask: layers that run staged when stage_rows > 0 (0 = all)."""
-    if not precision and not diagnostic and not stage_rows and not stage_mask:
+    (0 = library default, -1 = off); stage_mask: layers that run staged when stage_rows > 0 (0 = all); bev_format 1: the
+    BEV map as split-format token matrices (one per 256-channel group) instead of fp32 [B, C*D, H, W]."""
+    if not precision and not diagnostic and not stage_rows and not stage_mask and not bev_format:
         return None
-    return ctypes.byref(EncoderOptions(int(precision), int(diagnostic), int(stage_rows), int(stage_mask)))
+    return ctypes.byref(EncoderOptions(int(precision), int(diagnostic), int(stage_rows), int(stage_mask), int(bev_format)))
 
 
 class ConvCuPlan(ctypes.Structure):
@@ -211,6 +213,8 @@ SIGNATURES = {
     "isf_channel_attention_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "isf_p2g_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_p2g_forward_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_instance_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
     "isf_msda_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -116,6 +116,74 @@ int sparse_to_dense_bev_impl(Arena& a, const void* feats, int fmt, const int32_t
   return ISF_OK;
 }
 
+// BEV map of the last level as SPLIT-FORMAT TOKEN MATRICES (isf_encoder_options.bev_format = 1): what the fusion encoder's
+// 3 x 3 convolutions read (dense_conv.SplitMap) -- no fp32 [B, C*D, H, W] map, no NCHW -> split pass behind it.  Group g
+// (256 channels) = matrix [B*H*W, 256] at out + g * B*H*W * 64 (uint4), token = (b*H + y)*W + x, channel = c*D + z
+// (the reference's view(N, C*D, H, W), sparse_encoder.py:137-139).  Thread -> (token, 8-channel unit); every unit written.
+__global__ __launch_bounds__(256) void bev_split_kernel(const uint4* __restrict__ fs, int C, int D, int H, int W,
+                                                        const unsigned long long* __restrict__ bits,
+                                                        const uint32_t* __restrict__ prefix, long long ntok,
+                                                        uint4* __restrict__ out) {
+  const int upt = C * D / 8;                                   // 8-channel units per token
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntok * upt) return;
+  const long long tok = t / upt;
+  const int j = (int)(t - tok * upt);
+  const int hw = H * W;
+  const int b = (int)(tok / hw), pos = (int)(tok - (long long)b * hw);
+  const int y = pos / W, x = pos - y * W;
+  _Float16 hi[8], lo[8];
+  if (D == 2) {   // channels 8 j .. 8 j + 7 = (c, z) = (4 j, 0), (4 j, 1), (4 j + 1, 0), ...: four channels of two rows
+    const int r0 = occ_lookup(bits, prefix, (((unsigned long long)b * 2 + 0) * H + y) * W + x);
+    const int r1 = occ_lookup(bits, prefix, (((unsigned long long)b * 2 + 1) * H + y) * W + x);
+    uint2 h0 = make_uint2(0, 0), l0 = h0, h1 = h0, l1 = h0;
+    const int uc = j >> 1, e = j & 1;                          // the rows' 8-channel unit, its lower / upper four channels
+    if (r0 >= 0) {
+      const uint2* p = reinterpret_cast<const uint2*>(fs + split_hi_index((size_t)r0, C >> 3, uc));
+      h0 = p[e];
+      l0 = p[8 + e];                                           // lo piece: 4 uint4 = 8 uint2 further
+    }
+    if (r1 >= 0) {
+      const uint2* p = reinterpret_cast<const uint2*>(fs + split_hi_index((size_t)r1, C >> 3, uc));
+      h1 = p[e];
+      l1 = p[8 + e];
+    }
+    const _Float16 *a0 = reinterpret_cast<const _Float16*>(&h0), *a1 = reinterpret_cast<const _Float16*>(&h1);
+    const _Float16 *b0 = reinterpret_cast<const _Float16*>(&l0), *b1 = reinterpret_cast<const _Float16*>(&l1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hi[2 * q] = a0[q]; hi[2 * q + 1] = a1[q];
+      lo[2 * q] = b0[q]; lo[2 * q + 1] = b1[q];
+    }
+  } else {
+    for (int q = 0; q < 8; ++q) {
+      const int ch = 8 * j + q, c = ch / D, z = ch - c * D;
+      const int r = occ_lookup(bits, prefix, (((unsigned long long)b * D + z) * H + y) * W + x);
+      hi[q] = lo[q] = (_Float16)0.f;
+      if (r >= 0) {
+        const _Float16* p = reinterpret_cast<const _Float16*>(fs + split_hi_index((size_t)r, C >> 3, c >> 3));
+        hi[q] = p[c & 7];
+        lo[q] = p[32 + (c & 7)];                               // 4 uint4 = 32 halves further
+      }
+    }
+  }
+  const int g = j >> 5, ju = j & 31;                           // 256-channel group, unit inside it
+  uint4* o = out + (size_t)g * ntok * 64 + split_hi_index((size_t)tok, 32, ju);
+  o[0] = *reinterpret_cast<const uint4*>(hi);
+  o[4] = *reinterpret_cast<const uint4*>(lo);
+}
+
+int sparse_to_bev_split_impl(const void* feats_split, int C, int B, int D, int H, int W, const OccIndex& occ, void* out,
+                             hipStream_t st) {
+  ISF_REQUIRE(C % 32 == 0 && (C * D) % 256 == 0, ISF_ERR_UNSUPPORTED,
+              "bev (split token matrices): %d x %d channels are not whole 256-channel groups", C, D);
+  const long long ntok = (long long)B * H * W, total = ntok * (C * D / 8);
+  hipLaunchKernelGGL(bev_split_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, reinterpret_cast<const uint4*>(feats_split),
+                     C, D, H, W, occ.bits, occ.prefix, ntok, reinterpret_cast<uint4*>(out));
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
+
 __global__ void check_rank_order_kernel(const int32_t* __restrict__ coors4, int n, int B, int D, int H, int W,
                                         const unsigned long long* __restrict__ bits,
                                         const uint32_t* __restrict__ prefix, int* __restrict__ flag) {
@@ -645,8 +713,15 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
   // dense BEV of the last level
   ISF_TRY(ensure_occ(a, L, B, sg));
   ISF_TRY(stream_wait_stream(a, st, sg));
-  ISF_TRY(sparse_to_dense_bev_impl(a, x, use16 ? (f16io ? 2 : 1) : 0, L.coors, L.n, c_last, B, L.shape[0], L.shape[1],
-                                   L.shape[2], spatial_features, &L.occ, st));
+  if (opt && opt->bev_format == 1) {   // split-format token matrices (same byte count as the fp32 map)
+    ISF_REQUIRE(use16 && !f16io, ISF_ERR_UNSUPPORTED, "sparse_encoder: bev_format 1 needs the split-precision path");
+    ISF_TRY(sparse_to_bev_split_impl(x, c_last, B, L.shape[0], L.shape[1], L.shape[2], L.occ, spatial_features, st));
+  } else {
+    ISF_REQUIRE(!opt || opt->bev_format == 0, ISF_ERR_ARG, "sparse_encoder: bev_format %d (0 fp32 map, 1 split token matrices)",
+                opt->bev_format);
+    ISF_TRY(sparse_to_dense_bev_impl(a, x, use16 ? (f16io ? 2 : 1) : 0, L.coors, L.n, c_last, B, L.shape[0], L.shape[1],
+                                     L.shape[2], spatial_features, &L.occ, st));
+  }
   if (stats) stats->precision = use16 ? 1 : 0;
   if (out_shape) { out_shape[0] = c_last * L.shape[0]; out_shape[1] = L.shape[1]; out_shape[2] = L.shape[2]; out_shape[3] = L.n; }
   if (stats) {

@@ -15,7 +15,7 @@ namespace isf {
 // registers and the canvas is written once.
 // cam[b*num_cam + k] = 20 floats: M (3x3 row-major) = lidar2img[:3,:3] . inv(lidar_aug[:3,:3]),
 //                      v (3) = lidar2img[:3,3] - M . lidar_aug[:3,3], A (2x3) = img_aug[:2,:3], a (2) = img_aug[:2,3]
-template <int CPL /* channels per lane */>
+template <int CPL /* channels per lane */, bool SPLIT = false /* out = one split-format token matrix [B*bev*bev, 256] */>
 __global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pillars, int pillar_ld, int T,
                                                   const int32_t* __restrict__ coors, int M,
                                                   const float* __restrict__ img /* [B*cam, H, W, C] */, int num_cam,
@@ -82,6 +82,19 @@ __global__ __launch_bounds__(256) void p2g_kernel(const float* __restrict__ pill
         }
       }
     }
+  }
+  if constexpr (SPLIT) {   // C == 256, CPL == 4: the pillar's cell is ONE token row, 1 KiB contiguous for the wave
+    static_assert(!SPLIT || CPL == 4, "split output: 256 channels, four per lane");
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {acc[0], acc[1], acc[2], acc[3]};
+    const h4 hi = __builtin_convertvector(v, h4);                  // the split of isf_f32_to_split, element for element
+    const h4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f4), h4);
+    const size_t tok = ((size_t)b * bev + y) * bev + x;
+    uint2* o2 = reinterpret_cast<uint2*>(out) + split_hi_index(tok, 32, lane >> 1) * 2 + (lane & 1);
+    o2[0] = *reinterpret_cast<const uint2*>(&hi);
+    o2[8] = *reinterpret_cast<const uint2*>(&lo);                  // the lo piece: 4 x 16 bytes further
+    return;
   }
   float* o = out + ((size_t)b * C + c0) * bev * bev + (size_t)y * bev + x;
 #pragma unroll
@@ -553,6 +566,25 @@ __global__ __launch_bounds__(256) void msda_backward_kernel(
 }  // namespace isf
 
 extern "C" {
+
+int isf_p2g_forward_split(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
+                          const float* img_nhwc, int batch_size, int num_cam, int feat_h, int feat_w, int channels,
+                          const float* cam_params, int input_h, int input_w, int bev_size, void* out_split,
+                          isf_stream_t stream) {
+  using namespace isf;
+  ISF_REQUIRE(num_pillars >= 0 && batch_size > 0 && slots > 0 && bev_size > 0, ISF_ERR_ARG, "p2g_split: bad sizes");
+  ISF_REQUIRE(out_split, ISF_ERR_ARG, "p2g_split: null output");
+  ISF_REQUIRE(channels == 256, ISF_ERR_UNSUPPORTED, "p2g_split: %d channels (one 256-channel token matrix)", channels);
+  hipStream_t st = as_stream(stream);
+  ISF_HIP_TRY(hipMemsetAsync(out_split, 0, (size_t)batch_size * channels * bev_size * bev_size * sizeof(float), st));
+  if (num_pillars == 0) return ISF_OK;
+  ISF_REQUIRE(pillars && pillar_coors && img_nhwc && cam_params && pillar_ld >= 3, ISF_ERR_ARG, "p2g_split: null pointer");
+  hipLaunchKernelGGL((p2g_kernel<4, true>), dim3(ceil_div(num_pillars, 4)), dim3(256), 0, st, pillars, pillar_ld, slots,
+                     pillar_coors, num_pillars, img_nhwc, num_cam, feat_h, feat_w, channels, cam_params, (float)input_h,
+                     (float)input_w, bev_size, reinterpret_cast<float*>(out_split));
+  ISF_LAUNCH_CHECK();
+  return ISF_OK;
+}
 
 int isf_p2g_forward(const float* pillars, int pillar_ld, int slots, const int32_t* pillar_coors, int num_pillars,
                     const float* img_nhwc, int batch_size, int num_cam, int feat_h, int feat_w, int channels,

@@ -158,7 +158,10 @@ class ISFusionPtsPath(nn.Module):
         # (profiles/r05_v2_timeline_gaps_cfg3.txt: copyBuffer -> copyBuffer).
         with torch.cuda.stream(side):
             finish = self.voxelize_async(pts)
-        x = self._lidar(pts)
+        # the BEV map leaves the branch as split-format token matrices when conv_fusion reads exactly that (no fp32 map, no
+        # NCHW -> split passes: -2 launches, -0.1 ms per forward at B = 2)
+        cd = self._lidar.pts_middle_encoder.out_channels_and_shape()[0]
+        x = self._lidar(pts, bev_split=getattr(self.fusion_encoder, "dense_conv", "") == "hip" and cd % 256 == 0)
         img_bev = None
         with torch.cuda.stream(side):
             pil = finish()                           # slices + concatenation, on the stream that produced them
@@ -167,9 +170,10 @@ class ISFusionPtsPath(nn.Module):
                 # of the LiDAR branch (its last launches are still running when the host gets here)
                 img_bev = self.fusion_encoder.img_fv_to_bev(
                     [img_feats[1]], len(pts), pts_metas=dict(pillars=pil[0], pillar_coors=pil[2]), img_metas=img_metas,
-                    **kwargs)
+                    p2g_split=getattr(self.fusion_encoder, "dense_conv", "") == "hip" and img_feats[1].shape[1] == 256,
+                    **kwargs)                        # (split rows: what conv_fusion reads, no NCHW -> split pass)
         main.wait_stream(side)
-        for t in pil + ((img_bev,) if img_bev is not None else ()):
+        for t in pil + ((getattr(img_bev, "data", img_bev),) if img_bev is not None else ()):
             t.record_stream(main)                    # allocated on the side stream, consumed on the main one
         feats, ins_heatmap = self.isfusion(pts, x, img_feats, img_metas, len(pts), pillars=pil, img_bev=img_bev, **kwargs)
         return (feats, ins_heatmap) if return_heatmap else feats

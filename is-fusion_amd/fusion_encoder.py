@@ -77,15 +77,22 @@ class ISFusionEncoder(nn.Module):
         return ops.p2g_sample(pm["pillars"], pm["pillar_coors"], mlvl_feats[0], kwargs.get("lidar2img"),
                               kwargs.get("img_aug_matrix"), kwargs.get("lidar_aug_matrix"),   # unused when p2g_cam is given
                               kwargs["img_metas"][0]["input_shape"], bs, self.bev_size, self.num_views,
-                              cam=kwargs.get("p2g_cam"), out=kwargs.get("p2g_out"))
+                              cam=kwargs.get("p2g_cam"), out=kwargs.get("p2g_out"), split=bool(kwargs.get("p2g_split")))
 
     def fuse(self, img_bev, lidar_feats):
         """conv_fusion(cat([img_bev, lidar_feats])) (fusion_encoder.py:1163-1165) -> [B, E, S, S]"""
         if self.dense_conv != "hip":
+            if isinstance(img_bev, SplitMap):
+                img_bev = img_bev.to_nchw()
+            if isinstance(lidar_feats, (list, tuple)):
+                lidar_feats = torch.cat([m.to_nchw() for m in lidar_feats], 1)
             return self.conv_fusion(torch.cat([img_bev, lidar_feats], dim=1))
-        maps = [SplitMap.from_nchw(img_bev)]
-        for off in range(0, lidar_feats.size(1), 256):
-            maps.append(SplitMap.from_nchw(lidar_feats, off, min(256, lidar_feats.size(1) - off)))
+        maps = [img_bev if isinstance(img_bev, SplitMap) else SplitMap.from_nchw(img_bev)]   # (Point-to-Grid wrote split rows)
+        if isinstance(lidar_feats, (list, tuple)):       # the LiDAR branch handed its map over in split form already
+            maps += list(lidar_feats)                    # (LidarBranch.forward(bev_split=True))
+        else:
+            for off in range(0, lidar_feats.size(1), 256):
+                maps.append(SplitMap.from_nchw(lidar_feats, off, min(256, lidar_feats.size(1) - off)))
         m = self._conv("conv_fusion")(maps)
         self.__dict__["_bev_split"] = m        # the instance branch convolves the same map: it takes the split form as it is
         return m.to_nchw()

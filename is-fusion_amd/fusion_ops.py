@@ -328,10 +328,11 @@ def p2g_camera_params(lidar2img, img_aug, lidar_aug, noise=None):
 
 
 def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, input_shape, bs, bev, num_cam=6, cam=None,
-               out=None):
+               out=None, split=False):
     """img_fv_to_bev (fusion_encoder.py:965-1013): pillars [M, T, >=3], pillar_coors [M, 4] (b, z, y, x),
     img_feat [bs*num_cam, C, H, W] -> [bs, C, bev, bev].  cam: p2g_camera_params(...) already on the device (the
-    detector computes it before it queues the LiDAR branch, so the host work hides behind GPU work)."""
+    detector computes it before it queues the LiDAR branch, so the host work hides behind GPU work).
+    split=True (C == 256): -> dense_conv.SplitMap, the form conv_fusion reads (isf_p2g_forward_split)."""
     _lib.require_cuda(img_feat)
     dev = img_feat.device
     pillars = pillars.float().contiguous()
@@ -340,6 +341,15 @@ def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, i
     if cam is None:
         cam = h2d_async(p2g_camera_params(lidar2img, img_aug, lidar_aug), dev)
     C, H, W = img_feat.shape[1:]
+    if split:
+        from .dense_conv import SplitMap
+        assert out is None and C == 256
+        raw = torch.empty(bs * C * bev * bev * 4, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().isf_p2g_forward_split(_lib.ptr(pillars), pillars.size(2), pillars.size(1), _lib.ptr(coors),
+                                                     pillars.size(0), _lib.ptr(nhwc), bs, num_cam, H, W, C, _lib.ptr(cam),
+                                                     int(input_shape[0]), int(input_shape[1]), bev, _lib.ptr(raw),
+                                                     _lib.stream()), "isf_p2g_forward_split")
+        return SplitMap(raw, bs, C, bev, bev)
     if out is None:
         out = torch.empty((bs, C, bev, bev), dtype=torch.float32, device=dev)
     assert tuple(out.shape) == (bs, C, bev, bev) and out.is_contiguous() and out.dtype == torch.float32

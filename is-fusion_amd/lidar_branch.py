@@ -127,18 +127,21 @@ class LidarBranch(nn.Module):
         return self.pts_middle_encoder.forward_modules(vf, vc, len(points))[0]
 
     def forward(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0, stage_rows=0,
-                stage_mask=0, out=None):
-        """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W].
+                stage_mask=0, out=None, bev_split=False):
+        """points: list of [P_i, C] tensors (one per sample) -> spatial_features [B, C*D, H, W]
+        (bev_split=True, inference: the same map as a list of dense_conv.SplitMap, one per 256-channel group -- the form the
+        fusion encoder's convolutions read; isf_encoder_options.bev_format = 1).
         precision: 0 = f16x3 split MFMA (default, fp32-class), 1 = fp32 MFMA kernels, 2 = single-pass f16 (opt-in,
         fp16-autocast accuracy); conv_diag: timing diagnostics of the conv kernels (results garbage except 16);
         stage_rows / stage_mask: LDS staging of the conv input rows (isf_encoder_options; 0 = library default)."""
         if self.training:
             return self.forward_train(points)
         with torch.no_grad():
-            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag, stage_rows, stage_mask, out)
+            return self.forward_eval(points, time_layers, want_stats, precision, conv_diag, stage_rows, stage_mask, out,
+                                     bev_split)
 
     def forward_eval(self, points, time_layers=False, want_stats=False, precision=0, conv_diag=0, stage_rows=0,
-                     stage_mask=0, out=None):
+                     stage_mask=0, out=None, bev_split=False):
         pts = torch.cat(points, dim=0).contiguous().float()
         _lib.require_cuda(pts)
         vfe = self.pts_voxel_encoder
@@ -166,9 +169,16 @@ class LidarBranch(nn.Module):
         _lib.check(lib.isf_lidar_branch_forward(
             _lib.ptr(pts), (ctypes.c_int64 * len(offs))(*offs), B, ctypes.byref(vp), _lib.i3(me.sparse_shape),
             arr, n, _lib.ptr(out), oshape, ctypes.byref(stats) if stats is not None else None,
-            int(bool(time_layers)), _lib.encoder_options(precision, conv_diag, stage_rows, stage_mask), _lib.stream()),
-            "isf_lidar_branch_forward")
+            int(bool(time_layers)), _lib.encoder_options(precision, conv_diag, stage_rows, stage_mask, int(bool(bev_split))),
+            _lib.stream()), "isf_lidar_branch_forward")
         self.last_stats = stats
+        if bev_split:     # the buffer holds cd / 256 split-format token matrices [B*H*W, 256] (same bytes as the fp32 map)
+            from .dense_conv import SplitMap
+            if cd % 256:
+                raise _lib.IsfError(f"LidarBranch: bev_split needs whole 256-channel groups, the BEV map has {cd} channels")
+            raw = out.view(torch.uint8).view(-1)
+            step = B * H * W * 256 * 4
+            return [SplitMap(raw[g * step:(g + 1) * step], B, 256, H, W) for g in range(cd // 256)]
         return out
 
     def conv_layer_table(self):

@@ -587,3 +587,18 @@ def test_window_block_kernel_matches_unfused_layers(dev, S, d, B, shift):
     assert torch.isfinite(fused).all()
     assert (fused.cpu().double() - ref).abs().max().item() < 1e-4
     assert (unfused.cpu().double() - ref).abs().max().item() < 1e-4
+
+
+def test_p2g_split_output_is_the_fp32_canvas_in_split_rows(dev):
+    """isf_p2g_forward_split: Point-to-Grid writing ONE split-format token matrix (what conv_fusion reads) instead of the
+    fp32 [B, C, bev, bev] canvas: converted back, the same values bit for bit (hi + lo is exact), zeros where no pillar"""
+    from isfusion_amd import fusion_ops as ops
+    cfg = CONFIGS["small"]
+    t = torch_inputs(cfg, dev)
+    args = (t["pillars"], t["pillar_coors"], t["img_feats"][1], t["lidar2img"], t["img_aug_matrix"], t["lidar_aug_matrix"],
+            t["input_shape"], cfg["B"], cfg["bev"])
+    want = ops.p2g_sample(*args)
+    got = ops.p2g_sample(*args, split=True)
+    assert (got.B, got.C, got.H, got.W) == tuple(want.shape)
+    assert torch.equal(got.to_nchw(), want)
+    assert (want != 0).any() and (want == 0).any()

@@ -495,6 +495,25 @@ def _encoder_case(oracle_mod, dev, P, B, seed):
     return lb, pl, ovf, ovc, bev, outs
 
 
+def test_lidar_branch_bev_map_as_split_token_matrices(dev):
+    """isf_encoder_options.bev_format = 1 (LidarBranch.forward(bev_split=True)): the BEV map leaves the branch as one
+    split-format token matrix per 256-channel group -- what conv_fusion reads -- instead of fp32 [B, C*D, H, W]; converted
+    back, it is the fp32 map bit for bit (hi + lo of every element is exact in fp32), empty cells included"""
+    import isfusion_amd as m
+    from isfusion_amd import synthetic
+    lb = m.LidarBranch().randomize_weights_(0).randomize_bn_(1).eval().to(dev)
+    for n, frames in ((3000, 1), (60000, 2), (300000, 3)):
+        pl = [T(synthetic.lidar_sweeps(1400 + i, n), dev) for i in range(frames)]
+        want = lb(pl)
+        maps = lb(pl, bev_split=True)
+        assert len(maps) == want.shape[1] // 256 and all(mp.C == 256 and mp.B == frames for mp in maps)
+        got = torch.cat([mp.to_nchw() for mp in maps], 1)
+        assert torch.equal(got, want), n
+        assert (want == 0).any() and (want != 0).any()
+    with pytest.raises(m._lib.IsfError):
+        lb(pl, bev_split=True, precision=2)      # the f16-storage mode has no split rows to hand over
+
+
 def test_sparse_encoder_and_lidar_branch_vs_oracle(dev, oracle_mod):
     """cfg-2-shaped (dynamic voxelize + DynamicVFE + full 21-layer SparseEncoder -> [B,512,180,180]) at a size
     the scalar oracle finishes in seconds.  Tolerance: 1e-3 absolute on BEV features (north_star)."""
