@@ -161,7 +161,8 @@ class ISFusionPtsPath(nn.Module):
         # the BEV map leaves the branch as split-format token matrices when conv_fusion reads exactly that (no fp32 map, no
         # NCHW -> split passes: -2 launches, -0.1 ms per forward at B = 2)
         cd = self._lidar.pts_middle_encoder.out_channels_and_shape()[0]
-        x = self._lidar(pts, bev_split=getattr(self.fusion_encoder, "dense_conv", "") == "hip" and cd % 256 == 0)
+        split = self._split_handover(img_feats[1].shape[1], cd)
+        x = self._lidar(pts, bev_split=split)
         img_bev = None
         with torch.cuda.stream(side):
             pil = finish()                           # slices + concatenation, on the stream that produced them
@@ -170,8 +171,7 @@ class ISFusionPtsPath(nn.Module):
                 # of the LiDAR branch (its last launches are still running when the host gets here)
                 img_bev = self.fusion_encoder.img_fv_to_bev(
                     [img_feats[1]], len(pts), pts_metas=dict(pillars=pil[0], pillar_coors=pil[2]), img_metas=img_metas,
-                    p2g_split=getattr(self.fusion_encoder, "dense_conv", "") == "hip" and img_feats[1].shape[1] == 256,
-                    **kwargs)                        # (split rows: what conv_fusion reads, no NCHW -> split pass)
+                    p2g_split=split, **kwargs)       # (split rows: what conv_fusion reads, no NCHW -> split pass)
         main.wait_stream(side)
         for t in pil + ((getattr(img_bev, "data", img_bev),) if img_bev is not None else ()):
             t.record_stream(main)                    # allocated on the side stream, consumed on the main one
@@ -209,7 +209,9 @@ class ISFusionPtsPath(nn.Module):
         self._lidar.train(False)
         dev = pts[0].device
         B = len(pts)
-        g, img_bev, x, out = self._graph_for(B, dev, img_feats[1].shape[1], self._lidar.pts_middle_encoder.out_channels_and_shape()[0])
+        c_lidar = self._lidar.pts_middle_encoder.out_channels_and_shape()[0]
+        g, img_bev, x, out = self._graph_for(B, dev, img_feats[1].shape[1], c_lidar)
+        split = self._split_handover(img_feats[1].shape[1], c_lidar)
         cam = kwargs.get("p2g_cam")
         if cam is None:
             cam = ops.h2d_async(ops.p2g_camera_params(kwargs["lidar2img"], kwargs["img_aug_matrix"],
@@ -224,7 +226,7 @@ class ISFusionPtsPath(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 finish = self.voxelize_async(pts)    # queued first, counts on the device (see extract_pts_feat)
-            self._lidar(pts, out=x)
+            self._lidar(pts, out=x, bev_split=split)
             with torch.cuda.stream(side):
                 pil = finish()
             main.wait_stream(side)
@@ -232,10 +234,10 @@ class ISFusionPtsPath(nn.Module):
                 t.record_stream(main)
         else:
             finish = self.voxelize_async(pts)        # same stream, in front of the branch: its counts are in host memory
-            self._lidar(pts, out=x)                  # long before the branch's own host waits are over
+            self._lidar(pts, out=x, bev_split=split)  # long before the branch's own host waits are over
             pil = finish()
         ops.p2g_sample(pil[0], pil[2], img_feats[1], None, None, None, img_metas[0]["input_shape"], B,
-                       self.fusion_encoder.bev_size, self.fusion_encoder.num_views, cam=cam, out=img_bev)
+                       self.fusion_encoder.bev_size, self.fusion_encoder.num_views, cam=cam, out=img_bev, split=split)
         g.replay()
         return out
 
@@ -290,17 +292,30 @@ class ISFusionPtsPath(nn.Module):
         cap = torch.cuda.Stream(device=dev)          # private capture stream: its library workspace is never used eagerly
         img_bev = torch.zeros((bs, c_img, S, S), dtype=torch.float32, device=dev)
         x = torch.zeros((bs, c_lidar, S, S), dtype=torch.float32, device=dev)
+        # the graph's inputs in the form conv_fusion reads (as in extract_pts_feat): the same buffers seen as split-format
+        # token matrices, filled by isf_p2g_forward_split / isf_encoder_options.bev_format = 1
+        tail_in = (img_bev, x)
+        if self._split_handover(c_img, c_lidar):
+            from .dense_conv import SplitMap
+            step = bs * S * S * 256 * 4
+            raw = x.view(torch.uint8).view(-1)
+            tail_in = (SplitMap(img_bev.view(torch.uint8).view(-1), bs, c_img, S, S),
+                       [SplitMap(raw[i * step:(i + 1) * step], bs, 256, S, S) for i in range(c_lidar // 256)])
         cap.wait_stream(main)
         with torch.cuda.stream(cap):
             for _ in range(3):                       # warm-up on the capture stream: workspace, packed caches, tables
-                self._tail(img_bev, x, bs)
+                self._tail(tail_in[0], tail_in[1], bs)
         cap.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=cap):
-            out = self._tail(img_bev, x, bs)
+            out = self._tail(tail_in[0], tail_in[1], bs)
         main.wait_stream(cap)
-        self._graphs[key] = (g, img_bev, x, out)
+        self._graphs[key] = (g, tail_in[0], x, out)
         return self._graphs[key]
+
+    def _split_handover(self, c_img, c_lidar):
+        """do Point-to-Grid and the LiDAR branch hand their maps to conv_fusion as split-format token matrices?"""
+        return getattr(self.fusion_encoder, "dense_conv", "") == "hip" and c_img == 256 and c_lidar % 256 == 0
 
     @torch.no_grad()
     def forward_pts(self, pts, img_feats, img_metas, **kwargs):

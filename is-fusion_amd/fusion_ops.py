@@ -343,13 +343,18 @@ def p2g_sample(pillars, pillar_coors, img_feat, lidar2img, img_aug, lidar_aug, i
     C, H, W = img_feat.shape[1:]
     if split:
         from .dense_conv import SplitMap
-        assert out is None and C == 256
-        raw = torch.empty(bs * C * bev * bev * 4, dtype=torch.uint8, device=dev)
+        assert C == 256
+        if out is not None:     # a caller-owned SplitMap (the detector's HIP-graph input)
+            assert isinstance(out, SplitMap) and (out.B, out.C, out.H, out.W) == (bs, C, bev, bev)
+            raw = out.data
+            assert raw.numel() == bs * C * bev * bev * 4 and raw.is_contiguous()
+        else:
+            raw = torch.empty(bs * C * bev * bev * 4, dtype=torch.uint8, device=dev)
         _lib.check(_lib.load().isf_p2g_forward_split(_lib.ptr(pillars), pillars.size(2), pillars.size(1), _lib.ptr(coors),
                                                      pillars.size(0), _lib.ptr(nhwc), bs, num_cam, H, W, C, _lib.ptr(cam),
                                                      int(input_shape[0]), int(input_shape[1]), bev, _lib.ptr(raw),
                                                      _lib.stream()), "isf_p2g_forward_split")
-        return SplitMap(raw, bs, C, bev, bev)
+        return out if out is not None else SplitMap(raw, bs, C, bev, bev)
     if out is None:
         out = torch.empty((bs, C, bev, bev), dtype=torch.float32, device=dev)
     assert tuple(out.shape) == (bs, C, bev, bev) and out.is_contiguous() and out.dtype == torch.float32
