@@ -40,6 +40,11 @@ class SplitMap:
                                                  _lib.stream()), "isf_nchw_to_split")
         return SplitMap(out, B, C, H, W)
 
+    def to_rows(self):
+        """[B*H*W, C] fp32 token rows (token = (b*H + y)*W + x): what the row-major fused Linear reads"""
+        from .spconv import from_split
+        return from_split(self.data, (self.num_tokens, self.C))
+
     def to_nchw(self, channels=None):
         """[B, C, H, W] fp32; channels: keep only the first `channels` (a view of the converted map)"""
         out = torch.empty((self.B, self.C, self.H, self.W), dtype=torch.float32, device=self.data.device)

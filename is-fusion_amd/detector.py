@@ -276,7 +276,7 @@ class ISFusionPtsPath(nn.Module):
 
     def _tail(self, img_bev, x, bs):
         enc = self.fusion_encoder
-        feats, _ = enc.forward_tail(img_bev, x, bs, pts_backbone=self.pts_backbone)
+        feats, _ = enc.forward_tail(img_bev, x, bs, pts_backbone=self.pts_backbone, feats_split=True)
         return self.pts_bbox_head.forward_split(self.pts_neck.forward_split(feats))
 
     def _graph_for(self, bs, dev, c_img, c_lidar):
@@ -325,7 +325,9 @@ class ISFusionPtsPath(nn.Module):
         if self.__dict__.get("_graph_on", False) and self.pts_neck.dense_conv == "hip" and \
                 self.pts_bbox_head.dense_conv == "hip" and self.fusion_encoder.dense_conv == "hip":
             return (self._forward_pts_graph(pts, img_feats, img_metas, **kwargs),)
-        feats = self.extract_pts_feat(pts, img_feats, img_metas, **kwargs)
+        engine = self.pts_neck.dense_conv == "hip" and self.pts_bbox_head.dense_conv == "hip" and \
+            getattr(self.pts_backbone, "dense_conv", "") == "hip"
+        feats = self.extract_pts_feat(pts, img_feats, img_metas, feats_split=engine, **kwargs)
         if self.pts_neck.dense_conv == "hip" and self.pts_bbox_head.dense_conv == "hip":
             # engine-level hand-over: the neck's levels stay split-format token matrices (no [B, 512, H, W] tensor, no
             # permute copy, no NCHW -> split pass); the public neck / head forwards keep the reference's tensors

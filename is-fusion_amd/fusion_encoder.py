@@ -190,7 +190,10 @@ class ISFusionEncoder(nn.Module):
                 _, query_pos = ops.gather_instances(x_scene_t, top_idx, S)
                 x_ins = tr.ins_context_att(self.instance_att, x_ins, query_pos, x_scene_t, S)
                 x = tr.instance_to_scene(self.instance_to_scene_att, q, x_ins, scene_feats, S)
-            nxt, _, this_feat = pts_backbone([x], "stage{}".format(i + 1))
+            if kwargs.get("feats_split"):     # engine-level hand-over: the stage's results stay split-format token matrices
+                nxt, _, this_feat = pts_backbone([x], "stage{}".format(i + 1), keep_split=True)
+            else:
+                nxt, _, this_feat = pts_backbone([x], "stage{}".format(i + 1))
             feats.append(this_feat)
             x = nxt
         return feats, ins_hm

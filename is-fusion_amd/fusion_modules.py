@@ -284,13 +284,15 @@ class SECONDV2(nn.Module):
             m = layer(m)
         return m
 
-    def forward(self, x, stage=None):
+    def forward(self, x, stage=None, keep_split=False):
         """(tokens, coords, feature) like the reference; tokens/coords of the dense grid are implicit here, so the
-        HIP fusion encoder consumes the [B, C, H, W] tensor directly: stage1 -> (ds_layer output, None, feature)."""
+        HIP fusion encoder consumes the [B, C, H, W] tensor directly: stage1 -> (ds_layer output, None, feature).
+        keep_split (engine-level hand-over, eval): the results stay dense_conv.SplitMap -- their readers (the SST's and the
+        neck's fused Linears) take token rows, so no [B, C, H, W] map is made of them."""
         from .dense_conv import SplitMap
 
         def nchw(t):
-            return t.to_nchw() if isinstance(t, SplitMap) else t
+            return t.to_nchw() if isinstance(t, SplitMap) and not keep_split else t
         if self.training:      # training: conv + BatchNorm (batch statistics) + ReLU with autograd -- on the sparse-conv
             from . import dense_train as dt      # kernels over the dense grid (dense_train.py), or the stock modules
             run = dt.conv_stack if self.dense_conv == "hip" else (lambda seq, t: seq(t))
@@ -438,8 +440,12 @@ class SECONDFPN(nn.Module):
         maps = []
         for i in range(len(self.deblocks)):
             w, b, s = self._folded_cached(i)
-            B, _, H, W = x[i].shape
-            y = linear_relu(x[i], w, b)                                   # [B*H*W, s*s*Cout], column = (dy*s + dx)*Cout + co
+            if isinstance(x[i], SplitMap):                                # token rows: the row-major GEMM (column-split
+                B, H, W = x[i].B, x[i].H, x[i].W                          # launches for the 90 x 90 level), no NCHW map
+                y = linear_relu(x[i].to_rows(), w, b)
+            else:
+                B, _, H, W = x[i].shape
+                y = linear_relu(x[i], w, b)                               # [B*H*W, s*s*Cout], column = (dy*s + dx)*Cout + co
             cout = y.shape[1] // (s * s)
             if s > 1:                                                     # sub-cells to their tokens: 1-KiB runs
                 y = y.view(B, H, W, s, s, cout).permute(0, 1, 3, 2, 4, 5).reshape(B * H * s * W * s, cout)

@@ -249,16 +249,26 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
     """get_regions[i] + grid2region_att[i] (sst_v2.py:65-133) on a dense grid: [B, C, S, S] -> [B, d, S, S].
     Per encoder layer: the attention half in one kernel (isf_window_block_forward), the feed-forward half as two fused
     linears (GELU; residual + LayerNorm)."""
-    _lib.require_cuda(bev)
-    B, C, S, _ = bev.shape
+    from .dense_conv import SplitMap
+    rows = None
+    if isinstance(bev, SplitMap):        # a SECONDV2 stage's result in split form: token rows, no [B, C, S, S] map
+        B, C, S = bev.B, bev.C, bev.H
+        rows = bev.to_rows()
+        dev = rows.device
+    else:
+        _lib.require_cuda(bev)
+        B, C, S, _ = bev.shape
+        dev = bev.device
     fused_io = (S * S) % 4 == 0          # channels-first loads / stores inside the GEMM need hw % 4 == 0
     d_model = sst.block_list[0].encoder_list[0].win_attn.self_attn.out_proj.in_features
     fused_block = WINDOW_BLOCK_FUSED and d_model == 128      # built (and measured faster) for the 128-wide level
     if hasattr(sst, "linear0"):
-        c = _cache(sst, bev.device)
+        c = _cache(sst, dev)
         if "linear0" not in c:
             c["linear0"] = PackedLinear(sst.linear0.weight, sst.linear0.bias)
-        x = linear(bev.float() if fused_io else to_tokens(bev.float()), c["linear0"])
+        x = linear(rows if rows is not None else (bev.float() if fused_io else to_tokens(bev.float())), c["linear0"])
+    elif rows is not None:
+        x = rows
     elif fused_block:                    # the block kernel reads token rows
         x = to_tokens(bev.float())
     else:   # the first layer reads the map channels-first both as GEMM input and as residual
@@ -266,7 +276,7 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
     d = x.size(1)
     layers = [(shift, layer) for block in sst.block_list for shift, layer in enumerate(block.encoder_list)]
     for li, (shift, layer) in enumerate(layers):
-        p = _encoder_layer_cache(layer, S, win, shift, temperature, bev.device, B)
+        p = _encoder_layer_cache(layer, S, win, shift, temperature, dev, B)
         if fused_block:
             y = window_block(x, p["block"], p["in_bias"], p["table"], p["out_bias"], layer.norm1, B, S, d,
                              layer.win_attn.nhead, win, shift)
