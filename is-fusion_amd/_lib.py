@@ -302,9 +302,22 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device, as an int.  Through the two C accessors torch's own
+    compiled-graph runtime uses: torch.cuda.current_stream().cuda_stream builds a Stream object and resolves the device
+    index in Python -- 5-10 us a call, ~800 calls per training step, which is paced by the host (tools/train_host_profile.py)."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get is not None and dev is not None:
+            _raw_stream = lambda: get(dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 def require_cuda(*tensors):

@@ -307,3 +307,14 @@ def test_lidar_branch_batches_in_flight_on_two_streams_reproduce_serial_bits(dev
     torch.cuda.synchronize()
     for k, (s, out) in enumerate(got):
         assert torch.equal(out, want[s]), (k, s)
+
+
+def test_lib_stream_is_torchs_current_stream(dev):
+    """_lib.stream() (the raw-handle fast path) == torch.cuda.current_stream().cuda_stream on the default stream, inside a
+    torch.cuda.stream() context, and after it"""
+    from isfusion_amd import _lib
+    assert _lib.stream() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        assert _lib.stream() == side.cuda_stream == torch.cuda.current_stream().cuda_stream
+    assert _lib.stream() == torch.cuda.current_stream().cuda_stream
