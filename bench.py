@@ -708,9 +708,11 @@ def train_leg(args, rank, world, dev, steps=10, B=2, points=300000):
     assert all(v == v and abs(v) < 1e30 for v in losses), losses
     return {"metric": "training step of the full point-cloud path (BASELINE configs[3] on 1 GPU)", "value": round(ms, 2),
             "unit": "ms per step", "higher_is_better": False, "steps": steps, "warmup": 2,
-            "dtype": "torch.autocast(bfloat16): stock convs / linears in bf16; the HIP sparse-conv autograd Functions run "
-                     "single-pass f16 MFMA with fp32 accumulate under autocast (spconv.AUTOCAST_HALF, the reference's "
-                     "custom_fwd(cast_inputs=torch.half)); the other HIP Functions compute in fp32-class f16x3 arithmetic",
+            "dtype": "torch.autocast(bfloat16): the remaining stock ops (neck deconvs, the 10-class heat-map conv, torch "
+                     "linears of the VFE) in bf16; the HIP sparse-conv autograd Functions -- the LiDAR encoder's and, since "
+                     "round 6, the dense 3x3 conv + BatchNorm2d stacks (dense_train.py) -- run single-pass f16 MFMA with fp32 "
+                     "accumulate under autocast (spconv.AUTOCAST_HALF, the reference's custom_fwd(cast_inputs=torch.half)); "
+                     "the other HIP Functions compute in fp32-class f16x3 arithmetic",
             "config": {"workload": f"forward_train_pts + stand-in loss + backward + SGD step, batch={B}/GPU, {points}-pt "
                                    "synthetic sweeps, 6-camera feature maps precomputed (random); detection losses / target "
                                    "assignment are the reference's control plane (out of scope)", "batch_per_gpu": B,
