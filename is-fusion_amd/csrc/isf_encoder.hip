@@ -470,8 +470,10 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
     };
     // ROW SORT (round 6): a SubM layer computes its rows in the order of their tap masks (deep layers on the tile kernel,
     // narrow layers on the LDS-DMA kernel, full or line-compressed table)
+    // (the f16-storage mode too, round 6: the sort only renames positions; its epilogue reads / writes through the row map)
+    const bool sort_mode_ok = conv_mode == (conv_mode & 32) || conv_mode == (257 | (conv_mode & 32));
     const bool sort_ok = row_sort && use16 && !cu && srows == 0 && ly.conv_type == ISF_CONV_SUBM && K == 27 &&
-                         conv_mode == (conv_mode & 32) && wide_cols == 0 && (stagger & ~64) == 0 && L.n >= sort_min_rows &&
+                         sort_mode_ok && wide_cols == 0 && (stagger & ~64) == 0 && L.n >= sort_min_rows &&
                          (dma ? narrow_sort : ly.c_out >= 128);
     const int32_t* rowmap = nullptr;
     auto launch_info = [&](const int32_t* table, int tstride, int rows, Conv16LaunchInfo* info) -> int {
@@ -638,7 +640,7 @@ int sparse_encoder_forward_impl(Arena& a, const float* x0, const int32_t* coors0
       // ROW SORT of a deep strided convolution's own table (its rows want 10 of 27 taps, in many patterns: -12 % tile-taps,
       // -26 % MFMA blocks at level 3 on the benchmark geometry, profiles/r06_row_sort.txt)
       if (row_sort && use16 && !dma && !cu && srows == 0 && !lmask && ly.c_out >= 128 && K == 27 &&
-          conv_mode == (conv_mode & 32) && wide_cols == 0 && (stagger & ~64) == 0 && Nx.n >= sort_min_rows) {
+          sort_mode_ok && wide_cols == 0 && (stagger & ~64) == 0 && Nx.n >= sort_min_rows) {
         Conv16LaunchInfo info;
         ISF_TRY(sparse_conv_forward_f16x3_impl(nullptr, ly.c_in, ly.packed16, K, ly.c_out, nbr, stride, Nx.n, nullptr, nullptr,
                                                nullptr, 0, nullptr, conv_mode | ksbit | stagger, sg, nullptr, &info));

@@ -642,6 +642,7 @@ def test_conv_tile_mix_reproduces_uniform_tile_bits(dev):
         # 16-row group of like rows walks fewer taps); every row still gets the same products in the same order, so the
         # un-sorted launch (diagnostic 33554432) gives the same bits
         assert torch.equal(lb(pl, conv_diag=33554432), want), n
+        assert torch.equal(lb(pl, precision=2), lb(pl, precision=2, conv_diag=33554432)), n    # f16 storage: sorted too
         assert torch.equal(lb(pl, conv_diag=67108864), want), n     # the narrow layers sorted as well (opt-in)
         # round 6 (opt-in, diagnostic 16777216): the launches of several rounds (levels 0 / 1) hand their tiles out band by
         # band in y (conv16_band_order_kernel) -- a permutation of the same tiles
