@@ -574,6 +574,15 @@ int isf_window_attention_forward(const float* qkv, int batch_size, int grid_size
 int isf_attention_forward(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
                           int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
                           isf_stream_t stream);
+/* ... in TRAINING mode with nn.MultiheadAttention's dropout on the attention probabilities (fusion_encoder.py:458
+ * F.dropout(attn_output_weights, p); the IGF modules use p = 0.1, :476, :614): a probability is zeroed with probability
+ * dropout_p and the kept ones scaled by 1 / (1 - dropout_p); the row normalisation keeps every term.  The keep / drop
+ * decision of (sample * heads + head, query, key) is a counter-based hash of `seed` (MurmurHash3's finaliser over the
+ * packed indices; isf_attention_backward_dropout recomputes it from the same seed), so no mask is stored.  dropout_p = 0
+ * is isf_attention_forward.  head_dim 16, num_keys <= 512. */
+int isf_attention_forward_dropout(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
+                                  int num_queries, int num_keys, int embed_dims, int num_heads, float dropout_p,
+                                  unsigned long long seed, float* out, int ldo, isf_stream_t stream);
 
 /* A14  per-channel map attention -----------------------------------------------------------------------
  * replaces fusion_encoder.py:497-502: for each of num_maps = B*C maps (size x size, row-major)
@@ -850,6 +859,11 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
                            const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
                            int embed_dims, int num_heads, float* grad_q, int ldgq, float* grad_k, float* grad_v,
                            int ldgkv, isf_stream_t stream);
+/* ... of isf_attention_forward_dropout (same dropout_p and seed; `out` = that call's result) */
+int isf_attention_backward_dropout(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                                   const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
+                                   int embed_dims, int num_heads, float dropout_p, unsigned long long seed, float* grad_q,
+                                   int ldgq, float* grad_k, float* grad_v, int ldgkv, isf_stream_t stream);
 int isf_window_attention_backward(const float* qkv, const float* grad_out, int batch_size, int grid_size,
                                   int embed_dims, int num_heads, int window, int shift, float* grad_qkv,
                                   isf_stream_t stream);

@@ -210,6 +210,8 @@ SIGNATURES = {
                                              c_void_p]),
     "isf_attention_forward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_int, c_void_p, c_int, c_void_p]),
+    "isf_attention_forward_dropout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                              c_int, ctypes.c_float, ctypes.c_uint64, c_void_p, c_int, c_void_p]),
     "isf_channel_attention_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "isf_p2g_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -258,6 +260,9 @@ SIGNATURES = {
     "isf_attention_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                        c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                        c_void_p]),
+    "isf_attention_backward_dropout": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                               c_int, c_int, c_int, c_int, ctypes.c_float, ctypes.c_uint64, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_int, c_void_p]),
     "isf_window_attention_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                               c_void_p]),
     "isf_dense_grid_rulebook": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,

@@ -284,7 +284,8 @@ template <bool PARTIAL>
 __global__ __launch_bounds__(256) void attention_mfma16_kernel(const float* __restrict__ q, int ldq,
                                                                const float* __restrict__ k, const float* __restrict__ v,
                                                                int ldk, int Lq, int Lk, int kps, int nsplit, float scale,
-                                                               float* __restrict__ out, int ldo, float* __restrict__ part) {
+                                                               float* __restrict__ out, int ldo, float* __restrict__ part,
+                                                               AttnDrop drop) {
   constexpr int HD = 16, LS = kAttnLs;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int head = blockIdx.y, b = blockIdx.z / nsplit, sp = blockIdx.z % nsplit;
@@ -343,6 +344,12 @@ __global__ __launch_bounds__(256) void attention_mfma16_kernel(const float* __re
       l = l * corr + ps;
       acc *= corr;
       m = mn;
+      if (drop.thresh) {   // training: dropout on the probabilities (the row sum l keeps every term, the products do not)
+        const unsigned bh = (unsigned)(b * gridDim.y + head);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          pr[t] = attn_keep(drop.seed, bh, (unsigned)qi, (unsigned)(k0 + kbase + t), drop.thresh) ? pr[t] * drop.inv_keep : 0.f;
+      }
       // A: V^T[d = col][key 4g + t] -- transposed read of the LDS tile (16 consecutive banks per register)
       const float* vp = vs + (kbase)*LS + col;
       ah4 vh, vl, ph, pl;
@@ -419,10 +426,12 @@ int isf_window_attention_forward(const float* qkv, int batch_size, int grid_size
   return ISF_OK;
 }
 
-int isf_attention_forward(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
-                          int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
-                          isf_stream_t stream) {
+static int attention_forward_impl(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
+                                  int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
+                                  isf::AttnDrop drop, isf_stream_t stream) {
   using namespace isf;
+  ISF_REQUIRE(drop.thresh == 0 || (num_heads > 0 && embed_dims == 16 * num_heads && num_keys <= 512), ISF_ERR_UNSUPPORTED,
+              "attention: probability dropout is built for head_dim 16 and <= 512 keys (the training path's two shapes)");
   ISF_REQUIRE(batch_size >= 0 && num_queries >= 0 && num_keys > 0, ISF_ERR_ARG, "attention: bad sizes");
   if (batch_size == 0 || num_queries == 0) return ISF_OK;
   ISF_REQUIRE(q && k && v && out, ISF_ERR_ARG, "attention: null pointer");
@@ -448,14 +457,14 @@ int isf_attention_forward(const float* q, int ldq, const float* k, const float* 
     }
     if (nsplit == 1) {
       hipLaunchKernelGGL((attention_mfma16_kernel<false>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries, num_keys,
-                         kps, 1, scale, out, ldo, static_cast<float*>(nullptr));
+                         kps, 1, scale, out, ldo, static_cast<float*>(nullptr), drop);
     } else {
       Arena& a = arena_for_stream(st);
       ISF_TRY(a.reset());
       float* part = nullptr;
       ISF_TRY(a.alloc_n(&part, (size_t)batch_size * num_heads * nsplit * num_queries * (hd + 2)));
       hipLaunchKernelGGL((attention_mfma16_kernel<true>), grid, block, lds, st, q, ldq, k, v, ldkv, num_queries, num_keys,
-                         kps, nsplit, scale, out, ldo, part);
+                         kps, nsplit, scale, out, ldo, part, drop);
       const long long total = (long long)batch_size * num_heads * num_queries * hd;
       hipLaunchKernelGGL((merge_key_splits_kernel<16>), dim3(ceil_div(total, 256)), dim3(256), 0, st, part, batch_size,
                          num_heads, nsplit, num_queries, out, ldo);
@@ -516,5 +525,20 @@ int isf_attention_forward(const float* q, int ldq, const float* k, const float* 
                        num_keys, scale, out, ldo);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
+}
+
+int isf_attention_forward(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
+                          int num_queries, int num_keys, int embed_dims, int num_heads, float* out, int ldo,
+                          isf_stream_t stream) {
+  return attention_forward_impl(q, ldq, k, v, ldkv, batch_size, num_queries, num_keys, embed_dims, num_heads, out, ldo,
+                                isf::attn_drop_of(0.f, 0ull), stream);
+}
+
+int isf_attention_forward_dropout(const float* q, int ldq, const float* k, const float* v, int ldkv, int batch_size,
+                                  int num_queries, int num_keys, int embed_dims, int num_heads, float dropout_p,
+                                  unsigned long long seed, float* out, int ldo, isf_stream_t stream) {
+  ISF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, ISF_ERR_ARG, "attention: dropout probability %g", (double)dropout_p);
+  return attention_forward_impl(q, ldq, k, v, ldkv, batch_size, num_queries, num_keys, embed_dims, num_heads, out, ldo,
+                                isf::attn_drop_of(dropout_p, seed), stream);
 }
 }  // extern "C"

@@ -52,7 +52,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
     const float* __restrict__ out, const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale,
-    float* __restrict__ gq, int ldgq, float* __restrict__ stat /* [B, heads, Lq, 2] = (L, D) */) {
+    float* __restrict__ gq, int ldgq, float* __restrict__ stat /* [B, heads, Lq, 2] = (L, D) */, AttnDrop drop) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256) void attention_bwd_rows_kernel(
     load_row<HD>(kb + (size_t)j * ldkv, kj);
     load_row<HD>(vb + (size_t)j * ldkv, vj);
     const float p = __expf(scale * dot_row<HD>(qi, kj) - L);
-    const float ds = p * (dot_row<HD>(go, vj) - D);
+    float dp = dot_row<HD>(go, vj);
+    if (drop.thresh)   // the forward's keep / drop decision for (query i, key j), recomputed
+      dp = attn_keep(drop.seed, (unsigned)(b * heads + head), (unsigned)i, (unsigned)j, drop.thresh) ? dp * drop.inv_keep : 0.f;
+    const float ds = p * (dp - D);
 #pragma unroll
     for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, kj[c], acc[c]);
   }
@@ -111,7 +114,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
     const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale, const float* __restrict__ stat,
-    float* __restrict__ gk, float* __restrict__ gv, int ldgkv, int chunks, int batch) {
+    float* __restrict__ gk, float* __restrict__ gv, int ldgkv, int chunks, int batch, AttnDrop drop) {
   const int lane = threadIdx.x & 63;
   const int kblocks = (Lk + 3) / 4;
   const int chunk = blockIdx.x / kblocks;
@@ -136,10 +139,16 @@ __global__ __launch_bounds__(256) void attention_bwd_cols_kernel(
     load_row<HD>(gb + (size_t)i * ldo, go);
     const float2 ld = *reinterpret_cast<const float2*>(st + (size_t)i * 2);
     const float p = __expf(scale * dot_row<HD>(qi, kj) - ld.x);
-    const float ds = p * (dot_row<HD>(go, vj) - ld.y);
+    float dp = dot_row<HD>(go, vj), pm = p;
+    if (drop.thresh) {
+      const float mk = attn_keep(drop.seed, (unsigned)(b * heads + head), (unsigned)i, (unsigned)j, drop.thresh) ? drop.inv_keep : 0.f;
+      dp *= mk;
+      pm *= mk;
+    }
+    const float ds = p * (dp - ld.y);
 #pragma unroll
     for (int c = 0; c < HD; ++c) {
-      dv[c] = fmaf(p, go[c], dv[c]);
+      dv[c] = fmaf(pm, go[c], dv[c]);
       dk[c] = fmaf(ds, qi[c], dk[c]);
     }
   }
@@ -176,7 +185,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attention_bwd_rows_lanes_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
     const float* __restrict__ out, const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale,
-    float* __restrict__ gq, int ldgq, float* __restrict__ stat) {
+    float* __restrict__ gq, int ldgq, float* __restrict__ stat, AttnDrop drop) {
   __shared__ __attribute__((aligned(16))) float ks[kAttTile][HD];
   __shared__ __attribute__((aligned(16))) float vs[kAttTile][HD];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -235,6 +244,8 @@ __global__ __launch_bounds__(256) void attention_bwd_rows_lanes_kernel(
         sdot = fmaf(qi[c], ks[j][c], sdot);
         dp = fmaf(go[c], vs[j][c], dp);
       }
+      if (drop.thresh)
+        dp = attn_keep(drop.seed, (unsigned)(b * heads + head), (unsigned)i, (unsigned)(j0 + j), drop.thresh) ? dp * drop.inv_keep : 0.f;
       const float ds = __expf(sdot - L) * (dp - D);
 #pragma unroll
       for (int c = 0; c < HD; ++c) acc[c] = fmaf(ds, ks[j][c], acc[c]);
@@ -256,7 +267,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attention_bwd_cols_lanes_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ k, const float* __restrict__ v, int ldkv,
     const float* __restrict__ gout, int ldo, int Lq, int Lk, float scale, const float* __restrict__ stat,
-    float* __restrict__ gk, float* __restrict__ gv, int ldgkv, int chunks, int batch) {
+    float* __restrict__ gk, float* __restrict__ gv, int ldgkv, int chunks, int batch, AttnDrop drop) {
   __shared__ __attribute__((aligned(16))) float qs[kAttTile][HD];
   __shared__ __attribute__((aligned(16))) float gs[kAttTile][HD];
   __shared__ float2 ld_s[kAttTile];
@@ -302,10 +313,16 @@ __global__ __launch_bounds__(256) void attention_bwd_cols_lanes_kernel(
       }
       const float2 ld = ld_s[i];
       const float p = __expf(sdot - ld.x);
+      float pm = p;
+      if (drop.thresh) {
+        const float mk = attn_keep(drop.seed, (unsigned)(b * heads + head), (unsigned)(i0 + i), (unsigned)j, drop.thresh) ? drop.inv_keep : 0.f;
+        dp *= mk;
+        pm *= mk;
+      }
       const float ds = p * (dp - ld.y);
 #pragma unroll
       for (int c = 0; c < HD; ++c) {
-        dv[c] = fmaf(p, gs[i][c], dv[c]);
+        dv[c] = fmaf(pm, gs[i][c], dv[c]);
         dk[c] = fmaf(ds, qs[i][c], dk[c]);
       }
     }
@@ -455,10 +472,10 @@ __global__ __launch_bounds__(64 * HPB) void window_attention_bwd_kernel(const fl
 
 extern "C" {
 
-int isf_attention_backward(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
-                           const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
-                           int embed_dims, int num_heads, float* grad_q, int ldgq, float* grad_k, float* grad_v,
-                           int ldgkv, isf_stream_t stream) {
+static int attention_backward_impl(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                                   const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
+                                   int embed_dims, int num_heads, float* grad_q, int ldgq, float* grad_k, float* grad_v,
+                                   int ldgkv, isf::AttnDrop drop, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(batch_size >= 0 && num_queries >= 0 && num_keys > 0 && num_heads > 0, ISF_ERR_ARG,
               "attention_backward: bad sizes");
@@ -486,10 +503,10 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
   const bool many = num_queries >= 2048;   // lanes own queries / keys (see attention_bwd_rows_lanes_kernel)
   if (many)
     hipLaunchKernelGGL((attention_bwd_rows_lanes_kernel<16>), dim3(ceil_div(num_queries, 256), num_heads, batch_size), dim3(256),
-                       0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
+                       0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat, drop);
   else
     hipLaunchKernelGGL((attention_bwd_rows_kernel<16>), dim3(ceil_div(num_queries, 4), num_heads, batch_size), dim3(256),
-                       0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat);
+                       0, st, q, ldq, k, v, ldkv, out, grad_out, ldo, num_queries, num_keys, scale, grad_q, ldgq, stat, drop);
   ISF_LAUNCH_CHECK();
   if (many) {
     // enough (key block, chunk, head, sample) workgroups to fill the chip: ~2000 of them, at least 2 query tiles each
@@ -501,7 +518,7 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
     ISF_TRY(a.alloc_n(&pk, (size_t)chunks * rows * ldgkv));
     ISF_TRY(a.alloc_n(&pv, (size_t)chunks * rows * ldgkv));
     hipLaunchKernelGGL((attention_bwd_cols_lanes_kernel<16>), dim3(kblocks * chunks, num_heads, batch_size), dim3(256), 0, st,
-                       q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, pk, pv, ldgkv, chunks, batch_size);
+                       q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, pk, pv, ldgkv, chunks, batch_size, drop);
     hipLaunchKernelGGL(attention_bwd_cols_reduce_kernel, dim3(ceil_div((long long)rows * embed_dims, 256)), dim3(256), 0, st,
                        pk, pv, chunks, rows, embed_dims, ldgkv, grad_k, grad_v);
     ISF_LAUNCH_CHECK();
@@ -511,7 +528,7 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
   if (chunks == 1) {
     hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4), num_heads, batch_size), dim3(256), 0,
                        st, q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, grad_k, grad_v, ldgkv, 1,
-                       batch_size);
+                       batch_size, drop);
   } else {
     const size_t rows = (size_t)batch_size * num_keys;
     float *pk = nullptr, *pv = nullptr;
@@ -519,12 +536,29 @@ int isf_attention_backward(const float* q, int ldq, const float* k, const float*
     ISF_TRY(a.alloc_n(&pv, (size_t)chunks * rows * ldgkv));
     hipLaunchKernelGGL((attention_bwd_cols_kernel<16>), dim3(ceil_div(num_keys, 4) * chunks, num_heads, batch_size),
                        dim3(256), 0, st, q, ldq, k, v, ldkv, grad_out, ldo, num_queries, num_keys, scale, stat, pk, pv,
-                       ldgkv, chunks, batch_size);
+                       ldgkv, chunks, batch_size, drop);
     hipLaunchKernelGGL(attention_bwd_cols_reduce_kernel, dim3(ceil_div((long long)rows * embed_dims, 256)), dim3(256), 0, st,
                        pk, pv, chunks, rows, embed_dims, ldgkv, grad_k, grad_v);
   }
   ISF_LAUNCH_CHECK();
   return ISF_OK;
+}
+
+int isf_attention_backward(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                           const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
+                           int embed_dims, int num_heads, float* grad_q, int ldgq, float* grad_k, float* grad_v,
+                           int ldgkv, isf_stream_t stream) {
+  return attention_backward_impl(q, ldq, k, v, ldkv, out, grad_out, ldo, batch_size, num_queries, num_keys, embed_dims,
+                                 num_heads, grad_q, ldgq, grad_k, grad_v, ldgkv, isf::attn_drop_of(0.f, 0ull), stream);
+}
+
+int isf_attention_backward_dropout(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                                   const float* grad_out, int ldo, int batch_size, int num_queries, int num_keys,
+                                   int embed_dims, int num_heads, float dropout_p, unsigned long long seed, float* grad_q,
+                                   int ldgq, float* grad_k, float* grad_v, int ldgkv, isf_stream_t stream) {
+  ISF_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, ISF_ERR_ARG, "attention_backward: dropout probability %g", (double)dropout_p);
+  return attention_backward_impl(q, ldq, k, v, ldkv, out, grad_out, ldo, batch_size, num_queries, num_keys, embed_dims,
+                                 num_heads, grad_q, ldgq, grad_k, grad_v, ldgkv, isf::attn_drop_of(dropout_p, seed), stream);
 }
 
 int isf_window_attention_backward(const float* qkv, const float* grad_out, int batch_size, int grid_size,

@@ -142,6 +142,37 @@ __device__ __forceinline__ int occ_lookup(const unsigned long long* __restrict__
   return (int)(prefix[w] + (uint32_t)__popcll(word & (bit - 1)));
 }
 
+// ----------------------------------------------------------------------------- attention-probability dropout
+// nn.MultiheadAttention(dropout = p) in training mode zeroes attention PROBABILITIES with probability p and scales the kept
+// ones by 1 / (1 - p) (fusion_encoder.py:458 F.dropout(attn_output_weights)).  The flash-style kernels never hold the
+// probability matrix, so forward and backward recompute the same keep / drop decision per (sample * heads + head, query, key)
+// from a counter-based hash of a per-call seed (the finaliser of MurmurHash3 over the packed indices).  thresh = p * 2^32;
+// thresh == 0: no dropout (every kernel skips the hash).  fusion_ops.attention_keep_mask restates it in torch for the tests.
+struct AttnDrop {
+  unsigned long long seed;
+  unsigned thresh;
+  float inv_keep;
+};
+__host__ __device__ inline bool attn_keep(unsigned long long seed, unsigned bh, unsigned i, unsigned j, unsigned thresh) {
+  unsigned long long x = seed ^ (((unsigned long long)bh << 48) | ((unsigned long long)(i & 0xffffffu) << 24) |
+                                 (unsigned long long)(j & 0xffffffu));
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return (unsigned)(x >> 32) >= thresh;
+}
+static inline AttnDrop attn_drop_of(float p, unsigned long long seed) {
+  AttnDrop d{seed, 0u, 1.f};
+  if (p > 0.f) {
+    const double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    d.inv_keep = 1.f / (1.f - p);
+  }
+  return d;
+}
+
 // ----------------------------------------------------------------------------- split activation format
 // Row-major [N][C/32] chunks of 128 bytes; a chunk holds 32 channels as 4 x (8 f16 hi) followed by 4 x (8 f16 lo)
 // (value = hi + lo).  The four 16-byte hi pieces of a chunk -- what the four k-group lanes of one MFMA row fetch

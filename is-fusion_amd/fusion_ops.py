@@ -592,12 +592,22 @@ class AttentionFunction(torch.autograd.Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, q, k, v, B, Lq, Lk, E, nhead):
+    def forward(ctx, q, k, v, B, Lq, Lk, E, nhead, dropout_p=0.0, seed=0):
+        """dropout_p > 0 (training): nn.MultiheadAttention's dropout on the attention probabilities
+        (fusion_encoder.py:458), decided per (sample, head, query, key) by a hash of `seed` that the backward pass
+        recomputes (isf_attention_forward_dropout / _backward_dropout; attention_keep_mask restates it)."""
         _lib.require_cuda(q, k, v)
         q, k, v = [t.detach().float().contiguous() for t in (q, k, v)]
-        out = attention(q, k, v, B, Lq, Lk, E, nhead)
+        if dropout_p > 0.0:
+            out = torch.empty((B * Lq, E), dtype=torch.float32, device=q.device)
+            _lib.check(_lib.load().isf_attention_forward_dropout(
+                _lib.ptr(q), q.stride(0), _lib.ptr(k), _lib.ptr(v), k.stride(0), B, Lq, Lk, E, nhead, float(dropout_p),
+                int(seed), _lib.ptr(out), out.stride(0), _lib.stream()), "isf_attention_forward_dropout")
+        else:
+            out = attention(q, k, v, B, Lq, Lk, E, nhead)
         ctx.save_for_backward(q, k, v, out)
         ctx.dims = (B, Lq, Lk, E, nhead)
+        ctx.drop = (float(dropout_p), int(seed))
         return out
 
     @staticmethod
@@ -607,11 +617,44 @@ class AttentionFunction(torch.autograd.Function):
         B, Lq, Lk, E, nhead = ctx.dims
         g = grad_out.contiguous().float()
         gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        _lib.check(_lib.load().isf_attention_backward(
-            _lib.ptr(q), q.stride(0), _lib.ptr(k), _lib.ptr(v), k.stride(0), _lib.ptr(out), _lib.ptr(g), g.stride(0),
-            B, Lq, Lk, E, nhead, _lib.ptr(gq), gq.stride(0), _lib.ptr(gk), _lib.ptr(gv), gk.stride(0), _lib.stream()),
-            "isf_attention_backward")
-        return (gq, gk, gv) + (None,) * 5
+        p, seed = ctx.drop
+        if p > 0.0:
+            _lib.check(_lib.load().isf_attention_backward_dropout(
+                _lib.ptr(q), q.stride(0), _lib.ptr(k), _lib.ptr(v), k.stride(0), _lib.ptr(out), _lib.ptr(g), g.stride(0),
+                B, Lq, Lk, E, nhead, p, seed, _lib.ptr(gq), gq.stride(0), _lib.ptr(gk), _lib.ptr(gv), gk.stride(0),
+                _lib.stream()), "isf_attention_backward_dropout")
+        else:
+            _lib.check(_lib.load().isf_attention_backward(
+                _lib.ptr(q), q.stride(0), _lib.ptr(k), _lib.ptr(v), k.stride(0), _lib.ptr(out), _lib.ptr(g), g.stride(0),
+                B, Lq, Lk, E, nhead, _lib.ptr(gq), gq.stride(0), _lib.ptr(gk), _lib.ptr(gv), gk.stride(0), _lib.stream()),
+                "isf_attention_backward")
+        return (gq, gk, gv) + (None,) * 7
+
+
+def attention_keep_mask(seed, B, nhead, Lq, Lk, p, device="cpu"):
+    """[B, nhead, Lq, Lk] bool: the keep / drop decisions of isf_attention_forward_dropout (AttnDrop in isf_common.h) restated
+    in torch -- the finaliser of MurmurHash3 over seed ^ (b*heads + head) << 48 | query << 24 | key, upper 32 bits >= p * 2^32.
+    int64 arithmetic wraps like uint64; logical right shifts are emulated by masking the sign extension."""
+    def shr33(x):
+        return (x >> 33) & 0x7FFFFFFF
+
+    def as_i64(v):
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >= (1 << 63) else v
+    bh = torch.arange(B * nhead, dtype=torch.int64, device=device).view(B, nhead, 1, 1)
+    i = torch.arange(Lq, dtype=torch.int64, device=device).view(1, 1, Lq, 1)
+    j = torch.arange(Lk, dtype=torch.int64, device=device).view(1, 1, 1, Lk)
+    x = (bh << 48) | (i << 24) | j
+    x = x ^ as_i64(int(seed))
+    x = x ^ shr33(x)
+    x = x * as_i64(0xff51afd7ed558ccd)
+    x = x ^ shr33(x)
+    x = x * as_i64(0xc4ceb9fe1a85ec53)
+    x = x ^ shr33(x)
+    hi = (x >> 32) & 0xFFFFFFFF
+    t = float(p) * 4294967296.0
+    thresh = 4294967295 if t >= 4294967295.0 else int(t)
+    return hi >= thresh
 
 
 class WindowAttentionFunction(torch.autograd.Function):

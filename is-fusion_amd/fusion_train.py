@@ -264,14 +264,21 @@ def sstv2_forward(sst, bev, win, temperature=1000.0):
 
 
 # ----------------------------------------------------------------------------------------------------- A13
-def _mha(q_in, k_in, v_in, attn, B, Lq, Lk, nhead):
-    """nn.MultiheadAttention arithmetic on row-major [B*L, E] tokens with the HIP attention core"""
+def _mha(q_in, k_in, v_in, attn, B, Lq, Lk, nhead, dropout_p=0.0):
+    """nn.MultiheadAttention arithmetic on row-major [B*L, E] tokens with the HIP attention core.  dropout_p > 0 (training):
+    the module's dropout on the attention probabilities (fusion_encoder.py:458), one fresh seed per call from torch's CPU
+    generator (torch.manual_seed makes a run repeatable)."""
     E = q_in.size(1)
     w, b = attn.in_proj_weight, attn.in_proj_bias
     q = linear_w(q_in, w[:E], b[:E])
     k = linear_w(k_in, w[E:2 * E], b[E:2 * E])
     v = linear_w(v_in, w[2 * E:], b[2 * E:])
-    return linear(ops.AttentionFunction.apply(q, k, v, B, Lq, Lk, E, nhead), attn.out_proj)
+    if dropout_p > 0.0 and Lk <= 512 and E == 16 * nhead:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        att = ops.AttentionFunction.apply(q, k, v, B, Lq, Lk, E, nhead, float(dropout_p), seed)
+    else:
+        att = ops.AttentionFunction.apply(q, k, v, B, Lq, Lk, E, nhead)
+    return linear(att, attn.out_proj)
 
 
 def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
@@ -293,7 +300,7 @@ def ins_context_att(mod, x_ins, query_pos, scene, bev_size):
         nhead, npts = ca.n_heads, ca.n_points
         p, tr = getattr(l, "dropout", 0.0), l.training      # dropout1..4 of the reference layer (:604-668, p = 0.1)
         qk_in = out + qpe
-        out = F.layer_norm(out + F.dropout(_mha(qk_in, qk_in, out, l.self_attn, B, Q, Q, nhead), p, tr), (E,),
+        out = F.layer_norm(out + F.dropout(_mha(qk_in, qk_in, out, l.self_attn, B, Q, Q, nhead, p if tr else 0.0), p, tr), (E,),
                            l.norm2.weight, l.norm2.bias, l.norm2.eps)                                       # dropout2
         q = out + qpe
         value = linear(src, ca.value_proj)
@@ -314,7 +321,8 @@ def instance_to_scene(mod, query, x_ins, scene_feats, bev_size):
     Q = x_ins.size(2)
     xq = ops.to_tokens(query.float())
     xk = x_ins.float().transpose(1, 2).reshape(B * Q, E)
-    att = F.dropout(_mha(xq, xk, xk, mod.multihead_attn, B, H * W, Q, mod.nhead), getattr(mod, "dropout", 0.0),
+    pd = getattr(mod, "dropout", 0.0)
+    att = F.dropout(_mha(xq, xk, xk, mod.multihead_attn, B, H * W, Q, mod.nhead, pd if mod.training else 0.0), pd,
                     mod.training)                                               # self.dropout (:478, :492)
     y = F.layer_norm(xq + att, (E,), mod.norm.weight, mod.norm.bias, mod.norm.eps)
     return ChannelAttentionFunction.apply(scene_feats, ops.from_tokens(y, B, H, W))

@@ -522,3 +522,37 @@ def test_dense_conv_stack_takes_a_list_of_maps_as_their_channel_concatenation(de
     assert rel_err(torch.cat([p.grad for p in parts], 1), xa.grad.cpu()) < 1e-6
     for p, g in zip(net.parameters(), ga):
         assert rel_err(p.grad, g.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 300, 200), (1, 2500, 200), (2, 200, 200), (1, 4100, 37)])
+def test_attention_probability_dropout_matches_the_masked_float64_reference(dev, B, Lq, Lk):
+    """nn.MultiheadAttention's dropout on the attention probabilities in training mode (fusion_encoder.py:458; p = 0.1 in the
+    two IGF modules): isf_attention_forward_dropout / _backward_dropout decide keep / drop per (sample, head, query, key) by a
+    hash of the call's seed, recomputed in the backward pass.  Against float64 softmax attention with the SAME mask
+    (fusion_ops.attention_keep_mask restates the hash): output and dq / dk / dv, on the few-query (wave kernels) and the
+    many-query (lane kernels) shapes; p = 0 is the plain call bit for bit; the keep rate is 1 - p."""
+    from isfusion_amd import fusion_ops as ops
+    E, nhead, p, seed = 128, 8, 0.3, 0x1234567890ABCDEF
+    hd = E // nhead
+    q, k, v = rnd((B * Lq, E), 81), rnd((B * Lk, E), 82), rnd((B * Lk, E), 83)
+    w = rnd((B * Lq, E), 84)
+    qg, kg, vg = (t.to(dev).requires_grad_() for t in (q, k, v))
+    out = ops.AttentionFunction.apply(qg, kg, vg, B, Lq, Lk, E, nhead, p, seed)
+    (out * w.to(dev)).sum().backward()
+    mask = ops.attention_keep_mask(seed, B, nhead, Lq, Lk, p)                     # [B, heads, Lq, Lk]
+    assert abs(mask.double().mean().item() - (1 - p)) < 0.01
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    q4 = qr.view(B, Lq, nhead, hd).transpose(1, 2)
+    k4 = kr.view(B, Lk, nhead, hd).transpose(1, 2)
+    v4 = vr.view(B, Lk, nhead, hd).transpose(1, 2)
+    prob = torch.softmax(q4 @ k4.transpose(2, 3) / hd ** 0.5, -1) * mask.double() / (1 - p)
+    ref = (prob @ v4).transpose(1, 2).reshape(B * Lq, E)
+    (ref * w.double()).sum().backward()
+    assert rel_err(out, ref.float()) < 1e-5
+    for got, want, name in ((qg.grad, qr.grad, "dq"), (kg.grad, kr.grad, "dk"), (vg.grad, vr.grad, "dv")):
+        assert rel_err(got, want.float()) < 1e-4, name
+    plain = ops.AttentionFunction.apply(q.to(dev), k.to(dev), v.to(dev), B, Lq, Lk, E, nhead)
+    assert torch.equal(ops.AttentionFunction.apply(q.to(dev), k.to(dev), v.to(dev), B, Lq, Lk, E, nhead, 0.0, seed), plain)
+    assert not torch.equal(out.detach(), plain)
+    other = ops.AttentionFunction.apply(q.to(dev), k.to(dev), v.to(dev), B, Lq, Lk, E, nhead, p, seed + 1)
+    assert not torch.equal(other, out.detach())                                  # another seed: another mask
