@@ -789,6 +789,11 @@ int isf_bn1d_apply_pivot(const float* x, int num_rows, int channels, const float
                          const float* gamma, const float* beta, float eps, float momentum, int unbiased_running_var,
                          float* running_mean, float* running_var, const float* residual, int relu, float* y,
                          float* mean_invstd, isf_stream_t stream);
+/* ... which also adds 1 to the module's num_batches_tracked (int64 device scalar, NULL = none) inside the same launch */
+int isf_bn1d_apply_pivot_counted(const float* x, int num_rows, int channels, const float* stats, const float* pivot, float count,
+                                 const float* gamma, const float* beta, float eps, float momentum, int unbiased_running_var,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked,
+                                 const float* residual, int relu, float* y, float* mean_invstd, isf_stream_t stream);
 int isf_bn1d_backward_sums(const float* grad_y, const float* x, const float* y_relu, int num_rows, int channels,
                            const float* mean_invstd, float* sums, isf_stream_t stream);
 int isf_bn1d_backward_apply(const float* grad_y, const float* x, const float* y_relu, int num_rows, int channels,

@@ -246,6 +246,9 @@ SIGNATURES = {
     "isf_bn1d_apply_pivot": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p,
                                      ctypes.c_float, ctypes.c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p]),
+    "isf_bn1d_apply_pivot_counted": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p,
+                                             ctypes.c_float, ctypes.c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_void_p, c_void_p, c_void_p]),
     "isf_bn1d_backward_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "isf_bn1d_backward_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -93,10 +93,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               const float* __restrict__ residual, int relu,
                                                               float* __restrict__ y, float* __restrict__ mean_invstd,
-                                                              const float* __restrict__ pivot /* [c] or nullptr */) {
+                                                              const float* __restrict__ pivot /* [c] or nullptr */,
+                                                              long long* __restrict__ num_batches_tracked /* or nullptr */) {
   const int cq = c >> 2;
   const float inv_n = 1.f / count;
   if (blockIdx.x == 0) {                                 // the layer's buffers: running statistics, saved mean / invstd
+    if (threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;   // (nn.BatchNorm's counter: no launch of its own)
     for (int ch = threadIdx.x; ch < c; ch += kBnThreads) {
       const float d = stats[ch] * inv_n;                 // mean about the pivot
       const float var = fmaxf(stats[c + ch] * inv_n - d * d, 0.f);
@@ -216,6 +218,15 @@ int isf_bn1d_apply_pivot(const float* x, int num_rows, int channels, const float
                          const float* gamma, const float* beta, float eps, float momentum, int unbiased_running_var,
                          float* running_mean, float* running_var, const float* residual, int relu, float* y,
                          float* mean_invstd, isf_stream_t stream) {
+  return isf_bn1d_apply_pivot_counted(x, num_rows, channels, stats, pivot, count, gamma, beta, eps, momentum,
+                                      unbiased_running_var, running_mean, running_var, nullptr, residual, relu, y, mean_invstd,
+                                      stream);
+}
+
+int isf_bn1d_apply_pivot_counted(const float* x, int num_rows, int channels, const float* stats, const float* pivot, float count,
+                                 const float* gamma, const float* beta, float eps, float momentum, int unbiased_running_var,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked,
+                                 const float* residual, int relu, float* y, float* mean_invstd, isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(x && stats && y && mean_invstd && num_rows > 0 && count >= 1.f && (running_mean == nullptr) == (running_var == nullptr),
               ISF_ERR_ARG, "bn1d_apply: bad arguments");
@@ -224,7 +235,7 @@ int isf_bn1d_apply_pivot(const float* x, int num_rows, int channels, const float
   const int blocks = (int)std::min<long long>(4096, (n4 + kBnThreads * 4 - 1) / (kBnThreads * 4));
   hipLaunchKernelGGL(bn_apply_kernel, dim3(std::max(1, blocks)), dim3(kBnThreads), 0, as_stream(stream), x, n4, channels, stats,
                      count, gamma, beta, eps, momentum, unbiased_running_var, running_mean, running_var, residual, relu, y,
-                     mean_invstd, pivot);
+                     mean_invstd, pivot, num_batches_tracked);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

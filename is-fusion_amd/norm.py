@@ -78,12 +78,16 @@ class _BN1dReLUFunction(Function):
         saved = torch.empty(2 * c, dtype=torch.float32, device=x.device)
         rm, rv = (mod.running_mean, mod.running_var) if mod.track_running_stats else (None, None)
         mom = mod.momentum if mod.momentum is not None else 0.1
-        _lib.check(lib.isf_bn1d_apply_pivot(_lib.ptr(x), n, c, _lib.ptr(stats), _lib.ptr(pivot), count, _lib.ptr(gamma),
-                                            _lib.ptr(beta), float(mod.eps), float(mom), 0 if sync else 1, _lib.ptr(rm),
-                                            _lib.ptr(rv), _lib.ptr(res), int(bool(relu)), _lib.ptr(y), _lib.ptr(saved),
-                                            _lib.stream()), "isf_bn1d_apply_pivot")
-        if mod.track_running_stats and mod.num_batches_tracked is not None:
-            mod.num_batches_tracked.add_(1)
+        # (the module's num_batches_tracked counter is bumped inside the same launch: 41 one-element add_ launches per
+        # training step otherwise, on a step that is paced by the host)
+        nbt = mod.num_batches_tracked if mod.track_running_stats else None
+        counted = nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64
+        _lib.check(lib.isf_bn1d_apply_pivot_counted(
+            _lib.ptr(x), n, c, _lib.ptr(stats), _lib.ptr(pivot), count, _lib.ptr(gamma), _lib.ptr(beta), float(mod.eps),
+            float(mom), 0 if sync else 1, _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(nbt) if counted else None, _lib.ptr(res),
+            int(bool(relu)), _lib.ptr(y), _lib.ptr(saved), _lib.stream()), "isf_bn1d_apply_pivot_counted")
+        if nbt is not None and not counted:
+            nbt.add_(1)
         ctx.save_for_backward(x, y if relu else None, gamma, saved)
         ctx.geom = (n, c, bwd_count, bool(relu), residual is not None, sync)
         return y
