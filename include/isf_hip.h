@@ -240,6 +240,10 @@ int isf_sparse_conv_forward_packed(const float* features, int num_in, int c_in, 
 size_t isf_packed_filter16_bytes(int num_taps, int c_in, int c_out);
 int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_out, void* packed16,
                            isf_stream_t stream);
+/* ... from the per-tap TRANSPOSE: filters_t [num_taps, c_out, c_in] -- e.g. the forward filter when the packed one (c_in x c_out
+ * = forward c_out x c_in) is the data gradient's, dX = dY W_k^T: no transposed copy of the weights per layer and step */
+int isf_pack_filters_f16x3_transposed(const float* filters_t, int num_taps, int c_in, int c_out, void* packed16,
+                                      isf_stream_t stream);
 int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream);
 int isf_split_to_f32(const void* xs, size_t num_elems, float* x, isf_stream_t stream);
 /* f16 STORAGE (mode 257 = 256 | 1 of isf_sparse_conv_forward_f16x3; isf_encoder_options.precision = 2): features,
@@ -530,6 +534,8 @@ int isf_lidar_branch_forward(const float* points, const int64_t* point_offsets_h
  * in_features in {32,64,128,256}; out_features % 16 == 0; ldx % 8 == 0. */
 size_t isf_packed_linear_bytes(int out_features, int in_features);
 int isf_pack_linear(const float* weight, int out_features, int in_features, void* packed, isf_stream_t stream);
+/* ... from the transpose: weight_t [in_features, out_features] row-major (the forward weight, for dX = dY W) */
+int isf_pack_linear_transposed(const float* weight_t, int out_features, int in_features, void* packed, isf_stream_t stream);
 int isf_linear_forward(const float* x, int num_rows, int in_features, int ldx, const void* packed_weight,
                        int out_features, const float* bias, const float* row_table, const int32_t* row_table_index,
                        int activation, const float* residual, const float* ln_gamma, const float* ln_beta,

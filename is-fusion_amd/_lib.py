@@ -136,6 +136,7 @@ SIGNATURES = {
                                                c_void_p]),
     "isf_packed_filter16_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "isf_pack_filters_f16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isf_pack_filters_f16x3_transposed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isf_f32_to_split": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_split_to_f32": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
     "isf_f32_to_half": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
@@ -203,6 +204,7 @@ SIGNATURES = {
                                          ctypes.POINTER(EncoderOptions), c_void_p]),
     "isf_packed_linear_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "isf_pack_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "isf_pack_linear_transposed": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "isf_linear_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_int, c_int,
                                    c_int, c_void_p]),

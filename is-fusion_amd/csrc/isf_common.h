@@ -367,7 +367,8 @@ int sparse_conv_forward_staged_impl(const void* xs, int c_in, const void* packed
                                     const int32_t* ucount, int n_out, const float* scale, const float* shift,
                                     const void* residual, int relu, void* ys, int stage_rows, int mode,
                                     hipStream_t st);
-int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st);
+int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st,
+                        bool transposed = false /* w = [K][cout][cin], the per-tap transpose of the packed filter */);
 int f32_to_split_impl(const float* x, size_t n_elems, void* xs, hipStream_t st);
 int split_to_f32_impl(const void* xs, size_t n_elems, float* x, hipStream_t st);
 int f32_to_half_impl(const float* x, size_t n_elems, void* xh, hipStream_t st);   // [N][C] f16 rows (f16 storage mode)

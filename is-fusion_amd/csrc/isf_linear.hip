@@ -348,8 +348,10 @@ __global__ __launch_bounds__(256, (KC == 8 && CT == 16) ? 1 : 2) void linear_f16
   }
 }
 
+// transposed: `w` is [K][N] row-major, the transpose of the weight that is packed (the forward weight when the packed one
+// is the data gradient's: dX = dY W)
 __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, const unsigned* __restrict__ amax_bits,
-                                   uint4* __restrict__ packed, float* __restrict__ header) {
+                                   uint4* __restrict__ packed, float* __restrict__ header, int transposed) {
   const float amax = __uint_as_float(*amax_bits);
   int e = 0;
   if (amax > 0.f) (void)frexpf(amax, &e);
@@ -364,7 +366,10 @@ __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, co
   const int kc = (int)((t >> 6) / ntiles);
   f32x8 v;
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj) v[jj] = w[(size_t)(16 * nt + (lane & 15)) * K + 32 * kc + 8 * (lane >> 4) + jj] * s;
+  for (int jj = 0; jj < 8; ++jj) {
+    const int n = 16 * nt + (lane & 15), k = 32 * kc + 8 * (lane >> 4) + jj;
+    v[jj] = (transposed ? w[(size_t)k * N + n] : w[(size_t)n * K + k]) * s;
+  }
   h8 hi, lo;
   lin_split8(v, hi, lo);
   const size_t base = ((size_t)kc * ntiles + nt) * 128;
@@ -449,7 +454,19 @@ size_t isf_packed_linear_bytes(int out_features, int in_features) {
   return (size_t)out_features * in_features * 4 + 64;
 }
 
+static int pack_linear_impl(const float* weight, int out_features, int in_features, void* packed, int transposed,
+                            isf_stream_t stream);
+
 int isf_pack_linear(const float* weight, int out_features, int in_features, void* packed, isf_stream_t stream) {
+  return pack_linear_impl(weight, out_features, in_features, packed, 0, stream);
+}
+
+int isf_pack_linear_transposed(const float* weight_t, int out_features, int in_features, void* packed, isf_stream_t stream) {
+  return pack_linear_impl(weight_t, out_features, in_features, packed, 1, stream);
+}
+
+static int pack_linear_impl(const float* weight, int out_features, int in_features, void* packed, int transposed,
+                            isf_stream_t stream) {
   using namespace isf;
   ISF_REQUIRE(weight && packed && out_features % 16 == 0 && in_features % 32 == 0 && out_features > 0 && in_features > 0,
               ISF_ERR_ARG, "pack_linear: need out %% 16 == 0 and in %% 32 == 0 (got %d, %d)", out_features, in_features);
@@ -465,7 +482,7 @@ int isf_pack_linear(const float* weight, int out_features, int in_features, void
   const long long total = (long long)(in_features / 32) * (out_features / 16) * 64;
   hipLaunchKernelGGL(pack_linear_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, weight, out_features,
                      in_features, amax, reinterpret_cast<uint4*>(packed),
-                     reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + n * 4));
+                     reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + n * 4), transposed);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }

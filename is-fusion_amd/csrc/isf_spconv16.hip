@@ -729,9 +729,11 @@ __global__ void absmax_kernel(const float* __restrict__ w, size_t n, unsigned* _
 // packed16[tap][chunk][ntile][hi|lo][lane][8 halves], lane = (col j = lane&15, k-group = lane>>4):
 //   element jj = W[tap][32*chunk + 8*(lane>>4) + jj][16*ntile + (lane&15)] * 2^sw
 // header (after the data): float inv_scale = 2^-sw
+// transposed: `w` is the per-tap TRANSPOSE of the filter that is packed -- [K][cout][cin], i.e. the forward filter when the
+// packed one is the data gradient's (dX = dY W_k^T): no transposed copy of the weights per layer and step
 __global__ void pack_filters16_kernel(const float* __restrict__ w, int K, int cin, int cout,
                                       const unsigned* __restrict__ absmax_bits, uint4* __restrict__ packed,
-                                      float* __restrict__ header) {
+                                      float* __restrict__ header, int transposed) {
   const float amax = __uint_as_float(*absmax_bits);
   int e = 0;
   if (amax > 0.f) (void)frexpf(amax, &e);
@@ -749,8 +751,10 @@ __global__ void pack_filters16_kernel(const float* __restrict__ w, int K, int ci
   const int k = (int)(r / nch);
   f32x8 v;
 #pragma unroll
-  for (int jj = 0; jj < 8; ++jj)
-    v[jj] = w[((size_t)k * cin + 32 * ch + 8 * (lane >> 4) + jj) * cout + 16 * nt + (lane & 15)] * s;
+  for (int jj = 0; jj < 8; ++jj) {
+    const int ci = 32 * ch + 8 * (lane >> 4) + jj, co = 16 * nt + (lane & 15);
+    v[jj] = (transposed ? w[((size_t)k * cout + co) * cin + ci] : w[((size_t)k * cin + ci) * cout + co]) * s;
+  }
   uint4 hi, lo;
   split8(v, hi, lo);
   const size_t base = (((size_t)k * nch + ch) * ntiles + nt) * 128;
@@ -1300,7 +1304,7 @@ int conv16_band_order_impl(const int32_t* coors4, int n_out, const Conv16LaunchI
   return ISF_OK;
 }
 
-int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st) {
+int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void* packed16, hipStream_t st, bool transposed) {
   unsigned* amax = nullptr;
   ISF_TRY(a.alloc_n(&amax, 64));
   ISF_HIP_TRY(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
@@ -1312,7 +1316,7 @@ int pack_filters16_impl(Arena& a, const float* w, int K, int cin, int cout, void
   const long long total = (long long)K * (cin >> 5) * (cout >> 4) * 64;
   hipLaunchKernelGGL(pack_filters16_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, w, K, cin, cout, amax,
                      reinterpret_cast<uint4*>(packed16),
-                     reinterpret_cast<float*>(reinterpret_cast<char*>(packed16) + n * 4));
+                     reinterpret_cast<float*>(reinterpret_cast<char*>(packed16) + n * 4), transposed ? 1 : 0);
   ISF_LAUNCH_CHECK();
   return ISF_OK;
 }
@@ -1369,6 +1373,16 @@ int isf_pack_filters_f16x3(const float* filters, int num_taps, int c_in, int c_o
   isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
   ISF_TRY(a.reset());
   return isf::pack_filters16_impl(a, filters, num_taps, c_in, c_out, packed16, isf::as_stream(stream));
+}
+
+int isf_pack_filters_f16x3_transposed(const float* filters_t, int num_taps, int c_in, int c_out, void* packed16,
+                                      isf_stream_t stream) {
+  ISF_REQUIRE(filters_t && packed16 && num_taps > 0, ISF_ERR_ARG, "pack_filters_f16x3_transposed: bad arguments");
+  ISF_REQUIRE(isf::sparse_conv_f16x3_supported(c_in, c_out), ISF_ERR_UNSUPPORTED,
+              "pack_filters_f16x3_transposed: (Cin,Cout)=(%d,%d) not built", c_in, c_out);
+  isf::Arena& a = isf::arena_for_stream(isf::as_stream(stream));
+  ISF_TRY(a.reset());
+  return isf::pack_filters16_impl(a, filters_t, num_taps, c_in, c_out, packed16, isf::as_stream(stream), true);
 }
 
 int isf_f32_to_split(const float* x, size_t num_elems, void* xs, isf_stream_t stream) {

@@ -78,8 +78,7 @@ def _groups(weight, transpose):
     while off < cin:
         c = min(256, cin - off)
         wk = w5[:, :, off:off + c].contiguous().view(1, 3, 3, c, cout)
-        wt = wk.view(9, c, cout).transpose(1, 2).contiguous().view(1, 3, 3, cout, c)
-        groups.append((off, c, sp.pack_filters_f16x3(wk), sp.pack_filters_f16x3(wt)))
+        groups.append((off, c, sp.pack_filters_f16x3(wk), sp.pack_filters_f16x3(wk, transposed=True)))
         off += c
     if len(_packed) > 256:
         _packed.clear()

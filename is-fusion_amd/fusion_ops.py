@@ -23,15 +23,17 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 class PackedLinear:
     """nn.Linear weights split once into f16 hi/lo MFMA fragments (isf_pack_linear)."""
 
-    def __init__(self, weight, bias=None):
+    def __init__(self, weight, bias=None, transposed=False):
+        """transposed: pack weight^T ([in, out] given, e.g. the forward weight for dX = dY W) without a transposed copy"""
         _lib.require_cuda(weight)
         w = weight.detach().float().contiguous()
-        self.out_features, self.in_features = w.shape
+        self.out_features, self.in_features = (w.shape[1], w.shape[0]) if transposed else w.shape
         lib = _lib.load()
         self.packed = torch.empty(lib.isf_packed_linear_bytes(self.out_features, self.in_features), dtype=torch.uint8,
                                   device=w.device)
-        _lib.check(lib.isf_pack_linear(_lib.ptr(w), self.out_features, self.in_features, _lib.ptr(self.packed),
-                                       _lib.stream()), "isf_pack_linear")
+        pack = lib.isf_pack_linear_transposed if transposed else lib.isf_pack_linear
+        _lib.check(pack(_lib.ptr(w), self.out_features, self.in_features, _lib.ptr(self.packed), _lib.stream()),
+                   "isf_pack_linear")
         self.bias = None if bias is None else bias.detach().float().contiguous()
 
 

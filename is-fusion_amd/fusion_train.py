@@ -124,7 +124,7 @@ class LinearFunction(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gs, sc = _lib.grad_rescale(g)           # gradients are tiny: keep the GEMM's f16 halves in range (exact)
-            gx = (ops.linear(gs, ops.PackedLinear(wd.t().contiguous())) * sc[1]).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
+            gx = (ops.linear(gs, ops.PackedLinear(wd, transposed=True)) * sc[1]).to(ctx.in_dtype)   # dX = dY W  (HIP GEMM)
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(g, xd)                                                      # dW = dY^T X (library GEMM)
         if ctx.has_bias and ctx.needs_input_grad[2]:

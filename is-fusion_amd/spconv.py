@@ -146,15 +146,22 @@ def f16x3_supported(c_in, c_out):
     return c_in in F16X3_CHANNELS and c_out in F16X3_CHANNELS
 
 
-def pack_filters_f16x3(weight):
-    """[kD,kH,kW,Cin,Cout] fp32 -> pre-split (hi|lo f16, power-of-two scaled) MFMA fragments + header."""
+def pack_filters_f16x3(weight, transposed=False):
+    """[kD,kH,kW,Cin,Cout] fp32 -> pre-split (hi|lo f16, power-of-two scaled) MFMA fragments + header.
+    transposed: pack the per-tap TRANSPOSED filters ([..., Cout, Cin] as a Cout -> Cin convolution: the data gradient's)
+    straight from `weight`, without a transposed copy."""
     w = weight.detach().float().contiguous()
     K = int(np.prod(w.shape[:-2]))
     lib = _lib.load()
-    nbytes = lib.isf_packed_filter16_bytes(K, w.shape[-2], w.shape[-1])
+    c_in, c_out = (w.shape[-1], w.shape[-2]) if transposed else (w.shape[-2], w.shape[-1])
+    nbytes = lib.isf_packed_filter16_bytes(K, c_in, c_out)
     packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _lib.check(lib.isf_pack_filters_f16x3(_lib.ptr(w), K, w.shape[-2], w.shape[-1], _lib.ptr(packed),
-                                          _lib.stream()), "isf_pack_filters_f16x3")
+    if transposed:
+        _lib.check(lib.isf_pack_filters_f16x3_transposed(_lib.ptr(w), K, c_in, c_out, _lib.ptr(packed), _lib.stream()),
+                   "isf_pack_filters_f16x3_transposed")
+    else:
+        _lib.check(lib.isf_pack_filters_f16x3(_lib.ptr(w), K, c_in, c_out, _lib.ptr(packed), _lib.stream()),
+                   "isf_pack_filters_f16x3")
     return packed
 
 
@@ -650,15 +657,13 @@ def _packed_pair(weight, w, K, c_in, c_out):
     packed once per parameter version: the forward pass packs both, the backward pass finds its half here instead of
     transposing + packing again (5 launches per layer and step)."""
     if not PACKED_PAIR_CACHE:
-        wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*weight.shape[:-2], c_out, c_in)
-        return pack_filters_f16x3(w), pack_filters_f16x3(wt)
+        return pack_filters_f16x3(w), pack_filters_f16x3(w, transposed=True)
     key = id(weight)
     hit = _PACKED_PAIRS.get(key)
     # the weak reference tells a live parameter from a new tensor that reuses a dead one's id / address / version 0
     if hit is not None and hit[4]() is weight and hit[0] == weight._version and hit[1] == weight.data_ptr():
         return hit[2], hit[3]
-    wt = w.view(K, c_in, c_out).transpose(1, 2).contiguous().view(*weight.shape[:-2], c_out, c_in)
-    pair = (pack_filters_f16x3(w), pack_filters_f16x3(wt))
+    pair = (pack_filters_f16x3(w), pack_filters_f16x3(w, transposed=True))    # (no transposed copy: the pack kernel reads it)
     if len(_PACKED_PAIRS) > 256:
         _PACKED_PAIRS.clear()
     _PACKED_PAIRS[key] = (weight._version, weight.data_ptr(), pair[0], pair[1], weakref.ref(weight))

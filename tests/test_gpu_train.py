@@ -556,3 +556,20 @@ def test_attention_probability_dropout_matches_the_masked_float64_reference(dev,
     assert not torch.equal(out.detach(), plain)
     other = ops.AttentionFunction.apply(q.to(dev), k.to(dev), v.to(dev), B, Lq, Lk, E, nhead, p, seed + 1)
     assert not torch.equal(other, out.detach())                                  # another seed: another mask
+
+
+def test_transposed_pack_entries_equal_the_pack_of_a_transposed_copy(dev):
+    """isf_pack_filters_f16x3_transposed / isf_pack_linear_transposed read the forward weight and pack its (per-tap) transpose
+    -- what the data-gradient passes multiply with -- without the transposed copy the backward paths used to make per layer
+    and step: byte for byte the pack of that copy"""
+    from isfusion_amd import fusion_ops as ops, spconv as sp
+    for K, cin, cout in ((27, 32, 64), (9, 128, 256), (3, 256, 256), (1, 64, 32)):
+        w = rnd((K, cin, cout), 91 + K).to(dev).view(K, 1, 1, cin, cout)
+        wt = w.view(K, cin, cout).transpose(1, 2).contiguous().view(K, 1, 1, cout, cin)
+        n = K * cin * cout * 4 + 4        # fragments + the scale word of the 64-byte header (the rest is never written)
+        assert torch.equal(sp.pack_filters_f16x3(w, transposed=True)[:n], sp.pack_filters_f16x3(wt)[:n]), (K, cin, cout)
+    for N, Kf in ((128, 128), (384, 128), (32, 256), (1024, 256), (64, 32)):
+        w = rnd((N, Kf), 95 + N).to(dev)
+        a, b = ops.PackedLinear(w, transposed=True), ops.PackedLinear(w.t().contiguous())
+        assert (a.out_features, a.in_features) == (b.out_features, b.in_features) == (Kf, N)
+        assert torch.equal(a.packed[:N * Kf * 4 + 4], b.packed[:N * Kf * 4 + 4]), (N, Kf)
