@@ -563,7 +563,7 @@ def ingroup_indices(group_inds):
 class MSDAFunction(torch.autograd.Function):
     """MultiScaleDeformableAttnFunction of the reference (multi_scale_deformable_attn_function.py; one level), taking
     the raw sampling offsets and attention logits: forward = isf_msda_forward, backward = isf_msda_backward
-    -> gradients for value, offsets and logits (SURVEY.md 8f #2; not yet validated on hardware)."""
+    -> gradients for value, offsets and logits (SURVEY.md 8f #2; validated on an MI355X: tests/test_gpu_train.py, tests/test_gpu_widened.py)."""
 
     @staticmethod
     @_amp_fwd
@@ -589,7 +589,7 @@ class MSDAFunction(torch.autograd.Function):
 
 class AttentionFunction(torch.autograd.Function):
     """softmax(q k^T / sqrt(hd)) v of nn.MultiheadAttention (fusion_encoder.py:371-470) with a gradient: forward =
-    isf_attention_forward, backward = isf_attention_backward (not yet validated on hardware).
+    isf_attention_forward, backward = isf_attention_backward (validated on an MI355X: tests/test_gpu_train.py, tests/test_gpu_widened.py).
     q [B*Lq, E], k / v [B*Lk, E] row-major."""
 
     @staticmethod
